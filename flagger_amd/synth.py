@@ -1,0 +1,262 @@
+"""Deterministic synthetic windowed-coverage inputs (BASELINE.json `configs`).
+
+The generator emits the reference's own `.bin` chunk format
+(/root/reference/programs/submodules/chunk/chunk.c:596-709), so the same file feeds this build, the
+oracle and a stock `hmm_flagger`.  Chunking follows chunk.c:240-294 (chunks of `chunk_len` bases,
+the last chunk of a contig absorbs the remainder) and windows restart at every chunk start with a
+trailing partial window (chunk.c:539-543).
+"""
+from __future__ import annotations
+
+import dataclasses
+import struct
+from typing import List, Sequence
+
+import numpy as np
+
+# human-like chromosome lengths (T2T-CHM13-ish, bases); two haplotypes => ~6.06 Gb
+_HUMAN_CHROMS = [
+    248_387_328, 242_696_752, 201_105_948, 193_574_945, 182_045_439, 172_126_628, 160_567_428,
+    146_259_331, 150_617_247, 134_758_134, 135_127_769, 133_324_548, 113_566_686, 101_161_492,
+    99_753_195, 96_330_374, 84_276_897, 80_542_538, 61_707_364, 66_210_255, 45_090_682,
+    51_324_926, 154_259_566,
+]
+
+HIFI_ALPHA = np.array([  # misc/alpha_tsv/HiFi_DC_1.2/...v1.1.0.tsv
+    [0.753, 0.000, 0.236, 0.000],
+    [0.000, 0.464, 0.440, 0.000],
+    [0.527, 0.162, 0.010, 0.218],
+    [0.000, 0.000, 0.041, 0.206]])
+ONT_R10_ALPHA = np.array([  # misc/alpha_tsv/ONT_R1041_Dorado/...v1.1.0.tsv
+    [0.684, 0.000, 0.478, 0.000],
+    [0.000, 0.800, 0.017, 0.000],
+    [0.006, 0.000, 0.722, 0.081],
+    [0.000, 0.000, 0.366, 0.476]])
+
+
+@dataclasses.dataclass
+class WindowStore:
+    """Flat SoA view of what the reference keeps as Chunk/CoverageInfo objects (chunk.h:11-34,
+    ptBlock.h:79-92): one record per window, chunks delimited by `chunk_off`."""
+    cov: np.ndarray          # u16 [N]
+    mapq: np.ndarray         # u16 [N]
+    clip: np.ndarray         # u16 [N]
+    annot: np.ndarray        # u64 [N], region index in bits 58..63 (ptBlock.c:294-304)
+    truth: np.ndarray        # i8  [N]
+    prediction: np.ndarray   # i8  [N]
+    chunk_off: np.ndarray    # i64 [C+1]
+    chunk_ctg: List[str]
+    chunk_ctg_len: np.ndarray  # i32 [C]
+    chunk_s: np.ndarray      # i32 [C]
+    chunk_e: np.ndarray      # i32 [C]
+    window_len: int
+    chunk_len: int
+    region_coverages: List[int]
+    avg_alignment_len: int = 15000
+    annotation_names: Sequence[str] = ("no_annotation", "whole_genome")
+    n_labels: int = 4
+    truth_available: bool = True
+    prediction_available: bool = False
+    start_only: bool = False
+
+    @property
+    def n_windows(self) -> int:
+        return int(self.chunk_off[-1])
+
+    @property
+    def n_chunks(self) -> int:
+        return len(self.chunk_ctg)
+
+    @property
+    def n_regions(self) -> int:
+        return len(self.region_coverages)
+
+    def regions(self) -> np.ndarray:
+        return (self.annot >> np.uint64(58)).astype(np.uint8)
+
+    def subset_chunks(self, idx: Sequence[int]) -> "WindowStore":
+        """Chunk-granular shard: keeps list order of the selected chunks."""
+        idx = list(idx)
+        sel = [np.arange(self.chunk_off[c], self.chunk_off[c + 1]) for c in idx]
+        w = np.concatenate(sel) if sel else np.zeros(0, dtype=np.int64)
+        off = np.zeros(len(idx) + 1, dtype=np.int64)
+        for k, c in enumerate(idx):
+            off[k + 1] = off[k] + (self.chunk_off[c + 1] - self.chunk_off[c])
+        return dataclasses.replace(
+            self, cov=self.cov[w], mapq=self.mapq[w], clip=self.clip[w], annot=self.annot[w],
+            truth=self.truth[w], prediction=self.prediction[w], chunk_off=off,
+            chunk_ctg=[self.chunk_ctg[c] for c in idx], chunk_ctg_len=self.chunk_ctg_len[idx],
+            chunk_s=self.chunk_s[idx], chunk_e=self.chunk_e[idx])
+
+    # ---- reference `.bin` format (chunk.c:596-709 / 713-828) ----
+    def write_bin(self, path: str) -> None:
+        with open(path, "wb") as f:
+            f.write(struct.pack("<i", len(self.annotation_names)))
+            for name in self.annotation_names:
+                b = name.encode() + b"\0"
+                f.write(struct.pack("<i", len(b)))
+                f.write(b)
+            f.write(struct.pack("<i", self.n_regions))
+            f.write(np.asarray(self.region_coverages, dtype="<i4").tobytes())
+            f.write(struct.pack("<i", self.n_labels))
+            f.write(struct.pack("<BBB", self.truth_available, self.prediction_available, self.start_only))
+            f.write(struct.pack("<iii", self.avg_alignment_len, self.chunk_len, self.window_len))
+            for c in range(self.n_chunks):
+                a, b_ = int(self.chunk_off[c]), int(self.chunk_off[c + 1])
+                name = self.chunk_ctg[c].encode() + b"\0"
+                f.write(struct.pack("<i", len(name)))
+                f.write(name)
+                f.write(struct.pack("<iiii", int(self.chunk_ctg_len[c]), int(self.chunk_s[c]),
+                                    int(self.chunk_e[c]), b_ - a))
+                f.write(self.cov[a:b_].astype("<u2").tobytes())
+                f.write(self.mapq[a:b_].astype("<u2").tobytes())
+                f.write(self.clip[a:b_].astype("<u2").tobytes())
+                f.write(self.annot[a:b_].astype("<u8").tobytes())
+                f.write(self.truth[a:b_].astype("i1").tobytes())
+                f.write(self.prediction[a:b_].astype("i1").tobytes())
+
+    @staticmethod
+    def read_bin(path: str) -> "WindowStore":
+        data = open(path, "rb").read()
+        p = 0
+
+        def i32():
+            nonlocal p
+            v = struct.unpack_from("<i", data, p)[0]
+            p += 4
+            return v
+        n_ann = i32()
+        names = []
+        for _ in range(n_ann):
+            ln = i32()
+            names.append(data[p:p + ln - 1].decode())
+            p += ln
+        n_reg = i32()
+        reg_cov = list(np.frombuffer(data, "<i4", n_reg, p).astype(int))
+        p += 4 * n_reg
+        n_labels = i32()
+        t_av, p_av, s_only = struct.unpack_from("<BBB", data, p)
+        p += 3
+        avg_len, chunk_len, window_len = struct.unpack_from("<iii", data, p)
+        p += 12
+        cov, mapq, clip, annot, truth, pred = [], [], [], [], [], []
+        ctgs, ctg_len, cs, ce, off = [], [], [], [], [0]
+        while p < len(data):
+            ln = i32()
+            ctgs.append(data[p:p + ln - 1].decode())
+            p += ln
+            cl, s, e, n = struct.unpack_from("<iiii", data, p)
+            p += 16
+            ctg_len.append(cl); cs.append(s); ce.append(e)
+            cov.append(np.frombuffer(data, "<u2", n, p)); p += 2 * n
+            mapq.append(np.frombuffer(data, "<u2", n, p)); p += 2 * n
+            clip.append(np.frombuffer(data, "<u2", n, p)); p += 2 * n
+            annot.append(np.frombuffer(data, "<u8", n, p)); p += 8 * n
+            truth.append(np.frombuffer(data, "i1", n, p)); p += n
+            pred.append(np.frombuffer(data, "i1", n, p)); p += n
+            off.append(off[-1] + n)
+
+        def cat(xs, dt):
+            return np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
+        return WindowStore(
+            cov=cat(cov, np.uint16), mapq=cat(mapq, np.uint16), clip=cat(clip, np.uint16),
+            annot=cat(annot, np.uint64), truth=cat(truth, np.int8), prediction=cat(pred, np.int8),
+            chunk_off=np.asarray(off, np.int64), chunk_ctg=ctgs,
+            chunk_ctg_len=np.asarray(ctg_len, np.int32), chunk_s=np.asarray(cs, np.int32),
+            chunk_e=np.asarray(ce, np.int32), window_len=window_len, chunk_len=chunk_len,
+            region_coverages=reg_cov, avg_alignment_len=avg_len, annotation_names=tuple(names),
+            n_labels=n_labels, truth_available=bool(t_av), prediction_available=bool(p_av),
+            start_only=bool(s_only))
+
+
+def chunk_bounds(ctg_len: int, chunk_len: int):
+    """(s, e) 0-based inclusive per chunk of one contig — chunk.c:259-286."""
+    out = []
+    s = 0
+    e = ctg_len - 1 if ctg_len < 2 * chunk_len else chunk_len - 1
+    out.append((s, e))
+    while e < ctg_len - 1:
+        s = e + 1
+        e = ctg_len - 1 if ctg_len < e + 2 * chunk_len else e + chunk_len
+        out.append((s, e))
+    return out
+
+
+def _sticky_states(rng: np.random.Generator, n: int, stay: np.ndarray, start_state: int = 2) -> np.ndarray:
+    """Hidden 4-state chain with self-transition `stay[s]`; leaving mass goes mostly to Hap."""
+    leave = np.array([[0.0, 0.1, 0.8, 0.1],
+                      [0.1, 0.0, 0.8, 0.1],
+                      [0.2, 0.4, 0.0, 0.4],
+                      [0.1, 0.1, 0.8, 0.0]])
+    out = np.empty(n, dtype=np.int8)
+    pos, s = 0, start_state
+    while pos < n:
+        run = int(rng.geometric(1.0 - stay[s]))
+        out[pos:pos + run] = s
+        pos += run
+        s = int(rng.choice(4, p=leave[s]))
+    return out
+
+
+def synthesize(contig_lengths: Sequence[int], window_len: int, chunk_len: int, region_coverages: Sequence[int],
+               seed: int, stay=(0.9, 0.9, 0.9975, 0.9), avg_alignment_len: int = 15000,
+               region_run_bases=(100_000, 5_000_000), contig_prefix: str = "ctg") -> WindowStore:
+    """cfg-2..5 style input: per contig a sticky hidden chain, cov ~ round(N(mu_s, 1.2*mu_s)) clipped
+    to [0,250] with mu = (0.1, 0.5, 1, 2..) x region coverage, mapq = cov except Dup (~0), clip = 0."""
+    rng = np.random.default_rng(seed)
+    stay = np.asarray(stay, dtype=np.float64)
+    R = len(region_coverages)
+    cov_l, mapq_l, ann_l, truth_l = [], [], [], []
+    ctgs, ctg_len_l, cs, ce, off = [], [], [], [], [0]
+    for ci, L in enumerate(contig_lengths):
+        nwin_ctg = 0
+        bounds = chunk_bounds(int(L), chunk_len)
+        sizes = [-(-(e - s + 1) // window_len) for s, e in bounds]
+        nwin_ctg = sum(sizes)
+        states = _sticky_states(rng, nwin_ctg, stay)
+        # region runs (in windows)
+        if R > 1:
+            region = np.zeros(nwin_ctg, dtype=np.uint8)
+            pos = 0
+            while pos < nwin_ctg:
+                run = max(1, int(rng.integers(region_run_bases[0], region_run_bases[1])) // window_len)
+                r = 0 if rng.random() < 0.6 else int(rng.integers(1, R))
+                region[pos:pos + run] = r
+                pos += run
+        else:
+            region = np.zeros(nwin_ctg, dtype=np.uint8)
+        base = np.asarray(region_coverages, dtype=np.float64)[region]
+        k = rng.integers(1, 4, size=nwin_ctg)  # collapsed copy number 2..4 => mean 2..4 x base
+        mu = np.where(states == 0, 0.1 * base,
+             np.where(states == 1, 0.5 * base,
+             np.where(states == 2, base, (k + 1) * base)))
+        cov = np.rint(rng.normal(mu, np.sqrt(1.2 * mu))).clip(0, 250).astype(np.uint16)
+        mapq = np.where(states == 1, (cov * rng.uniform(0.0, 0.1, size=nwin_ctg)).astype(np.uint16), cov)
+        annot = (np.uint64(1) << np.uint64(1)) | (region.astype(np.uint64) << np.uint64(58))
+        cov_l.append(cov); mapq_l.append(mapq.astype(np.uint16)); ann_l.append(annot); truth_l.append(states)
+        for (s, e), n in zip(bounds, sizes):
+            ctgs.append(f"{contig_prefix}{ci}")
+            ctg_len_l.append(int(L)); cs.append(s); ce.append(e)
+            off.append(off[-1] + n)
+    N = off[-1]
+    return WindowStore(
+        cov=np.concatenate(cov_l), mapq=np.concatenate(mapq_l), clip=np.zeros(N, np.uint16),
+        annot=np.concatenate(ann_l), truth=np.concatenate(truth_l).astype(np.int8),
+        prediction=np.full(N, -1, np.int8), chunk_off=np.asarray(off, np.int64), chunk_ctg=ctgs,
+        chunk_ctg_len=np.asarray(ctg_len_l, np.int32), chunk_s=np.asarray(cs, np.int32),
+        chunk_e=np.asarray(ce, np.int32), window_len=window_len, chunk_len=chunk_len,
+        region_coverages=[int(x) for x in region_coverages], avg_alignment_len=avg_alignment_len)
+
+
+def config(n: int, scale: float = 1.0) -> WindowStore:
+    """BASELINE.json `configs[n]` (seed 1234+n).  `scale` < 1 shrinks contig lengths for tests."""
+    seed = 1234 + n
+    if n == 1:   # 1 contig 10 Mb, 4 kb windows, fixed-parameter decode
+        return synthesize([int(10_000_000 * scale)], 4000, 20_000_000, [20], seed)
+    if n in (2, 3):  # 2 x 3.03 Gb diploid, 4 kb windows, full EM (3 = same input, 8 GPUs)
+        lens = [int(x * scale) for x in _HUMAN_CHROMS] * 2
+        return synthesize(lens, 4000, 20_000_000, [20], 1234 + 2, contig_prefix="hap_ctg")
+    if n == 4:   # ONT-R10 preset, 7 bias regions
+        lens = [int(x * scale) for x in _HUMAN_CHROMS] * 2
+        return synthesize(lens, 8000, 20_000_000, [20, 12, 16, 24, 28, 32, 14], seed, contig_prefix="hap_ctg")
+    raise ValueError("configs[0] is generated by tests/golden/make_golden.py (simulated .cov)")
