@@ -1,0 +1,125 @@
+"""ctypes binding of libhmmflagger_hip.so (include/hmm_flagger_hip.h, include/hmm_flagger_model.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C flagger_amd/csrc`.  There is no
+Python or CPU fallback for the E-step: if the shared object is missing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HF_NSTATES = 4
+HF_MAXCOMP = 16
+HF_MAXREGIONS = 64
+HF_MODEL_TRUNC_EXP_GAUSSIAN, HF_MODEL_GAUSSIAN = 0, 1
+HF_MODE_FULL, HF_MODE_FORWARD_ONLY = 0, 1
+HF_ALGO_SCAN, HF_ALGO_SEQ = 0, 1
+HF_OK, HF_E_ARG, HF_E_HIP, HF_E_SCALE, HF_E_NAN, HF_E_REGION, HF_E_NOGPU = 0, -1, -2, -3, -4, -5, -6
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhmmflagger_hip.so")
+
+
+class hf_windows(C.Structure):
+    _fields_ = [
+        ("n_windows", C.c_int64), ("n_chunks", C.c_int32),
+        ("chunk_off", C.POINTER(C.c_int64)),
+        ("cov", C.POINTER(C.c_uint16)), ("mapq", C.POINTER(C.c_uint16)), ("clip", C.POINTER(C.c_uint16)),
+        ("annot", C.POINTER(C.c_uint64)),
+        ("chunk_s", C.POINTER(C.c_int32)), ("chunk_e", C.POINTER(C.c_int32)), ("chunk_ctg_len", C.POINTER(C.c_int32)),
+        ("window_len", C.c_int32), ("mean_read_len", C.c_int32), ("adjust_contig_ends", C.c_int32),
+        ("min_read_frac", C.c_double), ("max_high_mapq_ratio", C.c_double), ("min_high_mapq_ratio", C.c_double),
+        ("min_highly_clipped_ratio", C.c_double),
+    ]
+
+
+class hf_params(C.Structure):
+    _fields_ = [
+        ("model_type", C.c_int32), ("n_regions", C.c_int32), ("ncomp", C.c_int32 * 4),
+        ("alpha", (C.c_double * 4) * 4),
+        ("trans", C.POINTER(C.c_double)), ("lambda_", C.POINTER(C.c_double)), ("trunc_point", C.POINTER(C.c_double)),
+        ("mean", C.POINTER(C.c_double)), ("var", C.POINTER(C.c_double)), ("weight", C.POINTER(C.c_double)),
+    ]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the native library once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C flagger_amd/csrc`). The HIP E-step has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    pd = C.POINTER(C.c_double)
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("hf_version", C.c_char_p)
+    sig("hf_last_error", C.c_char_p)
+    sig("hf_device_count", C.c_int)
+    sig("hf_create", C.c_int, C.POINTER(hf_windows), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp))
+    sig("hf_destroy", None, vp)
+    sig("hf_estep", C.c_int, vp, C.POINTER(hf_params), C.c_int, vp)
+    sig("hf_n_chunks", i32, vp)
+    sig("hf_n_windows", i64, vp)
+    sig("hf_chunk_stats_len", i64, vp)
+    sig("hf_chunk_stats_dev", vp, vp)
+    sig("hf_labels_dev", vp, vp)
+    sig("hf_copy_chunk_stats", C.c_int, vp, vp, vp)
+    sig("hf_reduce_chunks", C.c_int, vp, vp, i64, vp, vp)
+    sig("hf_finish", C.c_int, vp, pd, vp)
+    sig("hf_check", C.c_int, vp, vp)
+    sig("hf_get_labels", C.c_int, vp, C.POINTER(C.c_int8))
+    sig("hf_get_posterior", C.c_int, vp, i64, i64, pd)
+    sig("hf_get_forward_backward", C.c_int, vp, i64, i64, pd, pd, pd)
+    sig("hf_last_kernel_ms", C.c_int, vp, C.POINTER(C.c_float))
+    # host model
+    sig("hfm_create", vp, C.c_int, C.c_int, C.POINTER(i32), C.c_int, C.c_int, C.c_int, C.c_int, pd, dbl, dbl)
+    sig("hfm_copy", vp, vp)
+    sig("hfm_destroy", None, vp)
+    sig("hfm_n_regions", C.c_int, vp)
+    sig("hfm_max_comps", C.c_int, vp)
+    sig("hfm_model_type", C.c_int, vp)
+    sig("hfm_max_high_mapq_ratio", dbl, vp)
+    sig("hfm_min_high_mapq_ratio", dbl, vp)
+    sig("hfm_min_highly_clipped_ratio", dbl, vp)
+    sig("hfm_params", None, vp, C.POINTER(hf_params))
+    sig("hfm_estimate", C.c_int, vp, pd, dbl)
+    sig("hfm_loglikelihood", dbl, vp)
+    sig("hfm_write_transition_tsv", C.c_int, vp, C.c_char_p)
+    sig("hfm_write_emission_tsv", C.c_int, vp, C.c_char_p)
+    sig("hfm_param_len", i64, vp)
+    sig("hfm_get_param_vector", None, vp, pd)
+    sig("hfm_set_param_vector", None, vp, pd)
+    sig("hfm_best_collapsed_comps", C.c_int, C.POINTER(C.c_uint16), i64, C.POINTER(i32), C.c_int)
+    sig("hfm_read_alpha_tsv", C.c_int, C.c_char_p, pd)
+    _lib = L
+    return L
+
+
+def region_stride(max_comps: int) -> int:
+    return 24 * max_comps + 16
+
+
+def stats_len(n_regions: int, max_comps: int) -> int:
+    return 1 + n_regions * region_stride(max_comps)
+
+
+class HFError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        self.code = code
+        msg = lib().hf_last_error().decode(errors="replace")
+        super().__init__(f"{where} failed with code {code}: {msg}")
+
+
+def check(code: int, where: str) -> None:
+    if code != HF_OK:
+        raise HFError(code, where)

@@ -1,0 +1,81 @@
+// hf_device.h — device-side data layout and per-window math shared by all E-step kernels.
+// gfx950 only.  Compiled with -ffp-contract=off: every fp64 operation below is written in the
+// operand order of the reference (programs/submodules/hmm_utils/hmm_utils.c) so that the only
+// differences from the CPU path are the last-ulp behaviour of exp()/log().
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hmm_flagger_hip.h"
+
+#define HF_PI 3.14159              // common.h:15 (sic)
+#define HF_TERMINATION_PROB 1e-4   // hmm_utils.c:2112
+
+// device error flag bits
+#define HF_FLAG_SCALE 1u
+#define HF_FLAG_NAN 2u
+#define HF_FLAG_REGION 4u
+
+// ---- packed window record (4 B/window), built once by k_setup ----
+//   bits 0..7  x      = (uint8_t) coverage             hmm.c:345,384
+//   bits 8..15 region = annotation_flag >> 58          ptBlock.c:294-298
+//   bits 16..18 validity mask: Dup / Col / End(Msj)    hmm_utils.c:2229-2254
+//   bit 19     first window of its chunk
+//   bit 20     region differs from the previous window hmm.c:398
+#define REC_X(r) ((r) & 0xffu)
+#define REC_REGION(r) (((r) >> 8) & 0xffu)
+#define REC_VMASK(r) (((r) >> 16) & 0x7u)
+#define REC_FIRST(r) (((r) >> 19) & 1u)
+#define REC_REGCHG(r) (((r) >> 20) & 1u)
+
+struct DevRegion {
+    double trans[5][5];                 // Transition.matrix (row 4 Start, column 4 End)
+    double tcond[8][16];                // Transition_getProbConditional per validity mask, [pre*4+s]
+    double lambda, trunc_point;         // TruncExponential
+    double mean[HF_NSTATES][HF_MAXCOMP];
+    double var[HF_NSTATES][HF_MAXCOMP];
+    double weight[HF_NSTATES][HF_MAXCOMP];
+};
+
+struct DevParams {
+    int32_t model_type, n_regions;
+    int32_t ncomp[HF_NSTATES];
+    int32_t nuniq[HF_NSTATES];          // distinct alpha values in column s
+    int32_t umap[16];                   // [pre*4+s] -> index of alpha[pre][s] among column s' distinct values
+    double ualpha[HF_NSTATES][4];       // [s][u]
+    double alpha[16];                   // [pre*4+s]
+    DevRegion reg[1];                   // n_regions entries
+};
+
+__device__ __forceinline__ bool hf_err_is_truncexp(const DevParams* __restrict__ P) {
+    return P->model_type == HF_MODEL_TRUNC_EXP_GAUSSIAN;
+}
+
+// hmm_utils.c:941-947 TruncExponential_getProb
+__device__ __forceinline__ double hf_trunc_exp(double lambda, double trunc_point, double x, double beta) {
+    double lam = lambda / beta;
+    double b = beta * trunc_point;
+    if (trunc_point < x) return 0.0;
+    return lam * exp(-lam * x) / (1 - exp(-lam * b));
+}
+
+// one mixture component, hmm_utils.c:775-790; sets *nan when the reference would exit
+__device__ __forceinline__ double hf_gauss_comp(double mu, double var_c, double w, double x, double pre_x,
+                                                double alpha, double beta, unsigned* nan) {
+    double mean = (1 - alpha) * mu + alpha * pre_x;
+    mean *= beta;
+    double var = var_c * beta;
+    double d = x - mean;
+    double p = w / (sqrt(var * 2 * HF_PI)) * exp(-0.5 * (d * d) / var);
+    if (p != p) *nan |= HF_FLAG_NAN;
+    if (p < 1e-40) p = 1e-40;
+    return p;
+}
+
+// Gaussian_getProb, hmm_utils.c:753-758 (sum over components in index order)
+__device__ __forceinline__ double hf_gauss_sum(const DevRegion* __restrict__ R, int s, int ncomp, double x,
+                                               double pre_x, double alpha, double beta, unsigned* nan) {
+    double tot = 0.0;
+    for (int c = 0; c < ncomp; c++)
+        tot += hf_gauss_comp(R->mean[s][c], R->var[s][c], R->weight[s][c], x, pre_x, alpha, beta, nan);
+    return tot;
+}

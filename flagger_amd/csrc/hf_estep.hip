@@ -1,0 +1,746 @@
+// hf_estep.hip — MI355X (gfx950) E-step of HMM-Flagger: kernels + C ABI (include/hmm_flagger_hip.h).
+//
+// Replaces EM_runOneIterationForList / EM_runForwardForList (programs/submodules/hmm/hmm.c:739,790).
+// Pipeline of one pass (per EM iteration):
+//   k_emit      window-parallel  emission table E_t[pre][s]           (hmm_utils.c:753-793, 941-947)
+//   k_fwd_*     per chunk        scaled forward, log-likelihood       (hmm.c:333-434)
+//   k_bwd_*     per chunk        scaled backward, posterior argmax    (hmm.c:452-545, 671-692)
+//   k_stats     per chunk        xi sufficient statistics             (hmm.c:563-650, hmm_utils.c:812-839)
+//   k_reduce    ordered sum over chunks                               (hmm.c:759-763)
+// There is no CPU fallback: without a HIP device hf_create fails with HF_E_NOGPU.
+#include "hf_device.h"
+#include <string>
+#include <vector>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+
+static thread_local std::string g_err;
+static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
+    return set_err(HF_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+struct hf_ctx {
+    int device = 0, algo = HF_ALGO_SCAN;
+    int64_t N = 0; int32_t C = 0; int32_t maxT = 0;
+    int R = 1, K = 2;
+    int64_t V = 0;                 // per-chunk stats vector length
+    hf_windows meta{};             // scalar options only (pointers cleared)
+    // device-resident window store
+    int64_t* d_off = nullptr;      // [C+1]
+    uint32_t* d_rec = nullptr;     // [N]
+    double* d_beta = nullptr;      // [N]
+    uint64_t* d_regmask = nullptr; // [C] bit r set if region r occurs in the chunk
+    // per-pass work arrays
+    double* d_E = nullptr;         // [N][16]
+    double* d_f = nullptr;         // [N][4]
+    double* d_b = nullptr;         // [N][4]
+    double* d_scale = nullptr;     // [N]
+    int8_t* d_label = nullptr;     // [N]
+    double* d_chunk_stats = nullptr; // [C][V]
+    double* d_total = nullptr;     // [V]
+    unsigned* d_flags = nullptr;
+    DevParams* d_params = nullptr; DevParams* h_params = nullptr; size_t params_bytes = 0;
+    unsigned* h_flags = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
+    bool have_full = false;
+};
+
+// ------------------------------------------------------------------------------------------
+// setup: packed records + contig-end factor beta (hmm.c:301-316), once per run
+// ------------------------------------------------------------------------------------------
+__global__ void k_setup(const int64_t* __restrict__ off, const uint16_t* __restrict__ cov,
+                        const uint16_t* __restrict__ mapq, const uint16_t* __restrict__ clip,
+                        const uint64_t* __restrict__ annot, const int32_t* __restrict__ cs,
+                        const int32_t* __restrict__ ce, const int32_t* __restrict__ cl, int window_len,
+                        int mean_read_len, int adjust, double min_frac, double max_mapq, double min_mapq,
+                        double min_clip, int n_regions, uint32_t* __restrict__ rec, double* __restrict__ beta,
+                        unsigned* __restrict__ flags) {
+    const int c = blockIdx.y;
+    const int64_t t0 = off[c], T = off[c + 1] - t0;
+    const int64_t col = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= T) return;
+    const int64_t t = t0 + col;
+    const unsigned cv = cov[t];
+    const unsigned region = (unsigned) ((annot[t] & 0xFC00000000000000ULL) >> 58);
+    if ((int) region >= n_regions) atomicOr(flags, HF_FLAG_REGION);
+    // validity mask, hmm_utils.c:2229-2254
+    const double ratio_m = (double) mapq[t] / (0.1 + cv);
+    const double ratio_c = (double) clip[t] / (0.1 + cv);
+    unsigned vm = 0;
+    if (!(ratio_m > max_mapq)) vm |= 1u;  // Dup valid
+    if (!(ratio_m < min_mapq)) vm |= 2u;  // Col valid
+    if (!(ratio_c < min_clip)) vm |= 4u;  // End/Msj column valid
+    unsigned r = (cv & 0xffu) | (region << 8) | (vm << 16);
+    if (col == 0) r |= 1u << 19;
+    else {
+        const unsigned pre_region = (unsigned) ((annot[t - 1] & 0xFC00000000000000ULL) >> 58);
+        if (pre_region != region) r |= 1u << 20;
+    }
+    rec[t] = r;
+    // beta, hmm.c:301-316; min/max are the int functions of common.c:142-148
+    double bt = 1.0;
+    if (adjust) {
+        const int s = cs[c], e = ce[c], ctg_len = cl[c];
+        const int icol = (int) col;
+        const int a1 = (int) (s + (double) window_len * (icol + 0.5));
+        const int a2 = (int) ((s + (double) window_len * icol + e) / 2);
+        const int mid = a1 < a2 ? a1 : a2;
+        const int L = mean_read_len;
+        const int l1 = mid - L + 1, l2 = (int) (-(1 - min_frac) * L);
+        const int l = l2 < l1 ? l1 : l2;
+        const int u2 = (int) (ctg_len - min_frac * L);
+        const int u = mid < u2 ? mid : u2;
+        bt = (double) (u - l) / L;
+        if (bt <= 0.25) bt = 0.25;
+    }
+    beta[t] = bt;
+}
+
+__global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
+                          uint64_t* __restrict__ regmask) {
+    const int c = blockIdx.x;
+    const int64_t t0 = off[c], T = off[c + 1] - t0;
+    unsigned long long m = 0;
+    for (int64_t i = threadIdx.x; i < T; i += blockDim.x) m |= 1ull << (REC_REGION(rec[t0 + i]) & 63u);
+    for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o);
+    __shared__ unsigned long long sm[16];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long a = 0;
+        for (int w = 0; w < (int) (blockDim.x >> 6); w++) a |= sm[w];
+        regmask[c] = a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_emit: E_t[pre][s] = e_s(x_t | x_{t-1}, alpha[pre][s], beta_t) for every window (A8-A10).
+// Chunk-first windows hold e_s(x_0; alpha=0, preX=0) in row pre=0 (hmm.c:338-352).
+// Evaluated once per distinct alpha of a column; Err (trunc-exp) ignores alpha.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_emit(int64_t N, const uint32_t* __restrict__ rec,
+                                              const double* __restrict__ beta, const DevParams* __restrict__ P,
+                                              double* __restrict__ E, unsigned* __restrict__ flags) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const uint32_t r = rec[t];
+    const double x = (double) REC_X(r);
+    const DevRegion* __restrict__ R = &P->reg[REC_REGION(r) < (unsigned) P->n_regions ? REC_REGION(r) : 0];
+    const double bt = beta[t];
+    unsigned nan = 0;
+    double out[16];
+    const bool te = hf_err_is_truncexp(P);
+    if (REC_FIRST(r)) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) out[k] = 0.0;
+        out[0] = te ? hf_trunc_exp(R->lambda, R->trunc_point, x, bt)
+                    : hf_gauss_sum(R, 0, P->ncomp[0], x, 0.0, 0.0, bt, &nan);
+        for (int s = 1; s < 4; s++) out[s] = hf_gauss_sum(R, s, P->ncomp[s], x, 0.0, 0.0, bt, &nan);
+    } else {
+        const double px = (double) REC_X(rec[t - 1]);
+        for (int s = 0; s < 4; s++) {
+            double val[4];
+            if (s == 0 && te) {
+                const double v = hf_trunc_exp(R->lambda, R->trunc_point, x, bt);
+                val[0] = v; val[1] = v; val[2] = v; val[3] = v;
+            } else {
+                const int nu = P->nuniq[s], nc = P->ncomp[s];
+                val[0] = val[1] = val[2] = val[3] = 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (u < nu) val[u] = hf_gauss_sum(R, s, nc, x, px, P->ualpha[s][u], bt, &nan);
+            }
+#pragma unroll
+            for (int pre = 0; pre < 4; pre++) {
+                const int u = (s == 0 && te) ? 0 : P->umap[pre * 4 + s];
+                out[pre * 4 + s] = u == 0 ? val[0] : u == 1 ? val[1] : u == 2 ? val[2] : val[3];
+            }
+        }
+    }
+    if (nan) atomicOr(flags, nan);
+    double2* dst = reinterpret_cast<double2*>(E + t * 16);
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[k] = make_double2(out[2 * k], out[2 * k + 1]);
+}
+
+// transition row table for one window: region change => 1/(S+1) (hmm.c:398-400)
+__device__ __forceinline__ void load_T(const DevParams* __restrict__ P, uint32_t r, double Tm[16]) {
+    if (REC_REGCHG(r)) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) Tm[k] = 1.0 / (HF_NSTATES + 1);
+    } else {
+        const double* __restrict__ src = P->reg[REC_REGION(r)].tcond[REC_VMASK(r)];
+#pragma unroll
+        for (int k = 0; k < 16; k++) Tm[k] = src[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// HF_ALGO_SEQ: one wavefront per chunk, windows visited in order with the reference's exact
+// operation order; tiles of 64 windows are staged through LDS with coalesced loads/stores.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_fwd_seq(const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
+                                                const double* __restrict__ E, const DevParams* __restrict__ P,
+                                                double* __restrict__ F, double* __restrict__ scale,
+                                                double* __restrict__ chunk_stats, int64_t V,
+                                                unsigned* __restrict__ flags) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int64_t t0 = off[c], T = off[c + 1] - t0;
+    __shared__ double Es[64][17];
+    __shared__ double Fs[64][5];
+    __shared__ uint32_t rs[64];
+    double f[4] = {0.0, 0.0, 0.0, 0.0};
+    double ll = 0.0;
+    unsigned bad = 0;
+    for (int64_t base = 0; base < T; base += 64) {
+        const int n = (int) ((T - base) < 64 ? (T - base) : 64);
+        if (lane < n) {
+            const int64_t t = t0 + base + lane;
+            rs[lane] = rec[t];
+#pragma unroll
+            for (int k = 0; k < 16; k++) Es[lane][k] = E[t * 16 + k];
+        }
+        __syncthreads();
+        for (int j = 0; j < n; j++) {
+            const uint32_t r = rs[j];
+            double nf[4], sc = 0.0;
+            if (base + j == 0) { // hmm.c:333-364
+                const DevRegion* __restrict__ R = &P->reg[REC_REGION(r)];
+#pragma unroll
+                for (int s = 0; s < 4; s++) { nf[s] = Es[j][s] * R->trans[4][s]; sc += nf[s]; }
+            } else {             // hmm.c:366-420
+                double Tm[16];
+                load_T(P, r, Tm);
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int p = 0; p < 4; p++) acc += (f[p] * Tm[p * 4 + s] * Es[j][p * 4 + s]);
+                    nf[s] = acc;
+                    sc += acc;
+                }
+                if (sc < 1e-50) bad |= HF_FLAG_SCALE;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++) { f[s] = nf[s] / sc; }
+            ll += log(sc);
+            if (lane == 0) { Fs[j][0] = f[0]; Fs[j][1] = f[1]; Fs[j][2] = f[2]; Fs[j][3] = f[3]; Fs[j][4] = sc; }
+        }
+        __syncthreads();
+        if (lane < n) {
+            const int64_t t = t0 + base + lane;
+            reinterpret_cast<double2*>(F + t * 4)[0] = make_double2(Fs[lane][0], Fs[lane][1]);
+            reinterpret_cast<double2*>(F + t * 4)[1] = make_double2(Fs[lane][2], Fs[lane][3]);
+            scale[t] = Fs[lane][4];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        chunk_stats[(int64_t) c * V] = ll;
+        if (bad) atomicOr(flags, bad);
+    }
+}
+
+__device__ __forceinline__ int posterior_label(const double f[4], const double b[4], double sc) {
+    // hmm.c:671-692 + common.c:292-304 (strict >, first maximum wins)
+    double p[4], total = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) { p[s] = f[s] * b[s] * sc; total += p[s]; }
+#pragma unroll
+    for (int s = 0; s < 4; s++) p[s] /= total;
+    double mx = p[0]; int idx = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (mx < p[s]) { mx = p[s]; idx = s; }
+    return idx;
+}
+
+__global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
+                                                const double* __restrict__ E, const DevParams* __restrict__ P,
+                                                const double* __restrict__ F, const double* __restrict__ scale,
+                                                double* __restrict__ B, int8_t* __restrict__ label,
+                                                unsigned* __restrict__ flags) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int64_t t0 = off[c], T = off[c + 1] - t0;
+    if (T <= 0) return;
+    __shared__ double Es[64][17];   // E of window i+1
+    __shared__ double Fs[64][5];    // f_i[0..3], scale_i
+    __shared__ double Bs[64][4];
+    __shared__ uint32_t rs[64];     // rec of window i+1
+    __shared__ int8_t Ls[64];
+    double b[4];
+    unsigned bad = 0;
+    { // last column, hmm.c:452-467
+        const int64_t t = t0 + T - 1;
+        const DevRegion* __restrict__ R = &P->reg[REC_REGION(rec[t])];
+        const double sc = scale[t];
+        double f[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) { b[s] = R->trans[s][4] / sc; f[s] = F[t * 4 + s]; }
+        if (lane == 0) {
+            B[t * 4 + 0] = b[0]; B[t * 4 + 1] = b[1]; B[t * 4 + 2] = b[2]; B[t * 4 + 3] = b[3];
+            label[t] = (int8_t) posterior_label(f, b, sc);
+        }
+    }
+    // columns T-2 .. 0 in tiles; tile covers i in [lo, lo+n)
+    for (int64_t hi = T - 1; hi > 0; hi -= 64) {
+        const int64_t lo = hi >= 64 ? hi - 64 : 0;
+        const int n = (int) (hi - lo);
+        if (lane < n) {
+            const int64_t t = t0 + lo + lane; // window i
+            rs[lane] = rec[t + 1];
+#pragma unroll
+            for (int k = 0; k < 16; k++) Es[lane][k] = E[(t + 1) * 16 + k];
+#pragma unroll
+            for (int s = 0; s < 4; s++) Fs[lane][s] = F[t * 4 + s];
+            Fs[lane][4] = scale[t];
+        }
+        __syncthreads();
+        for (int j = n - 1; j >= 0; j--) { // hmm.c:470-529
+            double Tm[16];
+            load_T(P, rs[j], Tm);
+            double nb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) nb[p] += Tm[p * 4 + s] * Es[j][p * 4 + s] * b[s];
+            const double sc = Fs[j][4];
+            if (sc < 1e-50) bad |= HF_FLAG_SCALE;
+            double f[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) { b[s] = nb[s] / sc; f[s] = Fs[j][s]; }
+            const int lab = posterior_label(f, b, sc);
+            if (lane == 0) { Bs[j][0] = b[0]; Bs[j][1] = b[1]; Bs[j][2] = b[2]; Bs[j][3] = b[3]; Ls[j] = (int8_t) lab; }
+        }
+        __syncthreads();
+        if (lane < n) {
+            const int64_t t = t0 + lo + lane;
+            reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(Bs[lane][0], Bs[lane][1]);
+            reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(Bs[lane][2], Bs[lane][3]);
+            label[t] = Ls[lane];
+        }
+        __syncthreads();
+    }
+    if (lane == 0 && bad) atomicOr(flags, bad);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_stats: xi sufficient statistics of one chunk, one region at a time (A6, A12).
+// For every pair (i, i+1), i = 1..T-2:  xi = f_i[pre] * T * e * b_{i+1}[s] / terminationProb.
+// Distinct accumulators only (mean.den == var.den == weight.num; weight.den[i] all equal); they are
+// expanded into the reference's estimator layout when the chunk vector is written.
+// ------------------------------------------------------------------------------------------
+template <int KT>
+struct StatAcc {
+    double trans[16];
+    double g_mnum[3], g_vnum[3], g_den[3];      // single-component Gaussian states 0(Err, gaussian model),1,2
+    double te_num, te_den;                      // trunc-exp Err
+    double c_mnum[KT], c_vnum[KT], c_den[KT], c_wden; // Col components
+};
+
+template <int KT>
+__device__ __forceinline__ int acc_count() { return 16 + 9 + 2 + 3 * KT + 1; }
+
+template <int KT>
+__device__ __forceinline__ double& acc_ref(StatAcc<KT>& a, int i) { return reinterpret_cast<double*>(&a)[i]; }
+
+template <int KT>
+__global__ void __launch_bounds__(512) k_stats(const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
+                                               const double* __restrict__ beta, const double* __restrict__ E,
+                                               const DevParams* __restrict__ P, const double* __restrict__ F,
+                                               const double* __restrict__ B, const uint64_t* __restrict__ regmask,
+                                               double* __restrict__ chunk_stats, int64_t V, int Kctx,
+                                               unsigned* __restrict__ flags) {
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t t0 = off[c], T = off[c + 1] - t0;
+    constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
+    __shared__ double red[8][NA];
+    const bool te = hf_err_is_truncexp(P);
+    const int ncol = P->ncomp[3];
+    const int64_t rstride = 24 * (int64_t) Kctx + 16;
+    const uint64_t present = regmask[c];
+    unsigned nan = 0;
+    for (int r = 0; r < P->n_regions; r++) {
+        if (!((present >> r) & 1ull)) continue;
+        const DevRegion* __restrict__ R = &P->reg[r];
+        StatAcc<KT> a;
+#pragma unroll
+        for (int i = 0; i < NA; i++) acc_ref<KT>(a, i) = 0.0;
+        for (int64_t i = 1 + tid; i <= T - 2; i += blockDim.x) {
+            const int64_t t = t0 + i;
+            const uint32_t r1 = rec[t + 1];
+            if ((int) REC_REGION(r1) != r) continue;
+            const double x = (double) REC_X(r1), px = (double) REC_X(rec[t]);
+            const double bt = beta[t + 1];
+            double Tm[16];
+            load_T(P, r1, Tm);
+            double f[4], b1[4], Ev[16];
+#pragma unroll
+            for (int s = 0; s < 4; s++) { f[s] = F[t * 4 + s]; b1[s] = B[(t + 1) * 4 + s]; }
+#pragma unroll
+            for (int k = 0; k < 16; k++) Ev[k] = E[(t + 1) * 16 + k];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int k = p * 4 + s;
+                    const double count = f[p] * Tm[k] * Ev[k] * b1[s];
+                    const double adj = count / HF_TERMINATION_PROB; // hmm.c:613-614
+                    a.trans[k] += adj;                              // hmm_utils.c:2010-2015
+                    if (s == 0 && te) {                             // hmm_utils.c:1027-1034
+                        a.te_num += adj * x;
+                        a.te_den += adj;
+                    } else {                                        // hmm_utils.c:812-839
+                        const double alpha = P->alpha[k];
+                        const double x_adj = (x - alpha * px) / (1.0 - alpha);
+                        if (s < 3) {  // one component: componentProbs[0] == totProb == E
+                            const double w = adj * Ev[k] / Ev[k];
+                            a.g_mnum[s] += w * x_adj;
+                            const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
+                            a.g_vnum[s] += w * z * z;
+                            a.g_den[s] += w;
+                        } else {
+                            double pc[KT], tot = 0.0;
+#pragma unroll
+                            for (int cc = 0; cc < KT; cc++)
+                                if (cc < ncol) {
+                                    pc[cc] = hf_gauss_comp(R->mean[3][cc], R->var[3][cc], R->weight[3][cc], x, px,
+                                                           alpha, bt, &nan);
+                                    tot += pc[cc];
+                                }
+#pragma unroll
+                            for (int cc = 0; cc < KT; cc++)
+                                if (cc < ncol) {
+                                    const double w = adj * pc[cc] / tot;
+                                    a.c_mnum[cc] += w * x_adj;
+                                    const double z = (x_adj - R->mean[3][cc]) * (1.0 - alpha);
+                                    a.c_vnum[cc] += w * z * z;
+                                    a.c_den[cc] += w;
+                                    a.c_wden += w;
+                                }
+                        }
+                    }
+                }
+            }
+        }
+        // block reduction: fixed tree => deterministic
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            double v = acc_ref<KT>(a, i);
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0) red[wave][i] = v;
+        }
+        __syncthreads();
+        if (tid < NA) {
+            double v = 0.0;
+            for (int w = 0; w < (int) (blockDim.x >> 6); w++) v += red[w][tid];
+            red[0][tid] = v;
+        }
+        __syncthreads();
+        // expand into the estimator layout of include/hmm_flagger_hip.h
+        double* __restrict__ dst = chunk_stats + (int64_t) c * V + 1 + r * rstride;
+        const StatAcc<KT>* __restrict__ S = reinterpret_cast<const StatAcc<KT>*>(&red[0][0]);
+        if (tid < 16) dst[24 * Kctx + tid] = S->trans[tid];
+        if (tid == 32) {
+            if (te) { dst[(0 * 2 + 0) * Kctx] = S->te_num; dst[(0 * 2 + 1) * Kctx] = S->te_den; }
+        }
+        if (tid >= 64 && tid < 67) {
+            const int s = tid - 64;
+            if (!(s == 0 && te)) {
+                double* d = dst + (int64_t) (s * 3) * 2 * Kctx;
+                d[(0 * 2 + 0) * Kctx] = S->g_mnum[s]; d[(0 * 2 + 1) * Kctx] = S->g_den[s];
+                d[(1 * 2 + 0) * Kctx] = S->g_vnum[s]; d[(1 * 2 + 1) * Kctx] = S->g_den[s];
+                d[(2 * 2 + 0) * Kctx] = S->g_den[s];  d[(2 * 2 + 1) * Kctx] = S->g_den[s];
+            }
+        }
+        if (tid >= 128 && tid < 128 + KT && (tid - 128) < ncol) {
+            const int cc = tid - 128;
+            double* d = dst + (int64_t) (3 * 3) * 2 * Kctx;
+            d[(0 * 2 + 0) * Kctx + cc] = S->c_mnum[cc]; d[(0 * 2 + 1) * Kctx + cc] = S->c_den[cc];
+            d[(1 * 2 + 0) * Kctx + cc] = S->c_vnum[cc]; d[(1 * 2 + 1) * Kctx + cc] = S->c_den[cc];
+            d[(2 * 2 + 0) * Kctx + cc] = S->c_den[cc];  d[(2 * 2 + 1) * Kctx + cc] = S->c_wden;
+        }
+        __syncthreads();
+    }
+    if (nan) atomicOr(flags, nan);
+}
+
+// ordered sum over chunks (hmm.c:759-763): one thread per vector element, chunks in list order
+__global__ void k_reduce(const double* __restrict__ chunk_stats, int64_t n_chunks, int64_t V,
+                         double* __restrict__ out) {
+    const int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    double acc = 0.0;
+    for (int64_t c = 0; c < n_chunks; c++) acc += chunk_stats[c * V + v];
+    out[v] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side of the C ABI
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int dev_upload(T** dst, const T* src, size_t n) {
+    HIPCHK(hipMalloc((void**) dst, (n ? n : 1) * sizeof(T)));
+    if (n) HIPCHK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <int KT>
+static void launch_stats(hf_ctx* ctx, hipStream_t st) {
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats<KT>), dim3((unsigned) ctx->C), dim3(512), 0, st, ctx->d_off, ctx->d_rec,
+                       ctx->d_beta, ctx->d_E, ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_chunk_stats,
+                       ctx->V, ctx->K, ctx->d_flags);
+}
+
+extern "C" {
+
+const char* hf_version(void) { return "flagger_amd 0.1 (gfx950)"; }
+const char* hf_last_error(void) { return g_err.c_str(); }
+
+int hf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+
+int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int algo, hf_ctx** out) {
+    if (!w || !out || w->n_windows < 0 || w->n_chunks < 0 || n_regions < 1 || n_regions > HF_MAXREGIONS ||
+        max_comps < 1 || max_comps > HF_MAXCOMP || (algo != HF_ALGO_SCAN && algo != HF_ALGO_SEQ))
+        return set_err(HF_E_ARG, "hf_create: bad argument");
+    if (hf_device_count() <= 0) return set_err(HF_E_NOGPU, "hf_create: no HIP device (there is no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    hf_ctx* ctx = new hf_ctx();
+    ctx->device = device; ctx->algo = algo;
+    ctx->N = w->n_windows; ctx->C = w->n_chunks; ctx->R = n_regions; ctx->K = max_comps;
+    ctx->V = hf_stats_len(n_regions, max_comps);
+    ctx->meta = *w;
+    ctx->meta.chunk_off = nullptr; ctx->meta.cov = ctx->meta.mapq = ctx->meta.clip = nullptr;
+    ctx->meta.annot = nullptr; ctx->meta.chunk_s = ctx->meta.chunk_e = ctx->meta.chunk_ctg_len = nullptr;
+    int32_t maxT = 0;
+    for (int c = 0; c < w->n_chunks; c++) {
+        int64_t T = w->chunk_off[c + 1] - w->chunk_off[c];
+        if (T < 0 || T > INT32_MAX) { delete ctx; return set_err(HF_E_ARG, "hf_create: bad chunk_off"); }
+        if (T > maxT) maxT = (int32_t) T;
+    }
+    ctx->maxT = maxT;
+    const size_t N = (size_t) ctx->N, C = (size_t) ctx->C;
+    uint16_t *d_cov = nullptr, *d_mapq = nullptr, *d_clip = nullptr; uint64_t* d_annot = nullptr;
+    int32_t *d_cs = nullptr, *d_ce = nullptr, *d_cl = nullptr;
+    int rc = 0;
+#define TRY(x) do { rc = (x); if (rc) { hf_destroy(ctx); return rc; } } while (0)
+    TRY(dev_upload(&ctx->d_off, w->chunk_off, C + 1));
+    TRY(dev_upload(&d_cov, w->cov, N)); TRY(dev_upload(&d_mapq, w->mapq, N)); TRY(dev_upload(&d_clip, w->clip, N));
+    TRY(dev_upload(&d_annot, w->annot, N));
+    TRY(dev_upload(&d_cs, w->chunk_s, C)); TRY(dev_upload(&d_ce, w->chunk_e, C)); TRY(dev_upload(&d_cl, w->chunk_ctg_len, C));
+#define DMALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void**) &(p), (bytes) ? (bytes) : 8); \
+    if (e_ != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e_)); } } while (0)
+    DMALLOC(ctx->d_rec, N * 4); DMALLOC(ctx->d_beta, N * 8); DMALLOC(ctx->d_regmask, C * 8);
+    DMALLOC(ctx->d_E, N * 16 * 8); DMALLOC(ctx->d_f, N * 4 * 8); DMALLOC(ctx->d_b, N * 4 * 8);
+    DMALLOC(ctx->d_scale, N * 8); DMALLOC(ctx->d_label, N);
+    DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, (size_t) ctx->V * 8);
+    DMALLOC(ctx->d_flags, 4);
+    ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
+    DMALLOC(ctx->d_params, ctx->params_bytes);
+    if (hipHostMalloc((void**) &ctx->h_params, ctx->params_bytes) != hipSuccess ||
+        hipHostMalloc((void**) &ctx->h_flags, 4) != hipSuccess) {
+        hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed");
+    }
+    hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
+    hipMemset(ctx->d_flags, 0, 4);
+    hipMemset(ctx->d_label, 0xff, N ? N : 1);
+    if (N > 0 && C > 0) {
+        dim3 grid((unsigned) ((maxT + 255) / 256), (unsigned) C);
+        hipLaunchKernelGGL(k_setup, grid, dim3(256), 0, 0, ctx->d_off, d_cov, d_mapq, d_clip, d_annot, d_cs, d_ce, d_cl,
+                           w->window_len, w->mean_read_len, w->adjust_contig_ends, w->min_read_frac,
+                           w->max_high_mapq_ratio, w->min_high_mapq_ratio, w->min_highly_clipped_ratio, n_regions,
+                           ctx->d_rec, ctx->d_beta, ctx->d_flags);
+        hipLaunchKernelGGL(k_regmask, dim3((unsigned) C), dim3(256), 0, 0, ctx->d_off, ctx->d_rec, ctx->d_regmask);
+    }
+    hipError_t e = hipDeviceSynchronize();
+    hipFree(d_cov); hipFree(d_mapq); hipFree(d_clip); hipFree(d_annot); hipFree(d_cs); hipFree(d_ce); hipFree(d_cl);
+    if (e != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("setup: ") + hipGetErrorString(e)); }
+    unsigned fl = 0;
+    hipMemcpy(&fl, ctx->d_flags, 4, hipMemcpyDeviceToHost);
+    if (fl & HF_FLAG_REGION) { hf_destroy(ctx); return set_err(HF_E_REGION, "a window's region index is >= n_regions"); }
+    *out = ctx;
+    return HF_OK;
+}
+
+void hf_destroy(hf_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipFree(ctx->d_off); hipFree(ctx->d_rec); hipFree(ctx->d_beta); hipFree(ctx->d_regmask); hipFree(ctx->d_E);
+    hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); hipFree(ctx->d_chunk_stats);
+    hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
+    if (ctx->h_params) hipHostFree(ctx->h_params);
+    if (ctx->h_flags) hipHostFree(ctx->h_flags);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+// pack one iteration's model: conditional transition tables (hmm_utils.c:2278-2292) and the
+// distinct alpha values of each column
+static int pack_params(hf_ctx* ctx, const hf_params* p) {
+    if (p->n_regions != ctx->R) return set_err(HF_E_ARG, "hf_estep: n_regions differs from hf_create");
+    for (int s = 0; s < 4; s++)
+        if (p->ncomp[s] < 1 || p->ncomp[s] > ctx->K) return set_err(HF_E_ARG, "hf_estep: ncomp out of range");
+    if (p->ncomp[1] != 1 || p->ncomp[2] != 1 || p->ncomp[0] != 1)
+        return set_err(HF_E_ARG, "hf_estep: Err/Dup/Hap must have one component (hmm_flagger.c:180-182)");
+    DevParams* h = ctx->h_params;
+    h->model_type = p->model_type; h->n_regions = p->n_regions;
+    for (int s = 0; s < 4; s++) h->ncomp[s] = p->ncomp[s];
+    for (int pre = 0; pre < 4; pre++)
+        for (int s = 0; s < 4; s++) h->alpha[pre * 4 + s] = p->alpha[pre][s];
+    for (int s = 0; s < 4; s++) {
+        int nu = 0;
+        for (int pre = 0; pre < 4; pre++) {
+            const double a = p->alpha[pre][s];
+            int u = -1;
+            for (int k = 0; k < nu; k++) if (h->ualpha[s][k] == a) { u = k; break; }
+            if (u < 0) { u = nu; h->ualpha[s][nu++] = a; }
+            h->umap[pre * 4 + s] = u;
+        }
+        for (int k = nu; k < 4; k++) h->ualpha[s][k] = 0.0;
+        h->nuniq[s] = nu;
+    }
+    const double maxq = ctx->meta.max_high_mapq_ratio; (void) maxq;
+    for (int r = 0; r < ctx->R; r++) {
+        DevRegion* g = &h->reg[r];
+        std::memcpy(g->trans, p->trans + (size_t) r * 25, sizeof(double) * 25);
+        g->lambda = p->lambda ? p->lambda[r] : 1.0;
+        g->trunc_point = p->trunc_point ? p->trunc_point[r] : 0.0;
+        std::memcpy(g->mean, p->mean + (size_t) r * 4 * HF_MAXCOMP, sizeof(g->mean));
+        std::memcpy(g->var, p->var + (size_t) r * 4 * HF_MAXCOMP, sizeof(g->var));
+        std::memcpy(g->weight, p->weight + (size_t) r * 4 * HF_MAXCOMP, sizeof(g->weight));
+        for (int vm = 0; vm < 8; vm++) {
+            bool valid[5] = { true, (vm & 1) != 0, true, (vm & 2) != 0, (vm & 4) != 0 };
+            for (int pre = 0; pre < 4; pre++) {
+                double tot = 0.0;
+                for (int s = 0; s < 5; s++) if (valid[s]) tot += g->trans[pre][s];
+                for (int s = 0; s < 4; s++) g->tcond[vm][pre * 4 + s] = valid[s] ? g->trans[pre][s] / tot : 0.0;
+            }
+        }
+    }
+    return 0;
+}
+
+
+int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
+    if (!ctx || !p || (mode != HF_MODE_FULL && mode != HF_MODE_FORWARD_ONLY)) return set_err(HF_E_ARG, "hf_estep: bad argument");
+    hipStream_t st = (hipStream_t) stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = pack_params(ctx, p);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ctx->ev0, st));
+    HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(ctx->d_chunk_stats, 0, (size_t) ctx->C * ctx->V * 8 + (ctx->C ? 0 : 8), st));
+    HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
+    if (ctx->N > 0 && ctx->C > 0) {
+        hipLaunchKernelGGL(k_emit, dim3((unsigned) ((ctx->N + 255) / 256)), dim3(256), 0, st, ctx->N, ctx->d_rec,
+                           ctx->d_beta, ctx->d_params, ctx->d_E, ctx->d_flags);
+        hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_rec, ctx->d_E,
+                           ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_chunk_stats, ctx->V, ctx->d_flags);
+        if (mode == HF_MODE_FULL) {
+            hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_rec, ctx->d_E,
+                               ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
+            const int kc = p->ncomp[3];
+            if (kc <= 4) launch_stats<4>(ctx, st);
+            else if (kc <= 8) launch_stats<8>(ctx, st);
+            else launch_stats<16>(ctx, st);
+        }
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev1, st));
+    ctx->ev_valid = true;
+    ctx->have_full = (mode == HF_MODE_FULL);
+    return HF_OK;
+}
+
+int32_t hf_n_chunks(const hf_ctx* ctx) { return ctx ? ctx->C : 0; }
+int64_t hf_n_windows(const hf_ctx* ctx) { return ctx ? ctx->N : 0; }
+int64_t hf_chunk_stats_len(const hf_ctx* ctx) { return ctx ? ctx->V : 0; }
+double* hf_chunk_stats_dev(hf_ctx* ctx) { return ctx ? ctx->d_chunk_stats : nullptr; }
+int8_t* hf_labels_dev(hf_ctx* ctx) { return ctx ? ctx->d_label : nullptr; }
+
+int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
+    if (!ctx || !dst_dev) return set_err(HF_E_ARG, "hf_copy_chunk_stats: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(dst_dev, ctx->d_chunk_stats, (size_t) ctx->C * ctx->V * 8, hipMemcpyDeviceToDevice,
+                          (hipStream_t) stream));
+    return HF_OK;
+}
+
+int hf_reduce_chunks(hf_ctx* ctx, const double* chunk_stats_dev, int64_t n_chunks, double* out_dev, void* stream) {
+    if (!ctx || !chunk_stats_dev || !out_dev || n_chunks < 0) return set_err(HF_E_ARG, "hf_reduce_chunks: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned) ((ctx->V + 127) / 128)), dim3(128), 0, (hipStream_t) stream,
+                       chunk_stats_dev, n_chunks, ctx->V, out_dev);
+    HIPCHK(hipGetLastError());
+    return HF_OK;
+}
+
+static int flags_to_code(unsigned fl) {
+    if (fl & HF_FLAG_REGION) return set_err(HF_E_REGION, "a window's region index is >= n_regions");
+    if (fl & HF_FLAG_NAN) return set_err(HF_E_NAN, "[Error] prob is NAN");
+    if (fl & HF_FLAG_SCALE) return set_err(HF_E_SCALE, "scale is very low!");
+    return HF_OK;
+}
+
+int hf_check(hf_ctx* ctx, void* stream) {
+    if (!ctx) return set_err(HF_E_ARG, "hf_check: bad argument");
+    hipStream_t st = (hipStream_t) stream;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return flags_to_code(*ctx->h_flags);
+}
+
+int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
+    if (!ctx || !stats_host) return set_err(HF_E_ARG, "hf_finish: bad argument");
+    hipStream_t st = (hipStream_t) stream;
+    int rc = hf_reduce_chunks(ctx, ctx->d_chunk_stats, ctx->C, ctx->d_total, stream);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ctx->ev1, st));
+    HIPCHK(hipMemcpyAsync(stats_host, ctx->d_total, (size_t) ctx->V * 8, hipMemcpyDeviceToHost, st));
+    return hf_check(ctx, stream);
+}
+
+int hf_get_labels(hf_ctx* ctx, int8_t* labels_host) {
+    if (!ctx || !labels_host) return set_err(HF_E_ARG, "hf_get_labels: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpy(labels_host, ctx->d_label, (size_t) ctx->N, hipMemcpyDeviceToHost));
+    return HF_OK;
+}
+
+int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_host, double* b_host, double* scales_host) {
+    if (!ctx || first < 0 || n < 0 || first + n > ctx->N) return set_err(HF_E_ARG, "hf_get_forward_backward: bad range");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (f_host) HIPCHK(hipMemcpy(f_host, ctx->d_f + first * 4, (size_t) n * 32, hipMemcpyDeviceToHost));
+    if (b_host) HIPCHK(hipMemcpy(b_host, ctx->d_b + first * 4, (size_t) n * 32, hipMemcpyDeviceToHost));
+    if (scales_host) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
+    return HF_OK;
+}
+
+int hf_get_posterior(hf_ctx* ctx, int64_t first, int64_t n, double* post_host) {
+    if (!ctx || !post_host) return set_err(HF_E_ARG, "hf_get_posterior: bad argument");
+    std::vector<double> f((size_t) n * 4), b((size_t) n * 4), sc((size_t) n);
+    int rc = hf_get_forward_backward(ctx, first, n, f.data(), b.data(), sc.data());
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; i++) { // hmm.c:671-685
+        double total = 0.0;
+        for (int s = 0; s < 4; s++) { post_host[i * 4 + s] = f[i * 4 + s] * b[i * 4 + s] * sc[i]; total += post_host[i * 4 + s]; }
+        for (int s = 0; s < 4; s++) post_host[i * 4 + s] /= total;
+    }
+    return HF_OK;
+}
+
+int hf_last_kernel_ms(hf_ctx* ctx, float* ms) {
+    if (!ctx || !ms || !ctx->ev_valid) return set_err(HF_E_ARG, "hf_last_kernel_ms: nothing timed yet");
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return HF_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,299 @@
+"""Host-side mirror of the reference's HMM/EM interface for the hot path, on top of the C ABI.
+
+Names and call order follow mobinasri/flagger (programs/submodules/hmm/hmm.h:79-113 and
+programs/src/hmm_flagger.c:285-488):
+
+    model = createModel(...)                      # hmm_flagger.c:164-237
+    emList = EMList(store, model, ...)            # the list of per-chunk EM objects, hmm_flagger.c:320-330
+    EM_runOneIterationForList(emList, model)      # hmm.c:739   (HIP kernels)
+    converged = HMM_estimateParameters(model, tol)  # hmm.c:120
+    HMM_resetEstimators(model)                    # hmm.c:129
+
+One `EMList` is one GPU context holding every chunk of this process; with a process group the
+per-chunk statistics of all ranks are all-gathered and summed in global chunk order, so the
+result does not depend on the number of GPUs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+from .synth import WindowStore
+
+MODEL_TRUNC_EXP_GAUSSIAN = N.HF_MODEL_TRUNC_EXP_GAUSSIAN
+MODEL_GAUSSIAN = N.HF_MODEL_GAUSSIAN
+STATE_NAMES = ("Err", "Dup", "Hap", "Col")
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class HMM:
+    """The model (HMM struct, hmm.h:14-25) + the pending sufficient statistics of the last E-step
+    (the reference keeps them inside the model's estimator objects)."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._L = N.lib()
+        self.estimators: Optional[np.ndarray] = None   # reduced statistics vector of the last pass
+        self.loglikelihood = 0.0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.hfm_destroy(self._h)
+            self._h = None
+
+    @property
+    def numberOfRegions(self) -> int:
+        return self._L.hfm_n_regions(self._h)
+
+    @property
+    def maxNumberOfComps(self) -> int:
+        return self._L.hfm_max_comps(self._h)
+
+    @property
+    def modelType(self) -> int:
+        return self._L.hfm_model_type(self._h)
+
+    def params(self) -> N.hf_params:
+        p = N.hf_params()
+        self._L.hfm_params(self._h, C.byref(p))
+        return p
+
+    def param_vector(self) -> np.ndarray:
+        v = np.empty(self._L.hfm_param_len(self._h), dtype=np.float64)
+        self._L.hfm_get_param_vector(self._h, _dptr(v))
+        return v
+
+    def set_param_vector(self, v: np.ndarray) -> None:
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        assert v.size == self._L.hfm_param_len(self._h)
+        self._L.hfm_set_param_vector(self._h, _dptr(v))
+
+    def copy(self) -> "HMM":
+        m = HMM(self._L.hfm_copy(self._h))
+        m.loglikelihood = self.loglikelihood
+        return m
+
+    def unpack(self) -> dict:
+        """Parameter arrays by name (tests / reporting)."""
+        R, K = self.numberOfRegions, N.HF_MAXCOMP
+        v = self.param_vector().reshape(R, -1)
+        out = {"trans": v[:, :25].reshape(R, 5, 5).copy(), "lambda": v[:, 25].copy(), "trunc_point": v[:, 26].copy()}
+        o = 27
+        for name in ("mean", "var", "weight"):
+            out[name] = v[:, o:o + 4 * K].reshape(R, 4, K).copy()
+            o += 4 * K
+        return out
+
+    def writeTransitionTsv(self, path: str) -> None:
+        if self._L.hfm_write_transition_tsv(self._h, path.encode()) != 0:
+            raise OSError(f"cannot write {path}")
+
+    def writeEmissionTsv(self, path: str) -> None:
+        if self._L.hfm_write_emission_tsv(self._h, path.encode()) != 0:
+            raise OSError(f"cannot write {path}")
+
+
+def getAlphaMatrix(alphaTsvPath: Optional[str]) -> np.ndarray:
+    """hmm_flagger.c:491-515 (None => zeros)."""
+    a = np.zeros((4, 4))
+    if alphaTsvPath is not None:
+        rc = N.lib().hfm_read_alpha_tsv(alphaTsvPath.encode(), _dptr(a))
+        if rc == -2:
+            raise ValueError(f"There is at least one alpha value in '{alphaTsvPath}' not between 0 and 1.")
+        if rc != 0:
+            raise OSError(f"cannot read {alphaTsvPath}")
+    return a
+
+
+def getBestNumberOfCollapsedComps(store: WindowStore) -> int:
+    """hmm_flagger.c:105-111 with the [2,10] clamp of :1012-1013."""
+    cov = np.ascontiguousarray(store.cov, dtype=np.uint16)
+    rc = np.asarray(store.region_coverages, dtype=np.int32)
+    k = N.lib().hfm_best_collapsed_comps(cov.ctypes.data_as(C.POINTER(C.c_uint16)), cov.size,
+                                         rc.ctypes.data_as(C.POINTER(C.c_int32)), rc.size)
+    if k < 0:
+        raise ValueError("a region coverage of 0 in the header")
+    return k
+
+
+def createModel(modelType: int, numberOfCollapsedComps: int, store: WindowStore, alphaMatrix: np.ndarray,
+                maxHighMapqRatio: float = 0.25, minHighMapqRatio: float = 0.75) -> HMM:
+    """hmm_flagger.c:164-237 (initialRandomDev = 0)."""
+    rc = np.asarray(store.region_coverages, dtype=np.int32)
+    a = np.ascontiguousarray(alphaMatrix, dtype=np.float64)
+    h = N.lib().hfm_create(modelType, numberOfCollapsedComps, rc.ctypes.data_as(C.POINTER(C.c_int32)), rc.size,
+                           int(store.start_only), store.avg_alignment_len, store.window_len, _dptr(a),
+                           maxHighMapqRatio, minHighMapqRatio)
+    if not h:
+        raise ValueError("createModel: bad arguments")
+    return HMM(h)
+
+
+class EMList:
+    """All per-chunk EM objects of this process (stList<EM*> in the reference) as ONE device context:
+    the windows are uploaded once and stay resident in HBM (hf_create)."""
+
+    def __init__(self, store: WindowStore, model: HMM, adjustContigEnds: bool = True,
+                 minReadFractionAtEnds: float = 0.95, device: int = 0, algo: int = N.HF_ALGO_SCAN,
+                 stream: int = 0):
+        L = N.lib()
+        self._L = L
+        self.store = store
+        self.stream = C.c_void_p(stream)
+        self._keep = dict(
+            off=np.ascontiguousarray(store.chunk_off, np.int64), cov=np.ascontiguousarray(store.cov, np.uint16),
+            mapq=np.ascontiguousarray(store.mapq, np.uint16), clip=np.ascontiguousarray(store.clip, np.uint16),
+            annot=np.ascontiguousarray(store.annot, np.uint64), s=np.ascontiguousarray(store.chunk_s, np.int32),
+            e=np.ascontiguousarray(store.chunk_e, np.int32), cl=np.ascontiguousarray(store.chunk_ctg_len, np.int32))
+        k = self._keep
+        w = N.hf_windows()
+        w.n_windows, w.n_chunks = store.n_windows, store.n_chunks
+        w.chunk_off = k["off"].ctypes.data_as(C.POINTER(C.c_int64))
+        w.cov = k["cov"].ctypes.data_as(C.POINTER(C.c_uint16))
+        w.mapq = k["mapq"].ctypes.data_as(C.POINTER(C.c_uint16))
+        w.clip = k["clip"].ctypes.data_as(C.POINTER(C.c_uint16))
+        w.annot = k["annot"].ctypes.data_as(C.POINTER(C.c_uint64))
+        w.chunk_s = k["s"].ctypes.data_as(C.POINTER(C.c_int32))
+        w.chunk_e = k["e"].ctypes.data_as(C.POINTER(C.c_int32))
+        w.chunk_ctg_len = k["cl"].ctypes.data_as(C.POINTER(C.c_int32))
+        w.window_len, w.mean_read_len = store.window_len, store.avg_alignment_len
+        w.adjust_contig_ends, w.min_read_frac = int(adjustContigEnds), float(minReadFractionAtEnds)
+        w.max_high_mapq_ratio = L.hfm_max_high_mapq_ratio(model._h)
+        w.min_high_mapq_ratio = L.hfm_min_high_mapq_ratio(model._h)
+        w.min_highly_clipped_ratio = L.hfm_min_highly_clipped_ratio(model._h)
+        self.n_regions, self.max_comps = model.numberOfRegions, model.maxNumberOfComps
+        self.stats_len = N.stats_len(self.n_regions, self.max_comps)
+        h = C.c_void_p()
+        N.check(L.hf_create(C.byref(w), self.n_regions, self.max_comps, device, algo, C.byref(h)), "hf_create")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    # --- E-step pieces (used directly by the multi-GPU path in dist.py) ---
+    def launch(self, model: HMM, mode: int = N.HF_MODE_FULL) -> None:
+        p = model.params()
+        N.check(self._L.hf_estep(self._h, C.byref(p), mode, self.stream), "hf_estep")
+
+    def finish(self) -> np.ndarray:
+        out = np.empty(self.stats_len, dtype=np.float64)
+        N.check(self._L.hf_finish(self._h, _dptr(out), self.stream), "hf_finish")
+        return out
+
+    def check(self) -> None:
+        N.check(self._L.hf_check(self._h, self.stream), "hf_check")
+
+    def copy_chunk_stats(self, dst_dev_ptr: int) -> None:
+        N.check(self._L.hf_copy_chunk_stats(self._h, C.c_void_p(dst_dev_ptr), self.stream), "hf_copy_chunk_stats")
+
+    def reduce_chunks(self, src_dev_ptr: int, n_chunks: int, dst_dev_ptr: int) -> None:
+        N.check(self._L.hf_reduce_chunks(self._h, C.c_void_p(src_dev_ptr), n_chunks, C.c_void_p(dst_dev_ptr),
+                                         self.stream), "hf_reduce_chunks")
+
+    def kernel_ms(self) -> float:
+        ms = C.c_float()
+        N.check(self._L.hf_last_kernel_ms(self._h, C.byref(ms)), "hf_last_kernel_ms")
+        return float(ms.value)
+
+    # --- results ---
+    def labels(self) -> np.ndarray:
+        out = np.empty(self.store.n_windows, dtype=np.int8)
+        N.check(self._L.hf_get_labels(self._h, out.ctypes.data_as(C.POINTER(C.c_int8))), "hf_get_labels")
+        return out
+
+    def posterior(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
+        """EM_getPosterior for windows [first, first+n) — hmm.c:671-685."""
+        n = self.store.n_windows - first if n is None else n
+        out = np.empty((n, 4), dtype=np.float64)
+        N.check(self._L.hf_get_posterior(self._h, first, n, _dptr(out)), "hf_get_posterior")
+        return out
+
+    def forward_backward(self, first: int = 0, n: Optional[int] = None):
+        n = self.store.n_windows - first if n is None else n
+        f, b, sc = np.empty((n, 4)), np.empty((n, 4)), np.empty(n)
+        N.check(self._L.hf_get_forward_backward(self._h, first, n, _dptr(f), _dptr(b), _dptr(sc)),
+                "hf_get_forward_backward")
+        return f, b, sc
+
+
+def EM_runOneIterationForList(emList, model: HMM, threads: int = 0) -> None:
+    """hmm.c:739-763.  `threads` is accepted for signature compatibility; the result never depended
+    on it.  `emList` is an EMList or a dist.ShardedEMList."""
+    if hasattr(emList, "run_sharded"):
+        stats = emList.run_sharded(model, N.HF_MODE_FULL)
+    else:
+        emList.launch(model, N.HF_MODE_FULL)
+        stats = emList.finish()
+    model.estimators = stats
+    model.loglikelihood = float(stats[0])
+
+
+def EM_runForwardForList(emList, model: HMM, threads: int = 0) -> None:
+    """hmm.c:790-816 — forward only; sets model.loglikelihood."""
+    if hasattr(emList, "run_sharded"):
+        stats = emList.run_sharded(model, N.HF_MODE_FORWARD_ONLY)
+    else:
+        emList.launch(model, N.HF_MODE_FORWARD_ONLY)
+        stats = emList.finish()
+    model.loglikelihood = float(stats[0])
+
+
+def HMM_estimateParameters(model: HMM, convergenceTol: float) -> bool:
+    """hmm.c:120-127; consumes the statistics left by EM_runOneIterationForList."""
+    if model.estimators is None:
+        raise RuntimeError("HMM_estimateParameters: no statistics (run EM_runOneIterationForList first)")
+    st = np.ascontiguousarray(model.estimators, dtype=np.float64)
+    return bool(N.lib().hfm_estimate(model._h, _dptr(st), float(convergenceTol)))
+
+
+def HMM_resetEstimators(model: HMM) -> None:
+    """hmm.c:129-134."""
+    model.estimators = None
+
+
+def runHMMFlagger(emList, model: HMM, numberOfIterations: int = 100, convergenceTol: float = 0.001,
+                  outputDir: Optional[str] = None, writeParameterStatsPerIteration: bool = False,
+                  is_writer: bool = True) -> List[float]:
+    """EM outer loop of hmm_flagger.c:285-488 (no --accelerate here; see squarem.py).  Returns the
+    log-likelihood of every E-pass (the rows of loglikelihood.tsv)."""
+    lls: List[float] = []
+    llf = None
+    write = outputDir is not None and is_writer
+    if write:
+        llf = open(os.path.join(outputDir, "loglikelihood.tsv"), "w")
+        llf.write("#Iteration\tEffective_Iteration\tLoglikelihood\n")
+        model.writeTransitionTsv(os.path.join(outputDir, "transition_initial.tsv"))
+        model.writeEmissionTsv(os.path.join(outputDir, "emission_initial.tsv"))
+    it, converged = 1, False
+    while it <= numberOfIterations and not converged:
+        EM_runOneIterationForList(emList, model)
+        lls.append(model.loglikelihood)
+        if llf:
+            llf.write("%d\t%d\t%.4f\n" % (it - 1, it - 1, model.loglikelihood))
+        converged = HMM_estimateParameters(model, convergenceTol)
+        HMM_resetEstimators(model)
+        if write and writeParameterStatsPerIteration:
+            model.writeTransitionTsv(os.path.join(outputDir, f"transition_iteration_{it}.tsv"))
+            model.writeEmissionTsv(os.path.join(outputDir, f"emission_iteration_{it}.tsv"))
+        it += 1
+    EM_runOneIterationForList(emList, model)   # final inference, hmm_flagger.c:464
+    lls.append(model.loglikelihood)
+    if llf:
+        llf.write("%d\t%d\t%.4f\n" % (it - 1, it - 1, model.loglikelihood))
+        llf.close()
+        model.writeTransitionTsv(os.path.join(outputDir, "transition_final.tsv"))
+        model.writeEmissionTsv(os.path.join(outputDir, "emission_final.tsv"))
+    return lls

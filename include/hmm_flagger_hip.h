@@ -1,0 +1,141 @@
+/*
+ * hmm_flagger_hip.h — C ABI of the MI355X (gfx950) E-step of HMM-Flagger.
+ *
+ * This is the drop-in boundary.  The reference has no FFI; the seam is the C
+ * function pair a maintainer would re-point at this library (citations relative to
+ * mobinasri/flagger, programs/submodules/hmm/):
+ *
+ *   void EM_runOneIterationForList(stList *emList, HMM *model, int threads);  hmm.h:109, hmm.c:739
+ *   void EM_runForwardForList   (stList *emList, HMM *model, int threads);  hmm.h:113, hmm.c:790
+ *   double *EM_getPosterior(EM *em, int pos);                               hmm.h:101, hmm.c:671
+ *   int     EM_getMostProbableState(EM *em, int pos);                       hmm.h:103, hmm.c:687
+ *
+ * Plain pointers and sizes only.  Window arrays are uploaded once (hf_create); per iteration
+ * only the parameter block goes up and the sufficient statistics + labels come back.
+ * All functions return 0 on success or a negative HF_E_* code; where the reference calls
+ * exit(EXIT_FAILURE) (hmm.c:412-415, 521-524; hmm_utils.c:782-786) the code says which check
+ * fired and the caller maps it to the reference's message and exit status.
+ */
+#ifndef HMM_FLAGGER_HIP_H
+#define HMM_FLAGGER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HF_NSTATES 4      /* Err, Dup, Hap, Col — hmm_flagger.c:173 */
+#define HF_MAXCOMP 16     /* per-state mixture components (reference clamps K to 2..10) */
+#define HF_MAXREGIONS 64  /* 6 region bits — ptBlock.c:294-304 */
+
+enum { HF_MODEL_TRUNC_EXP_GAUSSIAN = 0, HF_MODEL_GAUSSIAN = 1 };       /* hmm_utils.h:43-48 */
+enum { HF_MODE_FULL = 0,          /* EM_runOneIterationForList */
+       HF_MODE_FORWARD_ONLY = 1   /* EM_runForwardForList */ };
+enum { HF_ALGO_SCAN = 0,          /* in-chunk parallel prefix scan (default) */
+       HF_ALGO_SEQ = 1            /* one wavefront per chunk, reference operation order */ };
+
+enum {
+    HF_OK = 0,
+    HF_E_ARG = -1,        /* bad argument */
+    HF_E_HIP = -2,        /* HIP runtime error (hf_last_error() has the text) */
+    HF_E_SCALE = -3,      /* "scale (= ...) is very low!"      hmm.c:412-415, 521-524 */
+    HF_E_NAN = -4,        /* "[Error] prob is NAN"             hmm_utils.c:782-786 */
+    HF_E_REGION = -5,     /* a window's region index >= n_regions */
+    HF_E_NOGPU = -6       /* no HIP device: there is no CPU fallback */
+};
+
+typedef struct hf_ctx hf_ctx;
+
+/* The windowed coverage track, in the reference's packed-record fields (chunk.c:669-697):
+ * one entry per window, chunks delimited by chunk_off; all arrays in HOST memory. */
+typedef struct hf_windows {
+    int64_t n_windows;
+    int32_t n_chunks;
+    const int64_t *chunk_off;        /* [n_chunks+1] first window of each chunk */
+    const uint16_t *cov;             /* CoverageInfo.coverage            ptBlock.h:79-92 */
+    const uint16_t *mapq;            /* CoverageInfo.coverage_high_mapq */
+    const uint16_t *clip;            /* CoverageInfo.coverage_high_clip */
+    const uint64_t *annot;           /* annotation_flag, region index in bits 58..63 */
+    const int32_t *chunk_s;          /* [n_chunks] Chunk.s (0-based)     chunk.h:16-23 */
+    const int32_t *chunk_e;          /* [n_chunks] Chunk.e (0-based, inclusive) */
+    const int32_t *chunk_ctg_len;    /* [n_chunks] Chunk.ctgLen */
+    int32_t window_len;              /* Chunk.windowLen */
+    int32_t mean_read_len;           /* header averageAlignmentLength    hmm_flagger.c:312 */
+    int32_t adjust_contig_ends;      /* !--disableAdjustContigEnds       hmm_flagger.c:624 */
+    double min_read_frac;            /* --minReadFractionAtEnds          hmm.c:305 */
+    double max_high_mapq_ratio;      /* TransitionRequirements           hmm_utils.c:1950-1958 */
+    double min_high_mapq_ratio;
+    double min_highly_clipped_ratio;
+} hf_windows;
+
+/* One iteration's model (HMM struct, hmm.h:14-25), HOST memory, read during hf_estep only. */
+typedef struct hf_params {
+    int32_t model_type;              /* HF_MODEL_* */
+    int32_t n_regions;
+    int32_t ncomp[HF_NSTATES];       /* components per state */
+    double alpha[4][4];              /* alpha[preState][state]           hmm.c:388 */
+    const double *trans;             /* [n_regions][5][5] row 4 = Start, col 4 = End */
+    const double *lambda;            /* [n_regions] Err trunc-exp rate   hmm_utils.h:393-397 */
+    const double *trunc_point;       /* [n_regions] */
+    const double *mean;              /* [n_regions][4][HF_MAXCOMP] */
+    const double *var;               /* [n_regions][4][HF_MAXCOMP] */
+    const double *weight;            /* [n_regions][4][HF_MAXCOMP] */
+} hf_params;
+
+/* Layout of one statistics vector (doubles):
+ *   [0]                                   log-likelihood (sum of log scale, hmm.c:428)
+ *   per region r, base = 1 + r*hf_region_stride(K):
+ *     base + ((s*3 + p)*2 + 0)*K + c      numeratorPerComp[c]   of state s, parameter p
+ *     base + ((s*3 + p)*2 + 1)*K + c      denominatorPerComp[c]
+ *         p = 0 mean (or trunc-exp lambda for Err), 1 var, 2 weight   hmm_utils.h:50-54,64-68
+ *     base + 24*K + pre*4 + s             TransitionCountData.countMatrix[pre][s]
+ * with K = max_comps given to hf_create. */
+static inline int64_t hf_region_stride(int max_comps) { return 24 * (int64_t) max_comps + 16; }
+static inline int64_t hf_stats_len(int n_regions, int max_comps) {
+    return 1 + (int64_t) n_regions * hf_region_stride(max_comps);
+}
+
+const char *hf_version(void);
+const char *hf_last_error(void);
+int hf_device_count(void);
+
+/* Upload the windows to `device` and build the device-resident window store. */
+int hf_create(const hf_windows *w, int n_regions, int max_comps, int device, int algo, hf_ctx **out);
+void hf_destroy(hf_ctx *ctx);
+
+/* Launch one E-step pass over every chunk of this context on `stream` (a hipStream_t, NULL =
+ * default stream); asynchronous.  Leaves one statistics vector PER CHUNK on the device. */
+int hf_estep(hf_ctx *ctx, const hf_params *p, int mode, void *stream);
+
+int32_t hf_n_chunks(const hf_ctx *ctx);
+int64_t hf_n_windows(const hf_ctx *ctx);
+int64_t hf_chunk_stats_len(const hf_ctx *ctx);        /* = hf_stats_len(n_regions, max_comps) */
+double *hf_chunk_stats_dev(hf_ctx *ctx);              /* device [n_chunks][hf_chunk_stats_len] */
+int8_t *hf_labels_dev(hf_ctx *ctx);                   /* device [n_windows] */
+/* device-to-device copy of the per-chunk vectors into a caller-owned device buffer (e.g. the
+ * send buffer of the multi-GPU all-gather); asynchronous on `stream`. */
+int hf_copy_chunk_stats(hf_ctx *ctx, double *dst_dev, void *stream);
+
+/* Sum `n_chunks` per-chunk vectors in list order (the reference's sequential reduction,
+ * hmm.c:759-763) into one vector; src/dst are DEVICE pointers; asynchronous on `stream`. */
+int hf_reduce_chunks(hf_ctx *ctx, const double *chunk_stats_dev, int64_t n_chunks, double *out_dev, void *stream);
+
+/* Single-GPU convenience: reduce this context's chunks, copy the vector to `stats_host`,
+ * wait for the stream and translate the device error flags (HF_E_SCALE / HF_E_NAN / ...). */
+int hf_finish(hf_ctx *ctx, double *stats_host, void *stream);
+/* Only wait + error flags (multi-GPU callers reduce the gathered vectors themselves). */
+int hf_check(hf_ctx *ctx, void *stream);
+
+/* Results of the last HF_MODE_FULL pass. */
+int hf_get_labels(hf_ctx *ctx, int8_t *labels_host);                                   /* hmm.c:730-736 */
+int hf_get_posterior(hf_ctx *ctx, int64_t first, int64_t n, double *post_host);        /* [n][4] hmm.c:671-685 */
+int hf_get_forward_backward(hf_ctx *ctx, int64_t first, int64_t n, double *f_host, double *b_host,
+                            double *scales_host);                                      /* EM.f/.b/.scales */
+/* kernel time of the last hf_estep + reduce in milliseconds (HIP events on the stream used) */
+int hf_last_kernel_ms(hf_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,66 @@
+/*
+ * hmm_flagger_model.h — C ABI of the host-side model object that sits on top of the E-step:
+ * initial parameters, the per-iteration parameter view handed to hf_estep(), and the M-step.
+ * These stay on the CPU in the reference's design too — they touch <= a few
+ * hundred scalars per iteration.
+ *
+ * Reference interfaces replaced (mobinasri/flagger, programs/):
+ *   createModel                          src/hmm_flagger.c:164-237
+ *   HMM_construct                        submodules/hmm/hmm.c:22-77
+ *   HMM_estimateParameters               submodules/hmm/hmm.c:120-127
+ *   HMM_resetEstimators                  submodules/hmm/hmm.c:129-134 (implicit: the statistics
+ *                                        vector of every pass starts from zero)
+ *   HMM_printTransitionMatrixInTsvFormat / HMM_printEmissionParametersInTsvFormat   hmm.c:137-239
+ *   getBestNumberOfCollapsedComps        src/hmm_flagger.c:105-111, 1012-1013
+ *   getAlphaMatrix                       src/hmm_flagger.c:491-515
+ */
+#ifndef HMM_FLAGGER_MODEL_H
+#define HMM_FLAGGER_MODEL_H
+
+#include <stdint.h>
+#include "hmm_flagger_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hfm_model hfm_model;
+
+/* alpha16: row-major alpha[preState][state]; NULL = all zero (preset arrays are `int`,
+ * src/hmm_flagger.c:21,36,50). Returns NULL on bad arguments. */
+hfm_model *hfm_create(int model_type, int n_collapsed, const int32_t *region_coverages, int n_regions,
+                      int start_only, int avg_alignment_len, int window_len, const double *alpha16,
+                      double max_high_mapq_ratio, double min_high_mapq_ratio);
+hfm_model *hfm_copy(const hfm_model *m);
+void hfm_destroy(hfm_model *m);
+
+int hfm_n_regions(const hfm_model *m);
+int hfm_max_comps(const hfm_model *m);                /* = K of hf_create / the stats layout */
+int hfm_model_type(const hfm_model *m);
+double hfm_max_high_mapq_ratio(const hfm_model *m);
+double hfm_min_high_mapq_ratio(const hfm_model *m);
+double hfm_min_highly_clipped_ratio(const hfm_model *m);
+
+/* Parameter view for hf_estep(); pointers stay valid until the model is changed or destroyed. */
+void hfm_params(const hfm_model *m, hf_params *out);
+
+/* M-step from one reduced statistics vector (layout: hmm_flagger_hip.h).  Stores stats[0] as the
+ * model log-likelihood.  Returns 1 if every parameter moved by less than `tol` (converged), else 0. */
+int hfm_estimate(hfm_model *m, const double *stats, double tol);
+double hfm_loglikelihood(const hfm_model *m);
+
+int hfm_write_transition_tsv(const hfm_model *m, const char *path);
+int hfm_write_emission_tsv(const hfm_model *m, const char *path);
+
+/* flat parameter vector (SQUAREM, tests): [R][ trans 25 | lambda | trunc | mean 4K | var 4K | weight 4K ] */
+int64_t hfm_param_len(const hfm_model *m);
+void hfm_get_param_vector(const hfm_model *m, double *out);
+void hfm_set_param_vector(hfm_model *m, const double *in);
+
+int hfm_best_collapsed_comps(const uint16_t *cov, int64_t n_windows, const int32_t *region_coverages, int n_regions);
+int hfm_read_alpha_tsv(const char *path, double *alpha16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,179 @@
+"""GPU parity: the HIP E-step (through the C ABI) against the oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): labels bit-exact; log-likelihood within 1e-6 relative (we hold
+1e-9); the fp64 sufficient statistics / forward / backward within 1e-9 relative — the only
+permitted difference is the last-ulp behaviour of exp()/log() on the device vs glibc.
+"""
+import numpy as np
+import pytest
+
+from flagger_amd import _native as N
+from flagger_amd import hmm, synth
+from oracle_py import Oracle
+
+pytestmark = pytest.mark.gpu
+
+LL_RTOL = 1e-9      # north_star asks for 1e-6
+STAT_RTOL = 1e-9
+
+
+def _check_pass(store, model_type, K, alpha, algo, adjust=True, frac=0.95, n_iter=2, max_mapq=0.25, min_mapq=0.75):
+    model = hmm.createModel(model_type, K, store, alpha, max_mapq, min_mapq)
+    em = hmm.EMList(store, model, adjust, frac, device=0, algo=algo)
+    orc = Oracle(store, model_type, K, alpha, max_mapq, min_mapq, adjust, frac, threads=8)
+    try:
+        assert np.array_equal(model.param_vector(), orc.param_vector())
+        for _ in range(n_iter):
+            hmm.EM_runOneIterationForList(em, model)
+            assert orc.run_iteration() == 0
+            ref = orc.stats_vector(model.maxNumberOfComps)
+            got = model.estimators
+            assert abs(got[0] - ref[0]) <= LL_RTOL * abs(ref[0]), (got[0], ref[0])
+            scale = np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+            assert np.all(np.abs(got - ref) <= STAT_RTOL * scale), np.max(np.abs(got - ref) / scale)
+            lab, olab = em.labels(), orc.labels()
+            assert np.array_equal(lab, olab), f"{np.count_nonzero(lab != olab)} label mismatches of {lab.size}"
+            f, b, sc = em.forward_backward()
+            of, ob, osc = orc.forward_backward()
+            assert np.allclose(sc, osc, rtol=1e-10, atol=0)
+            assert np.allclose(f, of, rtol=1e-9, atol=1e-300)
+            assert np.allclose(b, ob, rtol=1e-9, atol=1e-300)
+            c1 = hmm.HMM_estimateParameters(model, 1e-3)
+            hmm.HMM_resetEstimators(model)
+            c2 = orc.estimate_parameters(1e-3)
+            assert c1 == c2
+            assert np.allclose(model.param_vector(), orc.param_vector(), rtol=1e-8, atol=1e-300)
+            # continue from the ORACLE's parameters so both sides see identical inputs next pass
+            model.set_param_vector(orc.param_vector())
+    finally:
+        em.close()
+        orc.close()
+
+
+ALGOS = [pytest.param(N.HF_ALGO_SEQ, id="seq"), pytest.param(N.HF_ALGO_SCAN, id="scan")]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_cfg1_fixed_parameter_decode(algo):
+    """BASELINE configs[1]: 1 contig 10 Mb, 4 kb windows, fixed parameters (--iterations 0)."""
+    store = synth.config(1)
+    assert store.n_windows == 2500 and store.n_chunks == 1
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, hmm.getBestNumberOfCollapsedComps(store), synth.HIFI_ALPHA,
+                algo, n_iter=1)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("model_type", [hmm.MODEL_TRUNC_EXP_GAUSSIAN, hmm.MODEL_GAUSSIAN])
+@pytest.mark.parametrize("alpha_name", ["zero", "hifi", "ont"])
+def test_small_diploid(algo, model_type, alpha_name):
+    alpha = {"zero": np.zeros((4, 4)), "hifi": synth.HIFI_ALPHA, "ont": synth.ONT_R10_ALPHA}[alpha_name]
+    store = synth.config(2, scale=0.01)
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    _check_pass(store, model_type, K, alpha, algo)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("K", [2, 5, 10, 16])
+def test_collapsed_components(algo, K):
+    store = synth.config(2, scale=0.004)
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, synth.HIFI_ALPHA, algo)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_multi_region_ont(algo):
+    """configs[4] shape: 7 bias regions, 8 kb windows, region changes inside chunks."""
+    store = synth.config(4, scale=0.01)
+    assert store.n_regions == 7 and len(np.unique(store.regions())) > 3
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, hmm.getBestNumberOfCollapsedComps(store), synth.ONT_R10_ALPHA,
+                algo, frac=0.8)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("adjust,avg_len", [(False, 15000), (True, 0), (True, 15000), (True, 200000)])
+def test_contig_end_adjustment(algo, adjust, avg_len):
+    """beta: disabled (-e), missing #avg_alignment_len (=> 0.25 everywhere, Q4), normal, reads longer than chunks."""
+    store = synth.synthesize([700_000, 90_000, 4_100], 1000, 200_000, [20], seed=11, avg_alignment_len=avg_len)
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, synth.HIFI_ALPHA, algo, adjust=adjust)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_ragged_and_tiny_chunks(algo):
+    """chunks of 1, 2, 3, 63, 64, 65, 129 ... windows (tile edges of the kernels) in one list."""
+    W = 100
+    lens = [1 * W, 2 * W, 3 * W, 63 * W, 64 * W, 65 * W, 129 * W, 1000 * W + 37, 5 * W - 1, 2049 * W]
+    store = synth.synthesize(lens, W, 10_000_000, [20, 25], seed=5, region_run_bases=(2_000, 30_000))
+    assert sorted(np.diff(store.chunk_off))[:3] == [1, 2, 3]
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 3, synth.HIFI_ALPHA, algo)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_extreme_coverage_values(algo):
+    """coverage 0 and 250 (clip value), Dup/Col validity masks on and off, clip-driven End column."""
+    rng = np.random.default_rng(3)
+    store = synth.synthesize([2_000_000], 1000, 500_000, [20], seed=9)
+    n = store.n_windows
+    store.cov[rng.integers(0, n, 200)] = 250
+    store.cov[rng.integers(0, n, 200)] = 0
+    store.mapq[:] = (store.cov * rng.uniform(0, 1, n)).astype(np.uint16)
+    store.clip[:] = (store.cov * rng.uniform(0, 1.3, n)).astype(np.uint16)
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 6, synth.HIFI_ALPHA, algo)
+    _check_pass(store, hmm.MODEL_GAUSSIAN, 6, np.zeros((4, 4)), algo, max_mapq=0.5, min_mapq=0.5)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_forward_only_mode(algo):
+    """EM_runForwardForList (SQUAREM line search): log-likelihood only."""
+    store = synth.config(2, scale=0.004)
+    K = 4
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+    em = hmm.EMList(store, model, algo=algo)
+    orc = Oracle(store, 0, K, synth.HIFI_ALPHA)
+    hmm.EM_runForwardForList(em, model)
+    assert orc.run_iteration(forward_only=True) == 0
+    ref = orc.m.contents.loglikelihood
+    assert abs(model.loglikelihood - ref) <= LL_RTOL * abs(ref)
+    em.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_full_em_against_oracle(algo, tmp_path):
+    """Whole EM run (runHMMFlagger): every row of loglikelihood.tsv within 1e-6 relative, final labels
+    identical, final parameters equal to print precision."""
+    store = synth.config(2, scale=0.01)
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+    em = hmm.EMList(store, model, algo=algo)
+    out = tmp_path / "gpu"
+    out.mkdir()
+    lls = hmm.runHMMFlagger(em, model, 12, 1e-3, str(out))
+    orc = Oracle(store, 0, K, synth.HIFI_ALPHA)
+    oout = tmp_path / "oracle"
+    oout.mkdir()
+    olls = orc.run_em(12, 1e-3, str(oout))
+    assert len(lls) == len(olls)
+    assert np.allclose(lls, olls, rtol=1e-6, atol=0)
+    assert np.array_equal(em.labels(), orc.labels())
+    assert np.allclose(model.param_vector(), orc.param_vector(), rtol=1e-6, atol=1e-300)
+    for name in ("loglikelihood.tsv", "emission_final.tsv", "transition_final.tsv", "emission_initial.tsv"):
+        assert (out / name).read_text() == (oout / name).read_text(), name
+    em.close()
+    orc.close()
+
+
+def test_scale_underflow_is_reported():
+    """The reference exits with 'scale ... is very low!' (hmm.c:412-415); the ABI returns HF_E_SCALE."""
+    store = synth.synthesize([400_000], 1000, 1_000_000, [20], seed=2)
+    store.cov[100:110] = 250          # far outside every component of a 1-comp model with tiny variance
+    store.mapq[:] = 0                 # Col invalid everywhere (ratio 0 < 0.75) => only floors remain
+    model = hmm.createModel(hmm.MODEL_GAUSSIAN, 1, store, np.zeros((4, 4)))
+    em = hmm.EMList(store, model)
+    orc = Oracle(store, 1, 1, np.zeros((4, 4)))
+    ost = orc.run_iteration()
+    if ost == 0:
+        pytest.skip("input did not underflow in the oracle")
+    with pytest.raises(N.HFError) as ei:
+        hmm.EM_runOneIterationForList(em, model)
+    assert ei.value.code == N.HF_E_SCALE and ost == -1
+    em.close()
+    orc.close()
