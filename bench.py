@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py — windows/s through EM + decode on BASELINE.json's workload, with the roofline of the
+dominant kernel and a CPU baseline beside it.
+
+One "step" = one EM pass over the whole synthetic diploid track: E-step on the GPU (emission,
+forward, backward, posterior decode, sufficient statistics, ordered reduction), the statistics
+vector to the host, the M-step, and the next parameter block back up — i.e. exactly what
+runHMMFlagger repeats (hmm_flagger.c:337-445).  The windows are resident in HBM before the timed
+region.  With --gpus N (one process per GPU under torch.distributed.run) the chunk list is sharded
+across ranks and the per-chunk statistics are all-gathered every step (flagger_amd/dist.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALGO_BYTES_PER_WINDOW = 17.0   # 16-byte packed window record (chunk.c:669-697) + 1 label byte, SURVEY §8d
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(store_full, K, alpha, cores):
+    """Oracle (CPU port of the reference path) on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle_py import Oracle
+    from flagger_amd import synth
+    sample = synth.config(2, scale=0.25)   # same generator and seed, contigs shrunk 4x => ~380 k windows
+    orc = Oracle(sample, 0, K, alpha, threads=cores)
+    passes = 3
+    orc.run_iteration()                    # warm-up (allocates f/b)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        assert orc.run_iteration() == 0
+        orc.estimate_parameters(1e-3)
+    dt = time.perf_counter() - t0
+    n = sample.n_windows
+    orc.close()
+    return {"value": n * passes / dt, "unit": "windows/s", "cores": cores, "kind": "port",
+            "sample": f"{passes} EM passes over configs[2] generated at scale 0.25 ({n} windows, "
+                      f"{sample.n_chunks} chunks), oracle/ C port with {cores} threads over chunks"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink contig lengths (testing only; 1.0 = BASELINE workload)")
+    ap.add_argument("--algo", choices=["scan", "seq"], default="scan")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from flagger_amd import _native as N
+    from flagger_amd import dist as fdist
+    from flagger_amd import hmm, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node <gpus>"
+
+    # ---- workload: BASELINE.json configs[2] (= configs[3] when sharded over 8 GPUs) ----
+    store = synth.config(2, scale=args.scale)
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    alpha = synth.HIFI_ALPHA
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
+    algo = N.HF_ALGO_SCAN if args.algo == "scan" else N.HF_ALGO_SEQ
+    torch.cuda.set_device(local_rank)
+    sharded = fdist.make_sharded_hip(store, model, rank, world, local_rank, True, 0.95, algo)
+    em = sharded.local.em
+    em.set_profiling(True)
+    n_windows = store.n_windows
+
+    target = em if world == 1 else sharded   # single GPU: no exchange buffers in the path
+
+    def step():
+        hmm.EM_runOneIterationForList(target, model)          # E-step + decode (+ all-gather) + ordered reduce
+        hmm.HMM_estimateParameters(model, 1e-3)               # M-step on the host
+        hmm.HMM_resetEstimators(model)
+
+    def barrier():
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ksum = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in em.kernel_times().items():
+            ksum[k] = ksum.get(k, 0.0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = float(t.item())
+    ll = model.loglikelihood
+
+    if rank == 0:
+        kavg = {k: v / args.steps for k, v in ksum.items()}
+        dom = max(kavg, key=kavg.get)
+        local_windows = sharded.local_store.n_windows
+        achieved = ALGO_BYTES_PER_WINDOW * local_windows / (kavg[dom] * 1e-3) / 1e9 if kavg[dom] > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "coverage windows/sec through EM+decode; achieved HBM GB/s vs roofline",
+            "value": n_windows * args.steps / dt, "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: synthetic 2x3.03 Gb diploid HiFi-like coverage, "
+                                   "4 kb windows, 20 Mb chunks, trunc_exp_gaussian, HiFi v1.1.0 alpha, full EM step "
+                                   "(E-step+decode on GPU, M-step on host)" + ("" if args.scale == 1.0 else f" [scale {args.scale}]"),
+                       "n_windows": n_windows, "n_chunks": store.n_chunks, "collapsed_comps": K,
+                       "algo": args.algo, "parallelism": f"chunks sharded over {world} GPU(s), all-gather of per-chunk statistics"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
+                         "kernel_ms": kavg, "algorithmic_bytes_per_window": ALGO_BYTES_PER_WINDOW,
+                         "windows_per_launch": local_windows},
+            "loglikelihood_after_last_step": ll,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(store, K, alpha, os.cpu_count() or 1)
+        print(json.dumps(out))
+    if world > 1:
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,7 @@ struct hf_ctx {
     DevParams* d_params = nullptr; DevParams* h_params = nullptr; size_t params_bytes = 0;
     unsigned* h_flags = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
+    bool profiling = false; hipEvent_t kev[HF_NKERNELS + 2] = {}; bool kran[HF_NKERNELS] = {};  // kev[0..4] stage marks, kev[5..6] reduce
     bool have_full = false;
 };
 
@@ -577,6 +578,7 @@ void hf_destroy(hf_ctx* ctx) {
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < HF_NKERNELS + 2; i++) if (ctx->kev[i]) hipEventDestroy(ctx->kev[i]);
     delete ctx;
 }
 
@@ -637,18 +639,25 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
     HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(ctx->d_chunk_stats, 0, (size_t) ctx->C * ctx->V * 8 + (ctx->C ? 0 : 8), st));
     HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
+    for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
+    auto mark = [&](int stage) { if (ctx->profiling) hipEventRecord(ctx->kev[stage], st); };
     if (ctx->N > 0 && ctx->C > 0) {
+        mark(0);
         hipLaunchKernelGGL(k_emit, dim3((unsigned) ((ctx->N + 255) / 256)), dim3(256), 0, st, ctx->N, ctx->d_rec,
                            ctx->d_beta, ctx->d_params, ctx->d_E, ctx->d_flags);
+        mark(1); ctx->kran[0] = true;
         hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_rec, ctx->d_E,
                            ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_chunk_stats, ctx->V, ctx->d_flags);
+        mark(2); ctx->kran[1] = true;   // end of forward (= start of backward)
         if (mode == HF_MODE_FULL) {
             hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_rec, ctx->d_E,
                                ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
+            mark(3); ctx->kran[2] = true;
             const int kc = p->ncomp[3];
             if (kc <= 4) launch_stats<4>(ctx, st);
             else if (kc <= 8) launch_stats<8>(ctx, st);
             else launch_stats<16>(ctx, st);
+            mark(4); ctx->kran[3] = true;
         }
     }
     HIPCHK(hipGetLastError());
@@ -675,8 +684,11 @@ int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
 int hf_reduce_chunks(hf_ctx* ctx, const double* chunk_stats_dev, int64_t n_chunks, double* out_dev, void* stream) {
     if (!ctx || !chunk_stats_dev || !out_dev || n_chunks < 0) return set_err(HF_E_ARG, "hf_reduce_chunks: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
+    const bool own = ctx->profiling && chunk_stats_dev == ctx->d_chunk_stats;
+    if (own) hipEventRecord(ctx->kev[5], (hipStream_t) stream);
     hipLaunchKernelGGL(k_reduce, dim3((unsigned) ((ctx->V + 127) / 128)), dim3(128), 0, (hipStream_t) stream,
                        chunk_stats_dev, n_chunks, ctx->V, out_dev);
+    if (own) { hipEventRecord(ctx->kev[6], (hipStream_t) stream); ctx->kran[4] = true; }
     HIPCHK(hipGetLastError());
     return HF_OK;
 }
@@ -734,6 +746,28 @@ int hf_get_posterior(hf_ctx* ctx, int64_t first, int64_t n, double* post_host) {
         for (int s = 0; s < 4; s++) post_host[i * 4 + s] /= total;
     }
     return HF_OK;
+}
+
+int hf_set_profiling(hf_ctx* ctx, int on) {
+    if (!ctx) return set_err(HF_E_ARG, "hf_set_profiling: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (on && !ctx->kev[0]) for (int i = 0; i < HF_NKERNELS + 2; i++) HIPCHK(hipEventCreate(&ctx->kev[i]));
+    ctx->profiling = on != 0;
+    return HF_OK;
+}
+
+int hf_kernel_times(hf_ctx* ctx, float ms[HF_NKERNELS]) {
+    if (!ctx || !ms || !ctx->profiling) return set_err(HF_E_ARG, "hf_kernel_times: profiling is off");
+    for (int i = 0; i < HF_NKERNELS; i++) ms[i] = 0.f;
+    for (int i = 0; i < 4; i++)   // emit, forward, backward, stats: kev[i] -> kev[i+1]
+        if (ctx->kran[i]) HIPCHK(hipEventElapsedTime(&ms[i], ctx->kev[i], ctx->kev[i + 1]));
+    if (ctx->kran[4]) HIPCHK(hipEventElapsedTime(&ms[4], ctx->kev[5], ctx->kev[6]));
+    return HF_OK;
+}
+
+const char* hf_kernel_name(int stage) {
+    static const char* names[HF_NKERNELS] = {"emit", "forward", "backward", "stats", "reduce"};
+    return stage >= 0 && stage < HF_NKERNELS ? names[stage] : "?";
 }
 
 int hf_last_kernel_ms(hf_ctx* ctx, float* ms) {

@@ -1,0 +1,139 @@
+"""Multi-GPU E-step: chunks are statically sharded across ranks, one process per GPU, and the
+per-chunk sufficient-statistics vectors are exchanged with ONE all-gather per EM iteration over
+RCCL/xGMI (torch.distributed backend "nccl"); every rank then sums all chunks in global list order
+(hf_reduce_chunks), which makes the statistics — and therefore the whole EM trajectory and the
+labels — identical to a 1-GPU run (prefer all-gather + fixed-order summation over
+all-reduce at this message size; the collective is latency-bound either way).
+
+The reference has no counterpart: its only parallelism is a pthread pool over chunks followed by
+the same in-order reduction (programs/submodules/hmm/hmm.c:739-763).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native as N
+from .synth import WindowStore
+
+
+def shard_bounds(chunk_sizes: Sequence[int], world: int) -> List[int]:
+    """Contiguous runs of the chunk list, balanced by window count: bounds[r]..bounds[r+1] is rank r's run."""
+    sizes = np.asarray(chunk_sizes, dtype=np.int64)
+    C = len(sizes)
+    csum = np.concatenate([[0], np.cumsum(sizes)])
+    total = int(csum[-1])
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        k = int(np.searchsorted(csum, target, side="left"))
+        # choose the boundary closest to the target, never going backwards
+        if k > 0 and abs(csum[k - 1] - target) <= abs(csum[min(k, C)] - target):
+            k -= 1
+        bounds.append(min(max(k, bounds[-1]), C))
+    bounds.append(C)
+    return bounds
+
+
+class ShardedEMList:
+    """The EM list of one rank + the exchange.  `make_local(sub_store)` builds the per-rank E-step
+    object; the product passes an `hmm.EMList` factory, the CPU/gloo tests pass an oracle-backed one."""
+
+    def __init__(self, store: WindowStore, rank: int, world: int, make_local: Callable, stats_len: int,
+                 device=None, group=None):
+        import torch
+        self.torch = torch
+        self.rank, self.world, self.group = rank, world, group
+        sizes = np.diff(store.chunk_off)
+        self.bounds = shard_bounds(sizes, world)
+        self.counts = [self.bounds[r + 1] - self.bounds[r] for r in range(world)]
+        self.maxc = max(1, max(self.counts))
+        self.n_chunks_total = int(store.n_chunks)
+        self.n_windows_total = int(store.n_windows)
+        self.local_store = store.subset_chunks(range(self.bounds[rank], self.bounds[rank + 1]))
+        self.local = make_local(self.local_store)
+        self.V = stats_len
+        self.device = device if device is not None else torch.device("cpu")
+        self.send = torch.zeros((self.maxc, self.V), dtype=torch.float64, device=self.device)
+        self.recv = torch.zeros((world, self.maxc, self.V), dtype=torch.float64, device=self.device)
+        self.packed = torch.zeros((max(1, self.n_chunks_total), self.V), dtype=torch.float64, device=self.device)
+        self.total = torch.zeros((self.V,), dtype=torch.float64, device=self.device)
+
+    def run_sharded(self, model, mode: int) -> np.ndarray:
+        torch = self.torch
+        import torch.distributed as dist
+        self.local.launch(model, mode)
+        self.local.chunk_stats_into(self.send)            # [C_local, V] rows of this rank, device-to-device
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group)
+            o = 0
+            for r in range(self.world):                   # global chunk order = rank order of contiguous runs
+                n = self.counts[r]
+                if n:
+                    self.packed[o:o + n].copy_(self.recv[r, :n])
+                o += n
+        else:
+            self.packed[:self.counts[0]].copy_(self.send[:self.counts[0]])
+        self.local.reduce_into(self.packed, self.n_chunks_total, self.total)
+        stats = self.total.cpu().numpy().copy()           # device->host copy synchronises the stream
+        self.local.check()
+        return stats
+
+    def gather_labels(self) -> np.ndarray:
+        """Labels of every window in global order (only needed once, for the final BED)."""
+        torch = self.torch
+        import torch.distributed as dist
+        lab = self.local.labels()
+        if self.world == 1:
+            return lab
+        sizes = [0] * self.world
+        mine = torch.tensor([lab.size], dtype=torch.int64, device=self.device)
+        allsz = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(allsz, mine, group=self.group)
+        sizes = [int(t.item()) for t in allsz]
+        mx = max(1, max(sizes))
+        buf = torch.full((mx,), -1, dtype=torch.int8, device=self.device)
+        buf[:lab.size] = torch.from_numpy(lab).to(self.device)
+        out = [torch.empty(mx, dtype=torch.int8, device=self.device) for _ in range(self.world)]
+        dist.all_gather(out, buf, group=self.group)
+        return np.concatenate([out[r][:sizes[r]].cpu().numpy() for r in range(self.world)])
+
+
+class HipLocal:
+    """Adapter: hmm.EMList -> the local-backend protocol of ShardedEMList (tensors are torch CUDA tensors
+    whose data_ptr() is handed to the C ABI; all work is enqueued on torch's current stream)."""
+
+    def __init__(self, emlist):
+        self.em = emlist
+
+    def launch(self, model, mode):
+        self.em.launch(model, mode)
+
+    def chunk_stats_into(self, send):
+        self.em.copy_chunk_stats(send.data_ptr())
+
+    def reduce_into(self, packed, n_chunks, total):
+        self.em.reduce_chunks(packed.data_ptr(), n_chunks, total.data_ptr())
+
+    def check(self):
+        self.em.check()
+
+    def labels(self):
+        return self.em.labels()
+
+
+def make_sharded_hip(store: WindowStore, model, rank: int, world: int, local_rank: int, adjust=True, frac=0.95,
+                     algo: int = N.HF_ALGO_SCAN, group=None):
+    """One process per GPU: this rank's chunks live on cuda:<local_rank>; kernels and the collective share
+    torch's current stream so no extra synchronisation is needed."""
+    import torch
+    from . import hmm
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def factory(sub):
+        return HipLocal(hmm.EMList(sub, model, adjust, frac, device=local_rank, algo=algo, stream=stream))
+    V = N.stats_len(model.numberOfRegions, model.maxNumberOfComps)
+    return ShardedEMList(store, rank, world, factory, V, device=dev, group=group)

@@ -208,6 +208,15 @@ class EMList:
         N.check(self._L.hf_last_kernel_ms(self._h, C.byref(ms)), "hf_last_kernel_ms")
         return float(ms.value)
 
+    def set_profiling(self, on: bool = True) -> None:
+        N.check(self._L.hf_set_profiling(self._h, int(on)), "hf_set_profiling")
+
+    def kernel_times(self) -> dict:
+        """Duration (ms) of each stage of the last pass, from HIP events on the launch stream."""
+        ms = (C.c_float * N.HF_NKERNELS)()
+        N.check(self._L.hf_kernel_times(self._h, ms), "hf_kernel_times")
+        return {self._L.hf_kernel_name(i).decode(): float(ms[i]) for i in range(N.HF_NKERNELS)}
+
     # --- results ---
     def labels(self) -> np.ndarray:
         out = np.empty(self.store.n_windows, dtype=np.int8)

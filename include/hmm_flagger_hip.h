@@ -135,6 +135,14 @@ int hf_get_forward_backward(hf_ctx *ctx, int64_t first, int64_t n, double *f_hos
 /* kernel time of the last hf_estep + reduce in milliseconds (HIP events on the stream used) */
 int hf_last_kernel_ms(hf_ctx *ctx, float *ms);
 
+/* Per-kernel timing (bench.py's roofline leg): when enabled, hf_estep/hf_finish record a HIP event
+ * on the launch stream between kernels; hf_kernel_times returns the duration of each stage of the
+ * LAST pass in milliseconds (0 for stages that did not run).  Call after hf_finish/hf_check. */
+#define HF_NKERNELS 5
+int hf_set_profiling(hf_ctx *ctx, int on);
+int hf_kernel_times(hf_ctx *ctx, float ms[HF_NKERNELS]);
+const char *hf_kernel_name(int stage);   /* "emit", "forward", "backward", "stats", "reduce" */
+
 #ifdef __cplusplus
 }
 #endif
