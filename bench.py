@@ -23,12 +23,28 @@ ALGO_BYTES_PER_WINDOW = 17.0   # 16-byte packed window record (chunk.c:669-697) 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def effective_cores() -> int:
+    """Logical CPUs this process may actually use: min(os.cpu_count(), cgroup v2 cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(store_full, K, alpha, cores):
     """Oracle (CPU port of the reference path) on a bounded sample of the same workload."""
     import numpy as np
     from oracle_py import Oracle
     from flagger_amd import synth
-    sample = synth.config(2, scale=0.25)   # same generator and seed, contigs shrunk 4x => ~380 k windows
+    sample = store_full                    # the full workload: needs >= `cores` chunks to keep every core busy
     orc = Oracle(sample, 0, K, alpha, threads=cores)
     passes = 3
     orc.run_iteration()                    # warm-up (allocates f/b)
@@ -40,8 +56,9 @@ def cpu_baseline(store_full, K, alpha, cores):
     n = sample.n_windows
     orc.close()
     return {"value": n * passes / dt, "unit": "windows/s", "cores": cores, "kind": "port",
-            "sample": f"{passes} EM passes over configs[2] generated at scale 0.25 ({n} windows, "
-                      f"{sample.n_chunks} chunks), oracle/ C port with {cores} threads over chunks"}
+            "sample": f"{passes} EM passes (E-step + M-step) over the same workload ({n} windows, "
+                      f"{sample.n_chunks} chunks), oracle/ C port with {cores} threads over chunks "
+                      f"(~{n * passes / 2.3e5:.0f} s of single-core work)"}
 
 
 def main():
@@ -141,7 +158,7 @@ def main():
             "loglikelihood_after_last_step": ll,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(store, K, alpha, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(store, K, alpha, effective_cores())
         print(json.dumps(out))
     if world > 1:
         tdist.destroy_process_group()

@@ -9,6 +9,9 @@
 //   k_reduce    ordered sum over chunks                               (hmm.c:759-763)
 // There is no CPU fallback: without a HIP device hf_create fails with HF_E_NOGPU.
 #include "hf_device.h"
+#ifndef HF_SCAN_L
+#define HF_SCAN_L 4   // consecutive windows per lane in the scan kernels
+#endif
 #include <string>
 #include <vector>
 #include <cstring>
@@ -39,6 +42,9 @@ struct hf_ctx {
     int8_t* d_label = nullptr;     // [N]
     double* d_chunk_stats = nullptr; // [C][V]
     double* d_total = nullptr;     // [V]
+    // scan algorithm: tile tables and per-tile work arrays
+    int ntiles = 0; int32_t* d_tile_chunk = nullptr; int64_t* d_tile_base = nullptr; int32_t* d_chunk_tile0 = nullptr;
+    double* d_Pt = nullptr; double* d_cf = nullptr; double* d_cb = nullptr; double* d_tile_ll = nullptr;
     unsigned* d_flags = nullptr;
     DevParams* d_params = nullptr; DevParams* h_params = nullptr; size_t params_bytes = 0;
     unsigned* h_flags = nullptr;
@@ -325,6 +331,8 @@ __global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off,
     if (lane == 0 && bad) atomicOr(flags, bad);
 }
 
+#include "hf_scan.h"
+
 // ------------------------------------------------------------------------------------------
 // k_stats: xi sufficient statistics of one chunk, one region at a time (A6, A12).
 // For every pair (i, i+1), i = 1..T-2:  xi = f_i[pre] * T * e * b_{i+1}[s] / terminationProb.
@@ -541,6 +549,24 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     DMALLOC(ctx->d_scale, N * 8); DMALLOC(ctx->d_label, N);
     DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, (size_t) ctx->V * 8);
     DMALLOC(ctx->d_flags, 4);
+    {   // tiles of 64*HF_SCAN_L windows, enumerated chunk by chunk
+        std::vector<int32_t> tchunk, ctile0(C + 1, 0);
+        std::vector<int64_t> tbase;
+        const int64_t TW = 64 * HF_SCAN_L;
+        for (size_t c = 0; c < C; c++) {
+            const int64_t T = w->chunk_off[c + 1] - w->chunk_off[c];
+            ctile0[c] = (int32_t) tchunk.size();
+            for (int64_t b = 0; b < T; b += TW) { tchunk.push_back((int32_t) c); tbase.push_back(b); }
+        }
+        ctile0[C] = (int32_t) tchunk.size();
+        ctx->ntiles = (int) tchunk.size();
+        TRY(dev_upload(&ctx->d_tile_chunk, tchunk.data(), tchunk.size()));
+        TRY(dev_upload(&ctx->d_tile_base, tbase.data(), tbase.size()));
+        TRY(dev_upload(&ctx->d_chunk_tile0, ctile0.data(), ctile0.size()));
+        const size_t nt = (size_t) ctx->ntiles;
+        DMALLOC(ctx->d_Pt, nt * 16 * 8); DMALLOC(ctx->d_cf, nt * 4 * 8); DMALLOC(ctx->d_cb, nt * 4 * 8);
+        DMALLOC(ctx->d_tile_ll, nt * 8);
+    }
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
     DMALLOC(ctx->d_params, ctx->params_bytes);
     if (hipHostMalloc((void**) &ctx->h_params, ctx->params_bytes) != hipSuccess ||
@@ -574,6 +600,8 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_off); hipFree(ctx->d_rec); hipFree(ctx->d_beta); hipFree(ctx->d_regmask); hipFree(ctx->d_E);
     hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); hipFree(ctx->d_chunk_stats);
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
+    hipFree(ctx->d_tile_chunk); hipFree(ctx->d_tile_base); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
+    hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -646,12 +674,30 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
         hipLaunchKernelGGL(k_emit, dim3((unsigned) ((ctx->N + 255) / 256)), dim3(256), 0, st, ctx->N, ctx->d_rec,
                            ctx->d_beta, ctx->d_params, ctx->d_E, ctx->d_flags);
         mark(1); ctx->kran[0] = true;
-        hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_rec, ctx->d_E,
-                           ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_chunk_stats, ctx->V, ctx->d_flags);
+        if (ctx->algo == HF_ALGO_SEQ)
+            hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_rec, ctx->d_E,
+                               ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_chunk_stats, ctx->V, ctx->d_flags);
+        else {
+            const unsigned tb = (unsigned) ((ctx->ntiles + 3) / 4);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tileprod<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
+                               ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_E, ctx->d_params, ctx->d_Pt);
+            hipLaunchKernelGGL(k_carry, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
+                               ctx->d_E, ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fwd_tile<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
+                               ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_E, ctx->d_params, ctx->d_cf,
+                               ctx->d_f, ctx->d_scale, ctx->d_tile_ll, ctx->d_flags);
+            hipLaunchKernelGGL(k_chunk_ll, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_chunk_tile0, ctx->d_tile_ll,
+                               ctx->d_chunk_stats, ctx->V);
+        }
         mark(2); ctx->kran[1] = true;   // end of forward (= start of backward)
         if (mode == HF_MODE_FULL) {
-            hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_rec, ctx->d_E,
-                               ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
+            if (ctx->algo == HF_ALGO_SEQ)
+                hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_rec, ctx->d_E,
+                                   ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bwd_tile<HF_SCAN_L>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256), 0,
+                                   st, ctx->ntiles, ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_E,
+                                   ctx->d_params, ctx->d_cb, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
             mark(3); ctx->kran[2] = true;
             const int kc = p->ncomp[3];
             if (kc <= 4) launch_stats<4>(ctx, st);

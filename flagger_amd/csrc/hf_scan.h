@@ -1,0 +1,385 @@
+// hf_scan.h — HF_ALGO_SCAN: tile-parallel forward/backward for 4-state chains on gfx950.
+//
+// The scaled forward recurrence f_t ∝ f_{t-1}·A_t (A_t[pre][s] = T_t(pre,s)·e_t(pre,s), hmm.c:366-420)
+// is a product of 4x4 non-negative matrices, hence associative.  A chunk is cut into tiles of 64·L
+// windows, one wavefront per tile, every lane owning L consecutive windows:
+//   k_tileprod   product of the matrices of every tile                 (all tiles of all chunks at once)
+//   k_carry      per chunk: sequential sweep over its <= T/(64L) tile products -> carried-in forward
+//                vector and carried-in backward direction of every tile
+//   k_fwd_tile   per tile: Kogge-Stone scan of the 64 lane products (DPP/ds_bpermute shuffles, power-of-two
+//                renormalisation after every product: exact, nothing underflows) gives each lane the product
+//                of everything before it; the lane then REPLAYS its L windows with the reference's exact
+//                operation order from the carried-in, normalised vector
+//   k_bwd_tile   mirror image with suffix products (hmm.c:470-529) + posterior argmax (hmm.c:671-692); the
+//                absolute magnitude of a carried-in b vector is recovered from the invariant
+//                sum_s f_t[s]·b_t[s]·scale_t = terminationProb of the scaled forward-backward
+// Every f_t / b_t / scale_t is therefore produced by the reference's own arithmetic; only the carried-in
+// vectors differ from a purely sequential run, in the last ulp.
+#pragma once
+#include "hf_device.h"
+
+struct M4 { double m[16]; };
+
+__device__ __forceinline__ void m4_identity(M4& a) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) a.m[i] = (i % 5 == 0) ? 1.0 : 0.0;
+}
+
+// c = a·b (fused multiply-adds: scan products only steer carried-in directions)
+__device__ __forceinline__ void m4_mul(M4& c, const M4& a, const M4& b) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double s = a.m[i * 4] * b.m[j];
+            s = fma(a.m[i * 4 + 1], b.m[4 + j], s);
+            s = fma(a.m[i * 4 + 2], b.m[8 + j], s);
+            s = fma(a.m[i * 4 + 3], b.m[12 + j], s);
+            c.m[i * 4 + j] = s;
+        }
+}
+
+// scale by a power of two so that the largest entry is in [0.5, 1): exact
+__device__ __forceinline__ void m4_renorm(M4& a) {
+    double mx = a.m[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++) mx = fmax(mx, a.m[i]);
+    int e;
+    (void) frexp(mx, &e);
+    if (mx > 0.0) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) a.m[i] = ldexp(a.m[i], -e);
+    }
+}
+
+__device__ __forceinline__ void m4_shfl_up(M4& dst, const M4& src, int d) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) dst.m[i] = __shfl_up(src.m[i], d);
+}
+__device__ __forceinline__ void m4_shfl_down(M4& dst, const M4& src, int d) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) dst.m[i] = __shfl_down(src.m[i], d);
+}
+
+// T and E of one window; chunk-first windows use the start row for every pre (k_emit puts e_s(x_0) in row 0)
+__device__ __forceinline__ void load_pair(const DevParams* __restrict__ P, uint32_t r, const double* __restrict__ Erow,
+                                          double Tm[16], double Ev[16]) {
+    if (REC_FIRST(r)) {
+        const DevRegion* __restrict__ R = &P->reg[REC_REGION(r)];
+#pragma unroll
+        for (int k = 0; k < 16; k++) Tm[k] = R->trans[4][k & 3];
+    } else {
+        load_T(P, r, Tm);
+    }
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(Erow);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const double2 v = src[k]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
+}
+
+// product of the matrices of windows [a, a+L) of a chunk (absolute index t0+..); chunk-first windows and
+// windows past the end count as identity
+template <int L>
+__device__ __forceinline__ void lane_product(M4& Q, const DevParams* __restrict__ P, const uint32_t* __restrict__ rec,
+                                             const double* __restrict__ E, int64_t t0, int64_t a, int64_t T,
+                                             bool skip_first) {
+    m4_identity(Q);
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        if (a + i >= 0 && a + i < T) {
+            const int64_t t = t0 + a + i;
+            const uint32_t r = rec[t];
+            if (!(skip_first && REC_FIRST(r))) {
+                double Tm[16], Ev[16];
+                load_pair(P, r, E + t * 16, Tm, Ev);
+                M4 A, R;
+#pragma unroll
+                for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ev[k];
+                m4_mul(R, Q, A);
+                Q = R;
+                m4_renorm(Q);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tileprod: Pt[tile] = product of A_w over the tile's windows (window 0 of a chunk excluded), one wave
+// per tile, 4 tiles per 256-thread block.  tile_chunk / tile_base map a tile to (chunk, first window).
+// ------------------------------------------------------------------------------------------
+template <int L>
+__global__ void __launch_bounds__(256) k_tileprod(int ntiles, const int32_t* __restrict__ tile_chunk,
+                                                  const int64_t* __restrict__ tile_base,
+                                                  const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
+                                                  const double* __restrict__ E, const DevParams* __restrict__ P,
+                                                  double* __restrict__ Pt) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= ntiles) return;
+    const int c = tile_chunk[tile];
+    const int64_t t0 = off[c], T = off[c + 1] - t0, base = tile_base[tile];
+    M4 Q;
+    lane_product<L>(Q, P, rec, E, t0, base + (int64_t) lane * L, T, true);
+    // ordered tree product over lanes: after step d, lane l (l % 2d == 0) holds the product of lanes l..l+2d-1
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        M4 Rgt, R;
+        m4_shfl_down(Rgt, Q, d);
+        if ((lane & (2 * d - 1)) == 0) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
+    }
+    if (lane == 0) {
+        double2* dst = reinterpret_cast<double2*>(Pt + (int64_t) tile * 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[k] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_carry: per chunk, sweep the tile products.  cf[tile] = normalised forward vector entering the tile
+// (tile 0 of a chunk: unused, the tile kernel starts from window 0); cb[tile] = direction of b at the
+// first window after BACKWARD tile `tile` (backward tile k owns windows base_k-1 .. base_k+64L-2).
+// lane 0 sweeps forward, lane 1 sweeps backward.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_carry(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
+                                              const uint32_t* __restrict__ rec, const double* __restrict__ E,
+                                              const DevParams* __restrict__ P, const double* __restrict__ Pt,
+                                              double* __restrict__ cf, double* __restrict__ cb) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int64_t t0 = off[c], T = off[c + 1] - t0;
+    if (T <= 0 || lane > 1) return;
+    const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
+    if (lane == 0) {
+        const uint32_t r0 = rec[t0];
+        const DevRegion* __restrict__ R = &P->reg[REC_REGION(r0)];
+        double v[4], sv = 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) { v[s] = E[t0 * 16 + s] * R->trans[4][s]; sv += v[s]; }
+#pragma unroll
+        for (int s = 0; s < 4; s++) v[s] /= sv;
+        for (int k = 0; k < nt; k++) {
+            double* dst = cf + (int64_t) (k0 + k) * 4;
+            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
+            const double* __restrict__ M = Pt + (int64_t) (k0 + k) * 16;
+            double u[4], su = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                double s = v[0] * M[j];
+                s = fma(v[1], M[4 + j], s); s = fma(v[2], M[8 + j], s); s = fma(v[3], M[12 + j], s);
+                u[j] = s; su += s;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = u[j] / su;
+        }
+    } else {
+        const DevRegion* __restrict__ R = &P->reg[REC_REGION(rec[t0 + T - 1])];
+        double w[4], sw = 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) { w[s] = R->trans[s][4]; sw += w[s]; }
+#pragma unroll
+        for (int s = 0; s < 4; s++) w[s] /= sw;
+        for (int k = nt - 1; k >= 0; k--) {
+            double* dst = cb + (int64_t) (k0 + k) * 4;
+            dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
+            const double* __restrict__ M = Pt + (int64_t) (k0 + k) * 16;
+            double u[4], su = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                double s = M[i * 4] * w[0];
+                s = fma(M[i * 4 + 1], w[1], s); s = fma(M[i * 4 + 2], w[2], s); s = fma(M[i * 4 + 3], w[3], s);
+                u[i] = s; su += s;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) w[i] = u[i] / su;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_fwd_tile: one wavefront per tile
+// ------------------------------------------------------------------------------------------
+template <int L>
+__global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const int32_t* __restrict__ tile_chunk,
+                                                  const int64_t* __restrict__ tile_base,
+                                                  const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
+                                                  const double* __restrict__ E, const DevParams* __restrict__ P,
+                                                  const double* __restrict__ cf, double* __restrict__ F,
+                                                  double* __restrict__ scale, double* __restrict__ tile_ll,
+                                                  unsigned* __restrict__ flags) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= ntiles) return;
+    const int c = tile_chunk[tile];
+    const int64_t t0 = off[c], T = off[c + 1] - t0, base = tile_base[tile];
+    const int64_t a = base + (int64_t) lane * L;
+    double carry[4];
+    if (base == 0) { carry[0] = 1.0; carry[1] = 0.0; carry[2] = 0.0; carry[3] = 0.0; }  // (1,0,0,0)·A_first = start∘e
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) carry[j] = cf[(int64_t) tile * 4 + j];
+    }
+    unsigned bad = 0;
+    // phase 1 + 2: exclusive prefix product over lanes
+    M4 Q;
+    lane_product<L>(Q, P, rec, E, t0, a, T, false);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        M4 Lft, R;
+        m4_shfl_up(Lft, Q, d);
+        if (lane >= d) { m4_mul(R, Lft, Q); Q = R; m4_renorm(Q); }
+    }
+    M4 X;
+    m4_shfl_up(X, Q, 1);
+    double f[4];
+    {
+        double u[4], su = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            double s = carry[0] * X.m[j];
+            s = fma(carry[1], X.m[4 + j], s); s = fma(carry[2], X.m[8 + j], s); s = fma(carry[3], X.m[12 + j], s);
+            u[j] = s; su += s;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) f[j] = (lane == 0) ? carry[j] : u[j] / su;
+    }
+    // phase 3: replay this lane's windows in the reference's operation order (hmm.c:333-420)
+    double ll = 0.0;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        if (a + i < T) {
+            const int64_t t = t0 + a + i;
+            const uint32_t r = rec[t];
+            double Tm[16], Ev[16];
+            load_pair(P, r, E + t * 16, Tm, Ev);
+            double nf[4], sc = 0.0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                double acc = 0.0;
+#pragma unroll
+                for (int p = 0; p < 4; p++) acc += (f[p] * Tm[p * 4 + s] * Ev[p * 4 + s]);
+                nf[s] = acc;
+                sc += acc;
+            }
+            if (!REC_FIRST(r) && sc < 1e-50) bad |= HF_FLAG_SCALE;   // hmm.c:412-415
+#pragma unroll
+            for (int s = 0; s < 4; s++) f[s] = nf[s] / sc;
+            ll += log(sc);                                            // hmm.c:428
+            reinterpret_cast<double2*>(F + t * 4)[0] = make_double2(f[0], f[1]);
+            reinterpret_cast<double2*>(F + t * 4)[1] = make_double2(f[2], f[3]);
+            scale[t] = sc;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
+    if (lane == 0) tile_ll[tile] = ll;
+    if (bad) atomicOr(flags, bad);
+}
+
+// chunk log-likelihood = sum of its tiles' partial sums (fixed order)
+__global__ void __launch_bounds__(64) k_chunk_ll(const int32_t* __restrict__ chunk_tile0, const double* __restrict__ tile_ll,
+                                                 double* __restrict__ chunk_stats, int64_t V) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
+    double s = 0.0;
+    for (int k = lane; k < nt; k += 64) s += tile_ll[k0 + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) chunk_stats[(int64_t) c * V] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_bwd_tile: backward tile k owns windows i = base_k-1 .. base_k+64L-2 (i >= 0, i <= T-2); window i
+// uses G_i = A_{i+1}:  b_i = G_i·b_{i+1} / scale_i.  The chunk's last window b_{T-1} = term/scale_{T-1} is
+// written by the tile that contains window T-2 (or by tile 0 when T == 1).
+// ------------------------------------------------------------------------------------------
+template <int L>
+__global__ void __launch_bounds__(256) k_bwd_tile(int ntiles, const int32_t* __restrict__ tile_chunk,
+                                                  const int64_t* __restrict__ tile_base,
+                                                  const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
+                                                  const double* __restrict__ E, const DevParams* __restrict__ P,
+                                                  const double* __restrict__ cb, const double* __restrict__ F,
+                                                  const double* __restrict__ scale, double* __restrict__ B,
+                                                  int8_t* __restrict__ label, unsigned* __restrict__ flags) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= ntiles) return;
+    const int c = tile_chunk[tile];
+    const int64_t t0 = off[c], T = off[c + 1] - t0, base = tile_base[tile];
+    const int64_t Tm1 = T - 1;                              // windows 0..T-2 have a recurrence step
+    const int64_t a = base - 1 + (int64_t) lane * L;        // first window of this lane (may be -1)
+    const int64_t tend = base - 1 + 64 * (int64_t) L;       // first window after the tile
+    unsigned bad = 0;
+    const DevRegion* __restrict__ Rl = &P->reg[REC_REGION(rec[t0 + T - 1])];
+    const double term = Rl->trans[0][4];
+    double carry[4];
+    const bool last_tile = tend >= Tm1;
+    if (last_tile) {  // hmm.c:452-467: b_{T-1}[s] = M[s][End] / scale_{T-1}
+        const double sc = scale[t0 + T - 1];
+#pragma unroll
+        for (int s = 0; s < 4; s++) carry[s] = Rl->trans[s][4] / sc;
+        if (lane == 0) {
+            const int64_t t = t0 + T - 1;
+            double f[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) f[s] = F[t * 4 + s];
+            reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(carry[0], carry[1]);
+            reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(carry[2], carry[3]);
+            label[t] = (int8_t) posterior_label(f, carry, sc);
+        }
+    } else {          // direction from k_carry, magnitude from sum_s f·b·scale = terminationProb at window `tend`
+        const int64_t t = t0 + tend;
+        double dot = 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) { carry[s] = cb[(int64_t) tile * 4 + s]; dot += F[t * 4 + s] * carry[s]; }
+        const double k = term / (scale[t] * dot);
+#pragma unroll
+        for (int s = 0; s < 4; s++) carry[s] *= k;
+    }
+    // phase 1 + 2: exclusive SUFFIX product over lanes; lane windows i own A_{i+1}
+    M4 Q;
+    lane_product<L>(Q, P, rec, E, t0, a + 1, T, true);      // windows a+1 .. a+L, window 0 never owned
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        M4 Rgt, R;
+        m4_shfl_down(Rgt, Q, d);
+        if (lane + d < 64) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
+    }
+    M4 X;
+    m4_shfl_down(X, Q, 1);
+    double b[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double s = X.m[i * 4] * carry[0];
+        s = fma(X.m[i * 4 + 1], carry[1], s); s = fma(X.m[i * 4 + 2], carry[2], s); s = fma(X.m[i * 4 + 3], carry[3], s);
+        b[i] = s;
+    }
+    const int64_t nxt = a + L;                              // window whose b this lane starts from
+    if (lane == 63 || nxt >= Tm1) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) b[i] = carry[i];        // the carried vector itself
+    } else {
+        const int64_t t = t0 + nxt;
+        double dot = 0.0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) dot += F[t * 4 + s] * b[s];
+        const double k = term / (scale[t] * dot);
+#pragma unroll
+        for (int i = 0; i < 4; i++) b[i] *= k;
+    }
+    // phase 3: replay this lane's windows (decreasing i) in the reference's operation order (hmm.c:470-529)
+#pragma unroll
+    for (int i = L - 1; i >= 0; i--) {
+        if (a + i >= 0 && a + i < Tm1) {
+            const int64_t t = t0 + a + i;
+            double Tm[16], Ev[16];
+            load_pair(P, rec[t + 1], E + (t + 1) * 16, Tm, Ev);
+            double nb[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int p = 0; p < 4; p++) nb[p] += Tm[p * 4 + s] * Ev[p * 4 + s] * b[s];
+            const double sc = scale[t];
+            if (sc < 1e-50) bad |= HF_FLAG_SCALE;             // hmm.c:521-524
+            double f[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) { b[s] = nb[s] / sc; f[s] = F[t * 4 + s]; }
+            reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(b[0], b[1]);
+            reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(b[2], b[3]);
+            label[t] = (int8_t) posterior_label(f, b, sc);
+        }
+    }
+    if (bad) atomicOr(flags, bad);
+}
