@@ -45,6 +45,7 @@ struct hf_ctx {
     // scan algorithm: tile tables and per-tile work arrays
     int ntiles = 0; int32_t* d_tile_chunk = nullptr; int64_t* d_tile_base = nullptr; int32_t* d_chunk_tile0 = nullptr;
     double* d_Pt = nullptr; double* d_cf = nullptr; double* d_cb = nullptr; double* d_tile_ll = nullptr;
+    double* d_tile_stats = nullptr; // [ntiles][R][NA(16)]
     unsigned* d_flags = nullptr;
     DevParams* d_params = nullptr; DevParams* h_params = nullptr; size_t params_bytes = 0;
     unsigned* h_flags = nullptr;
@@ -342,117 +343,173 @@ __global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off,
 template <int KT>
 struct StatAcc {
     double trans[16];
-    double g_mnum[3], g_vnum[3], g_den[3];      // single-component Gaussian states 0(Err, gaussian model),1,2
+    double g_mnum[3], g_vnum[3], g_den[3];      // single-component Gaussian states 0 (Err, gaussian model), 1, 2
     double te_num, te_den;                      // trunc-exp Err
     double c_mnum[KT], c_vnum[KT], c_den[KT], c_wden; // Col components
 };
 
 template <int KT>
-__device__ __forceinline__ int acc_count() { return 16 + 9 + 2 + 3 * KT + 1; }
-
-template <int KT>
 __device__ __forceinline__ double& acc_ref(StatAcc<KT>& a, int i) { return reinterpret_cast<double*>(&a)[i]; }
 
+// contributions of the pair (i, i+1) — window t = t0+i — to the accumulators of region REC_REGION(rec[t+1])
 template <int KT>
-__global__ void __launch_bounds__(512) k_stats(const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
-                                               const double* __restrict__ beta, const double* __restrict__ E,
-                                               const DevParams* __restrict__ P, const double* __restrict__ F,
-                                               const double* __restrict__ B, const uint64_t* __restrict__ regmask,
-                                               double* __restrict__ chunk_stats, int64_t V, int Kctx,
-                                               unsigned* __restrict__ flags) {
-    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t t0 = off[c], T = off[c + 1] - t0;
+__device__ __forceinline__ void stats_pair(StatAcc<KT>& a, const DevParams* __restrict__ P, const DevRegion* __restrict__ R,
+                                           int64_t t, const uint32_t* __restrict__ rec, const double* __restrict__ beta,
+                                           const double* __restrict__ E, const double* __restrict__ F,
+                                           const double* __restrict__ B, bool te, int ncol, unsigned* nan) {
+    const uint32_t r1 = rec[t + 1];
+    const double x = (double) REC_X(r1), px = (double) REC_X(rec[t]);
+    const double bt = beta[t + 1];
+    double Tm[16];
+    load_T(P, r1, Tm);
+    double f[4], b1[4], Ev[16];
+    {
+        const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + t * 4);
+        const double2* __restrict__ bp = reinterpret_cast<const double2*>(B + (t + 1) * 4);
+        const double2 f01 = fp[0], f23 = fp[1], b01 = bp[0], b23 = bp[1];
+        f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
+        b1[0] = b01.x; b1[1] = b01.y; b1[2] = b23.x; b1[3] = b23.y;
+        const double2* __restrict__ ep = reinterpret_cast<const double2*>(E + (t + 1) * 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const double2 v = ep[k]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
+    }
+    // xi of all 16 (pre, state) pairs first: afterwards only adj[] and Ev[] stay live
+    double adj[16];
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int k = p * 4 + s;
+            const double count = f[p] * Tm[k] * Ev[k] * b1[s];
+            adj[k] = count / HF_TERMINATION_PROB;           // hmm.c:613-614
+            a.trans[k] += adj[k];                           // hmm_utils.c:2010-2015
+        }
+    // state outer, pre inner — the order in which the reference accumulates (hmm.c:588-589)
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int k = p * 4 + s;
+            if (s == 0 && te) {                             // hmm_utils.c:1027-1034
+                a.te_num += adj[k] * x;
+                a.te_den += adj[k];
+            } else {                                        // hmm_utils.c:812-839, one component:
+                const double alpha = P->alpha[k];           // componentProbs[0] == totProb == E
+                const double x_adj = (x - alpha * px) / (1.0 - alpha);
+                const double w = adj[k] * Ev[k] / Ev[k];
+                a.g_mnum[s] += w * x_adj;
+                const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
+                a.g_vnum[s] += w * z * z;
+                a.g_den[s] += w;
+            }
+        }
+    }
+#pragma unroll 1
+    for (int p = 0; p < 4; p++) {                           // Col: K components per pre state
+        const int k = p * 4 + 3;
+        const double alpha = P->alpha[k];
+        const double x_adj = (x - alpha * px) / (1.0 - alpha);
+        const double ak = p == 0 ? adj[3] : p == 1 ? adj[7] : p == 2 ? adj[11] : adj[15];
+        double pc[KT], tot = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < KT; cc++)
+            if (cc < ncol) {
+                pc[cc] = hf_gauss_comp(R->mean[3][cc], R->var[3][cc], R->weight[3][cc], x, px, alpha, bt, nan);
+                tot += pc[cc];
+            }
+#pragma unroll
+        for (int cc = 0; cc < KT; cc++)
+            if (cc < ncol) {
+                const double w = ak * pc[cc] / tot;
+                a.c_mnum[cc] += w * x_adj;
+                const double z = (x_adj - R->mean[3][cc]) * (1.0 - alpha);
+                a.c_vnum[cc] += w * z * z;
+                a.c_den[cc] += w;
+                a.c_wden += w;
+            }
+    }
+}
+
+// one wavefront per tile of 64*HF_SCAN_L pairs, lanes strided by 64 (coalesced); one partial vector per
+// (tile, region present in the tile); fixed shuffle tree => deterministic
+template <int KT>
+__global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const int32_t* __restrict__ tile_chunk,
+                                                    const int64_t* __restrict__ tile_base, const int64_t* __restrict__ off,
+                                                    const uint32_t* __restrict__ rec, const double* __restrict__ beta,
+                                                    const double* __restrict__ E, const DevParams* __restrict__ P,
+                                                    const double* __restrict__ F, const double* __restrict__ B,
+                                                    const uint64_t* __restrict__ regmask,
+                                                    double* __restrict__ tile_stats, unsigned* __restrict__ flags) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
-    __shared__ double red[8][NA];
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= ntiles) return;
+    const int c = tile_chunk[tile];
+    const int64_t t0 = off[c], T = off[c + 1] - t0, base = tile_base[tile];
     const bool te = hf_err_is_truncexp(P);
-    const int ncol = P->ncomp[3];
-    const int64_t rstride = 24 * (int64_t) Kctx + 16;
-    const uint64_t present = regmask[c];
+    const int ncol = P->ncomp[3], nreg = P->n_regions;
     unsigned nan = 0;
-    for (int r = 0; r < P->n_regions; r++) {
-        if (!((present >> r) & 1ull)) continue;
+    unsigned long long present = 0;
+#pragma unroll
+    for (int j = 0; j < HF_SCAN_L; j++) {
+        const int64_t i = base + j * 64 + lane;
+        if (i >= 1 && i <= T - 2) present |= 1ull << (REC_REGION(rec[t0 + i + 1]) & 63u);
+    }
+    for (int o = 32; o > 0; o >>= 1) present |= __shfl_xor(present, o);
+    const unsigned long long in_chunk = regmask[c];
+    for (int r = 0; r < nreg; r++) {
+        if (!((in_chunk >> r) & 1ull)) continue;   // k_chunk_stats never reads this slot
+        if (!((present >> r) & 1ull)) {            // region occurs in the chunk but not in this tile
+            double* __restrict__ z = tile_stats + ((int64_t) tile * nreg + r) * NA;
+            for (int i = lane; i < NA; i += 64) z[i] = 0.0;
+            continue;
+        }
         const DevRegion* __restrict__ R = &P->reg[r];
         StatAcc<KT> a;
 #pragma unroll
         for (int i = 0; i < NA; i++) acc_ref<KT>(a, i) = 0.0;
-        for (int64_t i = 1 + tid; i <= T - 2; i += blockDim.x) {
-            const int64_t t = t0 + i;
-            const uint32_t r1 = rec[t + 1];
-            if ((int) REC_REGION(r1) != r) continue;
-            const double x = (double) REC_X(r1), px = (double) REC_X(rec[t]);
-            const double bt = beta[t + 1];
-            double Tm[16];
-            load_T(P, r1, Tm);
-            double f[4], b1[4], Ev[16];
-#pragma unroll
-            for (int s = 0; s < 4; s++) { f[s] = F[t * 4 + s]; b1[s] = B[(t + 1) * 4 + s]; }
-#pragma unroll
-            for (int k = 0; k < 16; k++) Ev[k] = E[(t + 1) * 16 + k];
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const int k = p * 4 + s;
-                    const double count = f[p] * Tm[k] * Ev[k] * b1[s];
-                    const double adj = count / HF_TERMINATION_PROB; // hmm.c:613-614
-                    a.trans[k] += adj;                              // hmm_utils.c:2010-2015
-                    if (s == 0 && te) {                             // hmm_utils.c:1027-1034
-                        a.te_num += adj * x;
-                        a.te_den += adj;
-                    } else {                                        // hmm_utils.c:812-839
-                        const double alpha = P->alpha[k];
-                        const double x_adj = (x - alpha * px) / (1.0 - alpha);
-                        if (s < 3) {  // one component: componentProbs[0] == totProb == E
-                            const double w = adj * Ev[k] / Ev[k];
-                            a.g_mnum[s] += w * x_adj;
-                            const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
-                            a.g_vnum[s] += w * z * z;
-                            a.g_den[s] += w;
-                        } else {
-                            double pc[KT], tot = 0.0;
-#pragma unroll
-                            for (int cc = 0; cc < KT; cc++)
-                                if (cc < ncol) {
-                                    pc[cc] = hf_gauss_comp(R->mean[3][cc], R->var[3][cc], R->weight[3][cc], x, px,
-                                                           alpha, bt, &nan);
-                                    tot += pc[cc];
-                                }
-#pragma unroll
-                            for (int cc = 0; cc < KT; cc++)
-                                if (cc < ncol) {
-                                    const double w = adj * pc[cc] / tot;
-                                    a.c_mnum[cc] += w * x_adj;
-                                    const double z = (x_adj - R->mean[3][cc]) * (1.0 - alpha);
-                                    a.c_vnum[cc] += w * z * z;
-                                    a.c_den[cc] += w;
-                                    a.c_wden += w;
-                                }
-                        }
-                    }
-                }
-            }
+#pragma unroll 1
+        for (int j = 0; j < HF_SCAN_L; j++) {
+            const int64_t i = base + j * 64 + lane;
+            if (i >= 1 && i <= T - 2 && (int) REC_REGION(rec[t0 + i + 1]) == r)
+                stats_pair<KT>(a, P, R, t0 + i, rec, beta, E, F, B, te, ncol, &nan);
         }
-        // block reduction: fixed tree => deterministic
+        double* __restrict__ dst = tile_stats + ((int64_t) tile * nreg + r) * NA;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             double v = acc_ref<KT>(a, i);
             for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-            if (lane == 0) red[wave][i] = v;
+            if (lane == 0) dst[i] = v;
         }
-        __syncthreads();
+    }
+    if (nan) atomicOr(flags, nan);
+}
+
+// per chunk: sum the tile partials in tile order and expand into the estimator layout of
+// include/hmm_flagger_hip.h (mean.den == var.den == weight.num; weight.den[i] all equal)
+template <int KT>
+__global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__ chunk_tile0, const uint64_t* __restrict__ regmask,
+                                                     const double* __restrict__ tile_stats, const DevParams* __restrict__ P,
+                                                     double* __restrict__ chunk_stats, int64_t V, int Kctx) {
+    constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
+    const int nreg = P->n_regions, ncol = P->ncomp[3];
+    const bool te = hf_err_is_truncexp(P);
+    const int64_t rstride = 24 * (int64_t) Kctx + 16;
+    const uint64_t present = regmask[c];
+    __shared__ double red[NA];
+    for (int r = 0; r < nreg; r++) {
+        if (!((present >> r) & 1ull)) continue;
         if (tid < NA) {
             double v = 0.0;
-            for (int w = 0; w < (int) (blockDim.x >> 6); w++) v += red[w][tid];
-            red[0][tid] = v;
+            for (int k = 0; k < nt; k++) v += tile_stats[((int64_t) (k0 + k) * nreg + r) * NA + tid];
+            red[tid] = v;
         }
         __syncthreads();
-        // expand into the estimator layout of include/hmm_flagger_hip.h
         double* __restrict__ dst = chunk_stats + (int64_t) c * V + 1 + r * rstride;
-        const StatAcc<KT>* __restrict__ S = reinterpret_cast<const StatAcc<KT>*>(&red[0][0]);
+        const StatAcc<KT>* __restrict__ S = reinterpret_cast<const StatAcc<KT>*>(red);
         if (tid < 16) dst[24 * Kctx + tid] = S->trans[tid];
-        if (tid == 32) {
-            if (te) { dst[(0 * 2 + 0) * Kctx] = S->te_num; dst[(0 * 2 + 1) * Kctx] = S->te_den; }
-        }
+        if (tid == 32 && te) { dst[(0 * 2 + 0) * Kctx] = S->te_num; dst[(0 * 2 + 1) * Kctx] = S->te_den; }
         if (tid >= 64 && tid < 67) {
             const int s = tid - 64;
             if (!(s == 0 && te)) {
@@ -462,8 +519,8 @@ __global__ void __launch_bounds__(512) k_stats(const int64_t* __restrict__ off, 
                 d[(2 * 2 + 0) * Kctx] = S->g_den[s];  d[(2 * 2 + 1) * Kctx] = S->g_den[s];
             }
         }
-        if (tid >= 128 && tid < 128 + KT && (tid - 128) < ncol) {
-            const int cc = tid - 128;
+        if (tid >= 96 && tid < 96 + KT && (tid - 96) < ncol) {
+            const int cc = tid - 96;
             double* d = dst + (int64_t) (3 * 3) * 2 * Kctx;
             d[(0 * 2 + 0) * Kctx + cc] = S->c_mnum[cc]; d[(0 * 2 + 1) * Kctx + cc] = S->c_den[cc];
             d[(1 * 2 + 0) * Kctx + cc] = S->c_vnum[cc]; d[(1 * 2 + 1) * Kctx + cc] = S->c_den[cc];
@@ -471,7 +528,6 @@ __global__ void __launch_bounds__(512) k_stats(const int64_t* __restrict__ off, 
         }
         __syncthreads();
     }
-    if (nan) atomicOr(flags, nan);
 }
 
 // ordered sum over chunks (hmm.c:759-763): one thread per vector element, chunks in list order
@@ -480,7 +536,15 @@ __global__ void k_reduce(const double* __restrict__ chunk_stats, int64_t n_chunk
     const int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     double acc = 0.0;
-    for (int64_t c = 0; c < n_chunks; c++) acc += chunk_stats[c * V + v];
+    int64_t c = 0;
+    for (; c + 8 <= n_chunks; c += 8) {   // 8 loads in flight, adds stay in list order
+        double x[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) x[j] = chunk_stats[(c + j) * V + v];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc += x[j];
+    }
+    for (; c < n_chunks; c++) acc += chunk_stats[c * V + v];
     out[v] = acc;
 }
 
@@ -496,9 +560,11 @@ static int dev_upload(T** dst, const T* src, size_t n) {
 
 template <int KT>
 static void launch_stats(hf_ctx* ctx, hipStream_t st) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats<KT>), dim3((unsigned) ctx->C), dim3(512), 0, st, ctx->d_off, ctx->d_rec,
-                       ctx->d_beta, ctx->d_E, ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_chunk_stats,
-                       ctx->V, ctx->K, ctx->d_flags);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256), 0, st, ctx->ntiles,
+                       ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_E, ctx->d_params,
+                       ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_stats, ctx->d_flags);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_chunk_tile0,
+                       ctx->d_regmask, ctx->d_tile_stats, ctx->d_params, ctx->d_chunk_stats, ctx->V, ctx->K);
 }
 
 extern "C" {
@@ -566,6 +632,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         const size_t nt = (size_t) ctx->ntiles;
         DMALLOC(ctx->d_Pt, nt * 16 * 8); DMALLOC(ctx->d_cf, nt * 4 * 8); DMALLOC(ctx->d_cb, nt * 4 * 8);
         DMALLOC(ctx->d_tile_ll, nt * 8);
+        DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
     }
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
     DMALLOC(ctx->d_params, ctx->params_bytes);
@@ -601,7 +668,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); hipFree(ctx->d_chunk_stats);
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
     hipFree(ctx->d_tile_chunk); hipFree(ctx->d_tile_base); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
-    hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll);
+    hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
