@@ -232,7 +232,7 @@ def synthesize(contig_lengths: Sequence[int], window_len: int, chunk_len: int, r
              np.where(states == 2, base, (k + 1) * base)))
         cov = np.rint(rng.normal(mu, np.sqrt(1.2 * mu))).clip(0, 250).astype(np.uint16)
         mapq = np.where(states == 1, (cov * rng.uniform(0.0, 0.1, size=nwin_ctg)).astype(np.uint16), cov)
-        annot = (np.uint64(1) << np.uint64(1)) | (region.astype(np.uint64) << np.uint64(58))
+        annot = np.uint64(1) | (region.astype(np.uint64) << np.uint64(58))   # annotation index 1 = bit 0 (ptBlock.c:225-228)
         cov_l.append(cov); mapq_l.append(mapq.astype(np.uint16)); ann_l.append(annot); truth_l.append(states)
         for (s, e), n in zip(bounds, sizes):
             ctgs.append(f"{contig_prefix}{ci}")

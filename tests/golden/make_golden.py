@@ -86,7 +86,7 @@ def simulate():
             c = np.minimum(250, np.asarray(obs[sl], dtype=np.float64)).astype(np.uint16)
             r = np.asarray(regions[sl], dtype=np.uint64)
             covs.append(c)
-            annots.append((np.uint64(1) << np.uint64(1)) | (np.uint64(1) << np.uint64(2 + ci)) | (r << np.uint64(58)))
+            annots.append((np.uint64(1) << np.uint64(0)) | (np.uint64(1) << np.uint64(1 + ci)) | (r << np.uint64(58)))  # bit = index-1, ptBlock.c:225-228
             truths.append(np.asarray(states[sl], dtype=np.int8))
             ctgs.append(f"TEST_CONTIG_{ci}"); cl.append(L); cs.append(s); ce.append(e); off.append(off[-1] + (e - s + 1))
         start += L
