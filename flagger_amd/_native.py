@@ -105,6 +105,36 @@ def lib() -> C.CDLL:
     sig("hfm_set_param_vector", None, vp, pd)
     sig("hfm_best_collapsed_comps", C.c_int, C.POINTER(C.c_uint16), i64, C.POINTER(i32), C.c_int)
     sig("hfm_read_alpha_tsv", C.c_int, C.c_char_p, pd)
+    # SQUAREM + misc model helpers
+    sig("hfm_scale_initial_means", None, vp, dbl)
+    sig("hfm_squarem_create", vp, vp, vp, vp)
+    sig("hfm_squarem_destroy", None, vp)
+    sig("hfm_squarem_alpha", dbl, vp)
+    sig("hfm_squarem_model_prime", vp, vp)
+    sig("hfm_squarem_shrink", vp, vp)
+    sig("hfm_is_feasible", C.c_int, vp)
+    sig("hfm_set_loglikelihood", None, vp, dbl)
+    # window table / file formats
+    sig("hfio_load", vp, C.c_char_p, C.c_int, C.c_int)
+    sig("hfio_destroy", None, vp)
+    sig("hfio_last_error", C.c_char_p)
+    sig("hfio_n_windows", i64, vp)
+    sig("hfio_n_chunks", i32, vp)
+    sig("hfio_n_regions", i32, vp)
+    sig("hfio_region_coverages", C.POINTER(i32), vp)
+    sig("hfio_window_len", i32, vp)
+    sig("hfio_chunk_len", i32, vp)
+    sig("hfio_avg_alignment_len", i32, vp)
+    sig("hfio_start_only", i32, vp)
+    sig("hfio_n_annotations", i32, vp)
+    sig("hfio_annotation_name", C.c_char_p, vp, C.c_int)
+    sig("hfio_chunk_ctg", C.c_char_p, vp, C.c_int)
+    sig("hfio_truth", C.POINTER(C.c_int8), vp)
+    sig("hfio_prediction", C.POINTER(C.c_int8), vp)
+    sig("hfio_windows", None, vp, C.POINTER(hf_windows))
+    sig("hfio_write_bin", C.c_int, vp, C.c_char_p)
+    sig("hfio_write_final_bed", C.c_int, vp, C.POINTER(C.c_int8), C.c_char_p, C.c_char_p, C.POINTER(i32))
+    sig("hfio_write_posterior_bed", C.c_int, vp, pd, C.POINTER(C.c_int8), C.c_char_p)
     _lib = L
     return L
 

@@ -1,0 +1,341 @@
+// hf_cli.cpp — `hmm_flagger` command line of the MI355X build: same options, inputs and output files as
+// mobinasri/flagger programs/src/hmm_flagger.c (main :611-1077, runHMMFlagger :285-488), with every E-step
+// delegated to the HIP kernels through the C ABI (include/hmm_flagger_hip.h).  No CPU E-step exists here.
+#include "../../include/hmm_flagger_hip.h"
+#include "../../include/hmm_flagger_io.h"
+#include "../../include/hmm_flagger_model.h"
+#include "hf_squarem.h"
+#include <getopt.h>
+#include <sys/resource.h>
+#include <sys/stat.h>
+#include <sys/time.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+static const char* ts() {                                   // common.c:116 get_timestamp
+    static char buf[64];
+    time_t t = time(nullptr);
+    struct tm tmv;
+    localtime_r(&t, &tmv);
+    strftime(buf, sizeof buf, "%Y-%m-%d %H:%M:%S", &tmv);
+    return buf;
+}
+static double real_time() { struct timeval tp; gettimeofday(&tp, nullptr); return tp.tv_sec + tp.tv_usec * 1e-6; }
+static double cpu_time() {
+    struct rusage r; getrusage(RUSAGE_SELF, &r);
+    return r.ru_utime.tv_sec + r.ru_stime.tv_sec + 1e-6 * (r.ru_utime.tv_usec + r.ru_stime.tv_usec);
+}
+static double peak_rss_gb() { struct rusage r; getrusage(RUSAGE_SELF, &r); return r.ru_maxrss * 1024.0 / 1073741824.0; }
+
+static struct option long_options[] = {                    // hmm_flagger.c:578-608
+    {"input", required_argument, nullptr, 'i'}, {"preset", required_argument, nullptr, 'x'},
+    {"iterations", required_argument, nullptr, 'n'}, {"convergenceTol", required_argument, nullptr, 't'},
+    {"disableAdjustContigEnds", no_argument, nullptr, 'e'}, {"minReadFractionAtEnds", required_argument, nullptr, 'f'},
+    {"modelType", required_argument, nullptr, 'm'}, {"maxHighMapqRatio", required_argument, nullptr, 'q'},
+    {"minHighMapqRatio", required_argument, nullptr, 'Q'}, {"chunkLen", required_argument, nullptr, 'C'},
+    {"windowLen", required_argument, nullptr, 'W'}, {"contigsList", required_argument, nullptr, 'c'},
+    {"threads", required_argument, nullptr, '@'}, {"collapsedComps", required_argument, nullptr, 'p'},
+    {"alphaTsv", required_argument, nullptr, 'A'}, {"binArrayFile", required_argument, nullptr, 'a'},
+    {"writeParameterStatsPerIteration", no_argument, nullptr, 'w'},
+    {"writeBenchmarkingStatsPerIteration", no_argument, nullptr, 'k'},
+    {"writePosteriorProbs", no_argument, nullptr, 'P'}, {"outputDir", required_argument, nullptr, 'o'},
+    {"overlapRatioThreshold", required_argument, nullptr, 'v'}, {"labelNames", required_argument, nullptr, 'l'},
+    {"initialRandomDev", required_argument, nullptr, 'D'}, {"trackName", required_argument, nullptr, 'N'},
+    {"dumpBin", no_argument, nullptr, 'B'}, {"accelerate", no_argument, nullptr, 's'},
+    {"minimumLengths", required_argument, nullptr, 'M'},
+    {"device", required_argument, nullptr, 1001},          // additions of this build (not in the reference)
+    {"algo", required_argument, nullptr, 1002},
+    {nullptr, 0, nullptr, 0}};
+
+static void usage(const char* program) {
+    fprintf(stderr, "\nUsage: %s  -i <INPUT_FILE> -o <OUTPUT_DIR> \n", program);
+    fprintf(stderr,
+            "Options (as mobinasri/flagger hmm_flagger v1.2.0):\n"
+            "         --input, -i                  cov / cov.gz / bin input\n"
+            "         --preset, -x                 hifi | ont-r9 | ont-r10 [hifi]\n"
+            "         --outputDir, -o              existing directory for the output files\n"
+            "         --modelType, -m              gaussian | trunc_exp_gaussian [preset]\n"
+            "         --trackName, -N              track name of the final BED [final_hmm_flagger]\n"
+            "         --chunkLen, -C               chunk length in bases [20000000]\n"
+            "         --windowLen, -W              window length in bases [preset]\n"
+            "         --iterations, -n             maximum EM iterations [100]\n"
+            "         --convergenceTol, -t         [0.001]\n"
+            "         --contigsList, -c            file with contig names to keep\n"
+            "         --disableAdjustContigEnds, -e\n"
+            "         --minReadFractionAtEnds, -f  [preset]\n"
+            "         --maxHighMapqRatio, -q       [0.25]     --minHighMapqRatio   [0.75]\n"
+            "         --alphaTsv, -A               4x4 tab-separated alpha matrix [all zero]\n"
+            "         --collapsedComps, -p         components of the collapsed state [auto 2..10]\n"
+            "         --writeParameterStatsPerIteration, -w     --writePosteriorProbs, -P\n"
+            "         --dumpBin, -B                --accelerate, -s (SQUAREM)\n"
+            "         --minimumLengths, -M         Err,Dup,Col minimum lengths [0,0,0]\n"
+            "         --threads, -@                accepted for compatibility (the E-step runs on the GPU)\n"
+            "         --labelNames -l, --binArrayFile -a, --overlapRatioThreshold -v, -k: accepted; the summary tables\n"
+            "                                      (prediction_summary_*.tsv) are not produced by this build yet\n"
+            "         --device                     GPU index [0]        --algo scan|seq [scan]\n");
+}
+
+static bool dir_exists(const char* p) { struct stat sb; return stat(p, &sb) == 0 && S_ISDIR(sb.st_mode); }
+
+static double random_factor(double dev) {                  // hmm_flagger.c:113-116 with (1-dev, 1+dev)
+    if (dev == 0.0) return 1.0;
+    srand((unsigned) time(nullptr));
+    const double start = 1.0 - dev, end = 1.0 + dev;
+    return (double) rand() / (double) (RAND_MAX / (end - start)) + start;
+}
+
+static int die_estep(int rc) {
+    if (rc == HF_E_SCALE) fprintf(stderr, "scale is very low!\n");                 // hmm.c:413
+    else if (rc == HF_E_NAN) fprintf(stderr, "[Error] prob is NAN\n");             // hmm_utils.c:784
+    else fprintf(stderr, "[%s] Error: %s\n", ts(), hf_last_error());
+    return EXIT_FAILURE;
+}
+
+struct Run {
+    hf_ctx* ctx = nullptr;
+    hfio_table* tab = nullptr;
+    std::vector<double> stats;
+    int estep(hfm_model* m, int mode) {
+        hf_params p;
+        hfm_params(m, &p);
+        int rc = hf_estep(ctx, &p, mode, nullptr);
+        if (rc == HF_OK) rc = hf_finish(ctx, stats.data(), nullptr);
+        return rc;
+    }
+};
+
+static void write_params(const hfm_model* m, const std::string& dir, const std::string& suffix) {   // hmm_flagger.c:119-132
+    fprintf(stderr, "[%s] Writing transition tsv...\n", ts());
+    hfm_write_transition_tsv(m, (dir + "/transition_" + suffix + ".tsv").c_str());
+    fprintf(stderr, "[%s] Writing emission tsv ...\n", ts());
+    hfm_write_emission_tsv(m, (dir + "/emission_" + suffix + ".tsv").c_str());
+}
+
+int main(int argc, char* argv[]) {
+    const char* trackName = "final_hmm_flagger";
+    std::string preset = "hifi";
+    const char *inputPath = nullptr, *alphaTsvPath = nullptr, *contigListPath = nullptr, *outputDir = nullptr;
+    int numberOfIterations = 100, numberOfCollapsedComps = -1, chunkLen = 20000000, windowLen = -1, threads = 4;
+    double convergenceTol = 0.001, maxHighMapqRatio = 0.25, minHighMapqRatio = 0.75, minReadFractionAtEnds = -1.0;
+    double initialRandomDeviation = 0.0;
+    bool adjustContigEnds = true, writeParamsPerIter = false, writePosterior = false, dumpBin = false, acceleration = false;
+    int modelType = -1, device = 0, algo = HF_ALGO_SCAN;
+    int32_t minLenPerState[4] = {0, 0, 0, 0};
+    const char* program = strrchr(argv[0], '/');
+    program = program ? program + 1 : argv[0];
+    int c;
+    while (~(c = getopt_long(argc, argv, "i:x:f:en:t:m:q:C:W:c:@:p:A:a:wkPo:v:l:D:BN:M:s", long_options, nullptr))) {
+        switch (c) {
+            case 'i': inputPath = optarg; break;
+            case 'x': preset = optarg; break;
+            case 'n': numberOfIterations = atoi(optarg); break;
+            case 'B': dumpBin = true; break;
+            case 'N': trackName = optarg; break;
+            case 't': convergenceTol = atof(optarg); break;
+            case 'e': adjustContigEnds = false; break;
+            case 'f': minReadFractionAtEnds = atof(optarg); break;
+            case 'm':                                           // hmm_utils.c:18-29
+                if (!strcmp(optarg, "gaussian")) modelType = HF_MODEL_GAUSSIAN;
+                else if (!strcmp(optarg, "trunc_exp_gaussian") || !strcmp(optarg, "truncated_exponential_gaussian"))
+                    modelType = HF_MODEL_TRUNC_EXP_GAUSSIAN;
+                else if (!strcmp(optarg, "nb") || !strcmp(optarg, "negative_binomial")) {
+                    fprintf(stderr, "[%s] Error: the negative_binomial model is not supported by the MI355X build.\n", ts());
+                    return EXIT_FAILURE;
+                } else modelType = -2;
+                break;
+            case 'a': case 'k': case 'l': case 'v': break;      // summary-table options: accepted, unused
+            case 'c': contigListPath = optarg; break;
+            case 'p': numberOfCollapsedComps = atoi(optarg); break;
+            case '@': threads = atoi(optarg); break;
+            case 'A': alphaTsvPath = optarg; break;
+            case 'C': chunkLen = atoi(optarg); break;
+            case 'W': windowLen = atoi(optarg); break;
+            case 'w': writeParamsPerIter = true; break;
+            case 'P': writePosterior = true; break;
+            case 'o': outputDir = optarg; break;
+            case 'D': initialRandomDeviation = atof(optarg); break;
+            case 'q': maxHighMapqRatio = atof(optarg); break;
+            case 'Q': minHighMapqRatio = atof(optarg); break;
+            case 's': acceleration = true; break;
+            case 'M': {                                          // hmm_flagger.c:737-749
+                int a, b, d;
+                if (sscanf(optarg, "%d,%d,%d", &a, &b, &d) != 3 || strchr(strchr(strchr(optarg, ',') + 1, ',') + 1, ',')) {
+                    fprintf(stderr, "[%s] Error: --minimumLengths should contain only 3 tab-delimited positive integers.\n", ts());
+                    return EXIT_FAILURE;
+                }
+                minLenPerState[0] = a; minLenPerState[1] = b; minLenPerState[3] = d;
+                break;
+            }
+            case 1001: device = atoi(optarg); break;
+            case 1002: algo = !strcmp(optarg, "seq") ? HF_ALGO_SEQ : HF_ALGO_SCAN; break;
+            default:
+                if (c != 'h') fprintf(stderr, "[E::%s] undefined option %c\n", __func__, c);
+                usage(program);
+                return 1;
+        }
+    }
+    (void) threads;
+    const double realtimeStart = real_time();
+    if (!inputPath) { fprintf(stderr, "[%s] Error: Input path cannot be NULL.\n", ts()); return EXIT_FAILURE; }
+    if (convergenceTol <= 0.0 || convergenceTol > 1.0) {
+        fprintf(stderr, "[%s] Error: convergence tol = %2.f should be between 0 and 1.\n", ts(), convergenceTol);
+        return EXIT_FAILURE;
+    }
+    if (!outputDir) { fprintf(stderr, "[%s] Error: --outputDir, -o should be specified.\n", ts()); return EXIT_FAILURE; }
+    if (!dir_exists(outputDir)) { fprintf(stderr, "[%s] Error: Output directory %s does not exist!\n", ts(), outputDir); return EXIT_FAILURE; }
+
+    // presets: hmm_flagger.c:17-58, 536-575, 945-956.  The preset alpha arrays are declared `int`, so every
+    // preset alpha is 0: alpha is non-zero only through --alphaTsv (:21,36,50,518-533).
+    int presetW; double presetF;
+    if (preset == "hifi") { presetW = 16000; presetF = 0.95; }
+    else if (preset == "ont-r9") { presetW = 16000; presetF = 1.0; }
+    else if (preset == "ont-r10") { presetW = 8000; presetF = 0.8; }
+    else { fprintf(stderr, "[%s] Error: preset can be one of hifi, ont-r9, ont-r10. It cannot be %s . \n", ts(), preset.c_str()); return EXIT_FAILURE; }
+    double alpha[16] = {0};
+    if (alphaTsvPath) {
+        const int rc = hfm_read_alpha_tsv(alphaTsvPath, alpha);
+        if (rc == -2) { fprintf(stderr, "[%s] Error: There is at least one alpha value in '%s' not between 0 and 1. \n", ts(), alphaTsvPath); return EXIT_FAILURE; }
+        if (rc != 0) { fprintf(stderr, "[%s] Error: cannot read %s\n", ts(), alphaTsvPath); return EXIT_FAILURE; }
+    }
+    if (minReadFractionAtEnds < 0.0 && adjustContigEnds) minReadFractionAtEnds = presetF;
+    if (windowLen < 0) windowLen = presetW;
+    if (modelType == -1) modelType = HF_MODEL_TRUNC_EXP_GAUSSIAN;
+    if (adjustContigEnds && (minReadFractionAtEnds > 1.0 || minReadFractionAtEnds < 0.0)) {
+        fprintf(stderr, "[%s] Error: --minReadFractionAtEnds, -f should be between 0 and 1.\n", ts()); return EXIT_FAILURE;
+    }
+    if (modelType == -2) { fprintf(stderr, "[%s] Error: Model type is not defined. Specify the model type with --model (-m) argument.\n", ts()); return EXIT_FAILURE; }
+    if (windowLen <= 0) { fprintf(stderr, "[%s] Error: windowLen cannot be <= 0.\n", ts()); return EXIT_FAILURE; }
+    if (0.5 < initialRandomDeviation) { fprintf(stderr, "[%s] Error: Initial random deviation for the model parameters cannot be greater than 0.5. \n", ts()); return EXIT_FAILURE; }
+
+    // 1. windows
+    fprintf(stderr, "[%s] Parsing/Creating coverage chunks. \n", ts());
+    Run run;
+    run.tab = hfio_load(inputPath, chunkLen, windowLen);
+    if (!run.tab) { fprintf(stderr, "[%s] %s\n", ts(), hfio_last_error()); return EXIT_FAILURE; }
+    hfio_table* tab = run.tab;
+    if (contigListPath) {
+        fprintf(stderr, "[%s] Error: --contigsList is not supported by the MI355X build yet.\n", ts());
+        return EXIT_FAILURE;
+    }
+    if (dumpBin) {
+        char binPath[2200];
+        snprintf(binPath, sizeof binPath, "%s/chunks.c_%d.w_%d.bin", outputDir, hfio_chunk_len(tab), hfio_window_len(tab));
+        fprintf(stderr, "[%s] Writing bin file into %s . \n", ts(), binPath);
+        if (hfio_write_bin(tab, binPath) != 0) { fprintf(stderr, "[%s] Error: cannot write %s\n", ts(), binPath); return EXIT_FAILURE; }
+    }
+    const int64_t N = hfio_n_windows(tab);
+    fprintf(stderr, "[%s] %d chunks are parsed (%ld windows of %d bases). \n", ts(), hfio_n_chunks(tab), (long) N, hfio_window_len(tab));
+    if (N == 0 || hfio_n_chunks(tab) == 0) { fprintf(stderr, "[%s] Error: no windows in the input.\n", ts()); return EXIT_FAILURE; }
+
+    // 2. number of collapsed components (hmm_flagger.c:1008-1022)
+    hf_windows w;
+    memset(&w, 0, sizeof w);
+    hfio_windows(tab, &w);
+    if (numberOfCollapsedComps == -1) {
+        numberOfCollapsedComps = hfm_best_collapsed_comps(w.cov, N, hfio_region_coverages(tab), hfio_n_regions(tab));
+        if (numberOfCollapsedComps < 0) { fprintf(stderr, "[%s] Error: a region coverage of 0 in the header.\n", ts()); return EXIT_FAILURE; }
+        fprintf(stderr, "[%s] The number of collapsed components (n=%d) is determined and adjusted automatically by taking the maximum observed coverage. \n", ts(), numberOfCollapsedComps);
+    } else {
+        fprintf(stderr, "[%s] The number of components for the 'collapsed' state is set by the program argument %d. \n", ts(), numberOfCollapsedComps);
+    }
+
+    // 3. model (createModel, hmm_flagger.c:164-237)
+    fprintf(stderr, "[%s] Creating HMM model. \n", ts());
+    hfm_model* model = hfm_create(modelType, numberOfCollapsedComps, hfio_region_coverages(tab), hfio_n_regions(tab),
+                                  hfio_start_only(tab), hfio_avg_alignment_len(tab), hfio_window_len(tab), alpha,
+                                  maxHighMapqRatio, minHighMapqRatio);
+    if (!model) { fprintf(stderr, "[%s] Error: cannot create the model (collapsedComps must be 1..%d, regions 1..%d).\n", ts(), HF_MAXCOMP, HF_MAXREGIONS); return EXIT_FAILURE; }
+    if (initialRandomDeviation > 0.0) {                    // hmm_flagger.c:213-220: same factor within one second
+        std::vector<double> pv((size_t) hfm_param_len(model));
+        hfm_get_param_vector(model, pv.data());
+        hfm_scale_initial_means(model, random_factor(initialRandomDeviation));
+    }
+
+    // 4. device context: windows resident in HBM for the whole run
+    w.adjust_contig_ends = adjustContigEnds ? 1 : 0; w.min_read_frac = adjustContigEnds ? minReadFractionAtEnds : 0.0;
+    w.max_high_mapq_ratio = maxHighMapqRatio; w.min_high_mapq_ratio = minHighMapqRatio;
+    w.min_highly_clipped_ratio = hfm_min_highly_clipped_ratio(model);
+    int rc = hf_create(&w, hfio_n_regions(tab), numberOfCollapsedComps, device, algo, &run.ctx);
+    if (rc != HF_OK) { fprintf(stderr, "[%s] Error: %s\n", ts(), hf_last_error()); return EXIT_FAILURE; }
+    run.stats.assign((size_t) hf_chunk_stats_len(run.ctx), 0.0);
+
+    // 5. EM (runHMMFlagger, hmm_flagger.c:285-488)
+    fprintf(stderr, "[%s] Running EM for estimating parameters. \n", ts());
+    const std::string dir(outputDir);
+    FILE* llf = fopen((dir + "/loglikelihood.tsv").c_str(), "w+");
+    if (!llf) { fprintf(stderr, "[%s] Error: cannot write into %s\n", ts(), outputDir); return EXIT_FAILURE; }
+    fprintf(llf, "#Iteration\tEffective_Iteration\tLoglikelihood\n");
+    write_params(model, dir, "initial");
+    int iter = 1;
+    bool converged = false;
+    const int nChunks = hfio_n_chunks(tab);
+    const double emStart = real_time();
+    int passes = 0;
+    while (iter <= numberOfIterations && !converged) {
+        fprintf(stderr, "[%s] [Iteration %s = %d] Running EM jobs for %d chunks (on GPU %d) ...\n", ts(), acceleration ? "accelerated" : "", iter, nChunks, device);
+        if ((rc = run.estep(model, HF_MODE_FULL)) != HF_OK) return die_estep(rc);
+        passes++;
+        fprintf(stderr, "[%s] [Iteration %s = %d] EM jobs are all finished.\n", ts(), acceleration ? "accelerated" : "", iter);
+        fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, acceleration ? 3 * (iter - 1) : iter - 1, run.stats[0]);
+        if (acceleration) {                                  // hmm_flagger.c:382-416
+            fprintf(stderr, "[%s] [Iteration accelerated = %d] Running SQUAREM acceleration.\n", ts(), iter);
+            auto estep_cb = [&](hfm_model* m, int mode, double* st) -> int {
+                hf_params p; hfm_params(m, &p);
+                int r = hf_estep(run.ctx, &p, mode, nullptr);
+                if (r == HF_OK) r = hf_finish(run.ctx, st, nullptr);
+                return r;
+            };
+            rc = squarem_iteration(&model, run.stats, convergenceTol, estep_cb, &passes);
+            if (rc != HF_OK) return die_estep(rc);
+            fprintf(stderr, "[%s] [Iteration accelerated = %d] Finished SQUAREM acceleration.\n", ts(), iter);
+        }
+        converged = hfm_estimate(model, run.stats.data(), convergenceTol) != 0;
+        fprintf(stderr, "[%s] [Iteration %s = %d] Parameters are estimated and updated.\n", ts(), acceleration ? "accelerated" : "", iter);
+        if (writeParamsPerIter) {
+            char suffix[64];
+            snprintf(suffix, sizeof suffix, acceleration ? "iteration_accelerated_%d" : "iteration_%d", iter);
+            write_params(model, dir, suffix);
+        }
+        iter += 1;
+    }
+    if (converged) fprintf(stderr, "[%s] Parameters converged after %d iterations (tol=%.2e)\n", ts(), iter - 1, convergenceTol);
+    else fprintf(stderr, "[%s] Parameter estimation stopped (not yet converged based on the given tolerance) after %d iterations (tol=%.2e)\n", ts(), iter - 1, convergenceTol);
+    fprintf(stderr, "[%s] [Final Inference] Running EM jobs for %d chunks (on GPU %d) ...\n", ts(), nChunks, device);
+    if ((rc = run.estep(model, HF_MODE_FULL)) != HF_OK) return die_estep(rc);
+    passes++;
+    const double emTime = real_time() - emStart;
+    fprintf(stderr, "[%s] [Final Inference] EM jobs are all finished.\n", ts());
+    fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, acceleration ? 3 * (iter - 1) : iter - 1, run.stats[0]);
+    fclose(llf);
+    write_params(model, dir, "final");
+    std::vector<int8_t> labels((size_t) N);
+    if ((rc = hf_get_labels(run.ctx, labels.data())) != HF_OK) return die_estep(rc);
+    memcpy(hfio_prediction(tab), labels.data(), (size_t) N);
+    if (writePosterior) {
+        std::vector<double> post((size_t) N * 4);
+        if ((rc = hf_get_posterior(run.ctx, 0, N, post.data())) != HF_OK) return die_estep(rc);
+        const std::string pp = dir + "/posterior_prediction_final.bed";
+        fprintf(stderr, "[%s] Writing posterior bed : %s\n", ts(), pp.c_str());
+        hfio_write_posterior_bed(tab, post.data(), labels.data(), pp.c_str());
+    }
+    // 6. final BED
+    fprintf(stderr, "[%s] Writing final BED file. \n", ts());
+    if (hfio_write_final_bed(tab, labels.data(), (dir + "/final_flagger_prediction.bed").c_str(), trackName, minLenPerState) != 0) {
+        fprintf(stderr, "[%s] Error: %s/final_flagger_prediction.bed cannot be opened.\n", ts(), outputDir);
+        return EXIT_FAILURE;
+    }
+    fprintf(stderr, "[%s] EM+decode: %d passes over %ld windows in %.4f s = %.3e windows/s on GPU %d\n", ts(), passes, (long) N, emTime,
+            (double) N * passes / emTime, device);
+    hf_destroy(run.ctx);
+    hfm_destroy(model);
+    hfio_destroy(tab);
+    fprintf(stderr, "[%s] Done! \n", ts());
+    const double realtime = real_time() - realtimeStart, cputime = cpu_time();
+    fprintf(stderr, "Real time:  %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB; CPU usage: %.1f%%\n", realtime, cputime,
+            peak_rss_gb(), (cputime + 1e-9) / (realtime + 1e-9) * 100.0);
+    return 0;
+}

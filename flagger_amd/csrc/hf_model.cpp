@@ -271,6 +271,40 @@ void hfm_set_param_vector(hfm_model* m, const double* in) {
     }
 }
 
+void hfm_set_loglikelihood(hfm_model* m, double ll) { m->loglik = ll; }
+
+void hfm_scale_initial_means(hfm_model* m, double f) {
+    for (int r = 0; r < m->R; r++) {
+        for (int s = 0; s < S; s++)
+            for (int c = 0; c < m->ncomp[s]; c++) {
+                const double g = s == 3 ? f * f : f;
+                m->M(r, s, c) *= g;
+                m->Vr(r, s, c) = m->M(r, s, c) * 1.0;
+            }
+        m->trunc[r] = m->M(r, 2, 0) * kTruncFraction;
+    }
+}
+
+// hmm.c:80-87 HMM_isFeasible (hmm_utils.c:685-694, 920-925, 2130-2139)
+int hfm_is_feasible(const hfm_model* mc) {
+    hfm_model* m = const_cast<hfm_model*>(mc);
+    bool ok = true;
+    for (int r = 0; r < m->R; r++) {
+        for (int s = 0; s < S; s++) {
+            if (!m->gaussian_state(s)) { ok &= 0 < m->lambda[r]; ok &= 0 < m->trunc[r]; continue; }
+            for (int c = 0; c < m->ncomp[s]; c++) {
+                ok &= 0 < m->M(r, s, c);
+                ok &= 0 < m->Vr(r, s, c);
+                ok &= (0 <= m->W(r, s, c)) && (m->W(r, s, c) <= 1);
+            }
+        }
+        for (int i = 0; i < S; i++)
+            for (int j = 0; j < S; j++)
+                if (m->T(r, i, j) < 0 || 1 < m->T(r, i, j)) return 0;
+    }
+    return ok ? 1 : 0;
+}
+
 // hmm_flagger.c:105-111 + 1012-1013
 int hfm_best_collapsed_comps(const uint16_t* cov, int64_t n, const int32_t* region_coverages, int n_regions) {
     int maxc = 0;
@@ -301,6 +335,92 @@ int hfm_read_alpha_tsv(const char* path, double* alpha16) {
     std::fclose(f);
     for (int k = 0; k < 16; k++) if (1.0 < alpha16[k] || alpha16[k] < 0.0) return -2;
     return 0;
+}
+
+
+} // extern "C"
+
+// ---- SQUAREM (hmm.c:820-1098).  Parameters are visited in the reference's iterator order: per region, per
+// state, per component, per parameter (mean, var, weight | lambda), then the 4x4 transition block. ----
+struct hfm_squarem {
+    hfm_model m0, prime, rates_r, rates_v;
+    double alpha = 0.0;
+    hfm_squarem(const hfm_model& a) : m0(a), prime(a), rates_r(a), rates_v(a) {}
+    template <class F> static void for_each_param(hfm_model& m, F f) {   // f(double& slot, int region)
+        for (int r = 0; r < m.R; r++) {
+            for (int s = 0; s < S; s++) {
+                if (!m.gaussian_state(s)) { f(m.lambda[r], 0); continue; }   // trunc point is not iterated (:1132-1134)
+                for (int c = 0; c < m.ncomp[s]; c++) { f(m.M(r, s, c), 0); f(m.Vr(r, s, c), 0); f(m.W(r, s, c), 0); }
+            }
+            for (int i = 0; i < S; i++) for (int j = 0; j < S; j++) f(m.T(r, i, j), 1);
+        }
+    }
+    static std::vector<double*> slots(hfm_model& m) {
+        std::vector<double*> v;
+        for_each_param(m, [&](double& x, int) { v.push_back(&x); });
+        return v;
+    }
+    void compute_values() {                                              // hmm.c:921-997
+        auto p0 = slots(m0), pp = slots(prime), pr = slots(rates_r), pv = slots(rates_v);
+        for (size_t i = 0; i < p0.size(); i++)
+            *pp[i] = *p0[i] - 2 * *pr[i] * alpha + *pv[i] * std::pow(alpha, 2);
+        for (int r = 0; r < prime.R; r++) {                              // HMM_normalizeWeightsAndTransitionRows, hmm.c:89-94
+            for (int s = 0; s < S; s++) {
+                if (!prime.gaussian_state(s)) continue;
+                double sum = 0.0;
+                for (int c = 0; c < prime.ncomp[s]; c++) sum += prime.W(r, s, c);
+                if (0.0 < sum) { const double k = 1.0 / sum; for (int c = 0; c < prime.ncomp[s]; c++) prime.W(r, s, c) *= k; }
+            }
+            for (int i = 0; i < S; i++) {                                // hmm_utils.c:2165-2183
+                double row = 0.0;
+                for (int j = 0; j < S; j++) row += prime.T(r, i, j);
+                for (int j = 0; j < S; j++) prime.T(r, i, j) = prime.T(r, i, j) / row * (1.0 - kTermination);
+            }
+            for (int i = 0; i < S; i++) prime.T(r, i, S) = kTermination;
+            prime.T(r, S, S) = 0.0;
+        }
+    }
+    hfm_model* shrink_once(double margin) {                              // hmm.c:871-884
+        alpha = (alpha - 1) / 2;
+        if (alpha > (-1 - margin)) { alpha = -1.0; prime = m0; return &prime; }
+        compute_values();
+        return &prime;
+    }
+};
+
+extern "C" {
+
+hfm_squarem* hfm_squarem_create(const hfm_model* m0, const hfm_model* m1c, const hfm_model* m2c) {
+    hfm_squarem* a = new hfm_squarem(*m0);
+    hfm_model m1(*m1c), m2(*m2c);
+    auto p0 = hfm_squarem::slots(a->m0), p1 = hfm_squarem::slots(m1), p2 = hfm_squarem::slots(m2);
+    auto pr = hfm_squarem::slots(a->rates_r), pv = hfm_squarem::slots(a->rates_v);
+    double num = 0.0, den = 0.0;                                         // hmm.c:999-1098
+    for (size_t i = 0; i < p0.size(); i++) {
+        const double r = *p1[i] - *p0[i];
+        const double v = *p2[i] - *p1[i] - r;
+        num += std::pow(r, 2);
+        den += std::pow(v, 2);
+        *pr[i] = r; *pv[i] = v;
+    }
+    a->alpha = -1 * std::sqrt(num / den);
+    if (a->alpha > -1) a->alpha = -1;
+    return a;
+}
+void hfm_squarem_destroy(hfm_squarem* a) { delete a; }
+double hfm_squarem_alpha(const hfm_squarem* a) { return a->alpha; }
+
+hfm_model* hfm_squarem_model_prime(hfm_squarem* a) {
+    a->compute_values();
+    hfm_model* p = &a->prime;
+    while (!hfm_is_feasible(p)) p = a->shrink_once(1e-2);
+    return p;
+}
+
+hfm_model* hfm_squarem_shrink(hfm_squarem* a) {
+    hfm_model* p = a->shrink_once(1e-2);
+    while (!hfm_is_feasible(p)) p = a->shrink_once(1e-2);
+    return p;
 }
 
 } // extern "C"

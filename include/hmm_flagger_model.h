@@ -57,6 +57,23 @@ int64_t hfm_param_len(const hfm_model *m);
 void hfm_get_param_vector(const hfm_model *m, double *out);
 void hfm_set_param_vector(hfm_model *m, const double *in);
 
+/* --initialRandomDev (hmm_flagger.c:213-220): every initial mean is multiplied by the same random factor
+ * (the reference reseeds with time(NULL) at every draw), the collapsed means twice. */
+void hfm_scale_initial_means(hfm_model *m, double factor);
+
+/* SQUAREM acceleration (--accelerate): SquareAccelerator_*, submodules/hmm/hmm.c:820-1098.
+ * m0 = parameters the last E-step ran with (with its log-likelihood), m1/m2 = after one/two EM updates. */
+typedef struct hfm_squarem hfm_squarem;
+hfm_squarem *hfm_squarem_create(const hfm_model *m0, const hfm_model *m1, const hfm_model *m2);   /* computeRates :999 */
+void hfm_squarem_destroy(hfm_squarem *a);
+double hfm_squarem_alpha(const hfm_squarem *a);
+/* model prime for the current alpha rate, shrinking alpha until it is feasible (:892-897); owned by `a` */
+hfm_model *hfm_squarem_model_prime(hfm_squarem *a);
+/* shrink alpha once and again until feasible (:907-910); owned by `a` */
+hfm_model *hfm_squarem_shrink(hfm_squarem *a);
+int hfm_is_feasible(const hfm_model *m);                                                            /* hmm.c:80-87 */
+void hfm_set_loglikelihood(hfm_model *m, double ll);
+
 int hfm_best_collapsed_comps(const uint16_t *cov, int64_t n_windows, const int32_t *region_coverages, int n_regions);
 int hfm_read_alpha_tsv(const char *path, double *alpha16);
 

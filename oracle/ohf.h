@@ -146,7 +146,9 @@ typedef struct {
     double tol;
     bool write_params_per_iter, write_posterior;
     const char *out_dir;           /* may be NULL: no files */
+    bool accelerate;               /* --accelerate (SQUAREM), hmm_flagger.c:382-416 */
 } ohf_em_opts;
+int ohf_squarem_iteration(ohf_chunks *cc, ohf_model *m, const ohf_run_opts *o, double tol, double *alpha_out);
 /* returns number of E-passes executed (I+1) or <0 */
 int ohf_run_em(ohf_chunks *cc, ohf_model *m, const ohf_run_opts *o, const ohf_em_opts *eo,
                double *ll_trace, int ll_cap);

@@ -24,6 +24,7 @@ static struct option long_options[] = { /* hmm_flagger.c:578-608 */
     {"writeParameterStatsPerIteration", no_argument, NULL, 'w'}, {"writePosteriorProbs", no_argument, NULL, 'P'},
     {"outputDir", required_argument, NULL, 'o'}, {"trackName", required_argument, NULL, 'N'},
     {"dumpBin", no_argument, NULL, 'B'}, {"minimumLengths", required_argument, NULL, 'M'},
+    {"accelerate", no_argument, NULL, 's'},
     {NULL, 0, NULL, 0}};
 
 static const char *file_ext(const char *p) { /* common.c:51-66 */
@@ -41,10 +42,10 @@ int main(int argc, char **argv) {
     const char *trackName = "final_hmm_flagger", *preset = "hifi", *inputPath = NULL, *alphaTsv = NULL, *outDir = NULL;
     int iterations = 100, collapsed = -1, chunkLen = 20000000, windowLen = -1, threads = 4, modelType = -1;
     double tol = 0.001, maxHighMapq = 0.25, minHighMapq = 0.75, minReadFrac = -1.0;
-    bool adjust = true, wparams = false, wpost = false, dumpBin = false;
+    bool adjust = true, wparams = false, wpost = false, dumpBin = false, accel = false;
     int minLen[4] = {0, 0, 0, 0};
     int c;
-    while (~(c = getopt_long(argc, argv, "i:x:f:en:t:m:q:Q:C:W:@:p:A:wPo:BN:M:", long_options, NULL))) {
+    while (~(c = getopt_long(argc, argv, "i:x:f:en:t:m:q:Q:C:W:@:p:A:wPo:BN:M:s", long_options, NULL))) {
         switch (c) {
             case 'i': inputPath = optarg; break;
             case 'x': preset = optarg; break;
@@ -69,6 +70,7 @@ int main(int argc, char **argv) {
             case 'P': wpost = true; break;
             case 'o': outDir = optarg; break;
             case 'B': dumpBin = true; break;
+            case 's': accel = true; break;
             case 'N': trackName = optarg; break;
             case 'M': {
                 int a, b, d;
@@ -110,7 +112,7 @@ int main(int argc, char **argv) {
                                     cc->avg_alignment_len, cc->window_len, alpha, maxHighMapq, minHighMapq);
     if (!m) { fprintf(stderr, "oracle: cannot create model\n"); return 1; }
     ohf_run_opts o = { adjust, minReadFrac, cc->avg_alignment_len, threads };
-    ohf_em_opts eo = { iterations, tol, wparams, wpost, outDir };
+    ohf_em_opts eo = { iterations, tol, wparams, wpost, outDir, accel };
     double t0 = now();
     int passes = ohf_run_em(cc, m, &o, &eo, NULL, 0);
     double t1 = now();

@@ -37,14 +37,18 @@ int ohf_run_em(ohf_chunks *cc, ohf_model *m, const ohf_run_opts *o, const ohf_em
         if (st) break;
         cc->prediction_available = true;                   /* :353-354 */
         cc->n_labels = 4;
-        if (llf) fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, iter - 1, m->loglikelihood); /* :357 */
+        if (llf) fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, eo->accelerate ? 3 * (iter - 1) : iter - 1, m->loglikelihood); /* :357 */
         if (ll_trace && passes < ll_cap) ll_trace[passes] = m->loglikelihood;
         passes++;
+        if (eo->accelerate) {                              /* :382-416 */
+            st = ohf_squarem_iteration(cc, m, o, eo->tol, NULL);
+            if (st) break;
+        }
         converged = ohf_estimate_parameters(m, eo->tol);   /* :419 */
         ohf_reset_estimators(m);                           /* :425 */
         if (eo->write_params_per_iter && eo->out_dir) {    /* :431-443 */
             char suffix[64];
-            snprintf(suffix, sizeof(suffix), "iteration_%d", iter);
+            snprintf(suffix, sizeof(suffix), eo->accelerate ? "iteration_accelerated_%d" : "iteration_%d", iter);
             write_params(m, eo->out_dir, suffix);
         }
         iter += 1;
@@ -54,7 +58,7 @@ int ohf_run_em(ohf_chunks *cc, ohf_model *m, const ohf_run_opts *o, const ohf_em
         cc->prediction_available = true;
         cc->n_labels = 4;
         if (!st) {
-            if (llf) fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, iter - 1, m->loglikelihood); /* :467 */
+            if (llf) fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, eo->accelerate ? 3 * (iter - 1) : iter - 1, m->loglikelihood); /* :467 */
             if (ll_trace && passes < ll_cap) ll_trace[passes] = m->loglikelihood;
             passes++;
             if (eo->out_dir) {

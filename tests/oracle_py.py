@@ -54,7 +54,7 @@ class ORunOpts(C.Structure):
 
 class OEmOpts(C.Structure):
     _fields_ = [("iterations", C.c_int), ("tol", C.c_double), ("write_params_per_iter", C.c_bool),
-                ("write_posterior", C.c_bool), ("out_dir", C.c_char_p)]
+                ("write_posterior", C.c_bool), ("out_dir", C.c_char_p), ("accelerate", C.c_bool)]
 
 
 _lib = None
@@ -218,9 +218,10 @@ class Oracle:
     def estimate_parameters(self, tol: float) -> bool:
         return bool(self.L.ohf_estimate_parameters(self.m, tol))
 
-    def run_em(self, iterations: int, tol: float, out_dir=None, write_params=False, write_posterior=False):
+    def run_em(self, iterations: int, tol: float, out_dir=None, write_params=False, write_posterior=False,
+               accelerate=False):
         ll = (C.c_double * (iterations + 2))()
-        eo = OEmOpts(iterations, tol, write_params, write_posterior, out_dir.encode() if out_dir else None)
+        eo = OEmOpts(iterations, tol, write_params, write_posterior, out_dir.encode() if out_dir else None, accelerate)
         passes = self.L.ohf_run_em(self.cc, self.m, C.byref(self.opts), C.byref(eo), ll, iterations + 2)
         assert passes > 0, f"oracle EM failed: {passes}"
         return list(ll[:passes])

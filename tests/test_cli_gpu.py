@@ -1,0 +1,92 @@
+"""Drop-in check of the `hmm_flagger` command line of this build (flagger_amd/csrc/hmm_flagger, HIP E-step)
+against the committed golden outputs and against the oracle command line on the same inputs:
+identical final_flagger_prediction.bed, loglikelihood.tsv, emission/transition TSVs, posterior BED, .bin dump."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from flagger_amd import synth
+from test_oracle_cpu import GOLD, ROOT
+
+pytestmark = pytest.mark.gpu
+
+CLI = os.path.join(ROOT, "flagger_amd", "csrc", "hmm_flagger")
+ORACLE = os.path.join(ROOT, "oracle", "hf_oracle")
+ALPHA = os.path.join(GOLD, "alpha_hifi.tsv")
+
+
+def _run(exe, args, out):
+    out.mkdir(exist_ok=True)
+    r = subprocess.run([exe] + args + ["-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r
+
+
+def _same_files(a, b, names):
+    for n in names:
+        assert (a / n).read_text() == (b / n).read_text(), n
+
+
+OUTPUTS = ["final_flagger_prediction.bed", "loglikelihood.tsv", "emission_initial.tsv", "emission_final.tsv",
+           "transition_initial.tsv", "transition_final.tsv"]
+
+
+@pytest.mark.parametrize("name,args", [
+    ("cfg1", ["-n", "0", "-W", "4000", "-A", ALPHA]),                       # BASELINE configs[1]: fixed-parameter decode
+    ("small_em", ["-n", "8", "-W", "2000", "-A", ALPHA, "-x", "ont-r10"]),
+])
+def test_cli_reproduces_committed_golden_outputs(name, args, tmp_path):
+    _run(CLI, ["-i", os.path.join(GOLD, f"{name}.bin")] + args, tmp_path / "o")
+    exp = os.path.join(GOLD, f"{name}_expected")
+    for f in sorted(os.listdir(exp)):
+        assert open(os.path.join(exp, f)).read() == (tmp_path / "o" / f).read_text(), f
+
+
+@pytest.mark.parametrize("extra", [[], ["--accelerate"], ["--algo", "seq"]], ids=["em", "squarem", "seq"])
+def test_cli_on_simulated_cov_gz_matches_oracle_cli(extra, tmp_path):
+    """configs[0]: the docs/hmm_test recipe on the .cov.gz written by the reference's simulator."""
+    cov = os.path.join(GOLD, "sim_gaussian_30k.cov.gz")
+    common = ["-i", cov, "--modelType", "gaussian", "--chunkLen", "1000", "--windowLen", "1", "--collapsedComps", "4",
+              "--convergenceTol", "1e-4", "--minHighMapqRatio", "0", "-e", "-n", "25", "--trackName", "gaussian_30k",
+              "--writePosteriorProbs", "--dumpBin", "-w"]
+    oextra = [x for x in extra if x not in ("--algo", "seq")]
+    _run(CLI, common + extra, tmp_path / "gpu")
+    _run(ORACLE, common + oextra, tmp_path / "cpu")
+    names = OUTPUTS + ["posterior_prediction_final.bed", "chunks.c_1000.w_1.bin"]
+    suffix = "iteration_accelerated_3" if "--accelerate" in extra else "iteration_3"
+    names += [f"emission_{suffix}.tsv", f"transition_{suffix}.tsv"]
+    for n in names:
+        a, b = (tmp_path / "gpu" / n).read_bytes(), (tmp_path / "cpu" / n).read_bytes()
+        assert a == b, n
+    assert (tmp_path / "gpu" / "final_flagger_prediction.bed").read_text().startswith("track name=gaussian_30k ")
+
+
+def test_cli_diploid_em_with_minimum_lengths(tmp_path):
+    store = synth.config(2, scale=0.01)
+    binp = tmp_path / "d.bin"
+    store.write_bin(str(binp))
+    args = ["-i", str(binp), "-n", "6", "-A", ALPHA, "--minimumLengths", "8000,12000,8000"]
+    _run(CLI, args, tmp_path / "gpu")
+    _run(ORACLE, args, tmp_path / "cpu")
+    _same_files(tmp_path / "gpu", tmp_path / "cpu", OUTPUTS)
+
+
+def test_cli_argument_errors(tmp_path):
+    binp = os.path.join(GOLD, "cfg1.bin")
+    r = subprocess.run([CLI, "-i", binp, "-o", str(tmp_path / "missing")], capture_output=True, text=True)
+    assert r.returncode != 0 and "does not exist" in r.stderr
+    r = subprocess.run([CLI, "-o", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode != 0 and "Input path cannot be NULL" in r.stderr
+    r = subprocess.run([CLI, "-i", str(tmp_path / "x.txt"), "-o", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode != 0
+    r = subprocess.run([CLI, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage:" in r.stderr
+    # GNU long-option prefix matching, relied upon by the WDL (--alpha, hmm_flagger.wdl:52)
+    (tmp_path / "o").mkdir()
+    r = subprocess.run([CLI, "--input", binp, "--output", str(tmp_path / "o"), "--alpha", ALPHA, "--iter", "0", "--window", "4000"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    assert (tmp_path / "o" / "final_flagger_prediction.bed").read_text() == open(
+        os.path.join(GOLD, "cfg1_expected", "final_flagger_prediction.bed")).read()

@@ -1,0 +1,119 @@
+"""Host loader / writers (include/hmm_flagger_io.h) on CPU: the reference's own known answers for window
+averaging, the oracle's loader and writers as cross-checks, `.bin` round trips."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from flagger_amd import io as fio
+from flagger_amd import synth
+from oracle_py import Oracle
+from test_oracle_cpu import GOLD, _oracle_load_cov, check_chunks_creator_expectations
+
+
+def _same_store(a, b):
+    for f in ("cov", "mapq", "clip", "annot", "truth", "prediction", "chunk_off", "chunk_s", "chunk_e", "chunk_ctg_len"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert a.chunk_ctg == b.chunk_ctg and a.region_coverages == b.region_coverages
+    assert (a.window_len, a.chunk_len, a.avg_alignment_len, a.start_only) == (b.window_len, b.chunk_len, b.avg_alignment_len, b.start_only)
+    assert list(a.annotation_names) == list(b.annotation_names)
+
+
+@pytest.mark.parametrize("fname,labels", [("chunks_creator_test_1.cov", False), ("chunks_creator_test_1.cov.gz", False),
+                                          ("chunks_creator_test_1_with_labels.cov", True)])
+def test_loader_reference_known_answers(fname, labels, tmp_path):
+    """programs/tests/test_chunks_creator.c:12-29,126-133 on its own data files."""
+    p = tmp_path / fname.replace("chunks_creator_", "")
+    shutil.copy(os.path.join(GOLD, fname), p)
+    t = fio.Table(str(p), 40, 20)
+    store = t.store()
+    assert store.region_coverages == [5, 10] and store.n_chunks == 3
+    check_chunks_creator_expectations(store, labels)
+    _same_store(store, _oracle_load_cov(str(p), 40, 20, tmp_path))
+    # chunkLen 20 reproduces the chunk list of the reference's committed index file (test_1.cov.gz.index)
+    s20 = fio.Table(str(p), 20, 20).store()
+    assert [(c, int(s), int(e)) for c, s, e in zip(s20.chunk_ctg, s20.chunk_s, s20.chunk_e)] == [
+        ("ctg1", 0, 19), ("ctg1", 20, 39), ("ctg1", 40, 59), ("ctg1", 60, 79), ("ctg1", 80, 109), ("ctg2", 0, 9)]
+
+
+def test_loader_matches_oracle_on_simulated_cov(tmp_path):
+    p = os.path.join(GOLD, "sim_gaussian_30k.cov.gz")
+    for chunk_len, window_len in [(1000, 1), (7000, 13), (50_000, 400)]:
+        mine = fio.Table(p, chunk_len, window_len).store()
+        _same_store(mine, _oracle_load_cov(p, chunk_len, window_len, tmp_path))
+    twin = synth.WindowStore.read_bin(os.path.join(GOLD, "sim_gaussian_30k.bin"))
+    _same_store(fio.Table(p, 1000, 1).store(), twin)
+
+
+def test_loader_run_lengths_fractions_and_start_only(tmp_path):
+    """Run-length rows with non-integer values must reproduce the reference's per-base accumulation exactly
+    (the oracle loops per base); start-only mode rescales partial windows (chunk.c:398-403)."""
+    rng = np.random.default_rng(4)
+    for start_only in (False, True):
+        lines = ["#annotation:len:2", "#annotation:name:0:no_annotation", "#annotation:name:1:whole_genome",
+                 "#region:len:2", "#region:coverage:0:20", "#region:coverage:1:31", "#label:len:4", "#truth:true",
+                 "#avg_alignment_len:12000", f"#start-only:{'true' if start_only else 'false'}"]
+        for ci, L in enumerate([5003, 777, 20011]):
+            lines.append(f">c{ci} {L}")
+            pos = 1
+            while pos <= L:
+                run = int(min(L - pos + 1, rng.integers(1, 400)))
+                cov = rng.choice([rng.integers(0, 300), round(float(rng.uniform(0, 60)), 2), 0.1, 1e-3])
+                lines.append(f"{pos}\t{pos + run - 1}\t{cov}\t{round(float(rng.uniform(0, 30)), 1)}\t{int(rng.integers(0, 9))}\t"
+                             f"{rng.choice(['0', '1', '1,2'])}\t{int(rng.integers(0, 2))}\t{int(rng.integers(-1, 4))}")
+                pos += run
+        p = tmp_path / f"so{int(start_only)}.cov"
+        p.write_text("\n".join(lines) + "\n")
+        for chunk_len, window_len in [(2000, 50), (100_000, 7), (3000, 3000)]:
+            _same_store(fio.Table(str(p), chunk_len, window_len).store(), _oracle_load_cov(str(p), chunk_len, window_len, tmp_path))
+
+
+def test_bin_round_trip_and_header(tmp_path):
+    store = synth.config(4, scale=0.003)
+    p1, p2 = tmp_path / "a.bin", tmp_path / "b.bin"
+    store.write_bin(str(p1))
+    t = fio.Table(str(p1))
+    _same_store(t.store(), store)
+    t.write_bin(str(p2))
+    assert p1.read_bytes() == p2.read_bytes()
+
+
+def test_loader_errors(tmp_path):
+    with pytest.raises(OSError):
+        fio.Table(str(tmp_path / "missing.cov"))
+    with pytest.raises(OSError):
+        fio.Table(str(tmp_path / "x.txt"))
+    bad = tmp_path / "bad.cov"
+    bad.write_text("#annotation:len:1\n>c 10\n1\t10\t3\t3\t0\t0\t0\n")     # no #region:len
+    with pytest.raises(OSError):
+        fio.Table(str(bad))
+    gap = tmp_path / "gap.cov"
+    gap.write_text("#annotation:len:1\n#region:len:1\n#region:coverage:0:20\n>c 10\n1\t4\t3\t3\t0\t0\t0\n6\t10\t3\t3\t0\t0\t0\n")
+    with pytest.raises(OSError):
+        fio.Table(str(gap))
+
+
+@pytest.mark.parametrize("min_len", [(0, 0, 0, 0), (2000, 0, 0, 0), (5000, 9000, 0, 3000)])
+def test_final_bed_and_posterior_bed_match_oracle_writers(min_len, tmp_path):
+    store = synth.synthesize([400_000, 90_500, 12_000], 1000, 150_000, [20], seed=6)
+    rng = np.random.default_rng(1)
+    # label runs of random lengths, including -1 (unknown)
+    lab = np.repeat(rng.integers(-1, 4, size=200), rng.integers(1, 9, size=200))[:store.n_windows].astype(np.int8)
+    assert lab.size == store.n_windows
+    binp = tmp_path / "s.bin"
+    store.write_bin(str(binp))
+    t = fio.Table(str(binp))
+    mine = tmp_path / "mine.bed"
+    t.write_final_bed(lab, str(mine), "trk", min_len)
+    orc = Oracle(store, 0, 3, None)
+    off = 0
+    for c in range(orc.cc.contents.n_chunks):
+        ch = orc.cc.contents.chunks[c]
+        for i in range(ch.n):
+            ch.prediction[i] = int(lab[off + i])
+        off += ch.n
+    theirs = tmp_path / "oracle.bed"
+    orc.write_final_bed(str(theirs), "trk", min_len)
+    assert mine.read_text() == theirs.read_text()
+    orc.close()
