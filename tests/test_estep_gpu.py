@@ -162,18 +162,72 @@ def test_full_em_against_oracle(algo, tmp_path):
 
 
 def test_scale_underflow_is_reported():
-    """The reference exits with 'scale ... is very low!' (hmm.c:412-415); the ABI returns HF_E_SCALE."""
+    """The reference exits with 'scale ... is very low!' (hmm.c:412-415); the ABI returns HF_E_SCALE.
+    Emissions are floored at 1e-40, so the scale only underflows through the transition matrix: put almost all
+    mass on Err and feed a window above the trunc point (Err emission exactly 0)."""
     store = synth.synthesize([400_000], 1000, 1_000_000, [20], seed=2)
-    store.cov[100:110] = 250          # far outside every component of a 1-comp model with tiny variance
-    store.mapq[:] = 0                 # Col invalid everywhere (ratio 0 < 0.75) => only floors remain
-    model = hmm.createModel(hmm.MODEL_GAUSSIAN, 1, store, np.zeros((4, 4)))
+    store.cov[100:104] = 250
+    for algo in (N.HF_ALGO_SEQ, N.HF_ALGO_SCAN):
+        model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 2, store, np.zeros((4, 4)))
+        v = model.param_vector().reshape(1, -1)
+        t = v[0, :25].reshape(5, 5)
+        t[:4, :4] = 1e-30
+        t[:4, 0] = 1.0 - 1e-4
+        model.set_param_vector(v.ravel())
+        em = hmm.EMList(store, model, algo=algo)
+        orc = Oracle(store, 0, 2, np.zeros((4, 4)))
+        orc.set_param_vector(model.param_vector())
+        assert orc.run_iteration() == -1
+        with pytest.raises(N.HFError) as ei:
+            hmm.EM_runOneIterationForList(em, model)
+        assert ei.value.code == N.HF_E_SCALE
+        em.close()
+        orc.close()
+
+
+def test_full_size_cfg2_one_pass_and_invariants():
+    """BASELINE configs[2] at full size (1.5 M windows, 286 chunks): one E-pass against the oracle plus
+    size-independent properties of the scaled forward-backward."""
+    store = synth.config(2)
+    assert 1_400_000 < store.n_windows < 1_700_000 and 250 < store.n_chunks < 330
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
     em = hmm.EMList(store, model)
-    orc = Oracle(store, 1, 1, np.zeros((4, 4)))
-    ost = orc.run_iteration()
-    if ost == 0:
-        pytest.skip("input did not underflow in the oracle")
-    with pytest.raises(N.HFError) as ei:
-        hmm.EM_runOneIterationForList(em, model)
-    assert ei.value.code == N.HF_E_SCALE and ost == -1
+    # one M-step first so the pass runs with non-trivial parameters
+    hmm.EM_runOneIterationForList(em, model)
+    hmm.HMM_estimateParameters(model, 1e-3)
+    hmm.EM_runOneIterationForList(em, model)
+    got = model.estimators.copy()
+    lab = em.labels()
+    orc = Oracle(store, 0, K, synth.HIFI_ALPHA, threads=16)
+    orc.set_param_vector(model.param_vector())
+    assert orc.run_iteration() == 0
+    ref = orc.stats_vector(K)
+    assert abs(got[0] - ref[0]) <= LL_RTOL * abs(ref[0])
+    scale = np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+    assert np.all(np.abs(got - ref) <= STAT_RTOL * scale)
+    olab = orc.labels()
+    assert np.array_equal(lab, olab), f"{np.count_nonzero(lab != olab)} label mismatches of {lab.size}"
+    # invariants: every pair (i, i+1), i = 1..T-2 contributes total xi mass 1 (after / terminationProb)
+    T = np.diff(store.chunk_off)
+    pairs = np.maximum(T - 2, 0).sum()
+    base, st = 1, N.region_stride(K)
+    trans = got[base + 24 * K: base + 24 * K + 16]
+    assert abs(trans.sum() - pairs) <= 1e-7 * pairs
+    # estimator identities of the reference: mean.den == var.den == weight.num; weight.den equal for all comps
+    for s in (1, 2, 3):
+        nc = K if s == 3 else 1
+        md = got[base + ((s * 3 + 0) * 2 + 1) * K: base + ((s * 3 + 0) * 2 + 1) * K + nc]
+        vd = got[base + ((s * 3 + 1) * 2 + 1) * K: base + ((s * 3 + 1) * 2 + 1) * K + nc]
+        wn = got[base + ((s * 3 + 2) * 2 + 0) * K: base + ((s * 3 + 2) * 2 + 0) * K + nc]
+        wd = got[base + ((s * 3 + 2) * 2 + 1) * K: base + ((s * 3 + 2) * 2 + 1) * K + nc]
+        assert np.array_equal(md, vd) and np.array_equal(md, wn) and np.all(wd == wd[0])
+        assert abs(wd[0] - md.sum()) <= 1e-9 * wd[0]
+        assert abs(md.sum() - trans.reshape(4, 4)[:, s].sum()) <= 1e-9 * md.sum()
+    post = em.posterior(0, 200_000)
+    assert np.allclose(post.sum(axis=1), 1.0, atol=1e-12) and np.array_equal(post.argmax(axis=1), lab[:200_000])
+    f, b, sc = em.forward_backward(0, 200_000)
+    assert np.allclose(f.sum(axis=1), 1.0, atol=1e-12)
+    assert np.allclose((f * b).sum(axis=1) * sc, 1e-4, rtol=1e-9)     # the scaling invariant used by the scan
     em.close()
     orc.close()
