@@ -79,3 +79,42 @@ __device__ __forceinline__ double hf_gauss_sum(const DevRegion* __restrict__ R, 
         tot += hf_gauss_comp(R->mean[s][c], R->var[s][c], R->weight[s][c], x, pre_x, alpha, beta, nan);
     return tot;
 }
+
+// E_t[pre][s] = e_s(x_t | x_{t-1}, alpha[pre][s], beta_t) of window t (A8-A10), evaluated once per distinct
+// alpha of a column; Err as trunc-exp ignores alpha.  Chunk-first windows hold e_s(x_0; alpha = 0, preX = 0)
+// in row pre = 0 and zeros elsewhere (hmm.c:338-352).
+__device__ __forceinline__ void hf_emit_row(const DevParams* __restrict__ P, const uint32_t* __restrict__ rec,
+                                            const double* __restrict__ beta, int64_t t, double out[16], unsigned* nan) {
+    const uint32_t r = rec[t];
+    const double x = (double) REC_X(r);
+    const DevRegion* __restrict__ R = &P->reg[REC_REGION(r) < (unsigned) P->n_regions ? REC_REGION(r) : 0];
+    const double bt = beta[t];
+    const bool te = hf_err_is_truncexp(P);
+    if (REC_FIRST(r)) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) out[k] = 0.0;
+        out[0] = te ? hf_trunc_exp(R->lambda, R->trunc_point, x, bt)
+                    : hf_gauss_sum(R, 0, P->ncomp[0], x, 0.0, 0.0, bt, nan);
+        for (int s = 1; s < 4; s++) out[s] = hf_gauss_sum(R, s, P->ncomp[s], x, 0.0, 0.0, bt, nan);
+    } else {
+        const double px = (double) REC_X(rec[t - 1]);
+        for (int s = 0; s < 4; s++) {
+            double val[4];
+            if (s == 0 && te) {
+                const double v = hf_trunc_exp(R->lambda, R->trunc_point, x, bt);
+                val[0] = v; val[1] = v; val[2] = v; val[3] = v;
+            } else {
+                const int nu = P->nuniq[s], nc = P->ncomp[s];
+                val[0] = val[1] = val[2] = val[3] = 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (u < nu) val[u] = hf_gauss_sum(R, s, nc, x, px, P->ualpha[s][u], bt, nan);
+            }
+#pragma unroll
+            for (int pre = 0; pre < 4; pre++) {
+                const int u = (s == 0 && te) ? 0 : P->umap[pre * 4 + s];
+                out[pre * 4 + s] = u == 0 ? val[0] : u == 1 ? val[1] : u == 2 ? val[2] : val[3];
+            }
+        }
+    }
+}

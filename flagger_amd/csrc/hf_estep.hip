@@ -46,6 +46,7 @@ struct hf_ctx {
     int ntiles = 0; int32_t* d_tile_chunk = nullptr; int64_t* d_tile_base = nullptr; int32_t* d_chunk_tile0 = nullptr;
     double* d_Pt = nullptr; double* d_cf = nullptr; double* d_cb = nullptr; double* d_tile_ll = nullptr;
     double* d_tile_stats = nullptr; // [ntiles][R][NA(16)]
+    double* d_Qs = nullptr;         // [ntiles][64][16] lane products
     unsigned* d_flags = nullptr;
     DevParams* d_params = nullptr; DevParams* h_params = nullptr; size_t params_bytes = 0;
     unsigned* h_flags = nullptr;
@@ -127,51 +128,6 @@ __global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __res
 // Chunk-first windows hold e_s(x_0; alpha=0, preX=0) in row pre=0 (hmm.c:338-352).
 // Evaluated once per distinct alpha of a column; Err (trunc-exp) ignores alpha.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_emit(int64_t N, const uint32_t* __restrict__ rec,
-                                              const double* __restrict__ beta, const DevParams* __restrict__ P,
-                                              double* __restrict__ E, unsigned* __restrict__ flags) {
-    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= N) return;
-    const uint32_t r = rec[t];
-    const double x = (double) REC_X(r);
-    const DevRegion* __restrict__ R = &P->reg[REC_REGION(r) < (unsigned) P->n_regions ? REC_REGION(r) : 0];
-    const double bt = beta[t];
-    unsigned nan = 0;
-    double out[16];
-    const bool te = hf_err_is_truncexp(P);
-    if (REC_FIRST(r)) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) out[k] = 0.0;
-        out[0] = te ? hf_trunc_exp(R->lambda, R->trunc_point, x, bt)
-                    : hf_gauss_sum(R, 0, P->ncomp[0], x, 0.0, 0.0, bt, &nan);
-        for (int s = 1; s < 4; s++) out[s] = hf_gauss_sum(R, s, P->ncomp[s], x, 0.0, 0.0, bt, &nan);
-    } else {
-        const double px = (double) REC_X(rec[t - 1]);
-        for (int s = 0; s < 4; s++) {
-            double val[4];
-            if (s == 0 && te) {
-                const double v = hf_trunc_exp(R->lambda, R->trunc_point, x, bt);
-                val[0] = v; val[1] = v; val[2] = v; val[3] = v;
-            } else {
-                const int nu = P->nuniq[s], nc = P->ncomp[s];
-                val[0] = val[1] = val[2] = val[3] = 0.0;
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (u < nu) val[u] = hf_gauss_sum(R, s, nc, x, px, P->ualpha[s][u], bt, &nan);
-            }
-#pragma unroll
-            for (int pre = 0; pre < 4; pre++) {
-                const int u = (s == 0 && te) ? 0 : P->umap[pre * 4 + s];
-                out[pre * 4 + s] = u == 0 ? val[0] : u == 1 ? val[1] : u == 2 ? val[2] : val[3];
-            }
-        }
-    }
-    if (nan) atomicOr(flags, nan);
-    double2* dst = reinterpret_cast<double2*>(E + t * 16);
-#pragma unroll
-    for (int k = 0; k < 8; k++) dst[k] = make_double2(out[2 * k], out[2 * k + 1]);
-}
-
 // transition row table for one window: region change => 1/(S+1) (hmm.c:398-400)
 __device__ __forceinline__ void load_T(const DevParams* __restrict__ P, uint32_t r, double Tm[16]) {
     if (REC_REGCHG(r)) {
@@ -184,11 +140,22 @@ __device__ __forceinline__ void load_T(const DevParams* __restrict__ P, uint32_t
     }
 }
 
+// emission row of window w (index within its chunk) from the tile-major/lane-minor stash (see hf_scan.h)
+__device__ __forceinline__ void load_E_window(const double* __restrict__ E, int tile0, int64_t w, double* Ev) {
+    const int64_t TW = 64 * HF_SCAN_L;
+    const int tile = tile0 + (int) (w / TW);
+    const int rem = (int) (w % TW), lane = rem / HF_SCAN_L, i = rem % HF_SCAN_L;
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(E) + (((int64_t) tile * HF_SCAN_L + i) * 8) * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const double2 v = src[k * 64]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
+}
+
 // ------------------------------------------------------------------------------------------
 // HF_ALGO_SEQ: one wavefront per chunk, windows visited in order with the reference's exact
 // operation order; tiles of 64 windows are staged through LDS with coalesced loads/stores.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_fwd_seq(const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
+__global__ void __launch_bounds__(64) k_fwd_seq(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
+                                                const uint32_t* __restrict__ rec,
                                                 const double* __restrict__ E, const DevParams* __restrict__ P,
                                                 double* __restrict__ F, double* __restrict__ scale,
                                                 double* __restrict__ chunk_stats, int64_t V,
@@ -206,8 +173,7 @@ __global__ void __launch_bounds__(64) k_fwd_seq(const int64_t* __restrict__ off,
         if (lane < n) {
             const int64_t t = t0 + base + lane;
             rs[lane] = rec[t];
-#pragma unroll
-            for (int k = 0; k < 16; k++) Es[lane][k] = E[t * 16 + k];
+            load_E_window(E, chunk_tile0[c], base + lane, &Es[lane][0]);
         }
         __syncthreads();
         for (int j = 0; j < n; j++) {
@@ -263,7 +229,10 @@ __device__ __forceinline__ int posterior_label(const double f[4], const double b
     return idx;
 }
 
-__global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
+#include "hf_scan.h"
+
+__global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
+                                                const uint32_t* __restrict__ rec,
                                                 const double* __restrict__ E, const DevParams* __restrict__ P,
                                                 const double* __restrict__ F, const double* __restrict__ scale,
                                                 double* __restrict__ B, int8_t* __restrict__ label,
@@ -297,8 +266,7 @@ __global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off,
         if (lane < n) {
             const int64_t t = t0 + lo + lane; // window i
             rs[lane] = rec[t + 1];
-#pragma unroll
-            for (int k = 0; k < 16; k++) Es[lane][k] = E[(t + 1) * 16 + k];
+            load_E_window(E, chunk_tile0[c], lo + lane + 1, &Es[lane][0]);
 #pragma unroll
             for (int s = 0; s < 4; s++) Fs[lane][s] = F[t * 4 + s];
             Fs[lane][4] = scale[t];
@@ -332,8 +300,6 @@ __global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off,
     if (lane == 0 && bad) atomicOr(flags, bad);
 }
 
-#include "hf_scan.h"
-
 // ------------------------------------------------------------------------------------------
 // k_stats: xi sufficient statistics of one chunk, one region at a time (A6, A12).
 // For every pair (i, i+1), i = 1..T-2:  xi = f_i[pre] * T * e * b_{i+1}[s] / terminationProb.
@@ -355,23 +321,20 @@ __device__ __forceinline__ double& acc_ref(StatAcc<KT>& a, int i) { return reint
 template <int KT>
 __device__ __forceinline__ void stats_pair(StatAcc<KT>& a, const DevParams* __restrict__ P, const DevRegion* __restrict__ R,
                                            int64_t t, const uint32_t* __restrict__ rec, const double* __restrict__ beta,
-                                           const double* __restrict__ E, const double* __restrict__ F,
+                                           const double* __restrict__ Ev, const double* __restrict__ F,
                                            const double* __restrict__ B, bool te, int ncol, unsigned* nan) {
     const uint32_t r1 = rec[t + 1];
     const double x = (double) REC_X(r1), px = (double) REC_X(rec[t]);
     const double bt = beta[t + 1];
     double Tm[16];
     load_T(P, r1, Tm);
-    double f[4], b1[4], Ev[16];
+    double f[4], b1[4];
     {
         const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + t * 4);
         const double2* __restrict__ bp = reinterpret_cast<const double2*>(B + (t + 1) * 4);
         const double2 f01 = fp[0], f23 = fp[1], b01 = bp[0], b23 = bp[1];
         f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
         b1[0] = b01.x; b1[1] = b01.y; b1[2] = b23.x; b1[3] = b23.y;
-        const double2* __restrict__ ep = reinterpret_cast<const double2*>(E + (t + 1) * 16);
-#pragma unroll
-        for (int k = 0; k < 8; k++) { const double2 v = ep[k]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
     }
     // xi of all 16 (pre, state) pairs first: afterwards only adj[] and Ev[] stay live
     double adj[16];
@@ -449,10 +412,11 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const int32_t
     const int ncol = P->ncomp[3], nreg = P->n_regions;
     unsigned nan = 0;
     unsigned long long present = 0;
+    const int64_t a0 = base + (int64_t) lane * HF_SCAN_L;   // this lane owns windows a0..a0+L-1 and the pairs ending there
 #pragma unroll
     for (int j = 0; j < HF_SCAN_L; j++) {
-        const int64_t i = base + j * 64 + lane;
-        if (i >= 1 && i <= T - 2) present |= 1ull << (REC_REGION(rec[t0 + i + 1]) & 63u);
+        const int64_t w = a0 + j;
+        if (w >= 2 && w <= T - 1) present |= 1ull << (REC_REGION(rec[t0 + w]) & 63u);
     }
     for (int o = 32; o > 0; o >>= 1) present |= __shfl_xor(present, o);
     const unsigned long long in_chunk = regmask[c];
@@ -469,9 +433,12 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const int32_t
         for (int i = 0; i < NA; i++) acc_ref<KT>(a, i) = 0.0;
 #pragma unroll 1
         for (int j = 0; j < HF_SCAN_L; j++) {
-            const int64_t i = base + j * 64 + lane;
-            if (i >= 1 && i <= T - 2 && (int) REC_REGION(rec[t0 + i + 1]) == r)
-                stats_pair<KT>(a, P, R, t0 + i, rec, beta, E, F, B, te, ncol, &nan);
+            const int64_t w = a0 + j;                         // pair (w-1, w), w = 2..T-1  (hmm.c:638-642)
+            if (w >= 2 && w <= T - 1 && (int) REC_REGION(rec[t0 + w]) == r) {
+                double Ev[16];
+                load_E<HF_SCAN_L>(E, tile, lane, j, Ev);
+                stats_pair<KT>(a, P, R, t0 + w - 1, rec, beta, Ev, F, B, te, ncol, &nan);
+            }
         }
         double* __restrict__ dst = tile_stats + ((int64_t) tile * nreg + r) * NA;
 #pragma unroll
@@ -611,7 +578,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
 #define DMALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void**) &(p), (bytes) ? (bytes) : 8); \
     if (e_ != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e_)); } } while (0)
     DMALLOC(ctx->d_rec, N * 4); DMALLOC(ctx->d_beta, N * 8); DMALLOC(ctx->d_regmask, C * 8);
-    DMALLOC(ctx->d_E, N * 16 * 8); DMALLOC(ctx->d_f, N * 4 * 8); DMALLOC(ctx->d_b, N * 4 * 8);
+    DMALLOC(ctx->d_f, N * 4 * 8); DMALLOC(ctx->d_b, N * 4 * 8);
     DMALLOC(ctx->d_scale, N * 8); DMALLOC(ctx->d_label, N);
     DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, (size_t) ctx->V * 8);
     DMALLOC(ctx->d_flags, 4);
@@ -632,6 +599,9 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         const size_t nt = (size_t) ctx->ntiles;
         DMALLOC(ctx->d_Pt, nt * 16 * 8); DMALLOC(ctx->d_cf, nt * 4 * 8); DMALLOC(ctx->d_cb, nt * 4 * 8);
         DMALLOC(ctx->d_tile_ll, nt * 8);
+        DMALLOC(ctx->d_Qs, nt * 64 * 16 * 8);
+        // emission stash, tile-major/lane-minor (hf_scan.h)
+        DMALLOC(ctx->d_E, nt * 64 * HF_SCAN_L * 16 * 8);
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
     }
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
@@ -668,7 +638,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); hipFree(ctx->d_chunk_stats);
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
     hipFree(ctx->d_tile_chunk); hipFree(ctx->d_tile_base); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
-    hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats);
+    hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -737,34 +707,34 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
     for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
     auto mark = [&](int stage) { if (ctx->profiling) hipEventRecord(ctx->kev[stage], st); };
     if (ctx->N > 0 && ctx->C > 0) {
+        const unsigned tb = (unsigned) ((ctx->ntiles + 3) / 4);
         mark(0);
-        hipLaunchKernelGGL(k_emit, dim3((unsigned) ((ctx->N + 255) / 256)), dim3(256), 0, st, ctx->N, ctx->d_rec,
-                           ctx->d_beta, ctx->d_params, ctx->d_E, ctx->d_flags);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_tile<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
+                               ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_params,
+                               ctx->d_E, ctx->d_Qs, ctx->d_Pt, ctx->d_flags);
         mark(1); ctx->kran[0] = true;
         if (ctx->algo == HF_ALGO_SEQ)
-            hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_rec, ctx->d_E,
+            hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec, ctx->d_E,
                                ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_chunk_stats, ctx->V, ctx->d_flags);
         else {
-            const unsigned tb = (unsigned) ((ctx->ntiles + 3) / 4);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tileprod<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
-                               ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_E, ctx->d_params, ctx->d_Pt);
-            hipLaunchKernelGGL(k_carry, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_carry<HF_SCAN_L>), dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
                                ctx->d_E, ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fwd_tile<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
-                               ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_E, ctx->d_params, ctx->d_cf,
-                               ctx->d_f, ctx->d_scale, ctx->d_tile_ll, ctx->d_flags);
+                               ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_E, ctx->d_Qs, ctx->d_params,
+                               ctx->d_cf, ctx->d_f, ctx->d_scale, ctx->d_tile_ll, ctx->d_flags);
             hipLaunchKernelGGL(k_chunk_ll, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_chunk_tile0, ctx->d_tile_ll,
                                ctx->d_chunk_stats, ctx->V);
         }
         mark(2); ctx->kran[1] = true;   // end of forward (= start of backward)
         if (mode == HF_MODE_FULL) {
             if (ctx->algo == HF_ALGO_SEQ)
-                hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_rec, ctx->d_E,
+                hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec, ctx->d_E,
                                    ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
             else
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bwd_tile<HF_SCAN_L>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256), 0,
                                    st, ctx->ntiles, ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_E,
-                                   ctx->d_params, ctx->d_cb, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
+                                   ctx->d_Qs, ctx->d_params, ctx->d_cb, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label,
+                                   ctx->d_flags);
             mark(3); ctx->kran[2] = true;
             const int kc = p->ncomp[3];
             if (kc <= 4) launch_stats<4>(ctx, st);

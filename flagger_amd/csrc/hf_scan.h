@@ -3,7 +3,7 @@
 // The scaled forward recurrence f_t ∝ f_{t-1}·A_t (A_t[pre][s] = T_t(pre,s)·e_t(pre,s), hmm.c:366-420)
 // is a product of 4x4 non-negative matrices, hence associative.  A chunk is cut into tiles of 64·L
 // windows, one wavefront per tile, every lane owning L consecutive windows:
-//   k_tileprod   product of the matrices of every tile                 (all tiles of all chunks at once)
+//   k_emit_tile  emission rows + lane products + the product of every tile (all tiles of all chunks at once)
 //   k_carry      per chunk: sequential sweep over its <= T/(64L) tile products -> carried-in forward
 //                vector and carried-in backward direction of every tile
 //   k_fwd_tile   per tile: Kogge-Stone scan of the 64 lane products (DPP/ds_bpermute shuffles, power-of-two
@@ -61,9 +61,28 @@ __device__ __forceinline__ void m4_shfl_down(M4& dst, const M4& src, int d) {
     for (int i = 0; i < 16; i++) dst.m[i] = __shfl_down(src.m[i], d);
 }
 
-// T and E of one window; chunk-first windows use the start row for every pre (k_emit puts e_s(x_0) in row 0)
-__device__ __forceinline__ void load_pair(const DevParams* __restrict__ P, uint32_t r, const double* __restrict__ Erow,
-                                          double Tm[16], double Ev[16]) {
+// Scan-mode layout of the emission stash: tile-major, lane-minor, so that the 64 lanes of the wavefront that owns a
+// tile read/write 1 KiB contiguous per instruction: E2[((tile*L + i)*8 + k2)*64 + lane] = (E[2*k2], E[2*k2+1]) of
+// the window `i` of `lane` (window index in chunk = tile_base + lane*L + i).
+template <int L>
+__device__ __forceinline__ int64_t e_slot(int tile, int lane, int i) { return (((int64_t) tile * L + i) * 8) * 64 + lane; }
+
+template <int L>
+__device__ __forceinline__ void load_E(const double* __restrict__ E, int tile, int lane, int i, double Ev[16]) {
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(E) + e_slot<L>(tile, lane, i);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const double2 v = src[k * 64]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
+}
+
+template <int L>
+__device__ __forceinline__ void store_E(double* __restrict__ E, int tile, int lane, int i, const double Ev[16]) {
+    double2* __restrict__ dst = reinterpret_cast<double2*>(E) + e_slot<L>(tile, lane, i);
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[k * 64] = make_double2(Ev[2 * k], Ev[2 * k + 1]);
+}
+
+// T of one window; chunk-first windows use the start row for every pre (k_emit puts e_s(x_0) in row 0)
+__device__ __forceinline__ void load_Tm(const DevParams* __restrict__ P, uint32_t r, double Tm[16]) {
     if (REC_FIRST(r)) {
         const DevRegion* __restrict__ R = &P->reg[REC_REGION(r)];
 #pragma unroll
@@ -71,26 +90,40 @@ __device__ __forceinline__ void load_pair(const DevParams* __restrict__ P, uint3
     } else {
         load_T(P, r, Tm);
     }
-    const double2* __restrict__ src = reinterpret_cast<const double2*>(Erow);
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const double2 v = src[k]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
 }
 
-// product of the matrices of windows [a, a+L) of a chunk (absolute index t0+..); chunk-first windows and
-// windows past the end count as identity
+// ------------------------------------------------------------------------------------------
+// k_emit_tile: one wavefront per tile.  Each lane evaluates the emission rows of its L windows (written to the
+// stash E, 128 B per window), multiplies them into its lane product Q_l (written to Qs: the forward AND the
+// backward tile kernels start from it instead of re-reading E for a first pass), and an ordered shuffle tree
+// over the lanes gives the tile product Pt.  Chunk-first windows are excluded from Q_l and Pt.
+// ------------------------------------------------------------------------------------------
 template <int L>
-__device__ __forceinline__ void lane_product(M4& Q, const DevParams* __restrict__ P, const uint32_t* __restrict__ rec,
-                                             const double* __restrict__ E, int64_t t0, int64_t a, int64_t T,
-                                             bool skip_first) {
+__global__ void __launch_bounds__(256) k_emit_tile(int ntiles, const int32_t* __restrict__ tile_chunk,
+                                                   const int64_t* __restrict__ tile_base,
+                                                   const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
+                                                   const double* __restrict__ beta, const DevParams* __restrict__ P,
+                                                   double* __restrict__ E, double* __restrict__ Qs,
+                                                   double* __restrict__ Pt, unsigned* __restrict__ flags) {
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (tile >= ntiles) return;
+    const int c = tile_chunk[tile];
+    const int64_t t0 = off[c], T = off[c + 1] - t0, base = tile_base[tile];
+    const int64_t a = base + (int64_t) lane * L;
+    unsigned nan = 0;
+    M4 Q;
     m4_identity(Q);
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < L; i++) {
-        if (a + i >= 0 && a + i < T) {
+        if (a + i < T) {
             const int64_t t = t0 + a + i;
+            double Ev[16];
+            hf_emit_row(P, rec, beta, t, Ev, &nan);
+            store_E<L>(E, tile, lane, i, Ev);
             const uint32_t r = rec[t];
-            if (!(skip_first && REC_FIRST(r))) {
-                double Tm[16], Ev[16];
-                load_pair(P, r, E + t * 16, Tm, Ev);
+            if (!REC_FIRST(r)) {
+                double Tm[16];
+                load_T(P, r, Tm);
                 M4 A, R;
 #pragma unroll
                 for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ev[k];
@@ -100,24 +133,11 @@ __device__ __forceinline__ void lane_product(M4& Q, const DevParams* __restrict_
             }
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_tileprod: Pt[tile] = product of A_w over the tile's windows (window 0 of a chunk excluded), one wave
-// per tile, 4 tiles per 256-thread block.  tile_chunk / tile_base map a tile to (chunk, first window).
-// ------------------------------------------------------------------------------------------
-template <int L>
-__global__ void __launch_bounds__(256) k_tileprod(int ntiles, const int32_t* __restrict__ tile_chunk,
-                                                  const int64_t* __restrict__ tile_base,
-                                                  const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
-                                                  const double* __restrict__ E, const DevParams* __restrict__ P,
-                                                  double* __restrict__ Pt) {
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (tile >= ntiles) return;
-    const int c = tile_chunk[tile];
-    const int64_t t0 = off[c], T = off[c + 1] - t0, base = tile_base[tile];
-    M4 Q;
-    lane_product<L>(Q, P, rec, E, t0, base + (int64_t) lane * L, T, true);
+    {
+        double2* dst = reinterpret_cast<double2*>(Qs + ((int64_t) tile * 64 + lane) * 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[k] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
+    }
     // ordered tree product over lanes: after step d, lane l (l % 2d == 0) holds the product of lanes l..l+2d-1
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -130,6 +150,13 @@ __global__ void __launch_bounds__(256) k_tileprod(int ntiles, const int32_t* __r
 #pragma unroll
         for (int k = 0; k < 8; k++) dst[k] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
     }
+    if (nan) atomicOr(flags, nan);
+}
+
+__device__ __forceinline__ void load_lane_product(M4& Q, const double* __restrict__ Qs, int tile, int lane) {
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(Qs + ((int64_t) tile * 64 + lane) * 16);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const double2 v = src[k]; Q.m[2 * k] = v.x; Q.m[2 * k + 1] = v.y; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -138,6 +165,7 @@ __global__ void __launch_bounds__(256) k_tileprod(int ntiles, const int32_t* __r
 // first window after BACKWARD tile `tile` (backward tile k owns windows base_k-1 .. base_k+64L-2).
 // lane 0 sweeps forward, lane 1 sweeps backward.
 // ------------------------------------------------------------------------------------------
+template <int L>
 __global__ void __launch_bounds__(64) k_carry(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
                                               const uint32_t* __restrict__ rec, const double* __restrict__ E,
                                               const DevParams* __restrict__ P, const double* __restrict__ Pt,
@@ -149,9 +177,10 @@ __global__ void __launch_bounds__(64) k_carry(const int64_t* __restrict__ off, c
     if (lane == 0) {
         const uint32_t r0 = rec[t0];
         const DevRegion* __restrict__ R = &P->reg[REC_REGION(r0)];
-        double v[4], sv = 0.0;
+        double v[4], sv = 0.0, E0[16];
+        load_E<L>(E, k0, 0, 0, E0);
 #pragma unroll
-        for (int s = 0; s < 4; s++) { v[s] = E[t0 * 16 + s] * R->trans[4][s]; sv += v[s]; }
+        for (int s = 0; s < 4; s++) { v[s] = E0[s] * R->trans[4][s]; sv += v[s]; }
 #pragma unroll
         for (int s = 0; s < 4; s++) v[s] /= sv;
         for (int k = 0; k < nt; k++) {
@@ -199,7 +228,8 @@ template <int L>
 __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const int32_t* __restrict__ tile_chunk,
                                                   const int64_t* __restrict__ tile_base,
                                                   const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
-                                                  const double* __restrict__ E, const DevParams* __restrict__ P,
+                                                  const double* __restrict__ E, const double* __restrict__ Qs,
+                                                  const DevParams* __restrict__ P,
                                                   const double* __restrict__ cf, double* __restrict__ F,
                                                   double* __restrict__ scale, double* __restrict__ tile_ll,
                                                   unsigned* __restrict__ flags) {
@@ -217,7 +247,18 @@ __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const int32_t* __r
     unsigned bad = 0;
     // phase 1 + 2: exclusive prefix product over lanes
     M4 Q;
-    lane_product<L>(Q, P, rec, E, t0, a, T, false);
+    load_lane_product(Q, Qs, tile, lane);
+    if (base == 0 && lane == 0) {   // the chunk's first window is not in Q_l: prepend A_first = start∘e (row 0 only)
+        double Tm[16], Ev[16];
+        load_Tm(P, rec[t0], Tm);
+        load_E<L>(E, tile, 0, 0, Ev);
+        M4 A, R;
+#pragma unroll
+        for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ev[k];
+        m4_mul(R, A, Q);
+        Q = R;
+        m4_renorm(Q);
+    }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         M4 Lft, R;
@@ -246,7 +287,8 @@ __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const int32_t* __r
             const int64_t t = t0 + a + i;
             const uint32_t r = rec[t];
             double Tm[16], Ev[16];
-            load_pair(P, r, E + t * 16, Tm, Ev);
+            load_Tm(P, r, Tm);
+            load_E<L>(E, tile, lane, i, Ev);
             double nf[4], sc = 0.0;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
@@ -290,7 +332,8 @@ template <int L>
 __global__ void __launch_bounds__(256) k_bwd_tile(int ntiles, const int32_t* __restrict__ tile_chunk,
                                                   const int64_t* __restrict__ tile_base,
                                                   const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
-                                                  const double* __restrict__ E, const DevParams* __restrict__ P,
+                                                  const double* __restrict__ E, const double* __restrict__ Qs,
+                                                  const DevParams* __restrict__ P,
                                                   const double* __restrict__ cb, const double* __restrict__ F,
                                                   const double* __restrict__ scale, double* __restrict__ B,
                                                   int8_t* __restrict__ label, unsigned* __restrict__ flags) {
@@ -330,7 +373,7 @@ __global__ void __launch_bounds__(256) k_bwd_tile(int ntiles, const int32_t* __r
     }
     // phase 1 + 2: exclusive SUFFIX product over lanes; lane windows i own A_{i+1}
     M4 Q;
-    lane_product<L>(Q, P, rec, E, t0, a + 1, T, true);      // windows a+1 .. a+L, window 0 never owned
+    load_lane_product(Q, Qs, tile, lane);                   // = product over windows a+1 .. a+L (window 0 excluded)
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         M4 Rgt, R;
@@ -365,7 +408,8 @@ __global__ void __launch_bounds__(256) k_bwd_tile(int ntiles, const int32_t* __r
         if (a + i >= 0 && a + i < Tm1) {
             const int64_t t = t0 + a + i;
             double Tm[16], Ev[16];
-            load_pair(P, rec[t + 1], E + (t + 1) * 16, Tm, Ev);
+            load_Tm(P, rec[t + 1], Tm);
+            load_E<L>(E, tile, lane, i, Ev);                  // window t+1 = base + lane*L + i of this tile
             double nb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < 4; s++)
