@@ -34,6 +34,12 @@ struct DevRegion {
     double mean[HF_NSTATES][HF_MAXCOMP];
     double var[HF_NSTATES][HF_MAXCOMP];
     double weight[HF_NSTATES][HF_MAXCOMP];
+    // iteration constants for windows whose contig-end factor is the dominant value beta_star (all interior
+    // windows): each is the reference's own sub-expression, evaluated once on the host instead of per window
+    double m1[HF_NSTATES][4][HF_MAXCOMP];   // (1 - alpha_u) * mean_c                 hmm_utils.c:775
+    double gvar[HF_NSTATES][HF_MAXCOMP];    // var_c * beta_star                      hmm_utils.c:777-778
+    double gnorm[HF_NSTATES][HF_MAXCOMP];   // w_c / sqrt(gvar * 2 * PI)              hmm_utils.c:781
+    double te_lam, te_den;                  // lambda / beta_star, 1 - exp(-te_lam * beta_star * trunc)  hmm_utils.c:942-946
 };
 
 struct DevParams {
@@ -43,6 +49,7 @@ struct DevParams {
     int32_t umap[16];                   // [pre*4+s] -> index of alpha[pre][s] among column s' distinct values
     double ualpha[HF_NSTATES][4];       // [s][u]
     double alpha[16];                   // [pre*4+s]
+    double beta_star;                   // value of beta_t for every window away from contig ends (hmm.c:301-316)
     DevRegion reg[1];                   // n_regions entries
 };
 
@@ -71,6 +78,31 @@ __device__ __forceinline__ double hf_gauss_comp(double mu, double var_c, double 
     return p;
 }
 
+// same component with the beta_star constants: m1 = (1-alpha)*mu, gvar = var*beta, gnorm = w/sqrt(gvar*2*PI)
+__device__ __forceinline__ double hf_gauss_comp_star(double m1, double gvar, double gnorm, double x, double pre_x,
+                                                     double alpha, double beta, unsigned* nan) {
+    double mean = m1 + alpha * pre_x;
+    mean *= beta;
+    const double d = x - mean;
+    double p = gnorm * exp(-0.5 * (d * d) / gvar);
+    if (p != p) *nan |= HF_FLAG_NAN;
+    if (p < 1e-40) p = 1e-40;
+    return p;
+}
+
+__device__ __forceinline__ double hf_gauss_sum_star(const DevRegion* __restrict__ R, int s, int u, int ncomp, double x,
+                                                    double pre_x, double alpha, double beta, unsigned* nan) {
+    double tot = 0.0;
+    for (int c = 0; c < ncomp; c++)
+        tot += hf_gauss_comp_star(R->m1[s][u][c], R->gvar[s][c], R->gnorm[s][c], x, pre_x, alpha, beta, nan);
+    return tot;
+}
+
+__device__ __forceinline__ double hf_trunc_exp_star(const DevRegion* __restrict__ R, double x) {
+    if (R->trunc_point < x) return 0.0;
+    return R->te_lam * exp(-R->te_lam * x) / R->te_den;
+}
+
 // Gaussian_getProb, hmm_utils.c:753-758 (sum over components in index order)
 __device__ __forceinline__ double hf_gauss_sum(const DevRegion* __restrict__ R, int s, int ncomp, double x,
                                                double pre_x, double alpha, double beta, unsigned* nan) {
@@ -80,35 +112,33 @@ __device__ __forceinline__ double hf_gauss_sum(const DevRegion* __restrict__ R, 
     return tot;
 }
 
-// E_t[pre][s] = e_s(x_t | x_{t-1}, alpha[pre][s], beta_t) of window t (A8-A10), evaluated once per distinct
-// alpha of a column; Err as trunc-exp ignores alpha.  Chunk-first windows hold e_s(x_0; alpha = 0, preX = 0)
-// in row pre = 0 and zeros elsewhere (hmm.c:338-352).
-__device__ __forceinline__ void hf_emit_row(const DevParams* __restrict__ P, const uint32_t* __restrict__ rec,
-                                            const double* __restrict__ beta, int64_t t, double out[16], unsigned* nan) {
-    const uint32_t r = rec[t];
-    const double x = (double) REC_X(r);
-    const DevRegion* __restrict__ R = &P->reg[REC_REGION(r) < (unsigned) P->n_regions ? REC_REGION(r) : 0];
-    const double bt = beta[t];
+// E[pre][s] = e_s(x | px, alpha[pre][s], bt) for region parameters R (A8-A10), evaluated once per distinct alpha
+// of a column; Err as trunc-exp ignores alpha.  `first` = chunk-first window: e_s(x; alpha = 0, preX = 0) in row
+// pre = 0 and zeros elsewhere (hmm.c:338-352).  STAR = true: bt == P->beta_star, per-iteration constants apply.
+template <bool STAR>
+__device__ __forceinline__ void hf_emit_values(const DevParams* __restrict__ P, const DevRegion* __restrict__ R, double x,
+                                               double px, bool first, double bt, double out[16], unsigned* nan) {
     const bool te = hf_err_is_truncexp(P);
-    if (REC_FIRST(r)) {
+    if (first) {
 #pragma unroll
         for (int k = 0; k < 16; k++) out[k] = 0.0;
         out[0] = te ? hf_trunc_exp(R->lambda, R->trunc_point, x, bt)
                     : hf_gauss_sum(R, 0, P->ncomp[0], x, 0.0, 0.0, bt, nan);
         for (int s = 1; s < 4; s++) out[s] = hf_gauss_sum(R, s, P->ncomp[s], x, 0.0, 0.0, bt, nan);
     } else {
-        const double px = (double) REC_X(rec[t - 1]);
         for (int s = 0; s < 4; s++) {
             double val[4];
             if (s == 0 && te) {
-                const double v = hf_trunc_exp(R->lambda, R->trunc_point, x, bt);
+                const double v = STAR ? hf_trunc_exp_star(R, x) : hf_trunc_exp(R->lambda, R->trunc_point, x, bt);
                 val[0] = v; val[1] = v; val[2] = v; val[3] = v;
             } else {
                 const int nu = P->nuniq[s], nc = P->ncomp[s];
                 val[0] = val[1] = val[2] = val[3] = 0.0;
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (u < nu) val[u] = hf_gauss_sum(R, s, nc, x, px, P->ualpha[s][u], bt, nan);
+                    if (u < nu)
+                        val[u] = STAR ? hf_gauss_sum_star(R, s, u, nc, x, px, P->ualpha[s][u], bt, nan)
+                                      : hf_gauss_sum(R, s, nc, x, px, P->ualpha[s][u], bt, nan);
             }
 #pragma unroll
             for (int pre = 0; pre < 4; pre++) {

@@ -53,6 +53,11 @@ struct hf_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
     bool profiling = false; hipEvent_t kev[HF_NKERNELS + 2] = {}; bool kran[HF_NKERNELS] = {};  // kev[0..4] stage marks, kev[5..6] reduce
     bool have_full = false;
+    double beta_star = 1.0;
+    // per-iteration emission tables over (x, x_prev) in [0, M)^2 for interior windows (k_lut)
+    int M = 1; double* d_lutE = nullptr; double* d_lutC = nullptr;
+    // pairs whose window has beta != beta_star (contig ends): statistics by the generic kernel
+    int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_slow_stats = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -318,11 +323,14 @@ template <int KT>
 __device__ __forceinline__ double& acc_ref(StatAcc<KT>& a, int i) { return reinterpret_cast<double*>(&a)[i]; }
 
 // contributions of the pair (i, i+1) — window t = t0+i — to the accumulators of region REC_REGION(rec[t+1])
-template <int KT>
+// LUT = true: the pair's window is an interior one; the collapsed state's component probabilities come from this
+// iteration's table (lutC row of (region, x, x_prev), k_lut) instead of being re-evaluated.
+template <int KT, bool LUT>
 __device__ __forceinline__ void stats_pair(StatAcc<KT>& a, const DevParams* __restrict__ P, const DevRegion* __restrict__ R,
                                            int64_t t, const uint32_t* __restrict__ rec, const double* __restrict__ beta,
                                            const double* __restrict__ Ev, const double* __restrict__ F,
-                                           const double* __restrict__ B, bool te, int ncol, unsigned* nan) {
+                                           const double* __restrict__ B, bool te, int ncol, const double* __restrict__ lutC_row,
+                                           int Kctx, unsigned* nan) {
     const uint32_t r1 = rec[t + 1];
     const double x = (double) REC_X(r1), px = (double) REC_X(rec[t]);
     const double bt = beta[t + 1];
@@ -377,7 +385,8 @@ __device__ __forceinline__ void stats_pair(StatAcc<KT>& a, const DevParams* __re
 #pragma unroll
         for (int cc = 0; cc < KT; cc++)
             if (cc < ncol) {
-                pc[cc] = hf_gauss_comp(R->mean[3][cc], R->var[3][cc], R->weight[3][cc], x, px, alpha, bt, nan);
+                pc[cc] = LUT ? lutC_row[P->umap[k] * Kctx + cc]
+                             : hf_gauss_comp(R->mean[3][cc], R->var[3][cc], R->weight[3][cc], x, px, alpha, bt, nan);
                 tot += pc[cc];
             }
 #pragma unroll
@@ -401,9 +410,12 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const int32_t
                                                     const uint32_t* __restrict__ rec, const double* __restrict__ beta,
                                                     const double* __restrict__ E, const DevParams* __restrict__ P,
                                                     const double* __restrict__ F, const double* __restrict__ B,
-                                                    const uint64_t* __restrict__ regmask,
+                                                    const uint64_t* __restrict__ regmask, const double* __restrict__ lutC,
+                                                    int M, int Kctx,
                                                     double* __restrict__ tile_stats, unsigned* __restrict__ flags) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
+    const int64_t MM = (int64_t) M * M;
+    const double bstar = P->beta_star;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
     const int c = tile_chunk[tile];
@@ -434,13 +446,58 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const int32_t
 #pragma unroll 1
         for (int j = 0; j < HF_SCAN_L; j++) {
             const int64_t w = a0 + j;                         // pair (w-1, w), w = 2..T-1  (hmm.c:638-642)
-            if (w >= 2 && w <= T - 1 && (int) REC_REGION(rec[t0 + w]) == r) {
+            // interior windows only: the pairs at contig ends (beta != beta_star) are on the slow list (k_stats_slow)
+            if (w >= 2 && w <= T - 1 && (int) REC_REGION(rec[t0 + w]) == r && beta[t0 + w] == bstar) {
                 double Ev[16];
                 load_E<HF_SCAN_L>(E, tile, lane, j, Ev);
-                stats_pair<KT>(a, P, R, t0 + w - 1, rec, beta, Ev, F, B, te, ncol, &nan);
+                const int64_t idx = (int64_t) REC_X(rec[t0 + w]) * M + REC_X(rec[t0 + w - 1]);
+                stats_pair<KT, true>(a, P, R, t0 + w - 1, rec, beta, Ev, F, B, te, ncol,
+                                     lutC + (((int64_t) r * MM + idx) * 4) * Kctx, Kctx, &nan);
             }
         }
         double* __restrict__ dst = tile_stats + ((int64_t) tile * nreg + r) * NA;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            double v = acc_ref<KT>(a, i);
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0) dst[i] = v;
+        }
+    }
+    if (nan) atomicOr(flags, nan);
+}
+
+// pairs at contig ends (beta != beta_star): generic evaluation, one wavefront per chunk over its slow list
+template <int KT>
+__global__ void __launch_bounds__(64) k_stats_slow(const int32_t* __restrict__ slow_off, const int64_t* __restrict__ slow_w,
+                                                   const int32_t* __restrict__ chunk_tile0, const int64_t* __restrict__ off,
+                                                   const uint32_t* __restrict__ rec, const double* __restrict__ beta,
+                                                   const double* __restrict__ E, const DevParams* __restrict__ P,
+                                                   const double* __restrict__ F, const double* __restrict__ B,
+                                                   const uint64_t* __restrict__ regmask, double* __restrict__ slow_stats,
+                                                   unsigned* __restrict__ flags) {
+    constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int s0 = slow_off[c], n = slow_off[c + 1] - s0;
+    if (n == 0) return;
+    const int64_t t0 = off[c];
+    const bool te = hf_err_is_truncexp(P);
+    const int ncol = P->ncomp[3], nreg = P->n_regions;
+    const unsigned long long in_chunk = regmask[c];
+    unsigned nan = 0;
+    for (int r = 0; r < nreg; r++) {
+        if (!((in_chunk >> r) & 1ull)) continue;
+        const DevRegion* __restrict__ R = &P->reg[r];
+        StatAcc<KT> a;
+#pragma unroll
+        for (int i = 0; i < NA; i++) acc_ref<KT>(a, i) = 0.0;
+        for (int k = lane; k < n; k += 64) {
+            const int64_t tw = slow_w[s0 + k];                     // global index of window w; pair (w-1, w)
+            if ((int) REC_REGION(rec[tw]) != r) continue;
+            double Ev[16];
+            load_E_window(E, chunk_tile0[c], tw - t0, Ev);
+            stats_pair<KT, false>(a, P, R, tw - 1, rec, beta, Ev, F, B, te, ncol, nullptr, 0, &nan);
+        }
+        double* __restrict__ dst = slow_stats + ((int64_t) c * nreg + r) * NA;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             double v = acc_ref<KT>(a, i);
@@ -455,7 +512,8 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const int32_t
 // include/hmm_flagger_hip.h (mean.den == var.den == weight.num; weight.den[i] all equal)
 template <int KT>
 __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__ chunk_tile0, const uint64_t* __restrict__ regmask,
-                                                     const double* __restrict__ tile_stats, const DevParams* __restrict__ P,
+                                                     const double* __restrict__ tile_stats, const int32_t* __restrict__ slow_off,
+                                                     const double* __restrict__ slow_stats, const DevParams* __restrict__ P,
                                                      double* __restrict__ chunk_stats, int64_t V, int Kctx) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -470,6 +528,7 @@ __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__
         if (tid < NA) {
             double v = 0.0;
             for (int k = 0; k < nt; k++) v += tile_stats[((int64_t) (k0 + k) * nreg + r) * NA + tid];
+            if (slow_off[c + 1] > slow_off[c]) v += slow_stats[((int64_t) c * nreg + r) * NA + tid];   // contig-end pairs
             red[tid] = v;
         }
         __syncthreads();
@@ -529,9 +588,14 @@ template <int KT>
 static void launch_stats(hf_ctx* ctx, hipStream_t st) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256), 0, st, ctx->ntiles,
                        ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_E, ctx->d_params,
-                       ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_stats, ctx->d_flags);
+                       ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_lutC, ctx->M, ctx->K, ctx->d_tile_stats, ctx->d_flags);
+    if (ctx->n_slow > 0)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_slow<KT>), dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_slow_off,
+                           ctx->d_slow_w, ctx->d_chunk_tile0, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_E, ctx->d_params,
+                           ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_slow_stats, ctx->d_flags);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_chunk_tile0,
-                       ctx->d_regmask, ctx->d_tile_stats, ctx->d_params, ctx->d_chunk_stats, ctx->V, ctx->K);
+                       ctx->d_regmask, ctx->d_tile_stats, ctx->d_slow_off, ctx->d_slow_stats, ctx->d_params, ctx->d_chunk_stats,
+                       ctx->V, ctx->K);
 }
 
 extern "C" {
@@ -566,6 +630,12 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         if (T > maxT) maxT = (int32_t) T;
     }
     ctx->maxT = maxT;
+    {   // beta of every interior window (hmm.c:301-316): u - l = L - 1 there
+        const int L = w->mean_read_len;
+        double bs = 1.0;
+        if (w->adjust_contig_ends) { bs = (double) (L - 1) / L; if (!(bs > 0.25)) bs = 0.25; }
+        ctx->beta_star = bs;
+    }
     const size_t N = (size_t) ctx->N, C = (size_t) ctx->C;
     uint16_t *d_cov = nullptr, *d_mapq = nullptr, *d_clip = nullptr; uint64_t* d_annot = nullptr;
     int32_t *d_cs = nullptr, *d_ce = nullptr, *d_cl = nullptr;
@@ -627,6 +697,30 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     unsigned fl = 0;
     hipMemcpy(&fl, ctx->d_flags, 4, hipMemcpyDeviceToHost);
     if (fl & HF_FLAG_REGION) { hf_destroy(ctx); return set_err(HF_E_REGION, "a window's region index is >= n_regions"); }
+    {
+        unsigned maxx = 0;
+        for (size_t t = 0; t < N; t++) { const unsigned x = w->cov[t] & 0xffu; if (x > maxx) maxx = x; }
+        ctx->M = (int) maxx + 1;
+        const size_t MM = (size_t) ctx->M * ctx->M;
+        DMALLOC(ctx->d_lutE, (size_t) n_regions * MM * 16 * 8);
+        DMALLOC(ctx->d_lutC, (size_t) n_regions * MM * 4 * (size_t) max_comps * 8);
+        // pairs (w-1, w), 2 <= w <= T-1, whose beta_w differs from beta_star
+        std::vector<double> hb(N);
+        if (N) { hipError_t e2 = hipMemcpy(hb.data(), ctx->d_beta, N * 8, hipMemcpyDeviceToHost);
+                 if (e2 != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "beta download failed"); } }
+        std::vector<int64_t> slow;
+        std::vector<int32_t> soff(C + 1, 0);
+        for (size_t c = 0; c < C; c++) {
+            soff[c] = (int32_t) slow.size();
+            const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+            for (int64_t x = 2; x <= T - 1; x++) if (hb[(size_t) (t0 + x)] != ctx->beta_star) slow.push_back(t0 + x);
+        }
+        soff[C] = (int32_t) slow.size();
+        ctx->n_slow = (int) slow.size();
+        TRY(dev_upload(&ctx->d_slow_w, slow.data(), slow.size()));
+        TRY(dev_upload(&ctx->d_slow_off, soff.data(), soff.size()));
+        DMALLOC(ctx->d_slow_stats, C * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
+    }
     *out = ctx;
     return HF_OK;
 }
@@ -637,6 +731,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_off); hipFree(ctx->d_rec); hipFree(ctx->d_beta); hipFree(ctx->d_regmask); hipFree(ctx->d_E);
     hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); hipFree(ctx->d_chunk_stats);
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
+    hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_slow_stats);
     hipFree(ctx->d_tile_chunk); hipFree(ctx->d_tile_base); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
@@ -657,6 +752,7 @@ static int pack_params(hf_ctx* ctx, const hf_params* p) {
         return set_err(HF_E_ARG, "hf_estep: Err/Dup/Hap must have one component (hmm_flagger.c:180-182)");
     DevParams* h = ctx->h_params;
     h->model_type = p->model_type; h->n_regions = p->n_regions;
+    h->beta_star = ctx->beta_star;
     for (int s = 0; s < 4; s++) h->ncomp[s] = p->ncomp[s];
     for (int pre = 0; pre < 4; pre++)
         for (int s = 0; s < 4; s++) h->alpha[pre * 4 + s] = p->alpha[pre][s];
@@ -681,6 +777,17 @@ static int pack_params(hf_ctx* ctx, const hf_params* p) {
         std::memcpy(g->mean, p->mean + (size_t) r * 4 * HF_MAXCOMP, sizeof(g->mean));
         std::memcpy(g->var, p->var + (size_t) r * 4 * HF_MAXCOMP, sizeof(g->var));
         std::memcpy(g->weight, p->weight + (size_t) r * 4 * HF_MAXCOMP, sizeof(g->weight));
+        const double bs = ctx->beta_star;
+        for (int s = 0; s < 4; s++)
+            for (int c = 0; c < HF_MAXCOMP; c++) {
+                double var = g->var[s][c];
+                var *= bs;
+                g->gvar[s][c] = var;
+                g->gnorm[s][c] = g->weight[s][c] / (std::sqrt(var * 2 * HF_PI));
+                for (int u = 0; u < 4; u++) g->m1[s][u][c] = (1 - h->ualpha[s][u]) * g->mean[s][c];
+            }
+        g->te_lam = g->lambda / bs;
+        g->te_den = 1 - std::exp(-g->te_lam * (bs * g->trunc_point));
         for (int vm = 0; vm < 8; vm++) {
             bool valid[5] = { true, (vm & 1) != 0, true, (vm & 2) != 0, (vm & 4) != 0 };
             for (int pre = 0; pre < 4; pre++) {
@@ -709,9 +816,14 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
     if (ctx->N > 0 && ctx->C > 0) {
         const unsigned tb = (unsigned) ((ctx->ntiles + 3) / 4);
         mark(0);
+        {
+            const int64_t MM = (int64_t) ctx->M * ctx->M;
+            hipLaunchKernelGGL(k_lut, dim3((unsigned) ((MM + 255) / 256), (unsigned) ctx->R), dim3(256), 0, st, ctx->M, ctx->K,
+                               ctx->d_params, ctx->d_lutE, ctx->d_lutC);
+        }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_tile<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
-                               ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_params,
-                               ctx->d_E, ctx->d_Qs, ctx->d_Pt, ctx->d_flags);
+                           ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_params,
+                           ctx->d_lutE, ctx->M, ctx->d_E, ctx->d_Qs, ctx->d_Pt, ctx->d_flags);
         mark(1); ctx->kran[0] = true;
         if (ctx->algo == HF_ALGO_SEQ)
             hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec, ctx->d_E,

@@ -93,6 +93,35 @@ __device__ __forceinline__ void load_Tm(const DevParams* __restrict__ P, uint32_
 }
 
 // ------------------------------------------------------------------------------------------
+// k_lut: this iteration's emission tables for interior windows (beta == beta_star), per region and per
+// (x, x_prev) in [0, M)^2 — the same device functions as the direct evaluation, so the values are identical:
+//   lutE[r][x*M+px][16]       the emission row E[pre][s]
+//   lutC[r][x*M+px][u][K]     component probabilities of the collapsed state for its u-th distinct alpha
+// NaNs are stored, not reported: only a window that actually uses the entry raises HF_E_NAN.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_lut(int M, int K, const DevParams* __restrict__ P, double* __restrict__ lutE,
+                                             double* __restrict__ lutC) {
+    const int r = blockIdx.y;
+    const int64_t MM = (int64_t) M * M;
+    const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= MM) return;
+    const double x = (double) (idx / M), px = (double) (idx % M);
+    const DevRegion* __restrict__ R = &P->reg[r];
+    const double bs = P->beta_star;
+    unsigned nan = 0;
+    double out[16];
+    hf_emit_values<true>(P, R, x, px, false, bs, out, &nan);
+    double2* dst = reinterpret_cast<double2*>(lutE) + ((int64_t) r * MM + idx) * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[k] = make_double2(out[2 * k], out[2 * k + 1]);
+    const int ncol = P->ncomp[3], nu = P->nuniq[3];
+    double* __restrict__ c = lutC + (((int64_t) r * MM + idx) * 4) * K;
+    for (int u = 0; u < nu; u++)
+        for (int cc = 0; cc < ncol; cc++)
+            c[u * K + cc] = hf_gauss_comp_star(R->m1[3][u][cc], R->gvar[3][cc], R->gnorm[3][cc], x, px, P->ualpha[3][u], bs, &nan);
+}
+
+// ------------------------------------------------------------------------------------------
 // k_emit_tile: one wavefront per tile.  Each lane evaluates the emission rows of its L windows (written to the
 // stash E, 128 B per window), multiplies them into its lane product Q_l (written to Qs: the forward AND the
 // backward tile kernels start from it instead of re-reading E for a first pass), and an ordered shuffle tree
@@ -103,8 +132,10 @@ __global__ void __launch_bounds__(256) k_emit_tile(int ntiles, const int32_t* __
                                                    const int64_t* __restrict__ tile_base,
                                                    const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
                                                    const double* __restrict__ beta, const DevParams* __restrict__ P,
+                                                   const double* __restrict__ lutE, int M,
                                                    double* __restrict__ E, double* __restrict__ Qs,
                                                    double* __restrict__ Pt, unsigned* __restrict__ flags) {
+    const int64_t MM = (int64_t) M * M;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
     const int c = tile_chunk[tile];
@@ -118,9 +149,24 @@ __global__ void __launch_bounds__(256) k_emit_tile(int ntiles, const int32_t* __
         if (a + i < T) {
             const int64_t t = t0 + a + i;
             double Ev[16];
-            hf_emit_row(P, rec, beta, t, Ev, &nan);
-            store_E<L>(E, tile, lane, i, Ev);
             const uint32_t r = rec[t];
+            const double bt = beta[t];
+            const unsigned xi = REC_X(r), reg = REC_REGION(r);
+            const unsigned pxi = REC_FIRST(r) ? 0u : REC_X(rec[t - 1]);
+            // wave-uniform choice: every active lane's window is an interior, non-first one => its emission row is a
+            // function of (region, x, x_prev) only and comes from this iteration's table (k_lut)
+            if (__all(bt == P->beta_star && !REC_FIRST(r))) {
+                const double2* __restrict__ src = reinterpret_cast<const double2*>(lutE) + (((int64_t) reg * MM + xi * M + pxi) * 8);
+#pragma unroll
+                for (int k = 0; k < 8; k++) { const double2 v = src[k]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
+                bool isnan = false;
+#pragma unroll
+                for (int k = 0; k < 16; k++) isnan |= Ev[k] != Ev[k];
+                if (isnan) nan |= HF_FLAG_NAN;
+            } else {
+                hf_emit_values<false>(P, &P->reg[reg], (double) xi, (double) pxi, REC_FIRST(r) != 0, bt, Ev, &nan);
+            }
+            store_E<L>(E, tile, lane, i, Ev);
             if (!REC_FIRST(r)) {
                 double Tm[16];
                 load_T(P, r, Tm);
