@@ -5,7 +5,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/hmm_flagger_hip.h"
+#include "../include/hmm_flagger_hip.h"
 
 #define HF_PI 3.14159              // common.h:15 (sic)
 #define HF_TERMINATION_PROB 1e-4   // hmm_utils.c:2112
@@ -26,10 +26,6 @@
 #define REC_VMASK(r) (((r) >> 16) & 0x7u)
 #define REC_FIRST(r) (((r) >> 19) & 1u)
 #define REC_REGCHG(r) (((r) >> 20) & 1u)
-
-// one record per tile of the scan kernels (built once in hf_create): removes the tile -> chunk -> offsets chain
-// of dependent loads
-struct TileDesc { long long t0; int T; int base; int chunk; int pad; };
 
 struct DevRegion {
     double trans[5][5];                 // Transition.matrix (row 4 Start, column 4 End)

@@ -43,7 +43,6 @@ struct hf_ctx {
     double* d_chunk_stats = nullptr; // [C][V]
     double* d_total = nullptr;     // [V]
     // scan algorithm: tile tables and per-tile work arrays
-    TileDesc* d_tile_desc = nullptr;
     int ntiles = 0; int32_t* d_tile_chunk = nullptr; int64_t* d_tile_base = nullptr; int32_t* d_chunk_tile0 = nullptr;
     double* d_Pt = nullptr; double* d_cf = nullptr; double* d_cb = nullptr; double* d_tile_ll = nullptr;
     double* d_tile_stats = nullptr; // [ntiles][R][NA(16)]
@@ -664,15 +663,6 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         }
         ctile0[C] = (int32_t) tchunk.size();
         ctx->ntiles = (int) tchunk.size();
-        {
-            std::vector<TileDesc> desc(tchunk.size());
-            for (size_t k = 0; k < tchunk.size(); k++) {
-                const size_t c = (size_t) tchunk[k];
-                desc[k].t0 = w->chunk_off[c]; desc[k].T = (int) (w->chunk_off[c + 1] - w->chunk_off[c]);
-                desc[k].base = (int) tbase[k]; desc[k].chunk = tchunk[k]; desc[k].pad = 0;
-            }
-            TRY(dev_upload(&ctx->d_tile_desc, desc.data(), desc.size()));
-        }
         TRY(dev_upload(&ctx->d_tile_chunk, tchunk.data(), tchunk.size()));
         TRY(dev_upload(&ctx->d_tile_base, tbase.data(), tbase.size()));
         TRY(dev_upload(&ctx->d_chunk_tile0, ctile0.data(), ctile0.size()));
@@ -742,7 +732,6 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); hipFree(ctx->d_chunk_stats);
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_slow_stats);
-    hipFree(ctx->d_tile_desc);
     hipFree(ctx->d_tile_chunk); hipFree(ctx->d_tile_base); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
@@ -826,7 +815,6 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
     auto mark = [&](int stage) { if (ctx->profiling) hipEventRecord(ctx->kev[stage], st); };
     if (ctx->N > 0 && ctx->C > 0) {
         const unsigned tb = (unsigned) ((ctx->ntiles + 3) / 4);
-        const size_t tab_bytes = (size_t) ctx->R * HF_TAB_STRIDE * 8;   // LDS transition tables
         mark(0);
         {
             const int64_t MM = (int64_t) ctx->M * ctx->M;
@@ -843,8 +831,8 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
         else {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_carry<HF_SCAN_L>), dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
                                ctx->d_E, ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fwd_tile<HF_SCAN_L>), dim3(tb), dim3(256), tab_bytes, st, ctx->ntiles,
-                               ctx->d_tile_desc, ctx->d_rec, ctx->d_E, ctx->d_Qs, ctx->d_params,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fwd_tile<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
+                               ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_E, ctx->d_Qs, ctx->d_params,
                                ctx->d_cf, ctx->d_f, ctx->d_scale, ctx->d_tile_ll, ctx->d_flags);
             hipLaunchKernelGGL(k_chunk_ll, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_chunk_tile0, ctx->d_tile_ll,
                                ctx->d_chunk_stats, ctx->V);
@@ -855,8 +843,8 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
                 hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec, ctx->d_E,
                                    ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
             else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bwd_tile<HF_SCAN_L>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256),
-                                   tab_bytes, st, ctx->ntiles, ctx->d_tile_desc, ctx->d_rec, ctx->d_E,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bwd_tile<HF_SCAN_L>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256), 0,
+                                   st, ctx->ntiles, ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_E,
                                    ctx->d_Qs, ctx->d_params, ctx->d_cb, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label,
                                    ctx->d_flags);
             mark(3); ctx->kran[2] = true;

@@ -1,0 +1,419 @@
+// hf_io.cpp — window table (SoA) + the file formats either side of the hot path
+// (include/hmm_flagger_io.h).  Citations: mobinasri/flagger programs/submodules/.
+#include "../include/hmm_flagger_io.h"
+#include <zlib.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+thread_local std::string g_io_err;
+constexpr int kMaxCoverage = 250;   // chunk.c:8
+
+struct ChunkMeta { std::string ctg; int32_t ctg_len, s, e; };
+
+// window accumulator of one chunk being filled (Chunk.windowSum*, chunk.h:24-33)
+struct WindowAcc {
+    int n = 0;                      // bases in the open window (windowItr + 1)
+    double cov = 0, mapq = 0, clip = 0;
+    uint64_t flag = 0;
+    int reg[101] = {0}, tru[12] = {0}, pre[12] = {0};   // value histograms for the mode rules
+    void reset() { n = 0; cov = mapq = clip = 0; flag = 0; std::memset(reg, 0, sizeof reg); std::memset(tru, 0, sizeof tru); std::memset(pre, 0, sizeof pre); }
+};
+
+// n repeated additions of v onto sum, as the reference does per base (chunk.c:459-461); when both are
+// integers below 2^53 every partial sum is exact, so one multiply-add gives the identical double
+inline void add_run(double& sum, double v, int n) {
+    const double lim = 4503599627370496.0;  // 2^52
+    if (v == std::floor(v) && sum == std::floor(sum) && std::fabs(v) * n + std::fabs(sum) < lim) { sum += v * n; return; }
+    for (int i = 0; i < n; i++) sum += v;
+}
+
+inline int hist_mode(const int* h, int n_values, int minv) {   // common.c:407-427, lowest value wins ties
+    int mode = minv, maxc = h[0];
+    for (int i = 1; i < n_values; i++) if (maxc < h[i]) { mode = minv + i; maxc = h[i]; }
+    return mode;
+}
+inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+}  // namespace
+
+struct hfio_table {
+    std::vector<std::string> annotation_names;
+    std::vector<int32_t> region_coverages;
+    int32_t n_labels = 0, avg_alignment_len = 0, chunk_len = 0, window_len = 0;
+    bool truth_available = false, prediction_available = false, start_only = false;
+    std::vector<ChunkMeta> chunks;
+    std::vector<int64_t> chunk_off{0};
+    std::vector<int32_t> chunk_s, chunk_e, chunk_ctg_len;
+    std::vector<uint16_t> cov, mapq, clip;
+    std::vector<uint64_t> annot;
+    std::vector<int8_t> truth, prediction;
+
+    void push_window(WindowAcc& a) {                      // chunk.c:393-441
+        if (a.n == 0) return;
+        double c, m, k;
+        if (start_only) {
+            c = a.cov * window_len / a.n; m = a.mapq * window_len / a.n; k = a.clip * window_len / a.n;
+        } else {
+            c = a.cov / a.n; m = a.mapq / a.n; k = a.clip / a.n;
+        }
+        cov.push_back((uint16_t) (kMaxCoverage < std::round(c) ? kMaxCoverage : std::round(c)));
+        mapq.push_back((uint16_t) (kMaxCoverage < std::round(m) ? kMaxCoverage : std::round(m)));
+        clip.push_back((uint16_t) (kMaxCoverage < std::round(k) ? kMaxCoverage : std::round(k)));
+        const int region = hist_mode(a.reg, 101, 0);
+        annot.push_back((a.flag & 0x03FFFFFFFFFFFFFFULL) | ((uint64_t) region << 58));   // ptBlock.c:300-304
+        truth.push_back((int8_t) hist_mode(a.tru, 12, -1));
+        prediction.push_back((int8_t) hist_mode(a.pre, 12, -1));
+        a.reset();
+    }
+    void close_chunk(const ChunkMeta& cm) {
+        if ((int64_t) cov.size() == chunk_off.back()) return;     // no window: the reference never makes such a chunk
+        chunks.push_back(cm);
+        chunk_s.push_back(cm.s); chunk_e.push_back(cm.e); chunk_ctg_len.push_back(cm.ctg_len);
+        chunk_off.push_back((int64_t) cov.size());
+    }
+};
+
+namespace {
+
+std::string file_ext(const std::string& p) {                      // common.c:51-66
+    int len = (int) p.size(), i = len - 1;
+    for (; 0 <= i; i--)
+        if (p[i] == '.') {
+            const char* t = p.c_str() + i;
+            if (std::strcmp(t, ".gz") != 0 && std::strcmp(t, ".tar") != 0 && std::strcmp(t, ".tar.gz") != 0 &&
+                std::strcmp(t, ".zip") != 0) break;
+        }
+    return p.substr(i + 1);
+}
+
+uint64_t annot_flag_of(const char* s) {                           // ptBlock.c:225-236
+    uint64_t flag = 0;
+    const char* p = s;
+    while (*p) {
+        const int idx = std::atoi(p);
+        if (0 < idx && idx <= 64) flag |= 1ULL << (idx - 1);
+        const char* q = std::strchr(p, ',');
+        if (!q) break;
+        p = q + 1;
+    }
+    return flag;
+}
+
+bool starts_with(const char* s, const char* pre) { return std::strncmp(s, pre, std::strlen(pre)) == 0; }
+const char* field_after(const char* line, int n_colons) {         // pointer just after the n-th ':'
+    const char* p = line;
+    for (int i = 0; i < n_colons; i++) { p = std::strchr(p, ':'); if (!p) return nullptr; p++; }
+    return p;
+}
+
+// ---- .cov / .cov.gz: header (track_reader.c:48-457), rows (:751-818), chunks (chunk.c:240-294), windows ----
+hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
+    if (chunk_len <= 0 || window_len <= 0) { g_io_err = "chunkLen/windowLen must be > 0"; return nullptr; }
+    gzFile f = gzopen(path, "r");                                   // also reads uncompressed text
+    if (!f) { g_io_err = std::string("[Error] Unable to open ") + path; return nullptr; }
+    gzbuffer(f, 1 << 20);
+    hfio_table* t = new hfio_table();
+    t->chunk_len = chunk_len; t->window_len = window_len;
+    std::vector<char> buf(8192);                                    // LINE_MAX_SIZE
+    bool have_ann = false, have_reg = false, have_lab = false, have_avg = false;
+    int n_ann = 0, n_reg = 0, parsed_cov = 0;
+    std::string ctg;
+    int ctg_len = 0;
+    bool in_contig = false;
+    ChunkMeta cur{};
+    WindowAcc acc;
+    int next_pos = 0;                                               // next base expected in the current contig
+    auto fail = [&](const std::string& m) { g_io_err = m; gzclose(f); delete t; return (hfio_table*) nullptr; };
+    auto first_chunk = [&]() {
+        cur.ctg = ctg; cur.ctg_len = ctg_len; cur.s = 0;
+        cur.e = ctg_len < 2 * chunk_len ? ctg_len - 1 : chunk_len - 1;   // chunk.c:262
+    };
+    auto next_chunk = [&]() {
+        const int pe = cur.e;
+        cur.s = pe + 1;
+        cur.e = ctg_len < pe + 2 * chunk_len ? ctg_len - 1 : pe + chunk_len;   // chunk.c:274-277
+    };
+    while (gzgets(f, buf.data(), (int) buf.size())) {
+        char* line = buf.data();
+        size_t L = std::strlen(line);
+        if (L && line[L - 1] == '\n') line[--L] = '\0';
+        if (L == 0) continue;
+        if (line[0] == '#') {
+            if (starts_with(line, "#annotation:len") && !have_ann) {
+                const char* p = field_after(line, 2); n_ann = p ? std::atoi(p) : 0; have_ann = true;
+                t->annotation_names.assign((size_t) (n_ann > 0 ? n_ann : 0), "NA");
+            } else if (starts_with(line, "#annotation:name:")) {
+                const char* p = field_after(line, 2); const char* q = field_after(line, 3);
+                const int idx = p ? std::atoi(p) : -1;
+                if (q && idx >= 0 && idx < (int) t->annotation_names.size()) {
+                    std::string nm(q); const size_t c = nm.find(':'); if (c != std::string::npos) nm.resize(c);
+                    t->annotation_names[(size_t) idx] = nm;
+                }
+            } else if (starts_with(line, "#region:len") && !have_reg) {
+                const char* p = field_after(line, 2); n_reg = p ? std::atoi(p) : 0; have_reg = true;
+                if (n_reg > 0 && n_reg <= HF_MAXREGIONS) t->region_coverages.assign((size_t) n_reg, 0);
+            } else if (starts_with(line, "#region:coverage:")) {
+                const char* p = field_after(line, 2); const char* q = field_after(line, 3);
+                const int idx = p ? std::atoi(p) : -1;
+                if (q && idx >= 0 && idx < (int) t->region_coverages.size()) t->region_coverages[(size_t) idx] = std::atoi(q);
+                parsed_cov++;
+            } else if (starts_with(line, "#label:len") && !have_lab) {
+                const char* p = field_after(line, 2); t->n_labels = p ? std::atoi(p) : 0; have_lab = true;
+            } else if (starts_with(line, "#truth:true")) t->truth_available = true;
+            else if (starts_with(line, "#prediction:true")) t->prediction_available = true;
+            else if (starts_with(line, "#start-only:true")) t->start_only = true;
+            else if (starts_with(line, "#avg_alignment_len:") && !have_avg) { t->avg_alignment_len = std::atoi(line + 19); have_avg = true; }
+            continue;
+        }
+        if (!have_ann) return fail("Error: No '#annotation:len:' found in the header. annotation len should be at least 1.");
+        if (n_ann <= 0) return fail("Error: The value of '#annotation:len:' in the header should be at least 1.");
+        if (!have_reg) return fail("Error: No '#region:len:' found in the header. region len should be at least 1.");
+        if (n_reg <= 0 || n_reg > HF_MAXREGIONS) return fail("Error: The value of '#region:len:' in the header should be at least 1 (and at most 64).");
+        if (line[0] == '>') {
+            if (in_contig) { t->push_window(acc); t->close_chunk(cur); }
+            char* sp = std::strchr(line, ' ');
+            ctg_len = sp ? std::atoi(sp + 1) : 0;
+            if (sp) *sp = '\0';
+            ctg = line + 1;
+            in_contig = true; next_pos = 0; acc.reset();
+            first_chunk();
+            continue;
+        }
+        if (!in_contig) return fail("Error: coverage row before any '>contig length' line");
+        // start end cov mapq clip annots region [truth [prediction]]
+        char* fld[10]; int nf = 0;
+        for (char* p = line; nf < 10;) {
+            fld[nf++] = p;
+            char* q = std::strchr(p, '\t');
+            if (!q) break;
+            *q = '\0'; p = q + 1;
+        }
+        if (nf < 7) return fail("Error: a coverage row has fewer than 7 columns");
+        const int s = std::atoi(fld[0]) - 1, e = std::atoi(fld[1]) - 1;          // 1-based inclusive -> 0-based
+        const double v_cov = std::atof(fld[2]), v_mapq = std::atof(fld[3]), v_clip = std::atof(fld[4]);
+        const uint64_t flag = annot_flag_of(fld[5]);
+        const int region = clampi(std::atoi(fld[6]), 0, 100);
+        const int truth = clampi((nf >= 8 ? std::atoi(fld[7]) : -1), -1, 10) + 1;
+        const int pred = clampi((nf >= 9 ? std::atoi(fld[8]) : -1), -1, 10) + 1;
+        if (s != next_pos || e < s) return fail("Error: coverage rows must tile each contig without gaps (chunk.c:451)");
+        int pos = s;
+        while (pos <= e && pos <= ctg_len - 1) {
+            const int wi = (pos - cur.s) / window_len;
+            int wend = cur.s + (wi + 1) * window_len - 1;
+            if (wend > cur.e) wend = cur.e;
+            const int seg_end = e < wend ? e : wend;
+            const int n = seg_end - pos + 1;
+            add_run(acc.cov, v_cov, n); add_run(acc.mapq, v_mapq, n); add_run(acc.clip, v_clip, n);
+            acc.flag |= flag; acc.reg[region] += n; acc.tru[truth] += n; acc.pre[pred] += n; acc.n += n;
+            if (seg_end == wend) t->push_window(acc);              // full window, or the chunk's trailing partial window
+            if (seg_end == cur.e) { t->close_chunk(cur); if (cur.e < ctg_len - 1) next_chunk(); }
+            pos = seg_end + 1;
+        }
+        next_pos = e + 1;
+    }
+    gzclose(f);
+    if (in_contig) { t->push_window(acc); t->close_chunk(cur); }
+    if (!have_ann || !have_reg) { g_io_err = "Error: missing '#annotation:len:' / '#region:len:' header"; delete t; return nullptr; }
+    if (parsed_cov != n_reg) { g_io_err = "Error: Number of parsed region coverages does not match '#region:len:' in the header line."; delete t; return nullptr; }
+    if ((t->truth_available || t->prediction_available) && !have_lab) {
+        g_io_err = "Error: '#label:len' should be set to a non-zero number if at least one of truth or prediction tags is set to true in the header.";
+        delete t; return nullptr;
+    }
+    if (t->start_only && (!have_avg || t->avg_alignment_len <= 0)) { g_io_err = "Error: '#avg_alignment_len:' > 0 is required for start-only mode"; delete t; return nullptr; }
+    return t;
+}
+
+// ---- .bin (chunk.c:596-709 write, 713-828 read): little-endian, no magic ----
+bool rd(FILE* f, void* p, size_t n) { return std::fread(p, 1, n, f) == n; }
+
+hfio_table* load_bin(const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) { g_io_err = std::string("Error: The bin file ") + path + " does not exist."; return nullptr; }
+    hfio_table* t = new hfio_table();
+    auto fail = [&](const char* m) { g_io_err = m; std::fclose(f); delete t; return (hfio_table*) nullptr; };
+    int32_t n_ann = 0, n_reg = 0;
+    if (!rd(f, &n_ann, 4) || n_ann < 0 || n_ann > 4096) return fail("bad .bin header");
+    for (int i = 0; i < n_ann; i++) {
+        int32_t len = 0;
+        if (!rd(f, &len, 4) || len <= 0 || len > 65536) return fail("bad .bin header");
+        std::string s((size_t) len, '\0');
+        if (!rd(f, &s[0], (size_t) len)) return fail("bad .bin header");
+        s.resize(std::strlen(s.c_str()));
+        t->annotation_names.push_back(s);
+    }
+    if (!rd(f, &n_reg, 4) || n_reg < 0 || n_reg > HF_MAXREGIONS) return fail("bad .bin header");
+    t->region_coverages.resize((size_t) n_reg);
+    if (n_reg && !rd(f, t->region_coverages.data(), 4 * (size_t) n_reg)) return fail("bad .bin header");
+    uint8_t b3[3];
+    if (!rd(f, &t->n_labels, 4) || !rd(f, b3, 3) || !rd(f, &t->avg_alignment_len, 4) || !rd(f, &t->chunk_len, 4) ||
+        !rd(f, &t->window_len, 4)) return fail("bad .bin header");
+    t->truth_available = b3[0]; t->prediction_available = b3[1]; t->start_only = b3[2];
+    int32_t name_len;
+    while (std::fread(&name_len, 4, 1, f) == 1) {
+        if (name_len <= 0 || name_len > 65536) return fail("bad .bin chunk");
+        std::string nm((size_t) name_len, '\0');
+        ChunkMeta cm{};
+        int32_t n = 0;
+        if (!rd(f, &nm[0], (size_t) name_len) || !rd(f, &cm.ctg_len, 4) || !rd(f, &cm.s, 4) || !rd(f, &cm.e, 4) || !rd(f, &n, 4) || n < 0)
+            return fail("bad .bin chunk");
+        nm.resize(std::strlen(nm.c_str()));
+        cm.ctg = nm;
+        const size_t o = t->cov.size(), N = o + (size_t) n;
+        t->cov.resize(N); t->mapq.resize(N); t->clip.resize(N); t->annot.resize(N); t->truth.resize(N); t->prediction.resize(N);
+        if (n && (!rd(f, &t->cov[o], 2 * (size_t) n) || !rd(f, &t->mapq[o], 2 * (size_t) n) || !rd(f, &t->clip[o], 2 * (size_t) n) ||
+                  !rd(f, &t->annot[o], 8 * (size_t) n) || !rd(f, &t->truth[o], (size_t) n) || !rd(f, &t->prediction[o], (size_t) n)))
+            return fail("truncated .bin chunk");
+        t->chunks.push_back(cm);
+        t->chunk_s.push_back(cm.s); t->chunk_e.push_back(cm.e); t->chunk_ctg_len.push_back(cm.ctg_len);
+        t->chunk_off.push_back((int64_t) N);
+    }
+    std::fclose(f);
+    return t;
+}
+
+const char* const kLabelColors[] = {"162,0,37", "250,104,0", "0,138,0", "170,0,255", "99, 99, 96", "250,200,0"};  // chunk.c:10-15
+const char* const kLabelNames[] = {"Err", "Dup", "Hap", "Col", "Unk", "Msj"};                                        // chunk.c:16-21
+const char* const kStateNames[] = {"Err", "Dup", "Hap", "Col"};
+
+struct Run { int s, e, label; };
+
+void emit_contig(FILE* out, const std::string& ctg, const std::vector<Run>& runs) {   // chunk.c:953-983 + 1058-1072
+    if (runs.empty()) return;
+    int start = 0, end = 0, label = -1;      // the merged block of a contig starts at 0 (preStart = 0 in the reference)
+    auto print = [&]() {
+        std::fprintf(out, "%s\t%d\t%d\t%s\t0\t.\t%d\t%d\t%s\n", ctg.c_str(), start, end + 1, kLabelNames[label], start, end + 1,
+                     kLabelColors[label]);
+    };
+    for (const Run& r : runs) {
+        if (label != -1 && r.label != label) { print(); start = r.s; }
+        end = r.e; label = r.label;
+    }
+    print();
+}
+}  // namespace
+
+extern "C" {
+
+const char* hfio_last_error(void) { return g_io_err.c_str(); }
+
+hfio_table* hfio_load(const char* path, int chunk_len, int window_len) {
+    if (!path) { g_io_err = "Error: Input path cannot be NULL."; return nullptr; }
+    const std::string ext = file_ext(path);
+    if (ext == "bin") return load_bin(path);
+    if (ext == "cov" || ext == "cov.gz") return load_cov(path, chunk_len, window_len);
+    g_io_err = "Error: input file should either cov/cov.gz or a binary file made with create_bin_chunks.";
+    return nullptr;
+}
+
+void hfio_destroy(hfio_table* t) { delete t; }
+int64_t hfio_n_windows(const hfio_table* t) { return (int64_t) t->cov.size(); }
+int32_t hfio_n_chunks(const hfio_table* t) { return (int32_t) t->chunks.size(); }
+int32_t hfio_n_regions(const hfio_table* t) { return (int32_t) t->region_coverages.size(); }
+const int32_t* hfio_region_coverages(const hfio_table* t) { return t->region_coverages.data(); }
+int32_t hfio_window_len(const hfio_table* t) { return t->window_len; }
+int32_t hfio_chunk_len(const hfio_table* t) { return t->chunk_len; }
+int32_t hfio_avg_alignment_len(const hfio_table* t) { return t->avg_alignment_len; }
+int32_t hfio_start_only(const hfio_table* t) { return t->start_only ? 1 : 0; }
+int32_t hfio_n_annotations(const hfio_table* t) { return (int32_t) t->annotation_names.size(); }
+const char* hfio_annotation_name(const hfio_table* t, int i) { return t->annotation_names[(size_t) i].c_str(); }
+const char* hfio_chunk_ctg(const hfio_table* t, int c) { return t->chunks[(size_t) c].ctg.c_str(); }
+int8_t* hfio_truth(hfio_table* t) { return t->truth.data(); }
+int8_t* hfio_prediction(hfio_table* t) { return t->prediction.data(); }
+
+void hfio_windows(const hfio_table* t, hf_windows* w) {
+    w->n_windows = (int64_t) t->cov.size(); w->n_chunks = (int32_t) t->chunks.size();
+    w->chunk_off = t->chunk_off.data(); w->cov = t->cov.data(); w->mapq = t->mapq.data(); w->clip = t->clip.data();
+    w->annot = t->annot.data(); w->chunk_s = t->chunk_s.data(); w->chunk_e = t->chunk_e.data();
+    w->chunk_ctg_len = t->chunk_ctg_len.data();
+    w->window_len = t->window_len; w->mean_read_len = t->avg_alignment_len;
+}
+
+int hfio_write_bin(const hfio_table* t, const char* path) {
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return -1;
+    const int32_t n_ann = (int32_t) t->annotation_names.size(), n_reg = (int32_t) t->region_coverages.size();
+    std::fwrite(&n_ann, 4, 1, f);
+    for (const std::string& s : t->annotation_names) { const int32_t len = (int32_t) s.size() + 1; std::fwrite(&len, 4, 1, f); std::fwrite(s.c_str(), 1, (size_t) len, f); }
+    std::fwrite(&n_reg, 4, 1, f);
+    std::fwrite(t->region_coverages.data(), 4, (size_t) n_reg, f);
+    std::fwrite(&t->n_labels, 4, 1, f);
+    const uint8_t b3[3] = {(uint8_t) t->truth_available, (uint8_t) t->prediction_available, (uint8_t) t->start_only};
+    std::fwrite(b3, 1, 3, f);
+    std::fwrite(&t->avg_alignment_len, 4, 1, f); std::fwrite(&t->chunk_len, 4, 1, f); std::fwrite(&t->window_len, 4, 1, f);
+    for (size_t c = 0; c < t->chunks.size(); c++) {
+        const ChunkMeta& cm = t->chunks[c];
+        const size_t o = (size_t) t->chunk_off[c]; const int32_t n = (int32_t) (t->chunk_off[c + 1] - t->chunk_off[c]);
+        const int32_t nl = (int32_t) cm.ctg.size() + 1;
+        std::fwrite(&nl, 4, 1, f); std::fwrite(cm.ctg.c_str(), 1, (size_t) nl, f);
+        std::fwrite(&cm.ctg_len, 4, 1, f); std::fwrite(&cm.s, 4, 1, f); std::fwrite(&cm.e, 4, 1, f); std::fwrite(&n, 4, 1, f);
+        std::fwrite(&t->cov[o], 2, (size_t) n, f); std::fwrite(&t->mapq[o], 2, (size_t) n, f); std::fwrite(&t->clip[o], 2, (size_t) n, f);
+        std::fwrite(&t->annot[o], 8, (size_t) n, f); std::fwrite(&t->truth[o], 1, (size_t) n, f); std::fwrite(&t->prediction[o], 1, (size_t) n, f);
+    }
+    return std::fclose(f) == 0 ? 0 : -1;
+}
+
+// chunk.c:985-1124: per contig, maximal runs of equal labels; a run shorter than its state's minimum length
+// becomes Hap; equal neighbours are then merged; rows are 0-based half-open
+int hfio_write_final_bed(const hfio_table* t, const int8_t* labels, const char* path, const char* track_name,
+                         const int32_t* min_len_per_state) {
+    FILE* out = std::fopen(path, "w");
+    if (!out) return -1;
+    std::fprintf(out, "track name=%s visibility=1 itemRgb=\"On\"\n", track_name);
+    const int hap = 2;
+    std::vector<Run> runs;
+    std::string pre_ctg;
+    int run_start = 0, pre_end = 0, pre_label = -1;
+    bool have = false;
+    auto close_run = [&]() {
+        const int len = pre_end + 1 - run_start;
+        const int minlen = (pre_label >= 0 && pre_label < 4 && min_len_per_state) ? min_len_per_state[pre_label] : 0;
+        runs.push_back(Run{run_start, pre_end, len < minlen ? hap : pre_label});
+    };
+    for (size_t c = 0; c < t->chunks.size(); c++) {
+        const ChunkMeta& cm = t->chunks[c];
+        const int64_t a = t->chunk_off[c], b = t->chunk_off[c + 1];
+        for (int64_t i = a; i < b; i++) {
+            const int k = (int) (i - a);
+            const int start = cm.s + k * t->window_len;                       // chunk.c:934-935
+            int end = cm.s + (k + 1) * t->window_len - 1;
+            if (cm.e < end) end = cm.e;
+            const int label = labels[i] != -1 ? labels[i] : 4;                // 4 = "Unk"
+            if (!have) run_start = start;
+            const bool label_changed = have && label != pre_label;
+            const bool ctg_changed = have && pre_ctg != cm.ctg;
+            if (label_changed || ctg_changed) { close_run(); run_start = start; }
+            if (ctg_changed) { emit_contig(out, pre_ctg, runs); runs.clear(); }
+            pre_end = end; pre_label = label; pre_ctg = cm.ctg; have = true;
+        }
+    }
+    if (have) { close_run(); emit_contig(out, pre_ctg, runs); }
+    return std::fclose(out) == 0 ? 0 : -1;
+}
+
+int hfio_write_posterior_bed(const hfio_table* t, const double* posterior, const int8_t* labels, const char* path) {  // hmm_flagger.c:240-282
+    FILE* out = std::fopen(path, "w");
+    if (!out) return -1;
+    std::fprintf(out, "#ctg\tstart\tend\t");
+    for (int s = 0; s < 4; s++) std::fprintf(out, "posterior_%s_%d\t", kStateNames[s], s);
+    std::fprintf(out, "prediction\n");
+    for (size_t c = 0; c < t->chunks.size(); c++) {
+        const ChunkMeta& cm = t->chunks[c];
+        const int64_t a = t->chunk_off[c], b = t->chunk_off[c + 1];
+        for (int64_t i = a; i < b; i++) {
+            const int k = (int) (i - a);
+            const int start = cm.s + k * t->window_len;
+            int end = cm.s + (k + 1) * t->window_len - 1;
+            if (cm.e < end) end = cm.e;
+            std::fprintf(out, "%s\t%d\t%d\t", cm.ctg.c_str(), start, end + 1);
+            for (int s = 0; s < 4; s++) std::fprintf(out, "%.2f\t", posterior[i * 4 + s]);
+            std::fprintf(out, "%s\n", kStateNames[labels[i] >= 0 && labels[i] < 4 ? labels[i] : 0]);
+        }
+    }
+    return std::fclose(out) == 0 ? 0 : -1;
+}
+
+}  // extern "C"

@@ -1,0 +1,426 @@
+// hf_model.cpp — host-side model of the MI355X build: initial parameters, the parameter view the
+// E-step consumes and the M-step (include/hmm_flagger_model.h).  The estimators of the reference
+// (ParameterEstimator / TransitionCountData, hmm_utils.h:93-107, 826-834) are not objects here:
+// the M-step reads the flat statistics vector the device produced.
+#include "../include/hmm_flagger_model.h"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <string>
+
+namespace {
+constexpr int S = HF_NSTATES;
+constexpr int KM = HF_MAXCOMP;
+constexpr double kMinCountForUpdate = 10;   // hmm_utils.h:11
+constexpr double kTruncFraction = 0.25;     // hmm_utils.h:12
+constexpr double kErrBinding = 0.1;         // hmm_utils.h:14
+constexpr double kTermination = 1e-4;       // hmm_utils.c:2112
+constexpr double kDiagProb = 0.99;          // hmm.c:15
+constexpr double kPseudoCount = 0.001;      // hmm.c:16
+}
+
+struct hfm_model {
+    int model_type = 0, R = 1, K = 2;
+    int ncomp[S] = {1, 1, 1, 2};
+    double alpha[4][4] = {};
+    double max_mapq = 0.25, min_mapq = 0.75, min_clip = 1.0;
+    double loglik = 0.0;
+    std::vector<double> trans;     // [R][5][5]
+    std::vector<double> lambda, trunc;  // [R]
+    std::vector<double> mean, var, weight; // [R][4][KM]
+    double& M(int r, int s, int c) { return mean[((size_t) r * S + s) * KM + c]; }
+    double& Vr(int r, int s, int c) { return var[((size_t) r * S + s) * KM + c]; }
+    double& W(int r, int s, int c) { return weight[((size_t) r * S + s) * KM + c]; }
+    double& T(int r, int i, int j) { return trans[(size_t) r * 25 + i * 5 + j]; }
+    bool gaussian_state(int s) const { return !(s == 0 && model_type == HF_MODEL_TRUNC_EXP_GAUSSIAN); }
+};
+
+extern "C" {
+
+hfm_model* hfm_create(int model_type, int n_collapsed, const int32_t* region_coverages, int n_regions,
+                      int start_only, int avg_alignment_len, int window_len, const double* alpha16,
+                      double max_high_mapq_ratio, double min_high_mapq_ratio) {
+    if ((model_type != HF_MODEL_TRUNC_EXP_GAUSSIAN && model_type != HF_MODEL_GAUSSIAN) || n_collapsed < 1 ||
+        n_collapsed > KM || n_regions < 1 || n_regions > HF_MAXREGIONS || !region_coverages)
+        return nullptr;
+    hfm_model* m = new hfm_model();
+    m->model_type = model_type; m->R = n_regions; m->K = n_collapsed;
+    m->ncomp[3] = n_collapsed;                                   // hmm_flagger.c:179-183
+    if (alpha16) std::memcpy(m->alpha, alpha16, sizeof(m->alpha));
+    m->max_mapq = max_high_mapq_ratio; m->min_mapq = min_high_mapq_ratio;
+    m->min_clip = 1.0;                                           // hmm_flagger.c:222
+    const size_t R = (size_t) n_regions;
+    m->trans.assign(R * 25, 0.0); m->lambda.assign(R, 1.0); m->trunc.assign(R, 0.0);
+    m->mean.assign(R * S * KM, 0.0); m->var.assign(R * S * KM, 0.0); m->weight.assign(R * S * KM, 0.0);
+    double median = region_coverages[0];                         // hmm_flagger.c:189-195
+    if (start_only) median *= (double) window_len / avg_alignment_len;
+    double base[S][KM] = {};
+    base[0][0] = median * kErrBinding * 1.0;                     // hmm_flagger.c:213-220, initialRandomDev = 0
+    base[1][0] = median * 0.5 * 1.0;
+    base[2][0] = median * 1.0 * 1.0;
+    for (int i = 0; i < n_collapsed; i++) base[3][i] = base[2][0] * (i + 2) * 1.0;
+    for (int r = 0; r < n_regions; r++) {
+        const double scale = (double) region_coverages[r] / median;  // hmm_flagger.c:199
+        m->lambda[r] = 1.0;                                      // hmm_utils.c:1620
+        m->trunc[r] = base[2][0] * scale * kTruncFraction;
+        for (int s = 0; s < S; s++)
+            for (int c = 0; c < m->ncomp[s]; c++) {              // hmm_utils.c:658-673, 733-741
+                const double mu = base[s][c] * scale;            // hmm.c:43-47
+                m->M(r, s, c) = mu;
+                m->Vr(r, s, c) = mu * 1.0;
+                m->W(r, s, c) = 1.0 / m->ncomp[s];
+            }
+        for (int i = 0; i < 5; i++)                              // hmm_utils.c:2109-2128
+            for (int j = 0; j < 5; j++)
+                m->T(r, i, j) = i == j ? kDiagProb * (1.0 - kTermination)
+                                       : (1.0 - kDiagProb) / (S - 1) * (1.0 - kTermination);
+        for (int s = 0; s < S; s++) { m->T(r, S, s) = 1.0 / S; m->T(r, s, S) = kTermination; }
+        m->T(r, S, S) = 0.0;
+    }
+    return m;
+}
+
+hfm_model* hfm_copy(const hfm_model* m) { return m ? new hfm_model(*m) : nullptr; }
+void hfm_destroy(hfm_model* m) { delete m; }
+int hfm_n_regions(const hfm_model* m) { return m->R; }
+int hfm_max_comps(const hfm_model* m) { return m->K; }
+int hfm_model_type(const hfm_model* m) { return m->model_type; }
+double hfm_max_high_mapq_ratio(const hfm_model* m) { return m->max_mapq; }
+double hfm_min_high_mapq_ratio(const hfm_model* m) { return m->min_mapq; }
+double hfm_min_highly_clipped_ratio(const hfm_model* m) { return m->min_clip; }
+double hfm_loglikelihood(const hfm_model* m) { return m->loglik; }
+
+void hfm_params(const hfm_model* m, hf_params* out) {
+    out->model_type = m->model_type; out->n_regions = m->R;
+    for (int s = 0; s < S; s++) out->ncomp[s] = m->ncomp[s];
+    std::memcpy(out->alpha, m->alpha, sizeof(out->alpha));
+    out->trans = m->trans.data(); out->lambda = m->lambda.data(); out->trunc_point = m->trunc.data();
+    out->mean = m->mean.data(); out->var = m->var.data(); out->weight = m->weight.data();
+}
+
+// hmm_utils.c:949-956
+static double trunc_exp_loglik(double lam, double b, double num, double den) {
+    return den * std::log(lam) - den * std::log(1.0 - std::exp(-lam * b)) - num * lam;
+}
+
+// hmm_utils.c:969-1011 TruncExponential_estimateLambda — golden-section search on [0, truncPoint]
+static double estimate_lambda(double trunc_point, double num, double den, double tol) {
+    double a = 0.0, b = trunc_point;
+    const double invphi = (std::sqrt(5.0) - 1.0) / 2.0, invphi2 = (3.0 - std::sqrt(5.0)) / 2.0;
+    double h = b - a;
+    if (h <= tol) return (b + a) / 2.0;
+    const int n = (int) std::ceil(std::log(tol / h) / std::log(invphi));
+    double c = a + invphi2 * h, d = a + invphi * h;
+    double yc = trunc_exp_loglik(c, trunc_point, num, den), yd = trunc_exp_loglik(d, trunc_point, num, den);
+    for (int k = 0; k < n - 1; k++) {
+        if (yc > yd) {
+            b = d; d = c; yd = yc; h = invphi * h; c = a + invphi2 * h;
+            yc = trunc_exp_loglik(c, trunc_point, num, den);
+        } else {
+            a = c; c = d; yc = yd; h = invphi * h; d = a + invphi * h;
+            yd = trunc_exp_loglik(d, trunc_point, num, den);
+        }
+    }
+    return yc > yd ? (a + d) / 2.0 : (c + b) / 2.0;
+}
+
+// binding factor of (state, parameter, component): hmm_utils.c:191-238, 290-304, 143-157
+static double binding(int s, int p, int c) {
+    if (p == 2) return 0.0;
+    if (s == 0) return kErrBinding;
+    if (s == 1) return 0.5;
+    if (s == 2) return 1.0;
+    return 2.0 + (double) c * 1.0;
+}
+
+int hfm_estimate(hfm_model* m, const double* stats, double tol) {
+    bool converged = true;
+    m->loglik = stats[0];
+    const int K = m->K;
+    const int64_t stride = hf_region_stride(K);
+    for (int r = 0; r < m->R; r++) {
+        const double* st = stats + 1 + r * stride;
+        auto num = [&](int s, int p, int c) { return st[((s * 3 + p) * 2 + 0) * K + c]; };
+        auto den = [&](int s, int p, int c) { return st[((s * 3 + p) * 2 + 1) * K + c]; };
+        // --- emissions: hmm_utils.c:1860-1903, one parameter type at a time (1817-1858) ---
+        for (int p = 0; p < 3; p++) {
+            double bnum = 0.0, bden = 0.0;                        // bound estimator, :1791-1815
+            for (int s = 0; s < S; s++) {
+                if (!m->gaussian_state(s)) continue;
+                for (int c = 0; c < m->ncomp[s]; c++) {
+                    const double f = binding(s, p, c);
+                    if (0.0 < f) { bnum += num(s, p, c) / f; bden += den(s, p, c); }
+                }
+            }
+            const double bound = bden == 0 ? 0.0 : bnum / bden;   // :76-92
+            for (int s = 0; s < S; s++) {
+                if (!m->gaussian_state(s)) continue;
+                for (int c = 0; c < m->ncomp[s]; c++) {
+                    const double f = binding(s, p, c);
+                    double est, count;
+                    if (0.0 < f) { est = bound * f; count = bden; }
+                    else { count = den(s, p, c); est = count == 0 ? 0.0 : num(s, p, c) / den(s, p, c); }
+                    if (kMinCountForUpdate < count) {             // :1846, 842-859
+                        double& slot = p == 0 ? m->M(r, s, c) : p == 1 ? m->Vr(r, s, c) : m->W(r, s, c);
+                        const double old = slot;
+                        slot = est;
+                        const double diff = 1.0e-4 < old ? std::fabs(est / old - 1.0) : 0.0;
+                        converged &= diff < tol;
+                    }
+                }
+            }
+        }
+        if (m->model_type == HF_MODEL_TRUNC_EXP_GAUSSIAN) {       // :1872-1884
+            const double n0 = num(0, 0, 0), d0 = den(0, 0, 0);
+            const double est = d0 == 0 ? 0.0 : estimate_lambda(m->trunc[r], n0, d0, 1e-6);
+            if (kMinCountForUpdate < d0) {                        // :1036-1054
+                const double old = m->lambda[r];
+                m->lambda[r] = est;
+                const double diff = 1.0e-4 < old ? std::fabs(est / old - 1.0) : 0.0;
+                converged &= diff < tol;
+            }
+            m->trunc[r] = m->M(r, 2, 0) * kTruncFraction;
+        }
+        // --- transitions: hmm_utils.c:2185-2219 ---
+        const double* cnt = st + 24 * K;
+        for (int i = 0; i < S; i++) {
+            double row = 0.0;
+            for (int j = 0; j < S; j++) row += cnt[i * 4 + j] + kPseudoCount;
+            for (int j = 0; j < S; j++) {
+                const double old = m->T(r, i, j);
+                const double nv = (cnt[i * 4 + j] + kPseudoCount) / row * (1.0 - kTermination);
+                m->T(r, i, j) = nv;
+                const double diff = 1.0e-6 < old ? std::fabs(nv / old - 1.0) : 0.0;
+                converged &= diff < tol;
+            }
+        }
+        for (int i = 0; i < S; i++) m->T(r, i, S) = kTermination;
+        for (int j = 0; j < S; j++) m->T(r, S, j) = 1.0 / S;
+        m->T(r, S, S) = 0.0;
+    }
+    return converged ? 1 : 0;
+}
+
+// ---- TSV writers: hmm.c:137-239 ----
+static const char* kStateNames[5] = {"Err", "Dup", "Hap", "Col", "Msj"};
+
+int hfm_write_transition_tsv(const hfm_model* mc, const char* path) {
+    hfm_model* m = const_cast<hfm_model*>(mc);
+    FILE* f = std::fopen(path, "w");
+    if (!f) return -1;
+    std::fprintf(f, "#Region\tState\tErr\tDup\tHap\tCol\tEnd\n");
+    for (int r = 0; r < m->R; r++)
+        for (int i = 0; i < S + 1; i++) {
+            std::fprintf(f, "%d\t%s", r, i < S ? kStateNames[i] : "Start");
+            for (int j = 0; j < S + 1; j++) std::fprintf(f, "\t%.5e", m->T(r, i, j));
+            std::fprintf(f, "\n");
+        }
+    std::fclose(f);
+    return 0;
+}
+
+int hfm_write_emission_tsv(const hfm_model* mc, const char* path) {
+    hfm_model* m = const_cast<hfm_model*>(mc);
+    FILE* f = std::fopen(path, "w");
+    if (!f) return -1;
+    std::fprintf(f, "#State\tDistribution\tComponents\tParameter");
+    for (int r = 0; r < m->R; r++) std::fprintf(f, "\tValues_Region_%d", r);
+    std::fprintf(f, "\n");
+    for (int s = 0; s < S; s++) {
+        const bool te = !m->gaussian_state(s);
+        const int np = te ? 2 : 3;                                // hmm_utils.c:1539-1575
+        for (int p = 0; p < np; p++) {
+            const char* pname = te ? (p == 0 ? "Mean" : "Trunc_Point") : (p == 0 ? "Mean" : p == 1 ? "Var" : "Weight");
+            std::fprintf(f, "%s\t%s\t%d\t%s", kStateNames[s], te ? "Truncated Exponential" : "Gaussian",
+                         te ? 1 : m->ncomp[s], pname);
+            for (int r = 0; r < m->R; r++) {
+                std::fprintf(f, "\t");
+                if (te) std::fprintf(f, "%.5e", p == 0 ? 1.0 / m->lambda[r] : m->trunc[r]);  // :1056-1069
+                else
+                    for (int c = 0; c < m->ncomp[s]; c++)
+                        std::fprintf(f, c ? ",%.5e" : "%.5e", p == 0 ? m->M(r, s, c) : p == 1 ? m->Vr(r, s, c) : m->W(r, s, c));
+            }
+            std::fprintf(f, "\n");
+        }
+    }
+    std::fclose(f);
+    return 0;
+}
+
+int64_t hfm_param_len(const hfm_model* m) { return (int64_t) m->R * (25 + 2 + 3 * S * KM); }
+
+void hfm_get_param_vector(const hfm_model* m, double* out) {
+    for (int r = 0; r < m->R; r++) {
+        std::memcpy(out, &m->trans[(size_t) r * 25], 25 * 8); out += 25;
+        *out++ = m->lambda[r]; *out++ = m->trunc[r];
+        std::memcpy(out, &m->mean[(size_t) r * S * KM], S * KM * 8); out += S * KM;
+        std::memcpy(out, &m->var[(size_t) r * S * KM], S * KM * 8); out += S * KM;
+        std::memcpy(out, &m->weight[(size_t) r * S * KM], S * KM * 8); out += S * KM;
+    }
+}
+
+void hfm_set_param_vector(hfm_model* m, const double* in) {
+    for (int r = 0; r < m->R; r++) {
+        std::memcpy(&m->trans[(size_t) r * 25], in, 25 * 8); in += 25;
+        m->lambda[r] = *in++; m->trunc[r] = *in++;
+        std::memcpy(&m->mean[(size_t) r * S * KM], in, S * KM * 8); in += S * KM;
+        std::memcpy(&m->var[(size_t) r * S * KM], in, S * KM * 8); in += S * KM;
+        std::memcpy(&m->weight[(size_t) r * S * KM], in, S * KM * 8); in += S * KM;
+    }
+}
+
+void hfm_set_loglikelihood(hfm_model* m, double ll) { m->loglik = ll; }
+
+void hfm_scale_initial_means(hfm_model* m, double f) {
+    for (int r = 0; r < m->R; r++) {
+        for (int s = 0; s < S; s++)
+            for (int c = 0; c < m->ncomp[s]; c++) {
+                const double g = s == 3 ? f * f : f;
+                m->M(r, s, c) *= g;
+                m->Vr(r, s, c) = m->M(r, s, c) * 1.0;
+            }
+        m->trunc[r] = m->M(r, 2, 0) * kTruncFraction;
+    }
+}
+
+// hmm.c:80-87 HMM_isFeasible (hmm_utils.c:685-694, 920-925, 2130-2139)
+int hfm_is_feasible(const hfm_model* mc) {
+    hfm_model* m = const_cast<hfm_model*>(mc);
+    bool ok = true;
+    for (int r = 0; r < m->R; r++) {
+        for (int s = 0; s < S; s++) {
+            if (!m->gaussian_state(s)) { ok &= 0 < m->lambda[r]; ok &= 0 < m->trunc[r]; continue; }
+            for (int c = 0; c < m->ncomp[s]; c++) {
+                ok &= 0 < m->M(r, s, c);
+                ok &= 0 < m->Vr(r, s, c);
+                ok &= (0 <= m->W(r, s, c)) && (m->W(r, s, c) <= 1);
+            }
+        }
+        for (int i = 0; i < S; i++)
+            for (int j = 0; j < S; j++)
+                if (m->T(r, i, j) < 0 || 1 < m->T(r, i, j)) return 0;
+    }
+    return ok ? 1 : 0;
+}
+
+// hmm_flagger.c:105-111 + 1012-1013
+int hfm_best_collapsed_comps(const uint16_t* cov, int64_t n, const int32_t* region_coverages, int n_regions) {
+    int maxc = 0;
+    for (int64_t i = 0; i < n; i++) if (maxc < cov[i]) maxc = cov[i];
+    int minr = region_coverages[0];
+    for (int r = 1; r < n_regions; r++) if (region_coverages[r] < minr) minr = region_coverages[r];
+    if (minr == 0) return -1;
+    int k = maxc / minr + 1;
+    return k < 2 ? 2 : (k > 10 ? 10 : k);
+}
+
+// hmm_flagger.c:491-515 + data_types.c:490-518 (tab-separated, no header, last character of each
+// line dropped before splitting)
+int hfm_read_alpha_tsv(const char* path, double* alpha16) {
+    FILE* f = std::fopen(path, "r");
+    if (!f) return -1;
+    for (int i = 0; i < 16; i++) alpha16[i] = 0.0;
+    char* line = nullptr; size_t cap = 0; int i = 0;
+    while (i < 4 && getline(&line, &cap, f) != -1) {
+        size_t L = std::strlen(line);
+        if (L > 0) line[L - 1] = '\0';
+        int j = 0; char* save = nullptr;
+        for (char* tok = strtok_r(line, "\t", &save); tok && j < 4; tok = strtok_r(nullptr, "\t", &save))
+            alpha16[i * 4 + j++] = std::atof(tok);
+        i++;
+    }
+    std::free(line);
+    std::fclose(f);
+    for (int k = 0; k < 16; k++) if (1.0 < alpha16[k] || alpha16[k] < 0.0) return -2;
+    return 0;
+}
+
+
+} // extern "C"
+
+// ---- SQUAREM (hmm.c:820-1098).  Parameters are visited in the reference's iterator order: per region, per
+// state, per component, per parameter (mean, var, weight | lambda), then the 4x4 transition block. ----
+struct hfm_squarem {
+    hfm_model m0, prime, rates_r, rates_v;
+    double alpha = 0.0;
+    hfm_squarem(const hfm_model& a) : m0(a), prime(a), rates_r(a), rates_v(a) {}
+    template <class F> static void for_each_param(hfm_model& m, F f) {   // f(double& slot, int region)
+        for (int r = 0; r < m.R; r++) {
+            for (int s = 0; s < S; s++) {
+                if (!m.gaussian_state(s)) { f(m.lambda[r], 0); continue; }   // trunc point is not iterated (:1132-1134)
+                for (int c = 0; c < m.ncomp[s]; c++) { f(m.M(r, s, c), 0); f(m.Vr(r, s, c), 0); f(m.W(r, s, c), 0); }
+            }
+            for (int i = 0; i < S; i++) for (int j = 0; j < S; j++) f(m.T(r, i, j), 1);
+        }
+    }
+    static std::vector<double*> slots(hfm_model& m) {
+        std::vector<double*> v;
+        for_each_param(m, [&](double& x, int) { v.push_back(&x); });
+        return v;
+    }
+    void compute_values() {                                              // hmm.c:921-997
+        auto p0 = slots(m0), pp = slots(prime), pr = slots(rates_r), pv = slots(rates_v);
+        for (size_t i = 0; i < p0.size(); i++)
+            *pp[i] = *p0[i] - 2 * *pr[i] * alpha + *pv[i] * std::pow(alpha, 2);
+        for (int r = 0; r < prime.R; r++) {                              // HMM_normalizeWeightsAndTransitionRows, hmm.c:89-94
+            for (int s = 0; s < S; s++) {
+                if (!prime.gaussian_state(s)) continue;
+                double sum = 0.0;
+                for (int c = 0; c < prime.ncomp[s]; c++) sum += prime.W(r, s, c);
+                if (0.0 < sum) { const double k = 1.0 / sum; for (int c = 0; c < prime.ncomp[s]; c++) prime.W(r, s, c) *= k; }
+            }
+            for (int i = 0; i < S; i++) {                                // hmm_utils.c:2165-2183
+                double row = 0.0;
+                for (int j = 0; j < S; j++) row += prime.T(r, i, j);
+                for (int j = 0; j < S; j++) prime.T(r, i, j) = prime.T(r, i, j) / row * (1.0 - kTermination);
+            }
+            for (int i = 0; i < S; i++) prime.T(r, i, S) = kTermination;
+            prime.T(r, S, S) = 0.0;
+        }
+    }
+    hfm_model* shrink_once(double margin) {                              // hmm.c:871-884
+        alpha = (alpha - 1) / 2;
+        if (alpha > (-1 - margin)) { alpha = -1.0; prime = m0; return &prime; }
+        compute_values();
+        return &prime;
+    }
+};
+
+extern "C" {
+
+hfm_squarem* hfm_squarem_create(const hfm_model* m0, const hfm_model* m1c, const hfm_model* m2c) {
+    hfm_squarem* a = new hfm_squarem(*m0);
+    hfm_model m1(*m1c), m2(*m2c);
+    auto p0 = hfm_squarem::slots(a->m0), p1 = hfm_squarem::slots(m1), p2 = hfm_squarem::slots(m2);
+    auto pr = hfm_squarem::slots(a->rates_r), pv = hfm_squarem::slots(a->rates_v);
+    double num = 0.0, den = 0.0;                                         // hmm.c:999-1098
+    for (size_t i = 0; i < p0.size(); i++) {
+        const double r = *p1[i] - *p0[i];
+        const double v = *p2[i] - *p1[i] - r;
+        num += std::pow(r, 2);
+        den += std::pow(v, 2);
+        *pr[i] = r; *pv[i] = v;
+    }
+    a->alpha = -1 * std::sqrt(num / den);
+    if (a->alpha > -1) a->alpha = -1;
+    return a;
+}
+void hfm_squarem_destroy(hfm_squarem* a) { delete a; }
+double hfm_squarem_alpha(const hfm_squarem* a) { return a->alpha; }
+
+hfm_model* hfm_squarem_model_prime(hfm_squarem* a) {
+    a->compute_values();
+    hfm_model* p = &a->prime;
+    while (!hfm_is_feasible(p)) p = a->shrink_once(1e-2);
+    return p;
+}
+
+hfm_model* hfm_squarem_shrink(hfm_squarem* a) {
+    hfm_model* p = a->shrink_once(1e-2);
+    while (!hfm_is_feasible(p)) p = a->shrink_once(1e-2);
+    return p;
+}
+
+} // extern "C"

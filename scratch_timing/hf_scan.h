@@ -20,33 +20,6 @@
 
 struct M4 { double m[16]; };
 
-// Conditional-transition and start tables of every region, staged once per block in LDS (136 doubles per region:
-// tcond[8][16], start[4], pad): the per-window lookup no longer waits on global memory behind the window record.
-#define HF_TAB_STRIDE 136
-__device__ __forceinline__ void fill_tab(const DevParams* __restrict__ P, double* __restrict__ s_tab) {
-    const int n = P->n_regions * HF_TAB_STRIDE;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int r = i / HF_TAB_STRIDE, k = i % HF_TAB_STRIDE;
-        s_tab[i] = k < 128 ? P->reg[r].tcond[k >> 4][k & 15] : (k < 132 ? P->reg[r].trans[4][k - 128] : 0.0);
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ void lds_Tm(const double* __restrict__ s_tab, uint32_t r, double Tm[16]) {
-    if (REC_FIRST(r)) {                       // chunk-first window: the start row for every pre
-        const double* __restrict__ s = s_tab + REC_REGION(r) * HF_TAB_STRIDE + 128;
-#pragma unroll
-        for (int k = 0; k < 16; k++) Tm[k] = s[k & 3];
-    } else if (REC_REGCHG(r)) {               // region change => 1/(S+1), hmm.c:398-400
-#pragma unroll
-        for (int k = 0; k < 16; k++) Tm[k] = 1.0 / (HF_NSTATES + 1);
-    } else {
-        const double* __restrict__ s = s_tab + REC_REGION(r) * HF_TAB_STRIDE + REC_VMASK(r) * 16;
-#pragma unroll
-        for (int k = 0; k < 16; k++) Tm[k] = s[k];
-    }
-}
-
 __device__ __forceinline__ void m4_identity(M4& a) {
 #pragma unroll
     for (int i = 0; i < 16; i++) a.m[i] = (i % 5 == 0) ? 1.0 : 0.0;
@@ -298,26 +271,20 @@ __global__ void __launch_bounds__(64) k_carry(const int64_t* __restrict__ off, c
 // k_fwd_tile: one wavefront per tile
 // ------------------------------------------------------------------------------------------
 template <int L>
-__global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const TileDesc* __restrict__ td,
-                                                  const uint32_t* __restrict__ rec,
+__global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const int32_t* __restrict__ tile_chunk,
+                                                  const int64_t* __restrict__ tile_base,
+                                                  const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
                                                   const double* __restrict__ E, const double* __restrict__ Qs,
                                                   const DevParams* __restrict__ P,
                                                   const double* __restrict__ cf, double* __restrict__ F,
                                                   double* __restrict__ scale, double* __restrict__ tile_ll,
                                                   unsigned* __restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    fill_tab(P, s_tab);
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
-    const TileDesc d = td[tile];
-    const int64_t t0 = d.t0, T = d.T, base = d.base;
+    long long tk0 = clock64(), tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0;
+    const int c = tile_chunk[tile];
+    const int64_t t0 = off[c], T = off[c + 1] - t0, base = tile_base[tile];
     const int64_t a = base + (int64_t) lane * L;
-    // everything phase 3 needs is requested now, so its latency hides behind the scan
-    uint32_t rr[L];
-#pragma unroll
-    for (int i = 0; i < L; i++) rr[i] = (a + i < T) ? rec[t0 + a + i] : 0u;
-    double Ecur[16];
-    load_E<L>(E, tile, lane, 0, Ecur);
     double carry[4];
     if (base == 0) { carry[0] = 1.0; carry[1] = 0.0; carry[2] = 0.0; carry[3] = 0.0; }  // (1,0,0,0)·A_first = start∘e
     else {
@@ -328,26 +295,28 @@ __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const TileDesc* __
     // phase 1 + 2: exclusive prefix product over lanes
     M4 Q;
     load_lane_product(Q, Qs, tile, lane);
+    if (Q.m[0] >= 0.0 && carry[0] >= -1.0 && T > 0) tk1 = clock64();
     if (base == 0 && lane == 0) {   // the chunk's first window is not in Q_l: prepend A_first = start∘e (row 0 only)
-        double Tm[16];
-        lds_Tm(s_tab, rr[0], Tm);
+        double Tm[16], Ev[16];
+        load_Tm(P, rec[t0], Tm);
+        load_E<L>(E, tile, 0, 0, Ev);
         M4 A, R;
 #pragma unroll
-        for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ecur[k];
+        for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ev[k];
         m4_mul(R, A, Q);
         Q = R;
         m4_renorm(Q);
     }
 #pragma unroll
-    for (int d2 = 1; d2 < 64; d2 <<= 1) {
+    for (int d = 1; d < 64; d <<= 1) {
         M4 Lft, R;
-        m4_shfl_up(Lft, Q, d2);
-        if (lane >= d2) { m4_mul(R, Lft, Q); Q = R; m4_renorm(Q); }
+        m4_shfl_up(Lft, Q, d);
+        if (lane >= d) { m4_mul(R, Lft, Q); Q = R; m4_renorm(Q); }
     }
+    M4 X;
+    m4_shfl_up(X, Q, 1);
     double f[4];
     {
-        M4 X;
-        m4_shfl_up(X, Q, 1);
         double u[4], su = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -358,23 +327,23 @@ __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const TileDesc* __
 #pragma unroll
         for (int j = 0; j < 4; j++) f[j] = (lane == 0) ? carry[j] : u[j] / su;
     }
+    if (f[0] >= -1.0) tk2 = clock64();
     // phase 3: replay this lane's windows in the reference's operation order (hmm.c:333-420)
     double ll = 0.0;
 #pragma unroll
     for (int i = 0; i < L; i++) {
-        double Enext[16];
-        if (i + 1 < L) load_E<L>(E, tile, lane, i + 1, Enext);     // next window's row is in flight during this one
         if (a + i < T) {
             const int64_t t = t0 + a + i;
-            const uint32_t r = rr[i];
-            double Tm[16];
-            lds_Tm(s_tab, r, Tm);
+            const uint32_t r = rec[t];
+            double Tm[16], Ev[16];
+            load_Tm(P, r, Tm);
+            load_E<L>(E, tile, lane, i, Ev);
             double nf[4], sc = 0.0;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 double acc = 0.0;
 #pragma unroll
-                for (int p = 0; p < 4; p++) acc += (f[p] * Tm[p * 4 + s] * Ecur[p * 4 + s]);
+                for (int p = 0; p < 4; p++) acc += (f[p] * Tm[p * 4 + s] * Ev[p * 4 + s]);
                 nf[s] = acc;
                 sc += acc;
             }
@@ -386,13 +355,12 @@ __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const TileDesc* __
             reinterpret_cast<double2*>(F + t * 4)[1] = make_double2(f[2], f[3]);
             scale[t] = sc;
         }
-        if (i + 1 < L) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) Ecur[k] = Enext[k];
-        }
     }
+    if (f[0] >= -1.0 && ll < 1e300) tk3 = clock64();
     for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
-    if (lane == 0) tile_ll[tile] = ll;
+    tk4 = clock64();
+    const long long dd[4] = {tk1 - tk0, tk2 - tk1, tk3 - tk2, tk4 - tk0};
+    if (lane == 0) tile_ll[tile] = (double) dd[HF_TIMING];
     if (bad) atomicOr(flags, bad);
 }
 
@@ -413,36 +381,23 @@ __global__ void __launch_bounds__(64) k_chunk_ll(const int32_t* __restrict__ chu
 // written by the tile that contains window T-2 (or by tile 0 when T == 1).
 // ------------------------------------------------------------------------------------------
 template <int L>
-__global__ void __launch_bounds__(256) k_bwd_tile(int ntiles, const TileDesc* __restrict__ td,
-                                                  const uint32_t* __restrict__ rec,
+__global__ void __launch_bounds__(256) k_bwd_tile(int ntiles, const int32_t* __restrict__ tile_chunk,
+                                                  const int64_t* __restrict__ tile_base,
+                                                  const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
                                                   const double* __restrict__ E, const double* __restrict__ Qs,
                                                   const DevParams* __restrict__ P,
                                                   const double* __restrict__ cb, const double* __restrict__ F,
                                                   const double* __restrict__ scale, double* __restrict__ B,
                                                   int8_t* __restrict__ label, unsigned* __restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    fill_tab(P, s_tab);
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
-    const TileDesc d = td[tile];
-    const int64_t t0 = d.t0, T = d.T, base = d.base;
+    const int c = tile_chunk[tile];
+    const int64_t t0 = off[c], T = off[c + 1] - t0, base = tile_base[tile];
     const int64_t Tm1 = T - 1;                              // windows 0..T-2 have a recurrence step
     const int64_t a = base - 1 + (int64_t) lane * L;        // first window of this lane (may be -1)
     const int64_t tend = base - 1 + 64 * (int64_t) L;       // first window after the tile
-    // requests for phase 3 go out first: window records of t+1, scales and the first emission row
-    uint32_t rr[L];
-    double scv[L];
-#pragma unroll
-    for (int i = 0; i < L; i++) {
-        const bool ok = a + i >= 0 && a + i < Tm1;
-        rr[i] = ok ? rec[t0 + a + i + 1] : 0u;
-        scv[i] = ok ? scale[t0 + a + i] : 1.0;
-    }
-    double Ecur[16];
-    load_E<L>(E, tile, lane, L - 1, Ecur);
     unsigned bad = 0;
-    const uint32_t rlast = rec[t0 + T - 1];
-    const DevRegion* __restrict__ Rl = &P->reg[REC_REGION(rlast)];
+    const DevRegion* __restrict__ Rl = &P->reg[REC_REGION(rec[t0 + T - 1])];
     const double term = Rl->trans[0][4];
     double carry[4];
     const bool last_tile = tend >= Tm1;
@@ -469,24 +424,22 @@ __global__ void __launch_bounds__(256) k_bwd_tile(int ntiles, const TileDesc* __
         for (int s = 0; s < 4; s++) carry[s] *= k;
     }
     // phase 1 + 2: exclusive SUFFIX product over lanes; lane windows i own A_{i+1}
+    M4 Q;
+    load_lane_product(Q, Qs, tile, lane);                   // = product over windows a+1 .. a+L (window 0 excluded)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        M4 Rgt, R;
+        m4_shfl_down(Rgt, Q, d);
+        if (lane + d < 64) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
+    }
+    M4 X;
+    m4_shfl_down(X, Q, 1);
     double b[4];
-    {
-        M4 Q;
-        load_lane_product(Q, Qs, tile, lane);               // = product over windows a+1 .. a+L (window 0 excluded)
 #pragma unroll
-        for (int d2 = 1; d2 < 64; d2 <<= 1) {
-            M4 Rgt, R;
-            m4_shfl_down(Rgt, Q, d2);
-            if (lane + d2 < 64) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
-        }
-        M4 X;
-        m4_shfl_down(X, Q, 1);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            double s = X.m[i * 4] * carry[0];
-            s = fma(X.m[i * 4 + 1], carry[1], s); s = fma(X.m[i * 4 + 2], carry[2], s); s = fma(X.m[i * 4 + 3], carry[3], s);
-            b[i] = s;
-        }
+    for (int i = 0; i < 4; i++) {
+        double s = X.m[i * 4] * carry[0];
+        s = fma(X.m[i * 4 + 1], carry[1], s); s = fma(X.m[i * 4 + 2], carry[2], s); s = fma(X.m[i * 4 + 3], carry[3], s);
+        b[i] = s;
     }
     const int64_t nxt = a + L;                              // window whose b this lane starts from
     if (lane == 63 || nxt >= Tm1) {
@@ -502,45 +455,26 @@ __global__ void __launch_bounds__(256) k_bwd_tile(int ntiles, const TileDesc* __
         for (int i = 0; i < 4; i++) b[i] *= k;
     }
     // phase 3: replay this lane's windows (decreasing i) in the reference's operation order (hmm.c:470-529)
-    double fcur[4] = {0.0, 0.0, 0.0, 0.0};
-    if (a + L - 1 >= 0 && a + L - 1 < Tm1) {
-        const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + (t0 + a + L - 1) * 4);
-        const double2 f01 = fp[0], f23 = fp[1];
-        fcur[0] = f01.x; fcur[1] = f01.y; fcur[2] = f23.x; fcur[3] = f23.y;
-    }
 #pragma unroll
     for (int i = L - 1; i >= 0; i--) {
-        double Enext[16], fnext[4] = {0.0, 0.0, 0.0, 0.0};
-        if (i > 0) {                                          // previous window's row and f are in flight during this one
-            load_E<L>(E, tile, lane, i - 1, Enext);
-            if (a + i - 1 >= 0 && a + i - 1 < Tm1) {
-                const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + (t0 + a + i - 1) * 4);
-                const double2 f01 = fp[0], f23 = fp[1];
-                fnext[0] = f01.x; fnext[1] = f01.y; fnext[2] = f23.x; fnext[3] = f23.y;
-            }
-        }
         if (a + i >= 0 && a + i < Tm1) {
             const int64_t t = t0 + a + i;
-            double Tm[16];
-            lds_Tm(s_tab, rr[i], Tm);                         // window t+1 = base + lane*L + i of this tile
+            double Tm[16], Ev[16];
+            load_Tm(P, rec[t + 1], Tm);
+            load_E<L>(E, tile, lane, i, Ev);                  // window t+1 = base + lane*L + i of this tile
             double nb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
-                for (int p = 0; p < 4; p++) nb[p] += Tm[p * 4 + s] * Ecur[p * 4 + s] * b[s];
-            const double sc = scv[i];
+                for (int p = 0; p < 4; p++) nb[p] += Tm[p * 4 + s] * Ev[p * 4 + s] * b[s];
+            const double sc = scale[t];
             if (sc < 1e-50) bad |= HF_FLAG_SCALE;             // hmm.c:521-524
+            double f[4];
 #pragma unroll
-            for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
+            for (int s = 0; s < 4; s++) { b[s] = nb[s] / sc; f[s] = F[t * 4 + s]; }
             reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(b[0], b[1]);
             reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(b[2], b[3]);
-            label[t] = (int8_t) posterior_label(fcur, b, sc);
-        }
-        if (i > 0) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) Ecur[k] = Enext[k];
-#pragma unroll
-            for (int k = 0; k < 4; k++) fcur[k] = fnext[k];
+            label[t] = (int8_t) posterior_label(f, b, sc);
         }
     }
     if (bad) atomicOr(flags, bad);
