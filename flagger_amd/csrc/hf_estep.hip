@@ -324,14 +324,11 @@ template <int KT>
 __device__ __forceinline__ double& acc_ref(StatAcc<KT>& a, int i) { return reinterpret_cast<double*>(&a)[i]; }
 
 // contributions of the pair (i, i+1) — window t = t0+i — to the accumulators of region REC_REGION(rec[t+1])
-// LUT = true: the pair's window is an interior one; the collapsed state's component probabilities come from this
-// iteration's table (lutC row of (region, x, x_prev), k_lut) instead of being re-evaluated.
-template <int KT, bool LUT>
+template <int KT>
 __device__ __forceinline__ void stats_pair(StatAcc<KT>& a, const DevParams* __restrict__ P, const DevRegion* __restrict__ R,
                                            int64_t t, const uint32_t* __restrict__ rec, const double* __restrict__ beta,
                                            const double* __restrict__ Ev, const double* __restrict__ F,
-                                           const double* __restrict__ B, bool te, int ncol, const double* __restrict__ lutC_row,
-                                           int Kctx, unsigned* nan) {
+                                           const double* __restrict__ B, bool te, int ncol, unsigned* nan) {
     const uint32_t r1 = rec[t + 1];
     const double x = (double) REC_X(r1), px = (double) REC_X(rec[t]);
     const double bt = beta[t + 1];
@@ -386,8 +383,7 @@ __device__ __forceinline__ void stats_pair(StatAcc<KT>& a, const DevParams* __re
 #pragma unroll
         for (int cc = 0; cc < KT; cc++)
             if (cc < ncol) {
-                pc[cc] = LUT ? lutC_row[P->umap[k] * Kctx + cc]
-                             : hf_gauss_comp(R->mean[3][cc], R->var[3][cc], R->weight[3][cc], x, px, alpha, bt, nan);
+                pc[cc] = hf_gauss_comp(R->mean[3][cc], R->var[3][cc], R->weight[3][cc], x, px, alpha, bt, nan);
                 tot += pc[cc];
             }
 #pragma unroll
@@ -403,11 +399,22 @@ __device__ __forceinline__ void stats_pair(StatAcc<KT>& a, const DevParams* __re
     }
 }
 
-// one wavefront per tile of 64*HF_SCAN_L pairs, lanes strided by 64 (coalesced); one partial vector per
-// (tile, region present in the tile); fixed shuffle tree => deterministic
+// ------------------------------------------------------------------------------------------
+// k_stats_tile: statistics of the interior pairs (beta == beta_star) of one tile per wavefront.
+// f, b1, Tm, Ev come from the pass arrays / LDS tables; the collapsed state's component probabilities from this
+// iteration's table row lutC[(r, x, x_prev)][K][4] (k_lut); their total is the emission value itself
+// (Ev[pre][Col] is the same sum of the same terms).  The 3K per-component accumulators of a lane live in LDS
+// (lane-minor, conflict-free) so the component loop stays rolled and the kernel keeps its occupancy; the
+// 27 scalar accumulators stay in registers.
+// ------------------------------------------------------------------------------------------
+struct StatAccSmall {
+    double trans[16];
+    double g_mnum[3], g_vnum[3], g_den[3];
+    double te_num, te_den;
+};
+
 template <int KT>
-__global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const int32_t* __restrict__ tile_chunk,
-                                                    const int64_t* __restrict__ tile_base, const int64_t* __restrict__ off,
+__global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDesc* __restrict__ td,
                                                     const uint32_t* __restrict__ rec, const double* __restrict__ beta,
                                                     const double* __restrict__ E, const DevParams* __restrict__ P,
                                                     const double* __restrict__ F, const double* __restrict__ B,
@@ -415,56 +422,143 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const int32_t
                                                     int M, int Kctx,
                                                     double* __restrict__ tile_stats, unsigned* __restrict__ flags) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
+    constexpr int NS = 16 + 9 + 2;                  // scalar accumulators kept in registers
+    constexpr int L = HF_SCAN_L;
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    fill_tab(P, s_tab);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= ntiles) return;
+    double* __restrict__ s_acc = s_tab + P->n_regions * HF_TAB_STRIDE + wave * (3 * KT * 64) + lane;   // [(q*KT+cc)*64]
+    const TileDesc d = td[tile];
+    const int64_t t0 = d.t0, T = d.T, base = d.base;
     const int64_t MM = (int64_t) M * M;
     const double bstar = P->beta_star;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (tile >= ntiles) return;
-    const int c = tile_chunk[tile];
-    const int64_t t0 = off[c], T = off[c + 1] - t0, base = tile_base[tile];
     const bool te = hf_err_is_truncexp(P);
     const int ncol = P->ncomp[3], nreg = P->n_regions;
-    unsigned nan = 0;
-    unsigned long long present = 0;
-    const int64_t a0 = base + (int64_t) lane * HF_SCAN_L;   // this lane owns windows a0..a0+L-1 and the pairs ending there
+    const int64_t a0 = base + (int64_t) lane * L;   // this lane owns windows a0..a0+L-1 and the pairs ending there
+    uint32_t rr[L + 1];
+    bool ok[L];
 #pragma unroll
-    for (int j = 0; j < HF_SCAN_L; j++) {
-        const int64_t w = a0 + j;
-        if (w >= 2 && w <= T - 1) present |= 1ull << (REC_REGION(rec[t0 + w]) & 63u);
+    for (int j = 0; j <= L; j++) { const int64_t w = a0 + j - 1; rr[j] = (w >= 0 && w < T) ? rec[t0 + w] : 0u; }
+    unsigned long long present = 0;
+#pragma unroll
+    for (int j = 0; j < L; j++) {
+        const int64_t w = a0 + j;                             // pair (w-1, w), w = 2..T-1  (hmm.c:638-642)
+        ok[j] = w >= 2 && w <= T - 1 && beta[t0 + w] == bstar; // the others are on the slow list (k_stats_slow)
+        if (w >= 2 && w <= T - 1) present |= 1ull << (REC_REGION(rr[j + 1]) & 63u);
     }
     for (int o = 32; o > 0; o >>= 1) present |= __shfl_xor(present, o);
-    const unsigned long long in_chunk = regmask[c];
+    const unsigned long long in_chunk = regmask[d.chunk];
+    double xa[4], om[4];
+    int um[4];
     for (int r = 0; r < nreg; r++) {
         if (!((in_chunk >> r) & 1ull)) continue;   // k_chunk_stats never reads this slot
+        double* __restrict__ dst = tile_stats + ((int64_t) tile * nreg + r) * NA;
         if (!((present >> r) & 1ull)) {            // region occurs in the chunk but not in this tile
-            double* __restrict__ z = tile_stats + ((int64_t) tile * nreg + r) * NA;
-            for (int i = lane; i < NA; i += 64) z[i] = 0.0;
+            for (int i = lane; i < NA; i += 64) dst[i] = 0.0;
             continue;
         }
         const DevRegion* __restrict__ R = &P->reg[r];
-        StatAcc<KT> a;
+        StatAccSmall a;
 #pragma unroll
-        for (int i = 0; i < NA; i++) acc_ref<KT>(a, i) = 0.0;
+        for (int i = 0; i < NS; i++) reinterpret_cast<double*>(&a)[i] = 0.0;
+        double c_wden = 0.0;
+        for (int i = 0; i < 3 * ncol; i++) s_acc[((i / ncol) * KT + (i % ncol)) * 64] = 0.0;
 #pragma unroll 1
-        for (int j = 0; j < HF_SCAN_L; j++) {
-            const int64_t w = a0 + j;                         // pair (w-1, w), w = 2..T-1  (hmm.c:638-642)
-            // interior windows only: the pairs at contig ends (beta != beta_star) are on the slow list (k_stats_slow)
-            if (w >= 2 && w <= T - 1 && (int) REC_REGION(rec[t0 + w]) == r && beta[t0 + w] == bstar) {
-                double Ev[16];
-                load_E<HF_SCAN_L>(E, tile, lane, j, Ev);
-                const int64_t idx = (int64_t) REC_X(rec[t0 + w]) * M + REC_X(rec[t0 + w - 1]);
-                stats_pair<KT, true>(a, P, R, t0 + w - 1, rec, beta, Ev, F, B, te, ncol,
-                                     lutC + (((int64_t) r * MM + idx) * 4) * Kctx, Kctx, &nan);
+        for (int j = 0; j < L; j++) {
+            if (!(ok[j] && (int) REC_REGION(rr[j + 1]) == r)) continue;
+            const int64_t t = t0 + a0 + j - 1;                // pair (t, t+1)
+            double Ev[16], Tm[16], f[4], b1[4];
+            load_E<L>(E, tile, lane, j, Ev);
+            const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + t * 4);
+            const double2* __restrict__ bp = reinterpret_cast<const double2*>(B + (t + 1) * 4);
+            const double2 f01 = fp[0], f23 = fp[1], b01 = bp[0], b23 = bp[1];
+            const unsigned xw = REC_X(rr[j + 1]), xp = REC_X(rr[j]);
+            const double2* __restrict__ crow =
+                reinterpret_cast<const double2*>(lutC + (((int64_t) r * MM + (int64_t) xw * M + xp) * 4) * Kctx);
+            lds_Tm(s_tab, rr[j + 1], Tm);
+            f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
+            b1[0] = b01.x; b1[1] = b01.y; b1[2] = b23.x; b1[3] = b23.y;
+            const double x = (double) xw, px = (double) xp;
+            // one state (column) at a time, with a scheduling barrier after each: keeps the live set small enough for
+            // 3 waves per SIMD; state outer / pre inner is also the order of the reference (hmm.c:588-589)
+            double adj3[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                double adj[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const int k = p * 4 + s;
+                    const double count = f[p] * Tm[k] * Ev[k] * b1[s];
+                    adj[p] = count / HF_TERMINATION_PROB;     // hmm.c:613-614
+                    a.trans[k] += adj[p];                     // hmm_utils.c:2010-2015
+                }
+                if (s == 3) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++) adj3[p] = adj[p];
+                } else if (s == 0 && te) {                    // hmm_utils.c:1027-1034
+#pragma unroll
+                    for (int p = 0; p < 4; p++) { a.te_num += adj[p] * x; a.te_den += adj[p]; }
+                } else {                                      // hmm_utils.c:812-839, one component
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int k = p * 4 + s;
+                        const double alpha = P->alpha[k];
+                        const double x_adj = (x - alpha * px) / (1.0 - alpha);
+                        const double w = adj[p] * Ev[k] / Ev[k];
+                        a.g_mnum[s] += w * x_adj;
+                        const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
+                        a.g_vnum[s] += w * z * z;
+                        a.g_den[s] += w;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // collapsed state, component-major: one 32-byte table row per component serves all four pre states
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const double alpha = P->alpha[p * 4 + 3];
+                xa[p] = (x - alpha * px) / (1.0 - alpha);
+                om[p] = 1.0 - alpha;
+                um[p] = P->umap[p * 4 + 3];
+            }
+#pragma unroll 1
+            for (int cc = 0; cc < ncol; cc++) {
+                const double2 u01 = crow[cc * 2], u23 = crow[cc * 2 + 1];
+                const double mu = R->mean[3][cc];
+                double mnum = s_acc[(0 * KT + cc) * 64], vnum = s_acc[(1 * KT + cc) * 64], den = s_acc[(2 * KT + cc) * 64];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const double pc = um[p] == 0 ? u01.x : um[p] == 1 ? u01.y : um[p] == 2 ? u23.x : u23.y;
+                    const double w = adj3[p] * pc / Ev[p * 4 + 3];
+                    mnum += w * xa[p];
+                    const double z = (xa[p] - mu) * om[p];
+                    vnum += w * z * z;
+                    den += w;
+                    c_wden += w;
+                }
+                s_acc[(0 * KT + cc) * 64] = mnum; s_acc[(1 * KT + cc) * 64] = vnum; s_acc[(2 * KT + cc) * 64] = den;
             }
         }
-        double* __restrict__ dst = tile_stats + ((int64_t) tile * nreg + r) * NA;
+        // fixed shuffle tree per accumulator, lane 0 stores in StatAcc<KT> order
 #pragma unroll
-        for (int i = 0; i < NA; i++) {
-            double v = acc_ref<KT>(a, i);
+        for (int i = 0; i < NS; i++) {
+            double v = reinterpret_cast<double*>(&a)[i];
             for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
             if (lane == 0) dst[i] = v;
         }
+        for (int i = 0; i < 3 * KT; i++) {
+            double v = (i % KT) < ncol ? s_acc[i * 64] : 0.0;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0) dst[NS + i] = v;
+        }
+        {
+            double v = c_wden;
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0) dst[NS + 3 * KT] = v;
+        }
     }
-    if (nan) atomicOr(flags, nan);
 }
 
 // pairs at contig ends (beta != beta_star): generic evaluation, one wavefront per chunk over its slow list
@@ -496,7 +590,7 @@ __global__ void __launch_bounds__(64) k_stats_slow(const int32_t* __restrict__ s
             if ((int) REC_REGION(rec[tw]) != r) continue;
             double Ev[16];
             load_E_window(E, chunk_tile0[c], tw - t0, Ev);
-            stats_pair<KT, false>(a, P, R, tw - 1, rec, beta, Ev, F, B, te, ncol, nullptr, 0, &nan);
+            stats_pair<KT>(a, P, R, tw - 1, rec, beta, Ev, F, B, te, ncol, &nan);
         }
         double* __restrict__ dst = slow_stats + ((int64_t) c * nreg + r) * NA;
 #pragma unroll
@@ -587,8 +681,8 @@ static int dev_upload(T** dst, const T* src, size_t n) {
 
 template <int KT>
 static void launch_stats(hf_ctx* ctx, hipStream_t st) {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256), 0, st, ctx->ntiles,
-                       ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_E, ctx->d_params,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256),
+                       ((size_t) ctx->R * HF_TAB_STRIDE + 4 * 3 * KT * 64) * 8, st, ctx->ntiles, ctx->d_tile_desc, ctx->d_rec, ctx->d_beta, ctx->d_E, ctx->d_params,
                        ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_lutC, ctx->M, ctx->K, ctx->d_tile_stats, ctx->d_flags);
     if (ctx->n_slow > 0)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_slow<KT>), dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_slow_off,

@@ -123,7 +123,7 @@ __device__ __forceinline__ void load_Tm(const DevParams* __restrict__ P, uint32_
 // k_lut: this iteration's emission tables for interior windows (beta == beta_star), per region and per
 // (x, x_prev) in [0, M)^2 — the same device functions as the direct evaluation, so the values are identical:
 //   lutE[r][x*M+px][16]       the emission row E[pre][s]
-//   lutC[r][x*M+px][u][K]     component probabilities of the collapsed state for its u-th distinct alpha
+//   lutC[r][x*M+px][K][4]     component probabilities of the collapsed state, [component][u-th distinct alpha]
 // NaNs are stored, not reported: only a window that actually uses the entry raises HF_E_NAN.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_lut(int M, int K, const DevParams* __restrict__ P, double* __restrict__ lutE,
@@ -143,9 +143,10 @@ __global__ void __launch_bounds__(256) k_lut(int M, int K, const DevParams* __re
     for (int k = 0; k < 8; k++) dst[k] = make_double2(out[2 * k], out[2 * k + 1]);
     const int ncol = P->ncomp[3], nu = P->nuniq[3];
     double* __restrict__ c = lutC + (((int64_t) r * MM + idx) * 4) * K;
-    for (int u = 0; u < nu; u++)
-        for (int cc = 0; cc < ncol; cc++)
-            c[u * K + cc] = hf_gauss_comp_star(R->m1[3][u][cc], R->gvar[3][cc], R->gnorm[3][cc], x, px, P->ualpha[3][u], bs, &nan);
+    for (int cc = 0; cc < ncol; cc++)
+        for (int u = 0; u < 4; u++)
+            c[cc * 4 + u] = u < nu ? hf_gauss_comp_star(R->m1[3][u][cc], R->gvar[3][cc], R->gnorm[3][cc], x, px,
+                                                        P->ualpha[3][u], bs, &nan) : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------
