@@ -102,9 +102,12 @@ def main():
     target = em if world == 1 else sharded   # single GPU: no exchange buffers in the path
 
     def step():
-        hmm.EM_runOneIterationForList(target, model)          # E-step + decode (+ all-gather) + ordered reduce
-        hmm.HMM_estimateParameters(model, 1e-3)               # M-step on the host
-        hmm.HMM_resetEstimators(model)
+        if world == 1:
+            em.em_iterate(model, True, 1e-3)                      # E-step + decode + ordered reduce + M-step, one native call
+        else:
+            hmm.EM_runOneIterationForList(target, model)          # E-step + decode + all-gather + ordered reduce
+            hmm.HMM_estimateParameters(model, 1e-3)               # M-step on the host (replicated on every rank)
+            hmm.HMM_resetEstimators(model)
 
     def barrier():
         if world > 1:

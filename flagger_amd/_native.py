@@ -105,6 +105,7 @@ def lib() -> C.CDLL:
     sig("hfm_set_param_vector", None, vp, pd)
     sig("hfm_best_collapsed_comps", C.c_int, C.POINTER(C.c_uint16), i64, C.POINTER(i32), C.c_int)
     sig("hfm_read_alpha_tsv", C.c_int, C.c_char_p, pd)
+    sig("hf_em_iterate", C.c_int, vp, vp, C.c_int, C.c_int, dbl, pd, C.POINTER(C.c_int), vp)
     # SQUAREM + misc model helpers
     sig("hfm_scale_initial_means", None, vp, dbl)
     sig("hfm_squarem_create", vp, vp, vp, vp)

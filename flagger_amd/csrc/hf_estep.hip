@@ -9,6 +9,7 @@
 //   k_reduce    ordered sum over chunks                               (hmm.c:759-763)
 // There is no CPU fallback: without a HIP device hf_create fails with HF_E_NOGPU.
 #include "hf_device.h"
+#include "../../include/hmm_flagger_model.h"
 #ifndef HF_SCAN_L
 #define HF_SCAN_L 4   // consecutive windows per lane in the scan kernels
 #endif
@@ -51,6 +52,7 @@ struct hf_ctx {
     unsigned* d_flags = nullptr;
     DevParams* d_params = nullptr; DevParams* h_params = nullptr; size_t params_bytes = 0;
     unsigned* h_flags = nullptr;
+    double* h_total = nullptr;     // pinned [V+1]: reduced vector + flag word, one copy per pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
     bool profiling = false; hipEvent_t kev[HF_NKERNELS + 2] = {}; bool kran[HF_NKERNELS] = {};  // kev[0..4] stage marks, kev[5..6] reduce
     bool have_full = false;
@@ -653,8 +655,9 @@ __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__
 
 // ordered sum over chunks (hmm.c:759-763): one thread per vector element, chunks in list order
 __global__ void k_reduce(const double* __restrict__ chunk_stats, int64_t n_chunks, int64_t V,
-                         double* __restrict__ out) {
+                         double* __restrict__ out, const unsigned* __restrict__ flags) {
     const int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (v == V && flags) { out[V] = (double) *flags; return; }   // error flags ride along with the vector
     if (v >= V) return;
     double acc = 0.0;
     int64_t c = 0;
@@ -745,7 +748,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     DMALLOC(ctx->d_rec, N * 4); DMALLOC(ctx->d_beta, N * 8); DMALLOC(ctx->d_regmask, C * 8);
     DMALLOC(ctx->d_f, N * 4 * 8); DMALLOC(ctx->d_b, N * 4 * 8);
     DMALLOC(ctx->d_scale, N * 8); DMALLOC(ctx->d_label, N);
-    DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, (size_t) ctx->V * 8);
+    DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, ((size_t) ctx->V + 1) * 8);
     DMALLOC(ctx->d_flags, 4);
     {   // tiles of 64*HF_SCAN_L windows, enumerated chunk by chunk
         std::vector<int32_t> tchunk, ctile0(C + 1, 0);
@@ -781,7 +784,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
     DMALLOC(ctx->d_params, ctx->params_bytes);
     if (hipHostMalloc((void**) &ctx->h_params, ctx->params_bytes) != hipSuccess ||
-        hipHostMalloc((void**) &ctx->h_flags, 4) != hipSuccess) {
+        hipHostMalloc((void**) &ctx->h_flags, 4) != hipSuccess ||
+        hipHostMalloc((void**) &ctx->h_total, ((size_t) ctx->V + 1) * 8) != hipSuccess) {
         hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed");
     }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
@@ -841,6 +845,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
+    if (ctx->h_total) hipHostFree(ctx->h_total);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     for (int i = 0; i < HF_NKERNELS + 2; i++) if (ctx->kev[i]) hipEventDestroy(ctx->kev[i]);
@@ -914,8 +919,9 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev0, st));
     HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(ctx->d_chunk_stats, 0, (size_t) ctx->C * ctx->V * 8 + (ctx->C ? 0 : 8), st));
-    HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
+    if (ctx->algo == HF_ALGO_SEQ || ctx->N == 0)   // the scan pass zeroes in k_chunk_ll / k_lut instead
+        HIPCHK(hipMemsetAsync(ctx->d_chunk_stats, 0, (size_t) ctx->C * ctx->V * 8 + (ctx->C ? 0 : 8), st));
+    if (ctx->N == 0) HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
     for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
     auto mark = [&](int stage) { if (ctx->profiling) hipEventRecord(ctx->kev[stage], st); };
     if (ctx->N > 0 && ctx->C > 0) {
@@ -925,7 +931,7 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
         {
             const int64_t MM = (int64_t) ctx->M * ctx->M;
             hipLaunchKernelGGL(k_lut, dim3((unsigned) ((MM + 255) / 256), (unsigned) ctx->R), dim3(256), 0, st, ctx->M, ctx->K,
-                               ctx->d_params, ctx->d_lutE, ctx->d_lutC);
+                               ctx->d_params, ctx->d_lutE, ctx->d_lutC, ctx->d_flags);
         }
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_tile<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
                            ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_params,
@@ -987,8 +993,8 @@ int hf_reduce_chunks(hf_ctx* ctx, const double* chunk_stats_dev, int64_t n_chunk
     HIPCHK(hipSetDevice(ctx->device));
     const bool own = ctx->profiling && chunk_stats_dev == ctx->d_chunk_stats;
     if (own) hipEventRecord(ctx->kev[5], (hipStream_t) stream);
-    hipLaunchKernelGGL(k_reduce, dim3((unsigned) ((ctx->V + 127) / 128)), dim3(128), 0, (hipStream_t) stream,
-                       chunk_stats_dev, n_chunks, ctx->V, out_dev);
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned) ((ctx->V + 1 + 127) / 128)), dim3(128), 0, (hipStream_t) stream,
+                       chunk_stats_dev, n_chunks, ctx->V, out_dev, out_dev == ctx->d_total ? ctx->d_flags : (const unsigned*) nullptr);
     if (own) { hipEventRecord(ctx->kev[6], (hipStream_t) stream); ctx->kran[4] = true; }
     HIPCHK(hipGetLastError());
     return HF_OK;
@@ -1016,8 +1022,29 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
     int rc = hf_reduce_chunks(ctx, ctx->d_chunk_stats, ctx->C, ctx->d_total, stream);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev1, st));
-    HIPCHK(hipMemcpyAsync(stats_host, ctx->d_total, (size_t) ctx->V * 8, hipMemcpyDeviceToHost, st));
-    return hf_check(ctx, stream);
+    HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
+    return flags_to_code((unsigned) ctx->h_total[ctx->V]);
+}
+
+// One EM step in one call: E-step with the model's current parameters, reduced statistics back on the host,
+// then (do_mstep) HMM_estimateParameters.  What runHMMFlagger repeats (hmm_flagger.c:337-445) without going back
+// to the caller between the two halves.
+int hf_em_iterate(hf_ctx* ctx, hfm_model* model, int mode, int do_mstep, double tol, double* stats_host, int* converged,
+                  void* stream) {
+    if (!ctx || !model || !stats_host) return set_err(HF_E_ARG, "hf_em_iterate: bad argument");
+    hf_params p;
+    hfm_params(model, &p);
+    int rc = hf_estep(ctx, &p, mode, stream);
+    if (rc == HF_OK) rc = hf_finish(ctx, stats_host, stream);
+    if (rc != HF_OK) return rc;
+    hfm_set_loglikelihood(model, stats_host[0]);
+    if (do_mstep && mode == HF_MODE_FULL) {
+        const int cv = hfm_estimate(model, stats_host, tol);
+        if (converged) *converged = cv;
+    }
+    return HF_OK;
 }
 
 int hf_get_labels(hf_ctx* ctx, int8_t* labels_host) {

@@ -127,7 +127,8 @@ __device__ __forceinline__ void load_Tm(const DevParams* __restrict__ P, uint32_
 // NaNs are stored, not reported: only a window that actually uses the entry raises HF_E_NAN.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_lut(int M, int K, const DevParams* __restrict__ P, double* __restrict__ lutE,
-                                             double* __restrict__ lutC) {
+                                             double* __restrict__ lutC, unsigned* __restrict__ flags) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *flags = 0u;   // first kernel of every pass
     const int r = blockIdx.y;
     const int64_t MM = (int64_t) M * M;
     const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -405,6 +406,8 @@ __global__ void __launch_bounds__(64) k_chunk_ll(const int32_t* __restrict__ chu
     double s = 0.0;
     for (int k = lane; k < nt; k += 64) s += tile_ll[k0 + k];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    // the chunk's statistics vector starts from zero every pass (HMM_resetEstimators, hmm.c:129-134)
+    for (int64_t v = 1 + lane; v < V; v += 64) chunk_stats[(int64_t) c * V + v] = 0.0;
     if (lane == 0) chunk_stats[(int64_t) c * V] = s;
 }
 

@@ -203,6 +203,18 @@ class EMList:
         N.check(self._L.hf_reduce_chunks(self._h, C.c_void_p(src_dev_ptr), n_chunks, C.c_void_p(dst_dev_ptr),
                                          self.stream), "hf_reduce_chunks")
 
+    def em_iterate(self, model: "HMM", do_mstep: bool = True, tol: float = 1e-3, mode: int = N.HF_MODE_FULL) -> bool:
+        """EM_runOneIterationForList + HMM_estimateParameters in one native call (hf_em_iterate).  Leaves the
+        statistics in model.estimators; returns the convergence flag of the M-step."""
+        if not hasattr(self, "_stats_buf"):
+            self._stats_buf = np.empty(self.stats_len, dtype=np.float64)
+        cv = C.c_int(0)
+        N.check(self._L.hf_em_iterate(self._h, model._h, mode, int(do_mstep), float(tol), _dptr(self._stats_buf),
+                                      C.byref(cv), self.stream), "hf_em_iterate")
+        model.estimators = self._stats_buf
+        model.loglikelihood = float(self._stats_buf[0])
+        return bool(cv.value)
+
     def kernel_ms(self) -> float:
         ms = C.c_float()
         N.check(self._L.hf_last_kernel_ms(self._h, C.byref(ms)), "hf_last_kernel_ms")
@@ -287,12 +299,17 @@ def runHMMFlagger(emList, model: HMM, numberOfIterations: int = 100, convergence
         model.writeTransitionTsv(os.path.join(outputDir, "transition_initial.tsv"))
         model.writeEmissionTsv(os.path.join(outputDir, "emission_initial.tsv"))
     it, converged = 1, False
+    fused = hasattr(emList, "em_iterate")      # single GPU: E-step + M-step in one native call
     while it <= numberOfIterations and not converged:
-        EM_runOneIterationForList(emList, model)
+        if fused:
+            converged = emList.em_iterate(model, True, convergenceTol)
+        else:
+            EM_runOneIterationForList(emList, model)
         lls.append(model.loglikelihood)
         if llf:
             llf.write("%d\t%d\t%.4f\n" % (it - 1, it - 1, model.loglikelihood))
-        converged = HMM_estimateParameters(model, convergenceTol)
+        if not fused:
+            converged = HMM_estimateParameters(model, convergenceTol)
         HMM_resetEstimators(model)
         if write and writeParameterStatsPerIteration:
             model.writeTransitionTsv(os.path.join(outputDir, f"transition_iteration_{it}.tsv"))

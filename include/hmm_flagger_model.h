@@ -74,6 +74,11 @@ hfm_model *hfm_squarem_shrink(hfm_squarem *a);
 int hfm_is_feasible(const hfm_model *m);                                                            /* hmm.c:80-87 */
 void hfm_set_loglikelihood(hfm_model *m, double ll);
 
+/* One EM step in one call (E-step on the GPU, statistics to the host, optional M-step): the body of the loop of
+ * runHMMFlagger, src/hmm_flagger.c:337-445.  stats_host: [hf_chunk_stats_len]. */
+int hf_em_iterate(hf_ctx *ctx, hfm_model *model, int mode, int do_mstep, double tol, double *stats_host, int *converged,
+                  void *stream);
+
 int hfm_best_collapsed_comps(const uint16_t *cov, int64_t n_windows, const int32_t *region_coverages, int n_regions);
 int hfm_read_alpha_tsv(const char *path, double *alpha16);
 

@@ -20,7 +20,7 @@ ALPHA = os.path.join(GOLD, "alpha_hifi.tsv")
 def _run(exe, args, out):
     out.mkdir(exist_ok=True)
     r = subprocess.run([exe] + args + ["-o", str(out)], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, (os.path.basename(exe), r.returncode, r.stderr[-2000:])
     return r
 
 
