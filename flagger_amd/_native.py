@@ -11,7 +11,7 @@ import os
 HF_NSTATES = 4
 HF_MAXCOMP = 16
 HF_MAXREGIONS = 64
-HF_NKERNELS = 5
+HF_NKERNELS = 10
 HF_MODEL_TRUNC_EXP_GAUSSIAN, HF_MODEL_GAUSSIAN = 0, 1
 HF_MODE_FULL, HF_MODE_FORWARD_ONLY = 0, 1
 HF_ALGO_SCAN, HF_ALGO_SEQ = 0, 1
@@ -82,7 +82,7 @@ def lib() -> C.CDLL:
     sig("hf_get_posterior", C.c_int, vp, i64, i64, pd)
     sig("hf_get_forward_backward", C.c_int, vp, i64, i64, pd, pd, pd)
     sig("hf_last_kernel_ms", C.c_int, vp, C.POINTER(C.c_float))
-    sig("hf_set_profiling", C.c_int, vp, C.c_int)
+    sig("hf_set_profiling", C.c_int, vp, C.c_uint)
     sig("hf_kernel_times", C.c_int, vp, C.POINTER(C.c_float))
     sig("hf_kernel_name", C.c_char_p, C.c_int)
     # host model

@@ -54,7 +54,8 @@ struct hf_ctx {
     unsigned* h_flags = nullptr;
     double* h_total = nullptr;     // pinned [V+1]: reduced vector + flag word, one copy per pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
-    bool profiling = false; hipEvent_t kev[HF_NKERNELS + 2] = {}; bool kran[HF_NKERNELS] = {};  // kev[0..4] stage marks, kev[5..6] reduce
+    unsigned prof_mask = 0;        // bit k: kernel k (HF_K_*) is bracketed by kev[2k], kev[2k+1]
+    hipEvent_t kev[2 * HF_NKERNELS] = {}; bool kran[HF_NKERNELS] = {};
     bool have_full = false;
     double beta_star = 1.0;
     // per-iteration emission tables over (x, x_prev) in [0, M)^2 for interior windows (k_lut)
@@ -682,15 +683,28 @@ static int dev_upload(T** dst, const T* src, size_t n) {
     return 0;
 }
 
+// event pair around one kernel launch, only for the kernels selected by hf_set_profiling
+struct KTimer {
+    hf_ctx* c; hipStream_t st; int k; bool on;
+    KTimer(hf_ctx* c_, hipStream_t s_, int k_) : c(c_), st(s_), k(k_), on((c_->prof_mask >> k_) & 1u) {
+        if (on) hipEventRecord(c->kev[2 * k], st);
+    }
+    ~KTimer() { if (on) { hipEventRecord(c->kev[2 * k + 1], st); c->kran[k] = true; } }
+};
+
 template <int KT>
 static void launch_stats(hf_ctx* ctx, hipStream_t st) {
+    { KTimer t(ctx, st, HF_K_STATS_TILE);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256),
                        ((size_t) ctx->R * HF_TAB_STRIDE + 4 * 3 * KT * 64) * 8, st, ctx->ntiles, ctx->d_tile_desc, ctx->d_rec, ctx->d_beta, ctx->d_E, ctx->d_params,
-                       ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_lutC, ctx->M, ctx->K, ctx->d_tile_stats, ctx->d_flags);
-    if (ctx->n_slow > 0)
+                       ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_lutC, ctx->M, ctx->K, ctx->d_tile_stats, ctx->d_flags); }
+    if (ctx->n_slow > 0) {
+        KTimer t(ctx, st, HF_K_STATS_SLOW);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_slow<KT>), dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_slow_off,
                            ctx->d_slow_w, ctx->d_chunk_tile0, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_E, ctx->d_params,
                            ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_slow_stats, ctx->d_flags);
+    }
+    KTimer t(ctx, st, HF_K_CHUNK_STATS);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_chunk_tile0,
                        ctx->d_regmask, ctx->d_tile_stats, ctx->d_slow_off, ctx->d_slow_stats, ctx->d_params, ctx->d_chunk_stats,
                        ctx->V, ctx->K);
@@ -848,7 +862,7 @@ void hf_destroy(hf_ctx* ctx) {
     if (ctx->h_total) hipHostFree(ctx->h_total);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
-    for (int i = 0; i < HF_NKERNELS + 2; i++) if (ctx->kev[i]) hipEventDestroy(ctx->kev[i]);
+    for (int i = 0; i < 2 * HF_NKERNELS; i++) if (ctx->kev[i]) hipEventDestroy(ctx->kev[i]);
     delete ctx;
 }
 
@@ -923,34 +937,40 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
         HIPCHK(hipMemsetAsync(ctx->d_chunk_stats, 0, (size_t) ctx->C * ctx->V * 8 + (ctx->C ? 0 : 8), st));
     if (ctx->N == 0) HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
     for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
-    auto mark = [&](int stage) { if (ctx->profiling) hipEventRecord(ctx->kev[stage], st); };
     if (ctx->N > 0 && ctx->C > 0) {
         const unsigned tb = (unsigned) ((ctx->ntiles + 3) / 4);
         const size_t tab_bytes = (size_t) ctx->R * HF_TAB_STRIDE * 8;   // LDS transition tables
-        mark(0);
         {
+            KTimer t(ctx, st, HF_K_LUT);
             const int64_t MM = (int64_t) ctx->M * ctx->M;
             hipLaunchKernelGGL(k_lut, dim3((unsigned) ((MM + 255) / 256), (unsigned) ctx->R), dim3(256), 0, st, ctx->M, ctx->K,
                                ctx->d_params, ctx->d_lutE, ctx->d_lutC, ctx->d_flags);
         }
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_tile<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
-                           ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_params,
-                           ctx->d_lutE, ctx->M, ctx->d_E, ctx->d_Qs, ctx->d_Pt, ctx->d_flags);
-        mark(1); ctx->kran[0] = true;
-        if (ctx->algo == HF_ALGO_SEQ)
+        {
+            KTimer t(ctx, st, HF_K_EMIT_TILE);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_tile<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
+                               ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_params,
+                               ctx->d_lutE, ctx->M, ctx->d_E, ctx->d_Qs, ctx->d_Pt, ctx->d_flags);
+        }
+        if (ctx->algo == HF_ALGO_SEQ) {
+            KTimer t(ctx, st, HF_K_FWD);
             hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec, ctx->d_E,
                                ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_chunk_stats, ctx->V, ctx->d_flags);
-        else {
+        } else {
+            { KTimer t(ctx, st, HF_K_CARRY);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_carry<HF_SCAN_L>), dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
-                               ctx->d_E, ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb);
+                               ctx->d_E, ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb); }
+            { KTimer t(ctx, st, HF_K_FWD);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fwd_tile<HF_SCAN_L>), dim3(tb), dim3(256), tab_bytes, st, ctx->ntiles,
                                ctx->d_tile_desc, ctx->d_rec, ctx->d_E, ctx->d_Qs, ctx->d_params,
-                               ctx->d_cf, ctx->d_f, ctx->d_scale, ctx->d_tile_ll, ctx->d_flags);
+                               ctx->d_cf, ctx->d_f, ctx->d_scale, ctx->d_tile_ll, ctx->d_flags); }
+            KTimer t(ctx, st, HF_K_CHUNK_LL);
             hipLaunchKernelGGL(k_chunk_ll, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_chunk_tile0, ctx->d_tile_ll,
                                ctx->d_chunk_stats, ctx->V);
         }
-        mark(2); ctx->kran[1] = true;   // end of forward (= start of backward)
         if (mode == HF_MODE_FULL) {
+            {
+            KTimer t(ctx, st, HF_K_BWD);
             if (ctx->algo == HF_ALGO_SEQ)
                 hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec, ctx->d_E,
                                    ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
@@ -959,12 +979,11 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
                                    tab_bytes, st, ctx->ntiles, ctx->d_tile_desc, ctx->d_rec, ctx->d_E,
                                    ctx->d_Qs, ctx->d_params, ctx->d_cb, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label,
                                    ctx->d_flags);
-            mark(3); ctx->kran[2] = true;
+            }
             const int kc = p->ncomp[3];
             if (kc <= 4) launch_stats<4>(ctx, st);
             else if (kc <= 8) launch_stats<8>(ctx, st);
             else launch_stats<16>(ctx, st);
-            mark(4); ctx->kran[3] = true;
         }
     }
     HIPCHK(hipGetLastError());
@@ -991,11 +1010,15 @@ int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
 int hf_reduce_chunks(hf_ctx* ctx, const double* chunk_stats_dev, int64_t n_chunks, double* out_dev, void* stream) {
     if (!ctx || !chunk_stats_dev || !out_dev || n_chunks < 0) return set_err(HF_E_ARG, "hf_reduce_chunks: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
-    const bool own = ctx->profiling && chunk_stats_dev == ctx->d_chunk_stats;
-    if (own) hipEventRecord(ctx->kev[5], (hipStream_t) stream);
+    const bool own = chunk_stats_dev == ctx->d_chunk_stats;
+    const unsigned keep = ctx->prof_mask;
+    if (!own) ctx->prof_mask = 0;
+    {
+    KTimer t(ctx, (hipStream_t) stream, HF_K_REDUCE);
     hipLaunchKernelGGL(k_reduce, dim3((unsigned) ((ctx->V + 1 + 127) / 128)), dim3(128), 0, (hipStream_t) stream,
                        chunk_stats_dev, n_chunks, ctx->V, out_dev, out_dev == ctx->d_total ? ctx->d_flags : (const unsigned*) nullptr);
-    if (own) { hipEventRecord(ctx->kev[6], (hipStream_t) stream); ctx->kran[4] = true; }
+    }
+    ctx->prof_mask = keep;
     HIPCHK(hipGetLastError());
     return HF_OK;
 }
@@ -1076,26 +1099,28 @@ int hf_get_posterior(hf_ctx* ctx, int64_t first, int64_t n, double* post_host) {
     return HF_OK;
 }
 
-int hf_set_profiling(hf_ctx* ctx, int on) {
+int hf_set_profiling(hf_ctx* ctx, unsigned kernel_mask) {
     if (!ctx) return set_err(HF_E_ARG, "hf_set_profiling: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
-    if (on && !ctx->kev[0]) for (int i = 0; i < HF_NKERNELS + 2; i++) HIPCHK(hipEventCreate(&ctx->kev[i]));
-    ctx->profiling = on != 0;
+    if (kernel_mask && !ctx->kev[0]) for (int i = 0; i < 2 * HF_NKERNELS; i++) HIPCHK(hipEventCreate(&ctx->kev[i]));
+    ctx->prof_mask = kernel_mask & ((1u << HF_NKERNELS) - 1u);
+    for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
     return HF_OK;
 }
 
 int hf_kernel_times(hf_ctx* ctx, float ms[HF_NKERNELS]) {
-    if (!ctx || !ms || !ctx->profiling) return set_err(HF_E_ARG, "hf_kernel_times: profiling is off");
-    for (int i = 0; i < HF_NKERNELS; i++) ms[i] = 0.f;
-    for (int i = 0; i < 4; i++)   // emit, forward, backward, stats: kev[i] -> kev[i+1]
-        if (ctx->kran[i]) HIPCHK(hipEventElapsedTime(&ms[i], ctx->kev[i], ctx->kev[i + 1]));
-    if (ctx->kran[4]) HIPCHK(hipEventElapsedTime(&ms[4], ctx->kev[5], ctx->kev[6]));
+    if (!ctx || !ms || !ctx->prof_mask) return set_err(HF_E_ARG, "hf_kernel_times: profiling is off");
+    for (int i = 0; i < HF_NKERNELS; i++) {
+        ms[i] = 0.f;
+        if (ctx->kran[i]) HIPCHK(hipEventElapsedTime(&ms[i], ctx->kev[2 * i], ctx->kev[2 * i + 1]));
+    }
     return HF_OK;
 }
 
-const char* hf_kernel_name(int stage) {
-    static const char* names[HF_NKERNELS] = {"emit", "forward", "backward", "stats", "reduce"};
-    return stage >= 0 && stage < HF_NKERNELS ? names[stage] : "?";
+const char* hf_kernel_name(int k) {
+    static const char* names[HF_NKERNELS] = {"k_lut", "k_emit_tile", "k_carry", "k_fwd", "k_chunk_ll", "k_bwd",
+                                             "k_stats_tile", "k_stats_slow", "k_chunk_stats", "k_reduce"};
+    return k >= 0 && k < HF_NKERNELS ? names[k] : "?";
 }
 
 int hf_last_kernel_ms(hf_ctx* ctx, float* ms) {

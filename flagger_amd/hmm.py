@@ -220,11 +220,21 @@ class EMList:
         N.check(self._L.hf_last_kernel_ms(self._h, C.byref(ms)), "hf_last_kernel_ms")
         return float(ms.value)
 
-    def set_profiling(self, on: bool = True) -> None:
-        N.check(self._L.hf_set_profiling(self._h, int(on)), "hf_set_profiling")
+    def set_profiling(self, kernels=True) -> None:
+        """True/False: all kernels / none; or an iterable of kernel names (hf_kernel_name) to bracket with events."""
+        names = [self._L.hf_kernel_name(i).decode() for i in range(N.HF_NKERNELS)]
+        if kernels is True:
+            mask = (1 << N.HF_NKERNELS) - 1
+        elif not kernels:
+            mask = 0
+        else:
+            mask = 0
+            for k in kernels:
+                mask |= 1 << names.index(k)
+        N.check(self._L.hf_set_profiling(self._h, mask), "hf_set_profiling")
 
     def kernel_times(self) -> dict:
-        """Duration (ms) of each stage of the last pass, from HIP events on the launch stream."""
+        """Duration (ms) of each selected kernel in the last pass, from HIP events on the launch stream."""
         ms = (C.c_float * N.HF_NKERNELS)()
         N.check(self._L.hf_kernel_times(self._h, ms), "hf_kernel_times")
         return {self._L.hf_kernel_name(i).decode(): float(ms[i]) for i in range(N.HF_NKERNELS)}

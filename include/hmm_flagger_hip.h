@@ -135,13 +135,16 @@ int hf_get_forward_backward(hf_ctx *ctx, int64_t first, int64_t n, double *f_hos
 /* kernel time of the last hf_estep + reduce in milliseconds (HIP events on the stream used) */
 int hf_last_kernel_ms(hf_ctx *ctx, float *ms);
 
-/* Per-kernel timing (bench.py's roofline leg): when enabled, hf_estep/hf_finish record a HIP event
- * on the launch stream between kernels; hf_kernel_times returns the duration of each stage of the
- * LAST pass in milliseconds (0 for stages that did not run).  Call after hf_finish/hf_check. */
-#define HF_NKERNELS 5
-int hf_set_profiling(hf_ctx *ctx, int on);
+/* Per-kernel timing (bench.py's roofline leg): every kernel k whose bit is set in kernel_mask is bracketed
+ * by a pair of HIP events on the launch stream; hf_kernel_times returns the duration of each selected kernel in
+ * the LAST pass in milliseconds (0 for kernels not selected or not run).  Call after hf_finish/hf_check.
+ * Each selected kernel adds two event packets to the stream, so select only what is being measured. */
+#define HF_NKERNELS 10
+enum { HF_K_LUT = 0, HF_K_EMIT_TILE, HF_K_CARRY, HF_K_FWD, HF_K_CHUNK_LL, HF_K_BWD, HF_K_STATS_TILE, HF_K_STATS_SLOW,
+       HF_K_CHUNK_STATS, HF_K_REDUCE };
+int hf_set_profiling(hf_ctx *ctx, unsigned kernel_mask);
 int hf_kernel_times(hf_ctx *ctx, float ms[HF_NKERNELS]);
-const char *hf_kernel_name(int stage);   /* "emit", "forward", "backward", "stats", "reduce" */
+const char *hf_kernel_name(int k);   /* "k_lut", "k_emit_tile", ... as they appear in a rocprofv3 kernel trace */
 
 #ifdef __cplusplus
 }
