@@ -654,23 +654,18 @@ __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__
     }
 }
 
-// ordered sum over chunks (hmm.c:759-763): one thread per vector element, chunks in list order
-__global__ void k_reduce(const double* __restrict__ chunk_stats, int64_t n_chunks, int64_t V,
-                         double* __restrict__ out, const unsigned* __restrict__ flags) {
-    const int64_t v = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (v == V && flags) { out[V] = (double) *flags; return; }   // error flags ride along with the vector
-    if (v >= V) return;
+// sum over chunks (hmm.c:759-763) in a fixed order that depends only on the chunk list: one wavefront per vector
+// element, lane l adds chunks l, l+64, ... in list order, then a fixed shuffle tree over the lanes.  The same
+// kernel reduces the local chunk list on one GPU and the all-gathered list on N GPUs => identical bits.
+__global__ void __launch_bounds__(64) k_reduce(const double* __restrict__ chunk_stats, int64_t n_chunks, int64_t V,
+                                               double* __restrict__ out, const unsigned* __restrict__ flags) {
+    const int64_t v = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (v == V) { if (flags && lane == 0) out[V] = (double) *flags; return; }   // error flags ride along with the vector
     double acc = 0.0;
-    int64_t c = 0;
-    for (; c + 8 <= n_chunks; c += 8) {   // 8 loads in flight, adds stay in list order
-        double x[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) x[j] = chunk_stats[(c + j) * V + v];
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc += x[j];
-    }
-    for (; c < n_chunks; c++) acc += chunk_stats[c * V + v];
-    out[v] = acc;
+    for (int64_t c = lane; c < n_chunks; c += 64) acc += chunk_stats[c * V + v];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane == 0) out[v] = acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -958,7 +953,7 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
                                ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_chunk_stats, ctx->V, ctx->d_flags);
         } else {
             { KTimer t(ctx, st, HF_K_CARRY);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_carry<HF_SCAN_L>), dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_carry<HF_SCAN_L>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
                                ctx->d_E, ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb); }
             { KTimer t(ctx, st, HF_K_FWD);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fwd_tile<HF_SCAN_L>), dim3(tb), dim3(256), tab_bytes, st, ctx->ntiles,
@@ -1015,7 +1010,7 @@ int hf_reduce_chunks(hf_ctx* ctx, const double* chunk_stats_dev, int64_t n_chunk
     if (!own) ctx->prof_mask = 0;
     {
     KTimer t(ctx, (hipStream_t) stream, HF_K_REDUCE);
-    hipLaunchKernelGGL(k_reduce, dim3((unsigned) ((ctx->V + 1 + 127) / 128)), dim3(128), 0, (hipStream_t) stream,
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned) (ctx->V + 1)), dim3(64), 0, (hipStream_t) stream,
                        chunk_stats_dev, n_chunks, ctx->V, out_dev, out_dev == ctx->d_total ? ctx->d_flags : (const unsigned*) nullptr);
     }
     ctx->prof_mask = keep;

@@ -238,61 +238,92 @@ __device__ __forceinline__ void load_lane_product(M4& Q, const double* __restric
 // k_carry: per chunk, sweep the tile products.  cf[tile] = normalised forward vector entering the tile
 // (tile 0 of a chunk: unused, the tile kernel starts from window 0); cb[tile] = direction of b at the
 // first window after BACKWARD tile `tile` (backward tile k owns windows base_k-1 .. base_k+64L-2).
-// lane 0 sweeps forward, lane 1 sweeps backward.
+// Wave 0 sweeps forward, wave 1 backward; each stages the tile products through its half of LDS in batches of
+// HF_CARRY_BATCH tiles (coalesced loads by all 64 lanes), then lane 0 runs the dependent chain out of LDS.
 // ------------------------------------------------------------------------------------------
+#define HF_CARRY_BATCH 128
 template <int L>
-__global__ void __launch_bounds__(64) k_carry(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
-                                              const uint32_t* __restrict__ rec, const double* __restrict__ E,
-                                              const DevParams* __restrict__ P, const double* __restrict__ Pt,
-                                              double* __restrict__ cf, double* __restrict__ cb) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+__global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
+                                               const uint32_t* __restrict__ rec, const double* __restrict__ E,
+                                               const DevParams* __restrict__ P, const double* __restrict__ Pt,
+                                               double* __restrict__ cf, double* __restrict__ cb) {
+    __shared__ __attribute__((aligned(16))) double s_pt[2][HF_CARRY_BATCH * 16];
+    __shared__ double s_out[2][HF_CARRY_BATCH * 4];
+    const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t t0 = off[c], T = off[c + 1] - t0;
-    if (T <= 0 || lane > 1) return;
+    if (T <= 0) return;
     const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
-    if (lane == 0) {
+    double* __restrict__ sp = s_pt[wave];
+    double* __restrict__ so = s_out[wave];
+    double v[4];
+    if (wave == 0) {
         const uint32_t r0 = rec[t0];
         const DevRegion* __restrict__ R = &P->reg[REC_REGION(r0)];
-        double v[4], sv = 0.0, E0[16];
+        double sv = 0.0, E0[16];
         load_E<L>(E, k0, 0, 0, E0);
 #pragma unroll
         for (int s = 0; s < 4; s++) { v[s] = E0[s] * R->trans[4][s]; sv += v[s]; }
 #pragma unroll
         for (int s = 0; s < 4; s++) v[s] /= sv;
-        for (int k = 0; k < nt; k++) {
-            double* dst = cf + (int64_t) (k0 + k) * 4;
-            dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
-            const double* __restrict__ M = Pt + (int64_t) (k0 + k) * 16;
-            double u[4], su = 0.0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                double s = v[0] * M[j];
-                s = fma(v[1], M[4 + j], s); s = fma(v[2], M[8 + j], s); s = fma(v[3], M[12 + j], s);
-                u[j] = s; su += s;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) v[j] = u[j] / su;
-        }
     } else {
         const DevRegion* __restrict__ R = &P->reg[REC_REGION(rec[t0 + T - 1])];
-        double w[4], sw = 0.0;
+        double sw = 0.0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) { w[s] = R->trans[s][4]; sw += w[s]; }
+        for (int s = 0; s < 4; s++) { v[s] = R->trans[s][4]; sw += v[s]; }
 #pragma unroll
-        for (int s = 0; s < 4; s++) w[s] /= sw;
-        for (int k = nt - 1; k >= 0; k--) {
-            double* dst = cb + (int64_t) (k0 + k) * 4;
-            dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
-            const double* __restrict__ M = Pt + (int64_t) (k0 + k) * 16;
-            double u[4], su = 0.0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                double s = M[i * 4] * w[0];
-                s = fma(M[i * 4 + 1], w[1], s); s = fma(M[i * 4 + 2], w[2], s); s = fma(M[i * 4 + 3], w[3], s);
-                u[i] = s; su += s;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) w[i] = u[i] / su;
+        for (int s = 0; s < 4; s++) v[s] /= sw;
+    }
+    const int nb = (nt + HF_CARRY_BATCH - 1) / HF_CARRY_BATCH;
+    for (int bi = 0; bi < nb; bi++) {
+        // forward takes the batches in increasing order, backward in decreasing order
+        const int b0 = wave == 0 ? bi * HF_CARRY_BATCH : (nb - 1 - bi) * HF_CARRY_BATCH;
+        const int n = nt - b0 < HF_CARRY_BATCH ? nt - b0 : HF_CARRY_BATCH;
+        {
+            const double2* __restrict__ src = reinterpret_cast<const double2*>(Pt + (int64_t) (k0 + b0) * 16);
+            double2* dst = reinterpret_cast<double2*>(sp);
+            for (int i = lane; i < n * 8; i += 64) dst[i] = src[i];
         }
+        __builtin_amdgcn_s_waitcnt(0);   // the wave's own LDS stores have landed (single wave per half: no barrier needed)
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            if (wave == 0) {
+                for (int k = 0; k < n; k++) {
+                    so[k * 4 + 0] = v[0]; so[k * 4 + 1] = v[1]; so[k * 4 + 2] = v[2]; so[k * 4 + 3] = v[3];
+                    const double* __restrict__ M = sp + k * 16;
+                    double u[4], su = 0.0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        double s = v[0] * M[j];
+                        s = fma(v[1], M[4 + j], s); s = fma(v[2], M[8 + j], s); s = fma(v[3], M[12 + j], s);
+                        u[j] = s; su += s;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) v[j] = u[j] / su;
+                }
+            } else {
+                for (int k = n - 1; k >= 0; k--) {
+                    so[k * 4 + 0] = v[0]; so[k * 4 + 1] = v[1]; so[k * 4 + 2] = v[2]; so[k * 4 + 3] = v[3];
+                    const double* __restrict__ M = sp + k * 16;
+                    double u[4], su = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        double s = M[i * 4] * v[0];
+                        s = fma(M[i * 4 + 1], v[1], s); s = fma(M[i * 4 + 2], v[2], s); s = fma(M[i * 4 + 3], v[3], s);
+                        u[i] = s; su += s;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) v[i] = u[i] / su;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        {
+            double* __restrict__ dst = (wave == 0 ? cf : cb) + (int64_t) (k0 + b0) * 4;
+            for (int i = lane; i < n * 4; i += 64) dst[i] = so[i];
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
