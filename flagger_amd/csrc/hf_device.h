@@ -21,15 +21,18 @@
 //   bits 16..18 validity mask: Dup / Col / End(Msj)    hmm_utils.c:2229-2254
 //   bit 19     first window of its chunk
 //   bit 20     region differs from the previous window hmm.c:398
+//   bit 21     "slow": chunk-first, or contig-end factor beta_t != beta_star => private emission row (hf_scan.h)
 #define REC_X(r) ((r) & 0xffu)
 #define REC_REGION(r) (((r) >> 8) & 0xffu)
 #define REC_VMASK(r) (((r) >> 16) & 0x7u)
 #define REC_FIRST(r) (((r) >> 19) & 1u)
 #define REC_REGCHG(r) (((r) >> 20) & 1u)
+#define REC_SLOW(r) (((r) >> 21) & 1u)
 
 // one record per tile of the scan kernels (built once in hf_create): removes the tile -> chunk -> offsets chain
 // of dependent loads
-struct TileDesc { long long t0; int T; int base; int chunk; int pad; };
+// slow0 = position in the slow list of the tile's first slow window
+struct TileDesc { long long t0; int T; int base; int chunk; int slow0; };
 
 struct DevRegion {
     double trans[5][5];                 // Transition.matrix (row 4 Start, column 4 End)

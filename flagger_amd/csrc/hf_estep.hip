@@ -1,12 +1,18 @@
 // hf_estep.hip — MI355X (gfx950) E-step of HMM-Flagger: kernels + C ABI (include/hmm_flagger_hip.h).
 //
 // Replaces EM_runOneIterationForList / EM_runForwardForList (programs/submodules/hmm/hmm.c:739,790).
-// Pipeline of one pass (per EM iteration):
-//   k_emit      window-parallel  emission table E_t[pre][s]           (hmm_utils.c:753-793, 941-947)
-//   k_fwd_*     per chunk        scaled forward, log-likelihood       (hmm.c:333-434)
-//   k_bwd_*     per chunk        scaled backward, posterior argmax    (hmm.c:452-545, 671-692)
-//   k_stats     per chunk        xi sufficient statistics             (hmm.c:563-650, hmm_utils.c:812-839)
-//   k_reduce    ordered sum over chunks                               (hmm.c:759-763)
+// Pipeline of one pass (per EM iteration), HF_ALGO_SCAN (hf_scan.h):
+//   k_tables      emission rows of this iteration (per occurring (region, x, x_prev) + per contig-end window)
+//                                                                        (hmm_utils.c:753-793, 941-947)
+//   k_prod_tile   lane / tile products of A_t = T_t∘E_t
+//   k_carry       per chunk: carried-in forward vector / backward direction of every tile
+//   k_fb_tile     scaled forward + log-likelihood, scaled backward + posterior argmax
+//                                                                        (hmm.c:333-434, 452-545, 671-692)
+//   k_stats_tile  xi sufficient statistics per tile                      (hmm.c:563-650, hmm_utils.c:812-839)
+//   k_chunk_stats per chunk: tile partials -> estimator layout, chunk log-likelihood
+//   k_reduce      sum over chunks in a fixed order                       (hmm.c:759-763)
+// HF_ALGO_SEQ keeps the first formulation as an independent check: k_emit_rows (direct evaluation of every
+// window's row), k_fwd_seq / k_bwd_seq (one wavefront per chunk, sequential recurrences), then the same statistics.
 // There is no CPU fallback: without a HIP device hf_create fails with HF_E_NOGPU.
 #include "hf_device.h"
 #include "../../include/hmm_flagger_model.h"
@@ -36,7 +42,7 @@ struct hf_ctx {
     double* d_beta = nullptr;      // [N]
     uint64_t* d_regmask = nullptr; // [C] bit r set if region r occurs in the chunk
     // per-pass work arrays
-    double* d_E = nullptr;         // [N][16]
+    double* d_E = nullptr;         // [N][16] emission rows, HF_ALGO_SEQ only
     double* d_f = nullptr;         // [N][4]
     double* d_b = nullptr;         // [N][4]
     double* d_scale = nullptr;     // [N]
@@ -45,7 +51,7 @@ struct hf_ctx {
     double* d_total = nullptr;     // [V]
     // scan algorithm: tile tables and per-tile work arrays
     TileDesc* d_tile_desc = nullptr;
-    int ntiles = 0; int32_t* d_tile_chunk = nullptr; int64_t* d_tile_base = nullptr; int32_t* d_chunk_tile0 = nullptr;
+    int ntiles = 0; int32_t* d_chunk_tile0 = nullptr;
     double* d_Pt = nullptr; double* d_cf = nullptr; double* d_cb = nullptr; double* d_tile_ll = nullptr;
     double* d_tile_stats = nullptr; // [ntiles][R][NA(16)]
     double* d_Qs = nullptr;         // [ntiles][64][16] lane products
@@ -58,10 +64,11 @@ struct hf_ctx {
     hipEvent_t kev[2 * HF_NKERNELS] = {}; bool kran[HF_NKERNELS] = {};
     bool have_full = false;
     double beta_star = 1.0;
-    // per-iteration emission tables over (x, x_prev) in [0, M)^2 for interior windows (k_lut)
+    // per-iteration emission rows (k_tables): keys = occurring (region, x, x_prev) of interior windows,
+    // slow = chunk-first and contig-end windows (beta != beta_star), ascending; slow_off[c] = chunk c's first entry
     int M = 1; double* d_lutE = nullptr; double* d_lutC = nullptr;
-    // pairs whose window has beta != beta_star (contig ends): statistics by the generic kernel
-    int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_slow_stats = nullptr;
+    int n_keys = 0; int32_t* d_keys = nullptr;
+    int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_Es = nullptr; double* d_Cs = nullptr;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -72,8 +79,8 @@ __global__ void k_setup(const int64_t* __restrict__ off, const uint16_t* __restr
                         const uint64_t* __restrict__ annot, const int32_t* __restrict__ cs,
                         const int32_t* __restrict__ ce, const int32_t* __restrict__ cl, int window_len,
                         int mean_read_len, int adjust, double min_frac, double max_mapq, double min_mapq,
-                        double min_clip, int n_regions, uint32_t* __restrict__ rec, double* __restrict__ beta,
-                        unsigned* __restrict__ flags) {
+                        double min_clip, int n_regions, double beta_star, uint32_t* __restrict__ rec,
+                        double* __restrict__ beta, unsigned* __restrict__ flags) {
     const int c = blockIdx.y;
     const int64_t t0 = off[c], T = off[c + 1] - t0;
     const int64_t col = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -95,7 +102,6 @@ __global__ void k_setup(const int64_t* __restrict__ off, const uint16_t* __restr
         const unsigned pre_region = (unsigned) ((annot[t - 1] & 0xFC00000000000000ULL) >> 58);
         if (pre_region != region) r |= 1u << 20;
     }
-    rec[t] = r;
     // beta, hmm.c:301-316; min/max are the int functions of common.c:142-148
     double bt = 1.0;
     if (adjust) {
@@ -113,6 +119,8 @@ __global__ void k_setup(const int64_t* __restrict__ off, const uint16_t* __restr
         if (bt <= 0.25) bt = 0.25;
     }
     beta[t] = bt;
+    if (col == 0 || bt != beta_star) r |= 1u << 21;   // private emission row (REC_SLOW)
+    rec[t] = r;
 }
 
 __global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
@@ -149,14 +157,29 @@ __device__ __forceinline__ void load_T(const DevParams* __restrict__ P, uint32_t
     }
 }
 
-// emission row of window w (index within its chunk) from the tile-major/lane-minor stash (see hf_scan.h)
-__device__ __forceinline__ void load_E_window(const double* __restrict__ E, int tile0, int64_t w, double* Ev) {
-    const int64_t TW = 64 * HF_SCAN_L;
-    const int tile = tile0 + (int) (w / TW);
-    const int rem = (int) (w % TW), lane = rem / HF_SCAN_L, i = rem % HF_SCAN_L;
-    const double2* __restrict__ src = reinterpret_cast<const double2*>(E) + (((int64_t) tile * HF_SCAN_L + i) * 8) * 64 + lane;
+// HF_ALGO_SEQ: emission row of every window by direct evaluation, E[t][16] (A8-A10); chunk-first windows hold
+// e_s(x_0; alpha=0, preX=0) in row pre=0 (hmm.c:338-352)
+__global__ void __launch_bounds__(256) k_emit_rows(int64_t N, const uint32_t* __restrict__ rec, const double* __restrict__ beta,
+                                                   const DevParams* __restrict__ P, double* __restrict__ E,
+                                                   unsigned* __restrict__ flags) {
+    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N) return;
+    const uint32_t r = rec[t];
+    const bool first = REC_FIRST(r) != 0;
+    const double x = (double) REC_X(r), px = first ? 0.0 : (double) REC_X(rec[t - 1]);
+    unsigned nan = 0;
+    double out[16];
+    hf_emit_values<false>(P, &P->reg[REC_REGION(r)], x, px, first, beta[t], out, &nan);
+    double2* dst = reinterpret_cast<double2*>(E) + t * 8;
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const double2 v = src[k * 64]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
+    for (int k = 0; k < 8; k++) dst[k] = make_double2(out[2 * k], out[2 * k + 1]);
+    if (nan) atomicOr(flags, nan);
+}
+
+__device__ __forceinline__ void load_E_window(const double* __restrict__ E, int64_t t, double* Ev) {
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(E) + t * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const double2 v = src[k]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -167,8 +190,7 @@ __global__ void __launch_bounds__(64) k_fwd_seq(const int64_t* __restrict__ off,
                                                 const uint32_t* __restrict__ rec,
                                                 const double* __restrict__ E, const DevParams* __restrict__ P,
                                                 double* __restrict__ F, double* __restrict__ scale,
-                                                double* __restrict__ chunk_stats, int64_t V,
-                                                unsigned* __restrict__ flags) {
+                                                double* __restrict__ tile_ll, unsigned* __restrict__ flags) {
     const int c = blockIdx.x, lane = threadIdx.x;
     const int64_t t0 = off[c], T = off[c + 1] - t0;
     __shared__ double Es[64][17];
@@ -182,7 +204,7 @@ __global__ void __launch_bounds__(64) k_fwd_seq(const int64_t* __restrict__ off,
         if (lane < n) {
             const int64_t t = t0 + base + lane;
             rs[lane] = rec[t];
-            load_E_window(E, chunk_tile0[c], base + lane, &Es[lane][0]);
+            load_E_window(E, t, &Es[lane][0]);
         }
         __syncthreads();
         for (int j = 0; j < n; j++) {
@@ -219,10 +241,10 @@ __global__ void __launch_bounds__(64) k_fwd_seq(const int64_t* __restrict__ off,
         }
         __syncthreads();
     }
-    if (lane == 0) {
-        chunk_stats[(int64_t) c * V] = ll;
-        if (bad) atomicOr(flags, bad);
-    }
+    // the chunk's log-likelihood goes through the same per-tile slots as the scan path (k_chunk_stats sums them)
+    const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
+    for (int k = lane; k < nt; k += 64) tile_ll[k0 + k] = k == 0 ? ll : 0.0;
+    if (lane == 0 && bad) atomicOr(flags, bad);
 }
 
 __device__ __forceinline__ int posterior_label(const double f[4], const double b[4], double sc) {
@@ -275,7 +297,7 @@ __global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off,
         if (lane < n) {
             const int64_t t = t0 + lo + lane; // window i
             rs[lane] = rec[t + 1];
-            load_E_window(E, chunk_tile0[c], lo + lane + 1, &Es[lane][0]);
+            load_E_window(E, t + 1, &Es[lane][0]);
 #pragma unroll
             for (int s = 0; s < 4; s++) Fs[lane][s] = F[t * 4 + s];
             Fs[lane][4] = scale[t];
@@ -310,10 +332,10 @@ __global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off,
 }
 
 // ------------------------------------------------------------------------------------------
-// k_stats: xi sufficient statistics of one chunk, one region at a time (A6, A12).
-// For every pair (i, i+1), i = 1..T-2:  xi = f_i[pre] * T * e * b_{i+1}[s] / terminationProb.
+// xi sufficient statistics (A6, A12).  For every pair (i, i+1), i = 1..T-2:
+//   xi = f_i[pre] * T * e * b_{i+1}[s] / terminationProb              (hmm.c:563-650)
 // Distinct accumulators only (mean.den == var.den == weight.num; weight.den[i] all equal); they are
-// expanded into the reference's estimator layout when the chunk vector is written.
+// expanded into the reference's estimator layout when the chunk vector is written (k_chunk_stats).
 // ------------------------------------------------------------------------------------------
 template <int KT>
 struct StatAcc {
@@ -323,92 +345,14 @@ struct StatAcc {
     double c_mnum[KT], c_vnum[KT], c_den[KT], c_wden; // Col components
 };
 
-template <int KT>
-__device__ __forceinline__ double& acc_ref(StatAcc<KT>& a, int i) { return reinterpret_cast<double*>(&a)[i]; }
-
-// contributions of the pair (i, i+1) — window t = t0+i — to the accumulators of region REC_REGION(rec[t+1])
-template <int KT>
-__device__ __forceinline__ void stats_pair(StatAcc<KT>& a, const DevParams* __restrict__ P, const DevRegion* __restrict__ R,
-                                           int64_t t, const uint32_t* __restrict__ rec, const double* __restrict__ beta,
-                                           const double* __restrict__ Ev, const double* __restrict__ F,
-                                           const double* __restrict__ B, bool te, int ncol, unsigned* nan) {
-    const uint32_t r1 = rec[t + 1];
-    const double x = (double) REC_X(r1), px = (double) REC_X(rec[t]);
-    const double bt = beta[t + 1];
-    double Tm[16];
-    load_T(P, r1, Tm);
-    double f[4], b1[4];
-    {
-        const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + t * 4);
-        const double2* __restrict__ bp = reinterpret_cast<const double2*>(B + (t + 1) * 4);
-        const double2 f01 = fp[0], f23 = fp[1], b01 = bp[0], b23 = bp[1];
-        f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
-        b1[0] = b01.x; b1[1] = b01.y; b1[2] = b23.x; b1[3] = b23.y;
-    }
-    // xi of all 16 (pre, state) pairs first: afterwards only adj[] and Ev[] stay live
-    double adj[16];
-#pragma unroll
-    for (int s = 0; s < 4; s++)
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int k = p * 4 + s;
-            const double count = f[p] * Tm[k] * Ev[k] * b1[s];
-            adj[k] = count / HF_TERMINATION_PROB;           // hmm.c:613-614
-            a.trans[k] += adj[k];                           // hmm_utils.c:2010-2015
-        }
-    // state outer, pre inner — the order in which the reference accumulates (hmm.c:588-589)
-#pragma unroll
-    for (int s = 0; s < 3; s++) {
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int k = p * 4 + s;
-            if (s == 0 && te) {                             // hmm_utils.c:1027-1034
-                a.te_num += adj[k] * x;
-                a.te_den += adj[k];
-            } else {                                        // hmm_utils.c:812-839, one component:
-                const double alpha = P->alpha[k];           // componentProbs[0] == totProb == E
-                const double x_adj = (x - alpha * px) / (1.0 - alpha);
-                const double w = adj[k] * Ev[k] / Ev[k];
-                a.g_mnum[s] += w * x_adj;
-                const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
-                a.g_vnum[s] += w * z * z;
-                a.g_den[s] += w;
-            }
-        }
-    }
-#pragma unroll 1
-    for (int p = 0; p < 4; p++) {                           // Col: K components per pre state
-        const int k = p * 4 + 3;
-        const double alpha = P->alpha[k];
-        const double x_adj = (x - alpha * px) / (1.0 - alpha);
-        const double ak = p == 0 ? adj[3] : p == 1 ? adj[7] : p == 2 ? adj[11] : adj[15];
-        double pc[KT], tot = 0.0;
-#pragma unroll
-        for (int cc = 0; cc < KT; cc++)
-            if (cc < ncol) {
-                pc[cc] = hf_gauss_comp(R->mean[3][cc], R->var[3][cc], R->weight[3][cc], x, px, alpha, bt, nan);
-                tot += pc[cc];
-            }
-#pragma unroll
-        for (int cc = 0; cc < KT; cc++)
-            if (cc < ncol) {
-                const double w = ak * pc[cc] / tot;
-                a.c_mnum[cc] += w * x_adj;
-                const double z = (x_adj - R->mean[3][cc]) * (1.0 - alpha);
-                a.c_vnum[cc] += w * z * z;
-                a.c_den[cc] += w;
-                a.c_wden += w;
-            }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// k_stats_tile: statistics of the interior pairs (beta == beta_star) of one tile per wavefront.
-// f, b1, Tm, Ev come from the pass arrays / LDS tables; the collapsed state's component probabilities from this
-// iteration's table row lutC[(r, x, x_prev)][K][4] (k_lut); their total is the emission value itself
-// (Ev[pre][Col] is the same sum of the same terms).  The 3K per-component accumulators of a lane live in LDS
-// (lane-minor, conflict-free) so the component loop stays rolled and the kernel keeps its occupancy; the
-// 27 scalar accumulators stay in registers.
+// k_stats_tile: statistics of the pairs of one tile per wavefront; lane l owns the pairs that END at its L windows.
+// f, b come from the pass arrays, T from the LDS tables, the emission row and the collapsed state's component
+// probabilities from this iteration's rows (k_tables: the table row of (region, x, x_prev), or the window's private
+// row at contig ends); the total of the component probabilities is the emission value itself (Ev[pre][Col] is
+// the same sum of the same terms).  The 3K per-component accumulators of a lane live in LDS (lane-minor,
+// conflict-free) so the component loop stays rolled and the kernel keeps its occupancy; the 27 scalar
+// accumulators stay in registers.
 // ------------------------------------------------------------------------------------------
 struct StatAccSmall {
     double trans[16];
@@ -418,12 +362,11 @@ struct StatAccSmall {
 
 template <int KT>
 __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDesc* __restrict__ td,
-                                                    const uint32_t* __restrict__ rec, const double* __restrict__ beta,
-                                                    const double* __restrict__ E, const DevParams* __restrict__ P,
+                                                    const uint32_t* __restrict__ rec, const RowSrc S,
+                                                    const DevParams* __restrict__ P,
                                                     const double* __restrict__ F, const double* __restrict__ B,
-                                                    const uint64_t* __restrict__ regmask, const double* __restrict__ lutC,
-                                                    int M, int Kctx,
-                                                    double* __restrict__ tile_stats, unsigned* __restrict__ flags) {
+                                                    const uint64_t* __restrict__ regmask,
+                                                    double* __restrict__ tile_stats) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NS = 16 + 9 + 2;                  // scalar accumulators kept in registers
     constexpr int L = HF_SCAN_L;
@@ -435,21 +378,20 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
     double* __restrict__ s_acc = s_tab + P->n_regions * HF_TAB_STRIDE + wave * (3 * KT * 64) + lane;   // [(q*KT+cc)*64]
     const TileDesc d = td[tile];
     const int64_t t0 = d.t0, T = d.T, base = d.base;
-    const int64_t MM = (int64_t) M * M;
-    const double bstar = P->beta_star;
     const bool te = hf_err_is_truncexp(P);
     const int ncol = P->ncomp[3], nreg = P->n_regions;
     const int64_t a0 = base + (int64_t) lane * L;   // this lane owns windows a0..a0+L-1 and the pairs ending there
-    uint32_t rr[L + 1];
+    uint32_t rr[L + 1];                             // rr[j+1] = window a0+j, rr[0] = the window before
+    rr[0] = load_recs<L>(rec, t0, T, a0, lane, rr + 1);
+    int sidx[L];
+    tile_slow_index<L>(rr + 1, lane, d.slow0, sidx);
     bool ok[L];
-#pragma unroll
-    for (int j = 0; j <= L; j++) { const int64_t w = a0 + j - 1; rr[j] = (w >= 0 && w < T) ? rec[t0 + w] : 0u; }
     unsigned long long present = 0;
 #pragma unroll
     for (int j = 0; j < L; j++) {
         const int64_t w = a0 + j;                             // pair (w-1, w), w = 2..T-1  (hmm.c:638-642)
-        ok[j] = w >= 2 && w <= T - 1 && beta[t0 + w] == bstar; // the others are on the slow list (k_stats_slow)
-        if (w >= 2 && w <= T - 1) present |= 1ull << (REC_REGION(rr[j + 1]) & 63u);
+        ok[j] = w >= 2 && w <= T - 1;
+        if (ok[j]) present |= 1ull << (REC_REGION(rr[j + 1]) & 63u);
     }
     for (int o = 32; o > 0; o >>= 1) present |= __shfl_xor(present, o);
     const unsigned long long in_chunk = regmask[d.chunk];
@@ -473,19 +415,18 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
             if (!(ok[j] && (int) REC_REGION(rr[j + 1]) == r)) continue;
             const int64_t t = t0 + a0 + j - 1;                // pair (t, t+1)
             double Ev[16], Tm[16], f[4], b1[4];
-            load_E<L>(E, tile, lane, j, Ev);
+            load_row(row_ptr(S, rr[j + 1], rr[j], sidx[j]), Ev);
             const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + t * 4);
             const double2* __restrict__ bp = reinterpret_cast<const double2*>(B + (t + 1) * 4);
             const double2 f01 = fp[0], f23 = fp[1], b01 = bp[0], b23 = bp[1];
             const unsigned xw = REC_X(rr[j + 1]), xp = REC_X(rr[j]);
-            const double2* __restrict__ crow =
-                reinterpret_cast<const double2*>(lutC + (((int64_t) r * MM + (int64_t) xw * M + xp) * 4) * Kctx);
+            const double2* __restrict__ crow = crow_ptr(S, rr[j + 1], rr[j], sidx[j]);
             lds_Tm(s_tab, rr[j + 1], Tm);
             f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
             b1[0] = b01.x; b1[1] = b01.y; b1[2] = b23.x; b1[3] = b23.y;
             const double x = (double) xw, px = (double) xp;
-            // one state (column) at a time, with a scheduling barrier after each: keeps the live set small enough for
-            // 3 waves per SIMD; state outer / pre inner is also the order of the reference (hmm.c:588-589)
+            // one state (column) at a time, with a scheduling barrier after each: keeps the live set small;
+            // state outer / pre inner is also the order of the reference (hmm.c:588-589)
             double adj3[4];
 #pragma unroll
             for (int s = 0; s < 4; s++) {
@@ -518,7 +459,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // collapsed state, component-major: one 32-byte table row per component serves all four pre states
+            // collapsed state, component-major: one 32-byte row per component serves all four pre states
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const double alpha = P->alpha[p * 4 + 3];
@@ -564,55 +505,15 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
     }
 }
 
-// pairs at contig ends (beta != beta_star): generic evaluation, one wavefront per chunk over its slow list
-template <int KT>
-__global__ void __launch_bounds__(64) k_stats_slow(const int32_t* __restrict__ slow_off, const int64_t* __restrict__ slow_w,
-                                                   const int32_t* __restrict__ chunk_tile0, const int64_t* __restrict__ off,
-                                                   const uint32_t* __restrict__ rec, const double* __restrict__ beta,
-                                                   const double* __restrict__ E, const DevParams* __restrict__ P,
-                                                   const double* __restrict__ F, const double* __restrict__ B,
-                                                   const uint64_t* __restrict__ regmask, double* __restrict__ slow_stats,
-                                                   unsigned* __restrict__ flags) {
-    constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int s0 = slow_off[c], n = slow_off[c + 1] - s0;
-    if (n == 0) return;
-    const int64_t t0 = off[c];
-    const bool te = hf_err_is_truncexp(P);
-    const int ncol = P->ncomp[3], nreg = P->n_regions;
-    const unsigned long long in_chunk = regmask[c];
-    unsigned nan = 0;
-    for (int r = 0; r < nreg; r++) {
-        if (!((in_chunk >> r) & 1ull)) continue;
-        const DevRegion* __restrict__ R = &P->reg[r];
-        StatAcc<KT> a;
-#pragma unroll
-        for (int i = 0; i < NA; i++) acc_ref<KT>(a, i) = 0.0;
-        for (int k = lane; k < n; k += 64) {
-            const int64_t tw = slow_w[s0 + k];                     // global index of window w; pair (w-1, w)
-            if ((int) REC_REGION(rec[tw]) != r) continue;
-            double Ev[16];
-            load_E_window(E, chunk_tile0[c], tw - t0, Ev);
-            stats_pair<KT>(a, P, R, tw - 1, rec, beta, Ev, F, B, te, ncol, &nan);
-        }
-        double* __restrict__ dst = slow_stats + ((int64_t) c * nreg + r) * NA;
-#pragma unroll
-        for (int i = 0; i < NA; i++) {
-            double v = acc_ref<KT>(a, i);
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-            if (lane == 0) dst[i] = v;
-        }
-    }
-    if (nan) atomicOr(flags, nan);
-}
-
-// per chunk: sum the tile partials in tile order and expand into the estimator layout of
-// include/hmm_flagger_hip.h (mean.den == var.den == weight.num; weight.den[i] all equal)
+// per chunk: log-likelihood = sum of the tiles' partial sums; statistics = sum of the tile partials in tile order,
+// expanded into the estimator layout of include/hmm_flagger_hip.h (mean.den == var.den == weight.num;
+// weight.den[i] all equal).  Writes the WHOLE chunk vector (zeros where nothing accumulates:
+// HMM_resetEstimators, hmm.c:129-134), so no memset is needed between passes.  full == 0: log-likelihood only.
 template <int KT>
 __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__ chunk_tile0, const uint64_t* __restrict__ regmask,
-                                                     const double* __restrict__ tile_stats, const int32_t* __restrict__ slow_off,
-                                                     const double* __restrict__ slow_stats, const DevParams* __restrict__ P,
-                                                     double* __restrict__ chunk_stats, int64_t V, int Kctx) {
+                                                     const double* __restrict__ tile_stats, const double* __restrict__ tile_ll,
+                                                     const DevParams* __restrict__ P, double* __restrict__ chunk_stats,
+                                                     int64_t V, int Kctx, int full) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     const int c = blockIdx.x, tid = threadIdx.x;
     const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
@@ -620,35 +521,44 @@ __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__
     const bool te = hf_err_is_truncexp(P);
     const int64_t rstride = 24 * (int64_t) Kctx + 16;
     const uint64_t present = regmask[c];
+    double* __restrict__ vec = chunk_stats + (int64_t) c * V;
+    if (tid < 64) {
+        double s = 0.0;
+        for (int k = tid; k < nt; k += 64) s += tile_ll[k0 + k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+        if (tid == 0) vec[0] = s;
+    }
+    for (int64_t v = 1 + tid; v < V; v += blockDim.x) vec[v] = 0.0;
+    if (!full) return;
     __shared__ double red[NA];
+    __syncthreads();
     for (int r = 0; r < nreg; r++) {
         if (!((present >> r) & 1ull)) continue;
         if (tid < NA) {
             double v = 0.0;
             for (int k = 0; k < nt; k++) v += tile_stats[((int64_t) (k0 + k) * nreg + r) * NA + tid];
-            if (slow_off[c + 1] > slow_off[c]) v += slow_stats[((int64_t) c * nreg + r) * NA + tid];   // contig-end pairs
             red[tid] = v;
         }
         __syncthreads();
-        double* __restrict__ dst = chunk_stats + (int64_t) c * V + 1 + r * rstride;
-        const StatAcc<KT>* __restrict__ S = reinterpret_cast<const StatAcc<KT>*>(red);
-        if (tid < 16) dst[24 * Kctx + tid] = S->trans[tid];
-        if (tid == 32 && te) { dst[(0 * 2 + 0) * Kctx] = S->te_num; dst[(0 * 2 + 1) * Kctx] = S->te_den; }
+        double* __restrict__ dst = vec + 1 + r * rstride;
+        const StatAcc<KT>* __restrict__ Sa = reinterpret_cast<const StatAcc<KT>*>(red);
+        if (tid < 16) dst[24 * Kctx + tid] = Sa->trans[tid];
+        if (tid == 32 && te) { dst[(0 * 2 + 0) * Kctx] = Sa->te_num; dst[(0 * 2 + 1) * Kctx] = Sa->te_den; }
         if (tid >= 64 && tid < 67) {
             const int s = tid - 64;
             if (!(s == 0 && te)) {
-                double* d = dst + (int64_t) (s * 3) * 2 * Kctx;
-                d[(0 * 2 + 0) * Kctx] = S->g_mnum[s]; d[(0 * 2 + 1) * Kctx] = S->g_den[s];
-                d[(1 * 2 + 0) * Kctx] = S->g_vnum[s]; d[(1 * 2 + 1) * Kctx] = S->g_den[s];
-                d[(2 * 2 + 0) * Kctx] = S->g_den[s];  d[(2 * 2 + 1) * Kctx] = S->g_den[s];
+                double* dd = dst + (int64_t) (s * 3) * 2 * Kctx;
+                dd[(0 * 2 + 0) * Kctx] = Sa->g_mnum[s]; dd[(0 * 2 + 1) * Kctx] = Sa->g_den[s];
+                dd[(1 * 2 + 0) * Kctx] = Sa->g_vnum[s]; dd[(1 * 2 + 1) * Kctx] = Sa->g_den[s];
+                dd[(2 * 2 + 0) * Kctx] = Sa->g_den[s];  dd[(2 * 2 + 1) * Kctx] = Sa->g_den[s];
             }
         }
         if (tid >= 96 && tid < 96 + KT && (tid - 96) < ncol) {
             const int cc = tid - 96;
-            double* d = dst + (int64_t) (3 * 3) * 2 * Kctx;
-            d[(0 * 2 + 0) * Kctx + cc] = S->c_mnum[cc]; d[(0 * 2 + 1) * Kctx + cc] = S->c_den[cc];
-            d[(1 * 2 + 0) * Kctx + cc] = S->c_vnum[cc]; d[(1 * 2 + 1) * Kctx + cc] = S->c_den[cc];
-            d[(2 * 2 + 0) * Kctx + cc] = S->c_den[cc];  d[(2 * 2 + 1) * Kctx + cc] = S->c_wden;
+            double* dd = dst + (int64_t) (3 * 3) * 2 * Kctx;
+            dd[(0 * 2 + 0) * Kctx + cc] = Sa->c_mnum[cc]; dd[(0 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
+            dd[(1 * 2 + 0) * Kctx + cc] = Sa->c_vnum[cc]; dd[(1 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
+            dd[(2 * 2 + 0) * Kctx + cc] = Sa->c_den[cc];  dd[(2 * 2 + 1) * Kctx + cc] = Sa->c_wden;
         }
         __syncthreads();
     }
@@ -687,22 +597,24 @@ struct KTimer {
     ~KTimer() { if (on) { hipEventRecord(c->kev[2 * k + 1], st); c->kran[k] = true; } }
 };
 
+static RowSrc row_src(const hf_ctx* ctx) {
+    RowSrc S;
+    S.lutE = ctx->d_lutE; S.lutC = ctx->d_lutC; S.Es = ctx->d_Es; S.Cs = ctx->d_Cs; S.M = ctx->M; S.K = ctx->K;
+    return S;
+}
+
 template <int KT>
-static void launch_stats(hf_ctx* ctx, hipStream_t st) {
-    { KTimer t(ctx, st, HF_K_STATS_TILE);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256),
-                       ((size_t) ctx->R * HF_TAB_STRIDE + 4 * 3 * KT * 64) * 8, st, ctx->ntiles, ctx->d_tile_desc, ctx->d_rec, ctx->d_beta, ctx->d_E, ctx->d_params,
-                       ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_lutC, ctx->M, ctx->K, ctx->d_tile_stats, ctx->d_flags); }
-    if (ctx->n_slow > 0) {
-        KTimer t(ctx, st, HF_K_STATS_SLOW);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_slow<KT>), dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_slow_off,
-                           ctx->d_slow_w, ctx->d_chunk_tile0, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_E, ctx->d_params,
-                           ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_slow_stats, ctx->d_flags);
+static void launch_stats(hf_ctx* ctx, hipStream_t st, int full) {
+    if (full) {
+        KTimer t(ctx, st, HF_K_STATS_TILE);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256),
+                           ((size_t) ctx->R * HF_TAB_STRIDE + 4 * 3 * KT * 64) * 8, st, ctx->ntiles, ctx->d_tile_desc, ctx->d_rec,
+                           row_src(ctx), ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_stats);
     }
     KTimer t(ctx, st, HF_K_CHUNK_STATS);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_chunk_tile0,
-                       ctx->d_regmask, ctx->d_tile_stats, ctx->d_slow_off, ctx->d_slow_stats, ctx->d_params, ctx->d_chunk_stats,
-                       ctx->V, ctx->K);
+                       ctx->d_regmask, ctx->d_tile_stats, ctx->d_tile_ll, ctx->d_params, ctx->d_chunk_stats, ctx->V, ctx->K,
+                       full);
 }
 
 extern "C" {
@@ -756,40 +668,10 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     if (e_ != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e_)); } } while (0)
     DMALLOC(ctx->d_rec, N * 4); DMALLOC(ctx->d_beta, N * 8); DMALLOC(ctx->d_regmask, C * 8);
     DMALLOC(ctx->d_f, N * 4 * 8); DMALLOC(ctx->d_b, N * 4 * 8);
+    if (algo == HF_ALGO_SEQ) DMALLOC(ctx->d_E, N * 16 * 8);
     DMALLOC(ctx->d_scale, N * 8); DMALLOC(ctx->d_label, N);
     DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, ((size_t) ctx->V + 1) * 8);
     DMALLOC(ctx->d_flags, 4);
-    {   // tiles of 64*HF_SCAN_L windows, enumerated chunk by chunk
-        std::vector<int32_t> tchunk, ctile0(C + 1, 0);
-        std::vector<int64_t> tbase;
-        const int64_t TW = 64 * HF_SCAN_L;
-        for (size_t c = 0; c < C; c++) {
-            const int64_t T = w->chunk_off[c + 1] - w->chunk_off[c];
-            ctile0[c] = (int32_t) tchunk.size();
-            for (int64_t b = 0; b < T; b += TW) { tchunk.push_back((int32_t) c); tbase.push_back(b); }
-        }
-        ctile0[C] = (int32_t) tchunk.size();
-        ctx->ntiles = (int) tchunk.size();
-        {
-            std::vector<TileDesc> desc(tchunk.size());
-            for (size_t k = 0; k < tchunk.size(); k++) {
-                const size_t c = (size_t) tchunk[k];
-                desc[k].t0 = w->chunk_off[c]; desc[k].T = (int) (w->chunk_off[c + 1] - w->chunk_off[c]);
-                desc[k].base = (int) tbase[k]; desc[k].chunk = tchunk[k]; desc[k].pad = 0;
-            }
-            TRY(dev_upload(&ctx->d_tile_desc, desc.data(), desc.size()));
-        }
-        TRY(dev_upload(&ctx->d_tile_chunk, tchunk.data(), tchunk.size()));
-        TRY(dev_upload(&ctx->d_tile_base, tbase.data(), tbase.size()));
-        TRY(dev_upload(&ctx->d_chunk_tile0, ctile0.data(), ctile0.size()));
-        const size_t nt = (size_t) ctx->ntiles;
-        DMALLOC(ctx->d_Pt, nt * 16 * 8); DMALLOC(ctx->d_cf, nt * 4 * 8); DMALLOC(ctx->d_cb, nt * 4 * 8);
-        DMALLOC(ctx->d_tile_ll, nt * 8);
-        DMALLOC(ctx->d_Qs, nt * 64 * 16 * 8);
-        // emission stash, tile-major/lane-minor (hf_scan.h)
-        DMALLOC(ctx->d_E, nt * 64 * HF_SCAN_L * 16 * 8);
-        DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
-    }
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
     DMALLOC(ctx->d_params, ctx->params_bytes);
     if (hipHostMalloc((void**) &ctx->h_params, ctx->params_bytes) != hipSuccess ||
@@ -805,7 +687,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         hipLaunchKernelGGL(k_setup, grid, dim3(256), 0, 0, ctx->d_off, d_cov, d_mapq, d_clip, d_annot, d_cs, d_ce, d_cl,
                            w->window_len, w->mean_read_len, w->adjust_contig_ends, w->min_read_frac,
                            w->max_high_mapq_ratio, w->min_high_mapq_ratio, w->min_highly_clipped_ratio, n_regions,
-                           ctx->d_rec, ctx->d_beta, ctx->d_flags);
+                           ctx->beta_star, ctx->d_rec, ctx->d_beta, ctx->d_flags);
         hipLaunchKernelGGL(k_regmask, dim3((unsigned) C), dim3(256), 0, 0, ctx->d_off, ctx->d_rec, ctx->d_regmask);
     }
     hipError_t e = hipDeviceSynchronize();
@@ -821,22 +703,56 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         const size_t MM = (size_t) ctx->M * ctx->M;
         DMALLOC(ctx->d_lutE, (size_t) n_regions * MM * 16 * 8);
         DMALLOC(ctx->d_lutC, (size_t) n_regions * MM * 4 * (size_t) max_comps * 8);
-        // pairs (w-1, w), 2 <= w <= T-1, whose beta_w differs from beta_star
+        // slow windows: chunk-first, or beta differs from beta_star (the same test as k_setup's REC_SLOW bit)
         std::vector<double> hb(N);
         if (N) { hipError_t e2 = hipMemcpy(hb.data(), ctx->d_beta, N * 8, hipMemcpyDeviceToHost);
                  if (e2 != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "beta download failed"); } }
         std::vector<int64_t> slow;
-        std::vector<int32_t> soff(C + 1, 0);
+        std::vector<int32_t> soff(C + 1, 0), keys;
+        std::vector<uint8_t> seen((size_t) n_regions * MM, 0);
         for (size_t c = 0; c < C; c++) {
             soff[c] = (int32_t) slow.size();
             const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-            for (int64_t x = 2; x <= T - 1; x++) if (hb[(size_t) (t0 + x)] != ctx->beta_star) slow.push_back(t0 + x);
+            for (int64_t x = 0; x < T; x++) {
+                const size_t t = (size_t) (t0 + x);
+                if (x == 0 || hb[t] != ctx->beta_star) { slow.push_back((int64_t) t); continue; }
+                const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
+                seen[(reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu)] = 1;
+            }
         }
         soff[C] = (int32_t) slow.size();
+        for (size_t k = 0; k < seen.size(); k++) if (seen[k]) keys.push_back((int32_t) k);
         ctx->n_slow = (int) slow.size();
+        ctx->n_keys = (int) keys.size();
         TRY(dev_upload(&ctx->d_slow_w, slow.data(), slow.size()));
         TRY(dev_upload(&ctx->d_slow_off, soff.data(), soff.size()));
-        DMALLOC(ctx->d_slow_stats, C * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
+        TRY(dev_upload(&ctx->d_keys, keys.data(), keys.size()));
+        DMALLOC(ctx->d_Es, slow.size() * 16 * 8);
+        DMALLOC(ctx->d_Cs, slow.size() * 4 * (size_t) max_comps * 8);
+        // tiles of 64*HF_SCAN_L windows, enumerated chunk by chunk
+        std::vector<int32_t> ctile0(C + 1, 0);
+        std::vector<TileDesc> desc;
+        const int64_t TW = 64 * HF_SCAN_L;
+        size_t si = 0;
+        for (size_t c = 0; c < C; c++) {
+            const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+            ctile0[c] = (int32_t) desc.size();
+            for (int64_t b = 0; b < T; b += TW) {
+                while (si < slow.size() && slow[si] < t0 + b) si++;
+                TileDesc d;
+                d.t0 = t0; d.T = (int) T; d.base = (int) b; d.chunk = (int) c; d.slow0 = (int) si;
+                desc.push_back(d);
+            }
+        }
+        ctile0[C] = (int32_t) desc.size();
+        ctx->ntiles = (int) desc.size();
+        TRY(dev_upload(&ctx->d_tile_desc, desc.data(), desc.size()));
+        TRY(dev_upload(&ctx->d_chunk_tile0, ctile0.data(), ctile0.size()));
+        const size_t nt = (size_t) ctx->ntiles;
+        DMALLOC(ctx->d_Pt, nt * 16 * 8); DMALLOC(ctx->d_cf, nt * 4 * 8); DMALLOC(ctx->d_cb, nt * 4 * 8);
+        DMALLOC(ctx->d_tile_ll, nt * 8);
+        DMALLOC(ctx->d_Qs, nt * 64 * 16 * 8);
+        DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
     }
     *out = ctx;
     return HF_OK;
@@ -848,9 +764,8 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_off); hipFree(ctx->d_rec); hipFree(ctx->d_beta); hipFree(ctx->d_regmask); hipFree(ctx->d_E);
     hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); hipFree(ctx->d_chunk_stats);
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
-    hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_slow_stats);
-    hipFree(ctx->d_tile_desc);
-    hipFree(ctx->d_tile_chunk); hipFree(ctx->d_tile_base); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
+    hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
+    hipFree(ctx->d_Es); hipFree(ctx->d_Cs); hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
@@ -928,58 +843,64 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev0, st));
     HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
-    if (ctx->algo == HF_ALGO_SEQ || ctx->N == 0)   // the scan pass zeroes in k_chunk_ll / k_lut instead
-        HIPCHK(hipMemsetAsync(ctx->d_chunk_stats, 0, (size_t) ctx->C * ctx->V * 8 + (ctx->C ? 0 : 8), st));
-    if (ctx->N == 0) HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
     for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
-    if (ctx->N > 0 && ctx->C > 0) {
+    if (ctx->C == 0) HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
+    if (ctx->C > 0) {
         const unsigned tb = (unsigned) ((ctx->ntiles + 3) / 4);
         const size_t tab_bytes = (size_t) ctx->R * HF_TAB_STRIDE * 8;   // LDS transition tables
-        {
-            KTimer t(ctx, st, HF_K_LUT);
-            const int64_t MM = (int64_t) ctx->M * ctx->M;
-            hipLaunchKernelGGL(k_lut, dim3((unsigned) ((MM + 255) / 256), (unsigned) ctx->R), dim3(256), 0, st, ctx->M, ctx->K,
-                               ctx->d_params, ctx->d_lutE, ctx->d_lutC, ctx->d_flags);
+        const RowSrc S = row_src(ctx);
+        const bool full = mode == HF_MODE_FULL;
+        {   // also clears the flag word: first kernel of every pass
+            KTimer t(ctx, st, HF_K_TABLES);
+            const int jobs = ctx->n_keys + ctx->n_slow;
+            hipLaunchKernelGGL(k_tables, dim3((unsigned) (jobs / 256 + 1)), dim3(256), 0, st, ctx->n_keys, ctx->d_keys, ctx->n_slow,
+                               ctx->d_slow_w, ctx->d_rec, ctx->d_beta, ctx->M, ctx->K, ctx->d_params, ctx->d_lutE, ctx->d_lutC,
+                               ctx->d_Es, ctx->d_Cs, ctx->d_flags);
         }
-        {
-            KTimer t(ctx, st, HF_K_EMIT_TILE);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_emit_tile<HF_SCAN_L>), dim3(tb), dim3(256), 0, st, ctx->ntiles,
-                               ctx->d_tile_chunk, ctx->d_tile_base, ctx->d_off, ctx->d_rec, ctx->d_beta, ctx->d_params,
-                               ctx->d_lutE, ctx->M, ctx->d_E, ctx->d_Qs, ctx->d_Pt, ctx->d_flags);
-        }
-        if (ctx->algo == HF_ALGO_SEQ) {
-            KTimer t(ctx, st, HF_K_FWD);
-            hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec, ctx->d_E,
-                               ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_chunk_stats, ctx->V, ctx->d_flags);
-        } else {
-            { KTimer t(ctx, st, HF_K_CARRY);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_carry<HF_SCAN_L>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
-                               ctx->d_E, ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb); }
-            { KTimer t(ctx, st, HF_K_FWD);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fwd_tile<HF_SCAN_L>), dim3(tb), dim3(256), tab_bytes, st, ctx->ntiles,
-                               ctx->d_tile_desc, ctx->d_rec, ctx->d_E, ctx->d_Qs, ctx->d_params,
-                               ctx->d_cf, ctx->d_f, ctx->d_scale, ctx->d_tile_ll, ctx->d_flags); }
-            KTimer t(ctx, st, HF_K_CHUNK_LL);
-            hipLaunchKernelGGL(k_chunk_ll, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_chunk_tile0, ctx->d_tile_ll,
-                               ctx->d_chunk_stats, ctx->V);
-        }
-        if (mode == HF_MODE_FULL) {
-            {
-            KTimer t(ctx, st, HF_K_BWD);
-            if (ctx->algo == HF_ALGO_SEQ)
-                hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec, ctx->d_E,
-                                   ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
-            else
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_bwd_tile<HF_SCAN_L>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256),
-                                   tab_bytes, st, ctx->ntiles, ctx->d_tile_desc, ctx->d_rec, ctx->d_E,
-                                   ctx->d_Qs, ctx->d_params, ctx->d_cb, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label,
-                                   ctx->d_flags);
+        if (ctx->ntiles > 0) {
+            if (ctx->algo == HF_ALGO_SEQ) {
+                {
+                    KTimer t(ctx, st, HF_K_EMIT_ROWS);
+                    hipLaunchKernelGGL(k_emit_rows, dim3((unsigned) ((ctx->N + 255) / 256)), dim3(256), 0, st, ctx->N, ctx->d_rec,
+                                       ctx->d_beta, ctx->d_params, ctx->d_E, ctx->d_flags);
+                }
+                {
+                    KTimer t(ctx, st, HF_K_FWD_SEQ);
+                    hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
+                                       ctx->d_E, ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_tile_ll, ctx->d_flags);
+                }
+                if (full) {
+                    KTimer t(ctx, st, HF_K_BWD_SEQ);
+                    hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
+                                       ctx->d_E, ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
+                }
+            } else {
+                {
+                    KTimer t(ctx, st, HF_K_PROD_TILE);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_tile<HF_SCAN_L>), dim3(tb), dim3(256), tab_bytes, st, ctx->ntiles,
+                                       ctx->d_tile_desc, ctx->d_rec, ctx->d_params, S, ctx->d_Qs, ctx->d_Pt, ctx->d_flags);
+                }
+                {
+                    KTimer t(ctx, st, HF_K_CARRY);
+                    hipLaunchKernelGGL(k_carry, dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
+                                       ctx->d_Es, ctx->d_slow_off, ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb);
+                }
+                KTimer t(ctx, st, HF_K_FB_TILE);
+                if (full)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true>), dim3(tb), dim3(256), tab_bytes, st, ctx->ntiles,
+                                       ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_f,
+                                       ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, false>), dim3(tb), dim3(256), tab_bytes, st, ctx->ntiles,
+                                       ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_f,
+                                       ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
             }
-            const int kc = p->ncomp[3];
-            if (kc <= 4) launch_stats<4>(ctx, st);
-            else if (kc <= 8) launch_stats<8>(ctx, st);
-            else launch_stats<16>(ctx, st);
         }
+        const int kc = p->ncomp[3];
+        const int fl = full && ctx->ntiles > 0;
+        if (kc <= 4) launch_stats<4>(ctx, st, fl);
+        else if (kc <= 8) launch_stats<8>(ctx, st, fl);
+        else launch_stats<16>(ctx, st, fl);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev1, st));
@@ -1113,8 +1034,8 @@ int hf_kernel_times(hf_ctx* ctx, float ms[HF_NKERNELS]) {
 }
 
 const char* hf_kernel_name(int k) {
-    static const char* names[HF_NKERNELS] = {"k_lut", "k_emit_tile", "k_carry", "k_fwd", "k_chunk_ll", "k_bwd",
-                                             "k_stats_tile", "k_stats_slow", "k_chunk_stats", "k_reduce"};
+    static const char* names[HF_NKERNELS] = {"k_tables", "k_prod_tile", "k_carry", "k_fb_tile", "k_stats_tile", "k_chunk_stats",
+                                             "k_reduce", "k_emit_rows", "k_fwd_seq", "k_bwd_seq"};
     return k >= 0 && k < HF_NKERNELS ? names[k] : "?";
 }
 

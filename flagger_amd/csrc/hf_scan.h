@@ -3,18 +3,20 @@
 // The scaled forward recurrence f_t ∝ f_{t-1}·A_t (A_t[pre][s] = T_t(pre,s)·e_t(pre,s), hmm.c:366-420)
 // is a product of 4x4 non-negative matrices, hence associative.  A chunk is cut into tiles of 64·L
 // windows, one wavefront per tile, every lane owning L consecutive windows:
-//   k_emit_tile  emission rows + lane products + the product of every tile (all tiles of all chunks at once)
-//   k_carry      per chunk: sequential sweep over its <= T/(64L) tile products -> carried-in forward
-//                vector and carried-in backward direction of every tile
-//   k_fwd_tile   per tile: Kogge-Stone scan of the 64 lane products (DPP/ds_bpermute shuffles, power-of-two
-//                renormalisation after every product: exact, nothing underflows) gives each lane the product
-//                of everything before it; the lane then REPLAYS its L windows with the reference's exact
-//                operation order from the carried-in, normalised vector
-//   k_bwd_tile   mirror image with suffix products (hmm.c:470-529) + posterior argmax (hmm.c:671-692); the
+//   k_tables     this iteration's emission rows: one per (region, x, x_prev) that occurs at an interior window, and
+//                one per contig-end / chunk-first window (generic evaluation with the window's own beta)
+//   k_prod_tile  lane products and the product of every tile (all tiles of all chunks at once)
+//   k_carry      per chunk: sweep over its tile products -> carried-in forward vector and carried-in backward
+//                direction of every tile
+//   k_fb_tile    per tile: Kogge-Stone scan of the 64 lane products (power-of-two renormalisation after every
+//                product: exact, nothing underflows) gives each lane the product of everything before it; the lane
+//                then REPLAYS its L windows with the reference's exact operation order from the carried-in,
+//                normalised vector (hmm.c:333-420).  The same wavefront then runs the mirror image with suffix
+//                products (hmm.c:470-529) + posterior argmax (hmm.c:671-692) with f and scale still in registers; the
 //                absolute magnitude of a carried-in b vector is recovered from the invariant
-//                sum_s f_t[s]·b_t[s]·scale_t = terminationProb of the scaled forward-backward
-// Every f_t / b_t / scale_t is therefore produced by the reference's own arithmetic; only the carried-in
-// vectors differ from a purely sequential run, in the last ulp.
+//                sum_s f_t[s]·b_t[s]·scale_t = terminationProb of the scaled forward-backward.
+// No emission value is ever written to HBM per window: a row is 128 B gathered from the tables (L2-resident) where
+// it is used.
 #pragma once
 #include "hf_device.h"
 
@@ -88,124 +90,183 @@ __device__ __forceinline__ void m4_shfl_down(M4& dst, const M4& src, int d) {
     for (int i = 0; i < 16; i++) dst.m[i] = __shfl_down(src.m[i], d);
 }
 
-// Scan-mode layout of the emission stash: tile-major, lane-minor, so that the 64 lanes of the wavefront that owns a
-// tile read/write 1 KiB contiguous per instruction: E2[((tile*L + i)*8 + k2)*64 + lane] = (E[2*k2], E[2*k2+1]) of
-// the window `i` of `lane` (window index in chunk = tile_base + lane*L + i).
-template <int L>
-__device__ __forceinline__ int64_t e_slot(int tile, int lane, int i) { return (((int64_t) tile * L + i) * 8) * 64 + lane; }
+// ------------------------------------------------------------------------------------------
+// Emission rows.  Interior windows (beta == beta_star, not chunk-first) read the row of their key
+// (region, x, x_prev) from lutE / lutC; the others ("slow": contig ends, chunk-first; REC_SLOW) have a private row
+// in Es / Cs, indexed by their position in the context's slow list (ascending window order).  A tile knows the
+// list position of its first slow window (TileDesc.slow0); the rank inside the tile comes from ballots.
+// ------------------------------------------------------------------------------------------
+struct RowSrc {
+    const double* lutE;   // [R*M*M][16]
+    const double* lutC;   // [R*M*M][K][4]
+    const double* Es;     // [n_slow][16]
+    const double* Cs;     // [n_slow][K][4]
+    int M, K;
+};
 
-template <int L>
-__device__ __forceinline__ void load_E(const double* __restrict__ E, int tile, int lane, int i, double Ev[16]) {
-    const double2* __restrict__ src = reinterpret_cast<const double2*>(E) + e_slot<L>(tile, lane, i);
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const double2 v = src[k * 64]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
+__device__ __forceinline__ int64_t row_key(const RowSrc& S, uint32_t r, uint32_t rprev) {
+    return ((int64_t) REC_REGION(r) * S.M + REC_X(r)) * S.M + REC_X(rprev);
 }
 
+// rr[j] = record of the lane's j-th window (0 when outside the chunk); sidx[j] = slow-list position if it is slow
 template <int L>
-__device__ __forceinline__ void store_E(double* __restrict__ E, int tile, int lane, int i, const double Ev[16]) {
-    double2* __restrict__ dst = reinterpret_cast<double2*>(E) + e_slot<L>(tile, lane, i);
+__device__ __forceinline__ void slow_index(const uint32_t rr[L], int lane, int slow0, int sidx[L]) {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int below = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) dst[k * 64] = make_double2(Ev[2 * k], Ev[2 * k + 1]);
+    for (int j = 0; j < L; j++) below += __popcll(__ballot(REC_SLOW(rr[j]) != 0) & lt);
+    int mine = 0;
+#pragma unroll
+    for (int j = 0; j < L; j++) { sidx[j] = slow0 + below + mine; mine += (int) REC_SLOW(rr[j]); }
 }
 
-// T of one window; chunk-first windows use the start row for every pre (k_emit puts e_s(x_0) in row 0)
-__device__ __forceinline__ void load_Tm(const DevParams* __restrict__ P, uint32_t r, double Tm[16]) {
-    if (REC_FIRST(r)) {
-        const DevRegion* __restrict__ R = &P->reg[REC_REGION(r)];
+// wave-uniform: does the tile hold any slow window?  fills sidx (zeros when it does not)
+template <int L>
+__device__ __forceinline__ void tile_slow_index(const uint32_t rr[L], int lane, int slow0, int sidx[L]) {
+    bool slow = false;
 #pragma unroll
-        for (int k = 0; k < 16; k++) Tm[k] = R->trans[4][k & 3];
+    for (int i = 0; i < L; i++) { slow |= REC_SLOW(rr[i]) != 0; sidx[i] = 0; }
+    if (__any(slow)) slow_index<L>(rr, lane, slow0, sidx);
+}
+
+__device__ __forceinline__ const double2* row_ptr(const RowSrc& S, uint32_t r, uint32_t rprev, int sidx) {
+    return reinterpret_cast<const double2*>(REC_SLOW(r) ? S.Es + (int64_t) sidx * 16 : S.lutE + row_key(S, r, rprev) * 16);
+}
+
+__device__ __forceinline__ const double2* crow_ptr(const RowSrc& S, uint32_t r, uint32_t rprev, int sidx) {
+    return reinterpret_cast<const double2*>(REC_SLOW(r) ? S.Cs + ((int64_t) sidx * 4) * S.K
+                                                         : S.lutC + (row_key(S, r, rprev) * 4) * S.K);
+}
+
+__device__ __forceinline__ void load_row(const double2* __restrict__ src, double Ev[16]) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const double2 v = src[k]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
+}
+
+__device__ __forceinline__ bool row_has_nan(const double Ev[16]) {
+    bool isnan = false;
+#pragma unroll
+    for (int k = 0; k < 16; k++) isnan |= Ev[k] != Ev[k];
+    return isnan;
+}
+
+// the lane's window records plus the record of the window before its first one (x_prev of window 0 of the lane)
+template <int L>
+__device__ __forceinline__ uint32_t load_recs(const uint32_t* __restrict__ rec, int64_t t0, int64_t T, int64_t a, int lane,
+                                              uint32_t rr[L]) {
+#pragma unroll
+    for (int i = 0; i < L; i++) rr[i] = (a + i < T) ? rec[t0 + a + i] : 0u;
+    uint32_t rp = __shfl_up(rr[L - 1], 1);
+    if (lane == 0) rp = a > 0 ? rec[t0 + a - 1] : 0u;
+    return rp;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tables: this iteration's emission rows, one thread per row.
+//   job < n_keys            key = (region*M + x)*M + x_prev of an interior window (beta == beta_star):
+//                           lutE[key][16] = E[pre][s], lutC[key][K][4] = component probabilities of the collapsed
+//                           state, [component][u-th distinct alpha] — the per-iteration constants apply
+//   job - n_keys < n_slow   the slow window slow_w[k]: the same two rows with the window's own beta (or the
+//                           chunk-first row, hmm.c:338-352), in Es[k] / Cs[k]
+// The same device functions as a direct per-window evaluation, so the values are identical.
+// NaNs are stored, not reported: only a window that actually uses the row raises HF_E_NAN.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __restrict__ keys, int n_slow,
+                                                const int64_t* __restrict__ slow_w, const uint32_t* __restrict__ rec,
+                                                const double* __restrict__ beta, int M, int K,
+                                                const DevParams* __restrict__ P, double* __restrict__ lutE,
+                                                double* __restrict__ lutC, double* __restrict__ Es,
+                                                double* __restrict__ Cs, unsigned* __restrict__ flags) {
+    const int job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job == 0) *flags = 0u;   // first kernel of every pass
+    if (job >= n_keys + n_slow) return;
+    const int ncol = P->ncomp[3], nu = P->nuniq[3];
+    unsigned nan = 0;
+    double out[16];
+    if (job < n_keys) {
+        const int64_t key = keys[job];
+        const int64_t MM = (int64_t) M * M;
+        const int r = (int) (key / MM);
+        const int64_t idx = key % MM;
+        const double x = (double) (idx / M), px = (double) (idx % M);
+        const DevRegion* __restrict__ R = &P->reg[r];
+        const double bs = P->beta_star;
+        hf_emit_values<true>(P, R, x, px, false, bs, out, &nan);
+        double2* dst = reinterpret_cast<double2*>(lutE) + key * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[k] = make_double2(out[2 * k], out[2 * k + 1]);
+        double* __restrict__ c = lutC + (key * 4) * K;
+        for (int cc = 0; cc < ncol; cc++)
+            for (int u = 0; u < 4; u++)
+                c[cc * 4 + u] = u < nu ? hf_gauss_comp_star(R->m1[3][u][cc], R->gvar[3][cc], R->gnorm[3][cc], x, px,
+                                                            P->ualpha[3][u], bs, &nan) : 0.0;
     } else {
-        load_T(P, r, Tm);
+        const int k = job - n_keys;
+        const int64_t t = slow_w[k];
+        const uint32_t r = rec[t];
+        const bool first = REC_FIRST(r) != 0;
+        const double x = (double) REC_X(r), px = first ? 0.0 : (double) REC_X(rec[t - 1]);
+        const double bt = beta[t];
+        const DevRegion* __restrict__ R = &P->reg[REC_REGION(r)];
+        hf_emit_values<false>(P, R, x, px, first, bt, out, &nan);
+        double2* dst = reinterpret_cast<double2*>(Es) + (int64_t) k * 8;
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[q] = make_double2(out[2 * q], out[2 * q + 1]);
+        double* __restrict__ c = Cs + ((int64_t) k * 4) * K;
+        for (int cc = 0; cc < ncol; cc++)
+            for (int u = 0; u < 4; u++)
+                c[cc * 4 + u] = (u < nu && !first) ? hf_gauss_comp(R->mean[3][cc], R->var[3][cc], R->weight[3][cc], x, px,
+                                                                    P->ualpha[3][u], bt, &nan) : 0.0;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_lut: this iteration's emission tables for interior windows (beta == beta_star), per region and per
-// (x, x_prev) in [0, M)^2 — the same device functions as the direct evaluation, so the values are identical:
-//   lutE[r][x*M+px][16]       the emission row E[pre][s]
-//   lutC[r][x*M+px][K][4]     component probabilities of the collapsed state, [component][u-th distinct alpha]
-// NaNs are stored, not reported: only a window that actually uses the entry raises HF_E_NAN.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_lut(int M, int K, const DevParams* __restrict__ P, double* __restrict__ lutE,
-                                             double* __restrict__ lutC, unsigned* __restrict__ flags) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *flags = 0u;   // first kernel of every pass
-    const int r = blockIdx.y;
-    const int64_t MM = (int64_t) M * M;
-    const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= MM) return;
-    const double x = (double) (idx / M), px = (double) (idx % M);
-    const DevRegion* __restrict__ R = &P->reg[r];
-    const double bs = P->beta_star;
-    unsigned nan = 0;
-    double out[16];
-    hf_emit_values<true>(P, R, x, px, false, bs, out, &nan);
-    double2* dst = reinterpret_cast<double2*>(lutE) + ((int64_t) r * MM + idx) * 8;
-#pragma unroll
-    for (int k = 0; k < 8; k++) dst[k] = make_double2(out[2 * k], out[2 * k + 1]);
-    const int ncol = P->ncomp[3], nu = P->nuniq[3];
-    double* __restrict__ c = lutC + (((int64_t) r * MM + idx) * 4) * K;
-    for (int cc = 0; cc < ncol; cc++)
-        for (int u = 0; u < 4; u++)
-            c[cc * 4 + u] = u < nu ? hf_gauss_comp_star(R->m1[3][u][cc], R->gvar[3][cc], R->gnorm[3][cc], x, px,
-                                                        P->ualpha[3][u], bs, &nan) : 0.0;
-}
-
-// ------------------------------------------------------------------------------------------
-// k_emit_tile: one wavefront per tile.  Each lane evaluates the emission rows of its L windows (written to the
-// stash E, 128 B per window), multiplies them into its lane product Q_l (written to Qs: the forward AND the
-// backward tile kernels start from it instead of re-reading E for a first pass), and an ordered shuffle tree
-// over the lanes gives the tile product Pt.  Chunk-first windows are excluded from Q_l and Pt.
+// k_prod_tile: one wavefront per tile.  Each lane multiplies the matrices A = T∘E of its L windows into its lane
+// product Q_l (written to Qs: the scans of k_fb_tile start from it), and an ordered shuffle tree over the lanes
+// gives the tile product Pt.  Chunk-first windows are excluded from Q_l and Pt.  Every row a pass uses goes
+// through here once: this is where a NaN row raises HF_E_NAN (hmm_utils.c:783-786).
 // ------------------------------------------------------------------------------------------
 template <int L>
-__global__ void __launch_bounds__(256) k_emit_tile(int ntiles, const int32_t* __restrict__ tile_chunk,
-                                                   const int64_t* __restrict__ tile_base,
-                                                   const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
-                                                   const double* __restrict__ beta, const DevParams* __restrict__ P,
-                                                   const double* __restrict__ lutE, int M,
-                                                   double* __restrict__ E, double* __restrict__ Qs,
-                                                   double* __restrict__ Pt, unsigned* __restrict__ flags) {
-    const int64_t MM = (int64_t) M * M;
+__global__ void __launch_bounds__(256) k_prod_tile(int ntiles, const TileDesc* __restrict__ td,
+                                                   const uint32_t* __restrict__ rec, const DevParams* __restrict__ P,
+                                                   const RowSrc S, double* __restrict__ Qs, double* __restrict__ Pt,
+                                                   unsigned* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    fill_tab(P, s_tab);
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
-    const int c = tile_chunk[tile];
-    const int64_t t0 = off[c], T = off[c + 1] - t0, base = tile_base[tile];
+    const TileDesc d = td[tile];
+    const int64_t t0 = d.t0, T = d.T, base = d.base;
     const int64_t a = base + (int64_t) lane * L;
+    uint32_t rr[L];
+    const uint32_t rp = load_recs<L>(rec, t0, T, a, lane, rr);
+    int sidx[L];
+    tile_slow_index<L>(rr, lane, d.slow0, sidx);
+    double Ecur[16];
+    if (a < T) load_row(row_ptr(S, rr[0], rp, sidx[0]), Ecur);
     unsigned nan = 0;
     M4 Q;
     m4_identity(Q);
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < L; i++) {
+        double Enext[16];
+        if (i + 1 < L && a + i + 1 < T) load_row(row_ptr(S, rr[i + 1], rr[i], sidx[i + 1]), Enext);
         if (a + i < T) {
-            const int64_t t = t0 + a + i;
-            double Ev[16];
-            const uint32_t r = rec[t];
-            const double bt = beta[t];
-            const unsigned xi = REC_X(r), reg = REC_REGION(r);
-            const unsigned pxi = REC_FIRST(r) ? 0u : REC_X(rec[t - 1]);
-            // wave-uniform choice: every active lane's window is an interior, non-first one => its emission row is a
-            // function of (region, x, x_prev) only and comes from this iteration's table (k_lut)
-            if (__all(bt == P->beta_star && !REC_FIRST(r))) {
-                const double2* __restrict__ src = reinterpret_cast<const double2*>(lutE) + (((int64_t) reg * MM + xi * M + pxi) * 8);
-#pragma unroll
-                for (int k = 0; k < 8; k++) { const double2 v = src[k]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
-                bool isnan = false;
-#pragma unroll
-                for (int k = 0; k < 16; k++) isnan |= Ev[k] != Ev[k];
-                if (isnan) nan |= HF_FLAG_NAN;
-            } else {
-                hf_emit_values<false>(P, &P->reg[reg], (double) xi, (double) pxi, REC_FIRST(r) != 0, bt, Ev, &nan);
-            }
-            store_E<L>(E, tile, lane, i, Ev);
-            if (!REC_FIRST(r)) {
+            if (row_has_nan(Ecur)) nan |= HF_FLAG_NAN;
+            if (!REC_FIRST(rr[i])) {
                 double Tm[16];
-                load_T(P, r, Tm);
+                lds_Tm(s_tab, rr[i], Tm);
                 M4 A, R;
 #pragma unroll
-                for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ev[k];
+                for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ecur[k];
                 m4_mul(R, Q, A);
                 Q = R;
                 m4_renorm(Q);
             }
+        }
+        if (i + 1 < L) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) Ecur[k] = Enext[k];
         }
     }
     {
@@ -215,10 +276,10 @@ __global__ void __launch_bounds__(256) k_emit_tile(int ntiles, const int32_t* __
     }
     // ordered tree product over lanes: after step d, lane l (l % 2d == 0) holds the product of lanes l..l+2d-1
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
+    for (int dd = 1; dd < 64; dd <<= 1) {
         M4 Rgt, R;
-        m4_shfl_down(Rgt, Q, d);
-        if ((lane & (2 * d - 1)) == 0) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
+        m4_shfl_down(Rgt, Q, dd);
+        if ((lane & (2 * dd - 1)) == 0) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
     }
     if (lane == 0) {
         double2* dst = reinterpret_cast<double2*>(Pt + (int64_t) tile * 16);
@@ -236,15 +297,15 @@ __device__ __forceinline__ void load_lane_product(M4& Q, const double* __restric
 
 // ------------------------------------------------------------------------------------------
 // k_carry: per chunk, sweep the tile products.  cf[tile] = normalised forward vector entering the tile
-// (tile 0 of a chunk: unused, the tile kernel starts from window 0); cb[tile] = direction of b at the
-// first window after BACKWARD tile `tile` (backward tile k owns windows base_k-1 .. base_k+64L-2).
+// (tile 0 of a chunk: unused, the tile kernel starts from window 0); cb[tile] = direction of b at the LAST window
+// of the tile (= product of all later tiles applied to the end vector).
 // Wave 0 sweeps forward, wave 1 backward; each stages the tile products through its half of LDS in batches of
 // HF_CARRY_BATCH tiles (coalesced loads by all 64 lanes), then lane 0 runs the dependent chain out of LDS.
 // ------------------------------------------------------------------------------------------
 #define HF_CARRY_BATCH 128
-template <int L>
 __global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
-                                               const uint32_t* __restrict__ rec, const double* __restrict__ E,
+                                               const uint32_t* __restrict__ rec, const double* __restrict__ Es,
+                                               const int32_t* __restrict__ slow_off,
                                                const DevParams* __restrict__ P, const double* __restrict__ Pt,
                                                double* __restrict__ cf, double* __restrict__ cb) {
     __shared__ __attribute__((aligned(16))) double s_pt[2][HF_CARRY_BATCH * 16];
@@ -256,11 +317,11 @@ __global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, 
     double* __restrict__ sp = s_pt[wave];
     double* __restrict__ so = s_out[wave];
     double v[4];
-    if (wave == 0) {
+    if (wave == 0) {   // start∘e of the chunk's first window (its row is the chunk's first entry of the slow list)
         const uint32_t r0 = rec[t0];
         const DevRegion* __restrict__ R = &P->reg[REC_REGION(r0)];
-        double sv = 0.0, E0[16];
-        load_E<L>(E, k0, 0, 0, E0);
+        const double* __restrict__ E0 = Es + (int64_t) slow_off[c] * 16;
+        double sv = 0.0;
 #pragma unroll
         for (int s = 0; s < 4; s++) { v[s] = E0[s] * R->trans[4][s]; sv += v[s]; }
 #pragma unroll
@@ -283,7 +344,7 @@ __global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, 
             double2* dst = reinterpret_cast<double2*>(sp);
             for (int i = lane; i < n * 8; i += 64) dst[i] = src[i];
         }
-        __builtin_amdgcn_s_waitcnt(0);   // the wave's own LDS stores have landed (single wave per half: no barrier needed)
+        __builtin_amdgcn_s_waitcnt(0);   // the wave's own LDS stores have landed (one wave per half: no block barrier)
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             if (wave == 0) {
@@ -328,16 +389,20 @@ __global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_fwd_tile: one wavefront per tile
+// k_fb_tile: one wavefront per tile, forward then (BWD) backward + posterior labels.
+// Lane l owns windows a = base + l*L .. a+L-1 in both directions.  Backward: b_i = A_{i+1}·b_{i+1} / scale_i
+// (hmm.c:470-529); the vector a lane starts from is b at its own LAST window: direction = (product of the lane
+// products after it)·cb[tile], magnitude from sum_s f·b·scale = terminationProb with the lane's own f and scale;
+// the chunk's last window is b_{T-1}[s] = M[s][End] / scale_{T-1} (hmm.c:452-467).
 // ------------------------------------------------------------------------------------------
-template <int L>
-__global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const TileDesc* __restrict__ td,
-                                                  const uint32_t* __restrict__ rec,
-                                                  const double* __restrict__ E, const double* __restrict__ Qs,
-                                                  const DevParams* __restrict__ P,
-                                                  const double* __restrict__ cf, double* __restrict__ F,
-                                                  double* __restrict__ scale, double* __restrict__ tile_ll,
-                                                  unsigned* __restrict__ flags) {
+template <int L, bool BWD>
+__global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __restrict__ td,
+                                                 const uint32_t* __restrict__ rec, const RowSrc S,
+                                                 const double* __restrict__ Qs, const DevParams* __restrict__ P,
+                                                 const double* __restrict__ cf, const double* __restrict__ cb,
+                                                 double* __restrict__ F, double* __restrict__ scale,
+                                                 double* __restrict__ B, int8_t* __restrict__ label,
+                                                 double* __restrict__ tile_ll, unsigned* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     fill_tab(P, s_tab);
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -345,12 +410,15 @@ __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const TileDesc* __
     const TileDesc d = td[tile];
     const int64_t t0 = d.t0, T = d.T, base = d.base;
     const int64_t a = base + (int64_t) lane * L;
-    // everything phase 3 needs is requested now, so its latency hides behind the scan
     uint32_t rr[L];
+    const uint32_t rp = load_recs<L>(rec, t0, T, a, lane, rr);
+    int sidx[L];
+    tile_slow_index<L>(rr, lane, d.slow0, sidx);
+    const double2* rowp[L];
 #pragma unroll
-    for (int i = 0; i < L; i++) rr[i] = (a + i < T) ? rec[t0 + a + i] : 0u;
+    for (int i = 0; i < L; i++) rowp[i] = row_ptr(S, rr[i], i == 0 ? rp : rr[i - 1], sidx[i]);
     double Ecur[16];
-    load_E<L>(E, tile, lane, 0, Ecur);
+    if (a < T) load_row(rowp[0], Ecur);           // in flight during the scan
     double carry[4];
     if (base == 0) { carry[0] = 1.0; carry[1] = 0.0; carry[2] = 0.0; carry[3] = 0.0; }  // (1,0,0,0)·A_first = start∘e
     else {
@@ -358,27 +426,27 @@ __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const TileDesc* __
         for (int j = 0; j < 4; j++) carry[j] = cf[(int64_t) tile * 4 + j];
     }
     unsigned bad = 0;
-    // phase 1 + 2: exclusive prefix product over lanes
-    M4 Q;
-    load_lane_product(Q, Qs, tile, lane);
-    if (base == 0 && lane == 0) {   // the chunk's first window is not in Q_l: prepend A_first = start∘e (row 0 only)
-        double Tm[16];
-        lds_Tm(s_tab, rr[0], Tm);
-        M4 A, R;
-#pragma unroll
-        for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ecur[k];
-        m4_mul(R, A, Q);
-        Q = R;
-        m4_renorm(Q);
-    }
-#pragma unroll
-    for (int d2 = 1; d2 < 64; d2 <<= 1) {
-        M4 Lft, R;
-        m4_shfl_up(Lft, Q, d2);
-        if (lane >= d2) { m4_mul(R, Lft, Q); Q = R; m4_renorm(Q); }
-    }
+    // ---- forward: exclusive prefix product over lanes ----
     double f[4];
     {
+        M4 Q;
+        load_lane_product(Q, Qs, tile, lane);
+        if (base == 0 && lane == 0) {   // the chunk's first window is not in Q_l: prepend A_first = start∘e (row 0 only)
+            double Tm[16];
+            lds_Tm(s_tab, rr[0], Tm);
+            M4 A, R;
+#pragma unroll
+            for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ecur[k];
+            m4_mul(R, A, Q);
+            Q = R;
+            m4_renorm(Q);
+        }
+#pragma unroll
+        for (int d2 = 1; d2 < 64; d2 <<= 1) {
+            M4 Lft, R;
+            m4_shfl_up(Lft, Q, d2);
+            if (lane >= d2) { m4_mul(R, Lft, Q); Q = R; m4_renorm(Q); }
+        }
         M4 X;
         m4_shfl_up(X, Q, 1);
         double u[4], su = 0.0;
@@ -391,12 +459,13 @@ __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const TileDesc* __
 #pragma unroll
         for (int j = 0; j < 4; j++) f[j] = (lane == 0) ? carry[j] : u[j] / su;
     }
-    // phase 3: replay this lane's windows in the reference's operation order (hmm.c:333-420)
+    // replay this lane's windows in the reference's operation order (hmm.c:333-420); f and scale stay in registers
+    double fw[L][4], scw[L];
     double ll = 0.0;
 #pragma unroll
     for (int i = 0; i < L; i++) {
         double Enext[16];
-        if (i + 1 < L) load_E<L>(E, tile, lane, i + 1, Enext);     // next window's row is in flight during this one
+        if (i + 1 < L && a + i + 1 < T) load_row(rowp[i + 1], Enext);   // next window's row is in flight during this one
         if (a + i < T) {
             const int64_t t = t0 + a + i;
             const uint32_t r = rr[i];
@@ -418,6 +487,13 @@ __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const TileDesc* __
             reinterpret_cast<double2*>(F + t * 4)[0] = make_double2(f[0], f[1]);
             reinterpret_cast<double2*>(F + t * 4)[1] = make_double2(f[2], f[3]);
             scale[t] = sc;
+#pragma unroll
+            for (int s = 0; s < 4; s++) fw[i][s] = f[s];
+            scw[i] = sc;
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; s++) fw[i][s] = 0.0;
+            scw[i] = 1.0;
         }
         if (i + 1 < L) {
 #pragma unroll
@@ -426,156 +502,90 @@ __global__ void __launch_bounds__(256) k_fwd_tile(int ntiles, const TileDesc* __
     }
     for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
     if (lane == 0) tile_ll[tile] = ll;
-    if (bad) atomicOr(flags, bad);
-}
-
-// chunk log-likelihood = sum of its tiles' partial sums (fixed order)
-__global__ void __launch_bounds__(64) k_chunk_ll(const int32_t* __restrict__ chunk_tile0, const double* __restrict__ tile_ll,
-                                                 double* __restrict__ chunk_stats, int64_t V) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
-    double s = 0.0;
-    for (int k = lane; k < nt; k += 64) s += tile_ll[k0 + k];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    // the chunk's statistics vector starts from zero every pass (HMM_resetEstimators, hmm.c:129-134)
-    for (int64_t v = 1 + lane; v < V; v += 64) chunk_stats[(int64_t) c * V + v] = 0.0;
-    if (lane == 0) chunk_stats[(int64_t) c * V] = s;
-}
-
-// ------------------------------------------------------------------------------------------
-// k_bwd_tile: backward tile k owns windows i = base_k-1 .. base_k+64L-2 (i >= 0, i <= T-2); window i
-// uses G_i = A_{i+1}:  b_i = G_i·b_{i+1} / scale_i.  The chunk's last window b_{T-1} = term/scale_{T-1} is
-// written by the tile that contains window T-2 (or by tile 0 when T == 1).
-// ------------------------------------------------------------------------------------------
-template <int L>
-__global__ void __launch_bounds__(256) k_bwd_tile(int ntiles, const TileDesc* __restrict__ td,
-                                                  const uint32_t* __restrict__ rec,
-                                                  const double* __restrict__ E, const double* __restrict__ Qs,
-                                                  const DevParams* __restrict__ P,
-                                                  const double* __restrict__ cb, const double* __restrict__ F,
-                                                  const double* __restrict__ scale, double* __restrict__ B,
-                                                  int8_t* __restrict__ label, unsigned* __restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    fill_tab(P, s_tab);
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (tile >= ntiles) return;
-    const TileDesc d = td[tile];
-    const int64_t t0 = d.t0, T = d.T, base = d.base;
-    const int64_t Tm1 = T - 1;                              // windows 0..T-2 have a recurrence step
-    const int64_t a = base - 1 + (int64_t) lane * L;        // first window of this lane (may be -1)
-    const int64_t tend = base - 1 + 64 * (int64_t) L;       // first window after the tile
-    // requests for phase 3 go out first: window records of t+1, scales and the first emission row
-    uint32_t rr[L];
-    double scv[L];
+    if (BWD) {
+        // ---- backward: exclusive SUFFIX product over lanes ----
+        const int64_t Tm1 = T - 1;
+        int jl = (int) (T - a < L ? T - a : L) - 1;          // the lane's last window inside the chunk (< 0: none)
+        double b[4];
+        double Er[16];
+        if (jl == L - 1 && L >= 2) load_row(rowp[L - 1], Er);   // row of the first replayed step, in flight during the scan
+        {
+            M4 Q;
+            load_lane_product(Q, Qs, tile, lane);
 #pragma unroll
-    for (int i = 0; i < L; i++) {
-        const bool ok = a + i >= 0 && a + i < Tm1;
-        rr[i] = ok ? rec[t0 + a + i + 1] : 0u;
-        scv[i] = ok ? scale[t0 + a + i] : 1.0;
-    }
-    double Ecur[16];
-    load_E<L>(E, tile, lane, L - 1, Ecur);
-    unsigned bad = 0;
-    const uint32_t rlast = rec[t0 + T - 1];
-    const DevRegion* __restrict__ Rl = &P->reg[REC_REGION(rlast)];
-    const double term = Rl->trans[0][4];
-    double carry[4];
-    const bool last_tile = tend >= Tm1;
-    if (last_tile) {  // hmm.c:452-467: b_{T-1}[s] = M[s][End] / scale_{T-1}
-        const double sc = scale[t0 + T - 1];
+            for (int d2 = 1; d2 < 64; d2 <<= 1) {
+                M4 Rgt, R;
+                m4_shfl_down(Rgt, Q, d2);
+                if (lane + d2 < 64) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
+            }
+            M4 X;
+            m4_shfl_down(X, Q, 1);
+            double cv[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) carry[s] = Rl->trans[s][4] / sc;
-        if (lane == 0) {
-            const int64_t t = t0 + T - 1;
-            double f[4];
+            for (int s = 0; s < 4; s++) cv[s] = cb[(int64_t) tile * 4 + s];
 #pragma unroll
-            for (int s = 0; s < 4; s++) f[s] = F[t * 4 + s];
-            reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(carry[0], carry[1]);
-            reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(carry[2], carry[3]);
-            label[t] = (int8_t) posterior_label(f, carry, sc);
-        }
-    } else {          // direction from k_carry, magnitude from sum_s f·b·scale = terminationProb at window `tend`
-        const int64_t t = t0 + tend;
-        double dot = 0.0;
-#pragma unroll
-        for (int s = 0; s < 4; s++) { carry[s] = cb[(int64_t) tile * 4 + s]; dot += F[t * 4 + s] * carry[s]; }
-        const double k = term / (scale[t] * dot);
-#pragma unroll
-        for (int s = 0; s < 4; s++) carry[s] *= k;
-    }
-    // phase 1 + 2: exclusive SUFFIX product over lanes; lane windows i own A_{i+1}
-    double b[4];
-    {
-        M4 Q;
-        load_lane_product(Q, Qs, tile, lane);               // = product over windows a+1 .. a+L (window 0 excluded)
-#pragma unroll
-        for (int d2 = 1; d2 < 64; d2 <<= 1) {
-            M4 Rgt, R;
-            m4_shfl_down(Rgt, Q, d2);
-            if (lane + d2 < 64) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
-        }
-        M4 X;
-        m4_shfl_down(X, Q, 1);
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            double s = X.m[i * 4] * carry[0];
-            s = fma(X.m[i * 4 + 1], carry[1], s); s = fma(X.m[i * 4 + 2], carry[2], s); s = fma(X.m[i * 4 + 3], carry[3], s);
-            b[i] = s;
-        }
-    }
-    const int64_t nxt = a + L;                              // window whose b this lane starts from
-    if (lane == 63 || nxt >= Tm1) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) b[i] = carry[i];        // the carried vector itself
-    } else {
-        const int64_t t = t0 + nxt;
-        double dot = 0.0;
-#pragma unroll
-        for (int s = 0; s < 4; s++) dot += F[t * 4 + s] * b[s];
-        const double k = term / (scale[t] * dot);
-#pragma unroll
-        for (int i = 0; i < 4; i++) b[i] *= k;
-    }
-    // phase 3: replay this lane's windows (decreasing i) in the reference's operation order (hmm.c:470-529)
-    double fcur[4] = {0.0, 0.0, 0.0, 0.0};
-    if (a + L - 1 >= 0 && a + L - 1 < Tm1) {
-        const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + (t0 + a + L - 1) * 4);
-        const double2 f01 = fp[0], f23 = fp[1];
-        fcur[0] = f01.x; fcur[1] = f01.y; fcur[2] = f23.x; fcur[3] = f23.y;
-    }
-#pragma unroll
-    for (int i = L - 1; i >= 0; i--) {
-        double Enext[16], fnext[4] = {0.0, 0.0, 0.0, 0.0};
-        if (i > 0) {                                          // previous window's row and f are in flight during this one
-            load_E<L>(E, tile, lane, i - 1, Enext);
-            if (a + i - 1 >= 0 && a + i - 1 < Tm1) {
-                const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + (t0 + a + i - 1) * 4);
-                const double2 f01 = fp[0], f23 = fp[1];
-                fnext[0] = f01.x; fnext[1] = f01.y; fnext[2] = f23.x; fnext[3] = f23.y;
+            for (int i = 0; i < 4; i++) {
+                double s = X.m[i * 4] * cv[0];
+                s = fma(X.m[i * 4 + 1], cv[1], s); s = fma(X.m[i * 4 + 2], cv[2], s); s = fma(X.m[i * 4 + 3], cv[3], s);
+                b[i] = lane == 63 ? cv[i] : s;
             }
         }
-        if (a + i >= 0 && a + i < Tm1) {
-            const int64_t t = t0 + a + i;
-            double Tm[16];
-            lds_Tm(s_tab, rr[i], Tm);                         // window t+1 = base + lane*L + i of this tile
-            double nb[4] = {0.0, 0.0, 0.0, 0.0};
+        if (jl >= 0) {
+            const uint32_t rlast = rec[t0 + T - 1];
+            const DevRegion* __restrict__ Rl = &P->reg[REC_REGION(rlast)];
+            double fl[4] = {0.0, 0.0, 0.0, 0.0}, scl = 1.0;      // f / scale of the lane's last window
 #pragma unroll
-            for (int s = 0; s < 4; s++)
+            for (int i = 0; i < L; i++)
+                if (i == jl) {
 #pragma unroll
-                for (int p = 0; p < 4; p++) nb[p] += Tm[p * 4 + s] * Ecur[p * 4 + s] * b[s];
-            const double sc = scv[i];
-            if (sc < 1e-50) bad |= HF_FLAG_SCALE;             // hmm.c:521-524
+                    for (int s = 0; s < 4; s++) fl[s] = fw[i][s];
+                    scl = scw[i];
+                }
+            if (a + jl == Tm1) {   // hmm.c:452-467
 #pragma unroll
-            for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
-            reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(b[0], b[1]);
-            reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(b[2], b[3]);
-            label[t] = (int8_t) posterior_label(fcur, b, sc);
+                for (int s = 0; s < 4; s++) b[s] = Rl->trans[s][4] / scl;
+            } else {               // jl == L-1: direction from the scan, magnitude from the invariant at this window
+                const double term = Rl->trans[0][4];
+                double dot = 0.0;
+#pragma unroll
+                for (int s = 0; s < 4; s++) dot += fl[s] * b[s];
+                const double k = term / (scl * dot);
+#pragma unroll
+                for (int s = 0; s < 4; s++) b[s] *= k;
+            }
+            {
+                const int64_t t = t0 + a + jl;
+                reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(b[0], b[1]);
+                reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(b[2], b[3]);
+                label[t] = (int8_t) posterior_label(fl, b, scl);
+            }
         }
-        if (i > 0) {
+        // replay the other windows (decreasing) in the reference's operation order: window i uses the row of i+1
 #pragma unroll
-            for (int k = 0; k < 16; k++) Ecur[k] = Enext[k];
+        for (int i = L - 2; i >= 0; i--) {
+            double Enext[16];
+            if (i >= 1 && i <= jl) load_row(rowp[i], Enext);          // row of window i, used by window i-1
+            if (i < jl) {
+                const int64_t t = t0 + a + i;
+                double Tm[16];
+                lds_Tm(s_tab, rr[i + 1], Tm);
+                double nb[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < 4; k++) fcur[k] = fnext[k];
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int p = 0; p < 4; p++) nb[p] += Tm[p * 4 + s] * Er[p * 4 + s] * b[s];
+                const double sc = scw[i];
+                if (sc < 1e-50) bad |= HF_FLAG_SCALE;                 // hmm.c:521-524
+#pragma unroll
+                for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
+                reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(b[0], b[1]);
+                reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(b[2], b[3]);
+                label[t] = (int8_t) posterior_label(fw[i], b, sc);
+            }
+            if (i >= 1) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) Er[k] = Enext[k];
+            }
         }
     }
     if (bad) atomicOr(flags, bad);

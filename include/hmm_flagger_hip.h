@@ -140,11 +140,11 @@ int hf_last_kernel_ms(hf_ctx *ctx, float *ms);
  * the LAST pass in milliseconds (0 for kernels not selected or not run).  Call after hf_finish/hf_check.
  * Each selected kernel adds two event packets to the stream, so select only what is being measured. */
 #define HF_NKERNELS 10
-enum { HF_K_LUT = 0, HF_K_EMIT_TILE, HF_K_CARRY, HF_K_FWD, HF_K_CHUNK_LL, HF_K_BWD, HF_K_STATS_TILE, HF_K_STATS_SLOW,
-       HF_K_CHUNK_STATS, HF_K_REDUCE };
+enum { HF_K_TABLES = 0, HF_K_PROD_TILE, HF_K_CARRY, HF_K_FB_TILE, HF_K_STATS_TILE, HF_K_CHUNK_STATS, HF_K_REDUCE,
+       HF_K_EMIT_ROWS, HF_K_FWD_SEQ, HF_K_BWD_SEQ };
 int hf_set_profiling(hf_ctx *ctx, unsigned kernel_mask);
 int hf_kernel_times(hf_ctx *ctx, float ms[HF_NKERNELS]);
-const char *hf_kernel_name(int k);   /* "k_lut", "k_emit_tile", ... as they appear in a rocprofv3 kernel trace */
+const char *hf_kernel_name(int k);   /* "k_tables", "k_prod_tile", ... as they appear in a rocprofv3 kernel trace */
 
 #ifdef __cplusplus
 }
