@@ -76,6 +76,7 @@ def lib() -> C.CDLL:
     sig("hf_labels_dev", vp, vp)
     sig("hf_copy_chunk_stats", C.c_int, vp, vp, vp)
     sig("hf_reduce_chunks", C.c_int, vp, vp, i64, vp, vp)
+    sig("hf_reduce_chunks_indexed", C.c_int, vp, vp, vp, i64, vp, vp)
     sig("hf_finish", C.c_int, vp, pd, vp)
     sig("hf_check", C.c_int, vp, vp)
     sig("hf_get_labels", C.c_int, vp, C.POINTER(C.c_int8))

@@ -567,13 +567,15 @@ __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__
 // sum over chunks (hmm.c:759-763) in a fixed order that depends only on the chunk list: one wavefront per vector
 // element, lane l adds chunks l, l+64, ... in list order, then a fixed shuffle tree over the lanes.  The same
 // kernel reduces the local chunk list on one GPU and the all-gathered list on N GPUs => identical bits.
-__global__ void __launch_bounds__(64) k_reduce(const double* __restrict__ chunk_stats, int64_t n_chunks, int64_t V,
-                                               double* __restrict__ out, const unsigned* __restrict__ flags) {
+__global__ void __launch_bounds__(64) k_reduce(const double* __restrict__ chunk_stats, const int32_t* __restrict__ row_index,
+                                               int64_t n_chunks, int64_t V, double* __restrict__ out,
+                                               const unsigned* __restrict__ flags) {
     const int64_t v = blockIdx.x;
     const int lane = threadIdx.x;
     if (v == V) { if (flags && lane == 0) out[V] = (double) *flags; return; }   // error flags ride along with the vector
     double acc = 0.0;
-    for (int64_t c = lane; c < n_chunks; c += 64) acc += chunk_stats[c * V + v];
+    // row_index (multi-GPU): row of global chunk c inside the all-gathered, per-rank padded buffer
+    for (int64_t c = lane; c < n_chunks; c += 64) acc += chunk_stats[(row_index ? (int64_t) row_index[c] : c) * V + v];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if (lane == 0) out[v] = acc;
 }
@@ -923,20 +925,25 @@ int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
     return HF_OK;
 }
 
-int hf_reduce_chunks(hf_ctx* ctx, const double* chunk_stats_dev, int64_t n_chunks, double* out_dev, void* stream) {
+int hf_reduce_chunks_indexed(hf_ctx* ctx, const double* chunk_stats_dev, const int32_t* row_index_dev, int64_t n_chunks,
+                             double* out_dev, void* stream) {
     if (!ctx || !chunk_stats_dev || !out_dev || n_chunks < 0) return set_err(HF_E_ARG, "hf_reduce_chunks: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
     const bool own = chunk_stats_dev == ctx->d_chunk_stats;
     const unsigned keep = ctx->prof_mask;
     if (!own) ctx->prof_mask = 0;
     {
-    KTimer t(ctx, (hipStream_t) stream, HF_K_REDUCE);
-    hipLaunchKernelGGL(k_reduce, dim3((unsigned) (ctx->V + 1)), dim3(64), 0, (hipStream_t) stream,
-                       chunk_stats_dev, n_chunks, ctx->V, out_dev, out_dev == ctx->d_total ? ctx->d_flags : (const unsigned*) nullptr);
+        KTimer t(ctx, (hipStream_t) stream, HF_K_REDUCE);
+        hipLaunchKernelGGL(k_reduce, dim3((unsigned) (ctx->V + 1)), dim3(64), 0, (hipStream_t) stream, chunk_stats_dev, row_index_dev,
+                           n_chunks, ctx->V, out_dev, out_dev == ctx->d_total ? ctx->d_flags : (const unsigned*) nullptr);
     }
     ctx->prof_mask = keep;
     HIPCHK(hipGetLastError());
     return HF_OK;
+}
+
+int hf_reduce_chunks(hf_ctx* ctx, const double* chunk_stats_dev, int64_t n_chunks, double* out_dev, void* stream) {
+    return hf_reduce_chunks_indexed(ctx, chunk_stats_dev, nullptr, n_chunks, out_dev, stream);
 }
 
 static int flags_to_code(unsigned fl) {

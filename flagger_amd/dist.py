@@ -57,25 +57,23 @@ class ShardedEMList:
         self.device = device if device is not None else torch.device("cpu")
         self.send = torch.zeros((self.maxc, self.V), dtype=torch.float64, device=self.device)
         self.recv = torch.zeros((world, self.maxc, self.V), dtype=torch.float64, device=self.device)
-        self.packed = torch.zeros((max(1, self.n_chunks_total), self.V), dtype=torch.float64, device=self.device)
+        # row of global chunk c inside recv viewed as [world*maxc, V]: rank-major, padded to maxc rows per rank
+        rows = [r * self.maxc + k for r in range(world) for k in range(self.counts[r])]
+        self.row_index = torch.tensor(rows if rows else [0], dtype=torch.int32, device=self.device)
+        self.force_collective = False      # run the collective even with world == 1 (exercises the RCCL path on one GPU)
         self.total = torch.zeros((self.V,), dtype=torch.float64, device=self.device)
 
     def run_sharded(self, model, mode: int) -> np.ndarray:
         torch = self.torch
         import torch.distributed as dist
         self.local.launch(model, mode)
-        self.local.chunk_stats_into(self.send)            # [C_local, V] rows of this rank, device-to-device
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
+            self.local.chunk_stats_into(self.send)        # [maxc, V] rows of this rank, device-to-device
             dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group)
-            o = 0
-            for r in range(self.world):                   # global chunk order = rank order of contiguous runs
-                n = self.counts[r]
-                if n:
-                    self.packed[o:o + n].copy_(self.recv[r, :n])
-                o += n
         else:
-            self.packed[:self.counts[0]].copy_(self.send[:self.counts[0]])
-        self.local.reduce_into(self.packed, self.n_chunks_total, self.total)
+            self.local.chunk_stats_into(self.recv[0])
+        # every rank sums ALL chunks in global list order straight out of the gathered buffer
+        self.local.reduce_into(self.recv.view(self.world * self.maxc, self.V), self.row_index, self.n_chunks_total, self.total)
         stats = self.total.cpu().numpy().copy()           # device->host copy synchronises the stream
         self.local.check()
         return stats
@@ -113,8 +111,8 @@ class HipLocal:
     def chunk_stats_into(self, send):
         self.em.copy_chunk_stats(send.data_ptr())
 
-    def reduce_into(self, packed, n_chunks, total):
-        self.em.reduce_chunks(packed.data_ptr(), n_chunks, total.data_ptr())
+    def reduce_into(self, rows, row_index, n_chunks, total):
+        self.em.reduce_chunks_indexed(rows.data_ptr(), row_index.data_ptr(), n_chunks, total.data_ptr())
 
     def check(self):
         self.em.check()

@@ -199,6 +199,10 @@ class EMList:
     def copy_chunk_stats(self, dst_dev_ptr: int) -> None:
         N.check(self._L.hf_copy_chunk_stats(self._h, C.c_void_p(dst_dev_ptr), self.stream), "hf_copy_chunk_stats")
 
+    def reduce_chunks_indexed(self, rows_dev_ptr: int, row_index_dev_ptr: int, n_chunks: int, dst_dev_ptr: int) -> None:
+        N.check(self._L.hf_reduce_chunks_indexed(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr), n_chunks,
+                                                 C.c_void_p(dst_dev_ptr), self.stream), "hf_reduce_chunks_indexed")
+
     def reduce_chunks(self, src_dev_ptr: int, n_chunks: int, dst_dev_ptr: int) -> None:
         N.check(self._L.hf_reduce_chunks(self._h, C.c_void_p(src_dev_ptr), n_chunks, C.c_void_p(dst_dev_ptr),
                                          self.stream), "hf_reduce_chunks")

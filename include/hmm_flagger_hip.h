@@ -117,9 +117,14 @@ int8_t *hf_labels_dev(hf_ctx *ctx);                   /* device [n_windows] */
  * send buffer of the multi-GPU all-gather); asynchronous on `stream`. */
 int hf_copy_chunk_stats(hf_ctx *ctx, double *dst_dev, void *stream);
 
-/* Sum `n_chunks` per-chunk vectors in list order (the reference's sequential reduction,
- * hmm.c:759-763) into one vector; src/dst are DEVICE pointers; asynchronous on `stream`. */
+/* Sum `n_chunks` per-chunk vectors (the reference's reduction over the chunk list, hmm.c:759-763) into one
+ * vector, in a fixed order that depends only on the position of a chunk in the list; src/dst are DEVICE
+ * pointers; asynchronous on `stream`. */
 int hf_reduce_chunks(hf_ctx *ctx, const double *chunk_stats_dev, int64_t n_chunks, double *out_dev, void *stream);
+/* Same, with the vector of list position c taken from row row_index_dev[c] of `rows_dev` (multi-GPU: the
+ * all-gathered buffer holds every rank's rows padded to a common count); identical result to the packed form. */
+int hf_reduce_chunks_indexed(hf_ctx *ctx, const double *rows_dev, const int32_t *row_index_dev, int64_t n_chunks,
+                             double *out_dev, void *stream);
 
 /* Single-GPU convenience: reduce this context's chunks, copy the vector to `stats_host`,
  * wait for the stream and translate the device error flags (HF_E_SCALE / HF_E_NAN / ...). */

@@ -90,3 +90,19 @@ def test_cli_argument_errors(tmp_path):
     assert r.returncode == 0, r.stderr[-1000:]
     assert (tmp_path / "o" / "final_flagger_prediction.bed").read_text() == open(
         os.path.join(GOLD, "cfg1_expected", "final_flagger_prediction.bed")).read()
+
+
+def test_bench_single_gpu_and_distributed_code_paths_agree():
+    """bench.py --dist-path runs the multi-GPU code path (RCCL process group of one rank, all-gather of the
+    per-chunk vectors, indexed fixed-order reduction): identical log-likelihood trajectory to the direct path."""
+    import json
+    import sys
+    outs = []
+    for extra in ([], ["--dist-path"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "0.02", "--steps", "3", "--warmup", "1",
+                            "--no-cpu-baseline"] + extra, capture_output=True, text=True,
+                           env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]))   # RCCL prints a banner too
+    assert outs[0]["loglikelihood_after_last_step"] == outs[1]["loglikelihood_after_last_step"]
+    assert outs[1]["n_gpus"] == 1 and outs[1]["value"] > 0

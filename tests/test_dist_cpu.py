@@ -45,11 +45,12 @@ class OracleLocal:
         for c, o in enumerate(self.orcs):
             send[c] = torch.from_numpy(o.stats_vector(K))
 
-    def reduce_into(self, packed, n_chunks, total):
-        acc = np.zeros(packed.shape[1])
-        p = packed.numpy()
+    def reduce_into(self, rows, row_index, n_chunks, total):
+        acc = np.zeros(rows.shape[1])
+        p = rows.numpy()
+        idx = row_index.numpy()
         for c in range(n_chunks):      # list order, as hmm.c:759-763
-            acc = acc + p[c]
+            acc = acc + p[idx[c]]
         total.copy_(torch.from_numpy(acc))
 
     def check(self):
