@@ -375,7 +375,12 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + wave;
     if (tile >= ntiles) return;
-    double* __restrict__ s_acc = s_tab + P->n_regions * HF_TAB_STRIDE + wave * (3 * KT * 64) + lane;   // [(q*KT+cc)*64]
+    // per-wave accumulator rows [row][lane], row stride 65 doubles: lane-minor accesses and the column sums at the
+    // end of a region are both bank-conflict free.  Rows 0..3*ncol-1: component accumulators (q*ncol + cc).
+    constexpr int RS = 65;
+    const int nrows = 3 * P->ncomp[3] > NS + 1 ? 3 * P->ncomp[3] : NS + 1;
+    double* __restrict__ s_row = s_tab + P->n_regions * HF_TAB_STRIDE + wave * (nrows * RS);
+    double* __restrict__ s_acc = s_row + lane;
     const TileDesc d = td[tile];
     const int64_t t0 = d.t0, T = d.T, base = d.base;
     const bool te = hf_err_is_truncexp(P);
@@ -409,7 +414,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
 #pragma unroll
         for (int i = 0; i < NS; i++) reinterpret_cast<double*>(&a)[i] = 0.0;
         double c_wden = 0.0;
-        for (int i = 0; i < 3 * ncol; i++) s_acc[((i / ncol) * KT + (i % ncol)) * 64] = 0.0;
+        for (int i = 0; i < 3 * ncol; i++) s_acc[i * RS] = 0.0;
 #pragma unroll 1
         for (int j = 0; j < L; j++) {
             if (!(ok[j] && (int) REC_REGION(rr[j + 1]) == r)) continue;
@@ -471,7 +476,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
             for (int cc = 0; cc < ncol; cc++) {
                 const double2 u01 = crow[cc * 2], u23 = crow[cc * 2 + 1];
                 const double mu = R->mean[3][cc];
-                double mnum = s_acc[(0 * KT + cc) * 64], vnum = s_acc[(1 * KT + cc) * 64], den = s_acc[(2 * KT + cc) * 64];
+                double mnum = s_acc[cc * RS], vnum = s_acc[(ncol + cc) * RS], den = s_acc[(2 * ncol + cc) * RS];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const double pc = um[p] == 0 ? u01.x : um[p] == 1 ? u01.y : um[p] == 2 ? u23.x : u23.y;
@@ -482,26 +487,43 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
                     den += w;
                     c_wden += w;
                 }
-                s_acc[(0 * KT + cc) * 64] = mnum; s_acc[(1 * KT + cc) * 64] = vnum; s_acc[(2 * KT + cc) * 64] = den;
+                s_acc[cc * RS] = mnum; s_acc[(ncol + cc) * RS] = vnum; s_acc[(2 * ncol + cc) * RS] = den;
             }
         }
-        // fixed shuffle tree per accumulator, lane 0 stores in StatAcc<KT> order
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-            double v = reinterpret_cast<double*>(&a)[i];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-            if (lane == 0) dst[i] = v;
-        }
-        for (int i = 0; i < 3 * KT; i++) {
-            double v = (i % KT) < ncol ? s_acc[i * 64] : 0.0;
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-            if (lane == 0) dst[NS + i] = v;
-        }
+        // sum over the 64 lanes in lane order: accumulator i is summed by lane i out of its LDS row (fixed order),
+        // results stored in StatAcc<KT> order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         {
-            double v = c_wden;
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-            if (lane == 0) dst[NS + 3 * KT] = v;
+            double v = 0.0;
+            if (lane < 3 * ncol) {
+                const double* __restrict__ row = s_row + lane * RS;
+                for (int l = 0; l < 64; l++) v += row[l];
+            }
+            for (int i = lane; i < 3 * KT; i += 64) dst[NS + i] = 0.0;       // slots of components >= ncol
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 3 * ncol) dst[NS + (lane / ncol) * KT + (lane % ncol)] = v;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < NS; i++) s_acc[i * RS] = reinterpret_cast<double*>(&a)[i];
+        s_acc[NS * RS] = c_wden;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane <= NS) {
+            const double* __restrict__ row = s_row + lane * RS;
+            double v = 0.0;
+            for (int l = 0; l < 64; l++) v += row[l];
+            dst[lane < NS ? lane : NS + 3 * KT] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -606,12 +628,13 @@ static RowSrc row_src(const hf_ctx* ctx) {
 }
 
 template <int KT>
-static void launch_stats(hf_ctx* ctx, hipStream_t st, int full) {
+static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
     if (full) {
         KTimer t(ctx, st, HF_K_STATS_TILE);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256),
-                           ((size_t) ctx->R * HF_TAB_STRIDE + 4 * 3 * KT * 64) * 8, st, ctx->ntiles, ctx->d_tile_desc, ctx->d_rec,
-                           row_src(ctx), ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_stats);
+                           ((size_t) ctx->R * HF_TAB_STRIDE + 4 * (size_t) (3 * ncol > 28 ? 3 * ncol : 28) * 65) * 8, st, ctx->ntiles,
+                           ctx->d_tile_desc, ctx->d_rec, row_src(ctx), ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask,
+                           ctx->d_tile_stats);
     }
     KTimer t(ctx, st, HF_K_CHUNK_STATS);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_chunk_tile0,
@@ -900,9 +923,9 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
         }
         const int kc = p->ncomp[3];
         const int fl = full && ctx->ntiles > 0;
-        if (kc <= 4) launch_stats<4>(ctx, st, fl);
-        else if (kc <= 8) launch_stats<8>(ctx, st, fl);
-        else launch_stats<16>(ctx, st, fl);
+        if (kc <= 4) launch_stats<4>(ctx, st, fl, kc);
+        else if (kc <= 8) launch_stats<8>(ctx, st, fl, kc);
+        else launch_stats<16>(ctx, st, fl, kc);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev1, st));
