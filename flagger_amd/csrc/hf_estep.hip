@@ -878,7 +878,7 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
         {   // also clears the flag word: first kernel of every pass
             KTimer t(ctx, st, HF_K_TABLES);
             const int jobs = ctx->n_keys + ctx->n_slow;
-            hipLaunchKernelGGL(k_tables, dim3((unsigned) (jobs / 256 + 1)), dim3(256), 0, st, ctx->n_keys, ctx->d_keys, ctx->n_slow,
+            hipLaunchKernelGGL(k_tables, dim3((unsigned) (jobs / HF_TABLE_JOBS_PER_BLOCK + 1)), dim3(256), 0, st, ctx->n_keys, ctx->d_keys, ctx->n_slow,
                                ctx->d_slow_w, ctx->d_rec, ctx->d_beta, ctx->M, ctx->K, ctx->d_params, ctx->d_lutE, ctx->d_lutC,
                                ctx->d_Es, ctx->d_Cs, ctx->d_flags);
         }

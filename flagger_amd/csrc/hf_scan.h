@@ -162,61 +162,90 @@ __device__ __forceinline__ uint32_t load_recs(const uint32_t* __restrict__ rec, 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_tables: this iteration's emission rows, one thread per row.
+// k_tables: this iteration's emission rows.
 //   job < n_keys            key = (region*M + x)*M + x_prev of an interior window (beta == beta_star):
 //                           lutE[key][16] = E[pre][s], lutC[key][K][4] = component probabilities of the collapsed
 //                           state, [component][u-th distinct alpha] — the per-iteration constants apply
 //   job - n_keys < n_slow   the slow window slow_w[k]: the same two rows with the window's own beta (or the
 //                           chunk-first row, hmm.c:338-352), in Es[k] / Cs[k]
+// 32 threads per job: thread `slot` evaluates one unit — a single-component state (slot 0..2: Err, Dup, Hap) or
+// one component of the collapsed state (slot 3+c) — for every distinct alpha of that column (<= 4 exp); then 16
+// threads assemble E[pre][s] (the collapsed state: components summed in index order, hmm_utils.c:753-758).
 // The same device functions as a direct per-window evaluation, so the values are identical.
 // NaNs are stored, not reported: only a window that actually uses the row raises HF_E_NAN.
 // ------------------------------------------------------------------------------------------
+#define HF_TABLE_JOBS_PER_BLOCK 8
 __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __restrict__ keys, int n_slow,
                                                 const int64_t* __restrict__ slow_w, const uint32_t* __restrict__ rec,
                                                 const double* __restrict__ beta, int M, int K,
                                                 const DevParams* __restrict__ P, double* __restrict__ lutE,
                                                 double* __restrict__ lutC, double* __restrict__ Es,
                                                 double* __restrict__ Cs, unsigned* __restrict__ flags) {
-    const int job = blockIdx.x * blockDim.x + threadIdx.x;
-    if (job == 0) *flags = 0u;   // first kernel of every pass
-    if (job >= n_keys + n_slow) return;
-    const int ncol = P->ncomp[3], nu = P->nuniq[3];
+    __shared__ double vals[HF_TABLE_JOBS_PER_BLOCK][3 + HF_MAXCOMP][4];
+    const int jl = threadIdx.x >> 5, slot = threadIdx.x & 31;
+    const int job = blockIdx.x * HF_TABLE_JOBS_PER_BLOCK + jl;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *flags = 0u;   // first kernel of every pass
+    const bool active = job < n_keys + n_slow;
+    const int ncol = P->ncomp[3];
+    const bool te = hf_err_is_truncexp(P);
+    const bool star = job < n_keys;
+    bool first = false;
+    double x = 0.0, px = 0.0, bt = P->beta_star;
+    int r = 0;
+    double *dstE = nullptr, *dstC = nullptr;
+    if (active) {
+        if (star) {
+            const int64_t key = keys[job];
+            const int64_t MM = (int64_t) M * M;
+            r = (int) (key / MM);
+            const int64_t idx = key % MM;
+            x = (double) (idx / M); px = (double) (idx % M);
+            dstE = lutE + key * 16; dstC = lutC + (key * 4) * K;
+        } else {
+            const int k = job - n_keys;
+            const int64_t t = slow_w[k];
+            const uint32_t rw = rec[t];
+            first = REC_FIRST(rw) != 0;
+            r = (int) REC_REGION(rw);
+            x = (double) REC_X(rw); px = first ? 0.0 : (double) REC_X(rec[t - 1]);
+            bt = beta[t];
+            dstE = Es + (int64_t) k * 16; dstC = Cs + ((int64_t) k * 4) * K;
+        }
+    }
+    const DevRegion* __restrict__ R = &P->reg[r];
     unsigned nan = 0;
-    double out[16];
-    if (job < n_keys) {
-        const int64_t key = keys[job];
-        const int64_t MM = (int64_t) M * M;
-        const int r = (int) (key / MM);
-        const int64_t idx = key % MM;
-        const double x = (double) (idx / M), px = (double) (idx % M);
-        const DevRegion* __restrict__ R = &P->reg[r];
-        const double bs = P->beta_star;
-        hf_emit_values<true>(P, R, x, px, false, bs, out, &nan);
-        double2* dst = reinterpret_cast<double2*>(lutE) + key * 8;
+    if (active && slot < 3 + ncol) {
+        const int s = slot < 3 ? slot : 3, c = slot < 3 ? 0 : slot - 3;
+        double v[4] = {0.0, 0.0, 0.0, 0.0};
+        if (s == 0 && te) {
+            v[0] = star ? hf_trunc_exp_star(R, x) : hf_trunc_exp(R->lambda, R->trunc_point, x, bt);
+        } else {
+            const int nu = first ? 1 : P->nuniq[s];
+            for (int u = 0; u < nu; u++) {
+                const double alpha = first ? 0.0 : P->ualpha[s][u];
+                v[u] = star ? hf_gauss_comp_star(R->m1[s][u][c], R->gvar[s][c], R->gnorm[s][c], x, px, alpha, bt, &nan)
+                            : hf_gauss_comp(R->mean[s][c], R->var[s][c], R->weight[s][c], x, px, alpha, bt, &nan);
+            }
+        }
 #pragma unroll
-        for (int k = 0; k < 8; k++) dst[k] = make_double2(out[2 * k], out[2 * k + 1]);
-        double* __restrict__ c = lutC + (key * 4) * K;
-        for (int cc = 0; cc < ncol; cc++)
-            for (int u = 0; u < 4; u++)
-                c[cc * 4 + u] = u < nu ? hf_gauss_comp_star(R->m1[3][u][cc], R->gvar[3][cc], R->gnorm[3][cc], x, px,
-                                                            P->ualpha[3][u], bs, &nan) : 0.0;
-    } else {
-        const int k = job - n_keys;
-        const int64_t t = slow_w[k];
-        const uint32_t r = rec[t];
-        const bool first = REC_FIRST(r) != 0;
-        const double x = (double) REC_X(r), px = first ? 0.0 : (double) REC_X(rec[t - 1]);
-        const double bt = beta[t];
-        const DevRegion* __restrict__ R = &P->reg[REC_REGION(r)];
-        hf_emit_values<false>(P, R, x, px, first, bt, out, &nan);
-        double2* dst = reinterpret_cast<double2*>(Es) + (int64_t) k * 8;
+        for (int u = 0; u < 4; u++) vals[jl][slot][u] = v[u];
+        if (slot >= 3) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) dst[q] = make_double2(out[2 * q], out[2 * q + 1]);
-        double* __restrict__ c = Cs + ((int64_t) k * 4) * K;
-        for (int cc = 0; cc < ncol; cc++)
-            for (int u = 0; u < 4; u++)
-                c[cc * 4 + u] = (u < nu && !first) ? hf_gauss_comp(R->mean[3][cc], R->var[3][cc], R->weight[3][cc], x, px,
-                                                                    P->ualpha[3][u], bt, &nan) : 0.0;
+            for (int u = 0; u < 4; u++) dstC[c * 4 + u] = first ? 0.0 : v[u];
+        }
+    }
+    __syncthreads();
+    if (active && slot < 16) {
+        const int pre = slot >> 2, s = slot & 3;
+        const int u = (first || (s == 0 && te)) ? 0 : P->umap[pre * 4 + s];
+        double e;
+        if (s < 3) e = vals[jl][s][u];
+        else {
+            e = 0.0;
+            for (int c = 0; c < ncol; c++) e += vals[jl][3 + c][u];
+        }
+        if (first && pre != 0) e = 0.0;
+        dstE[pre * 4 + s] = e;
     }
 }
 
