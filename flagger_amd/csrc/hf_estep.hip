@@ -438,10 +438,10 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
                 double adj[4];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
-                    const int k = p * 4 + s;
+                    const int k = HF_PS(p, s);                // rows and tables are state-major
                     const double count = f[p] * Tm[k] * Ev[k] * b1[s];
                     adj[p] = count / HF_TERMINATION_PROB;     // hmm.c:613-614
-                    a.trans[k] += adj[p];                     // hmm_utils.c:2010-2015
+                    a.trans[p * 4 + s] += adj[p];             // hmm_utils.c:2010-2015
                 }
                 if (s == 3) {
 #pragma unroll
@@ -452,8 +452,8 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
                 } else {                                      // hmm_utils.c:812-839, one component
 #pragma unroll
                     for (int p = 0; p < 4; p++) {
-                        const int k = p * 4 + s;
-                        const double alpha = P->alpha[k];
+                        const int k = HF_PS(p, s);
+                        const double alpha = P->alpha[p * 4 + s];
                         const double x_adj = (x - alpha * px) / (1.0 - alpha);
                         const double w = adj[p] * Ev[k] / Ev[k];
                         a.g_mnum[s] += w * x_adj;
@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const double pc = um[p] == 0 ? u01.x : um[p] == 1 ? u01.y : um[p] == 2 ? u23.x : u23.y;
-                    const double w = adj3[p] * pc / Ev[p * 4 + 3];
+                    const double w = adj3[p] * pc / Ev[HF_PS(p, 3)];
                     mnum += w * xa[p];
                     const double z = (xa[p] - mu) * om[p];
                     vnum += w * z * z;
@@ -499,6 +499,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
             double v = 0.0;
             if (lane < 3 * ncol) {
                 const double* __restrict__ row = s_row + lane * RS;
+#pragma unroll 8
                 for (int l = 0; l < 64; l++) v += row[l];
             }
             for (int i = lane; i < 3 * KT; i += 64) dst[NS + i] = 0.0;       // slots of components >= ncol
@@ -518,6 +519,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
         if (lane <= NS) {
             const double* __restrict__ row = s_row + lane * RS;
             double v = 0.0;
+#pragma unroll 8
             for (int l = 0; l < 64; l++) v += row[l];
             dst[lane < NS ? lane : NS + 3 * KT] = v;
         }

@@ -20,7 +20,11 @@
 #pragma once
 #include "hf_device.h"
 
-struct M4 { double m[16]; };
+struct M4 { double m[16]; };   // row-major: m[pre*4 + s]
+
+// Emission rows and the LDS transition tables are stored STATE-major: entry (pre, s) at s*4 + pre, so that the four
+// values of one state column are contiguous (the statistics kernel works one column at a time).
+#define HF_PS(p, s) ((s) * 4 + (p))
 
 // Conditional-transition and start tables of every region, staged once per block in LDS (136 doubles per region:
 // tcond[8][16], start[4], pad): the per-window lookup no longer waits on global memory behind the window record.
@@ -29,7 +33,8 @@ __device__ __forceinline__ void fill_tab(const DevParams* __restrict__ P, double
     const int n = P->n_regions * HF_TAB_STRIDE;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int r = i / HF_TAB_STRIDE, k = i % HF_TAB_STRIDE;
-        s_tab[i] = k < 128 ? P->reg[r].tcond[k >> 4][k & 15] : (k < 132 ? P->reg[r].trans[4][k - 128] : 0.0);
+        // k < 128: mask k>>4, entry (pre, s) of the state-major block at (k & 15) = s*4 + pre
+        s_tab[i] = k < 128 ? P->reg[r].tcond[k >> 4][(k & 3) * 4 + ((k >> 2) & 3)] : (k < 132 ? P->reg[r].trans[4][k - 128] : 0.0);
     }
     __syncthreads();
 }
@@ -38,7 +43,7 @@ __device__ __forceinline__ void lds_Tm(const double* __restrict__ s_tab, uint32_
     if (REC_FIRST(r)) {                       // chunk-first window: the start row for every pre
         const double* __restrict__ s = s_tab + REC_REGION(r) * HF_TAB_STRIDE + 128;
 #pragma unroll
-        for (int k = 0; k < 16; k++) Tm[k] = s[k & 3];
+        for (int k = 0; k < 16; k++) Tm[k] = s[k >> 2];
     } else if (REC_REGCHG(r)) {               // region change => 1/(S+1), hmm.c:398-400
 #pragma unroll
         for (int k = 0; k < 16; k++) Tm[k] = 1.0 / (HF_NSTATES + 1);
@@ -245,7 +250,7 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
             for (int c = 0; c < ncol; c++) e += vals[jl][3 + c][u];
         }
         if (first && pre != 0) e = 0.0;
-        dstE[pre * 4 + s] = e;
+        dstE[HF_PS(pre, s)] = e;
     }
 }
 
@@ -287,7 +292,7 @@ __global__ void __launch_bounds__(256) k_prod_tile(int ntiles, const TileDesc* _
                 lds_Tm(s_tab, rr[i], Tm);
                 M4 A, R;
 #pragma unroll
-                for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ecur[k];
+                for (int k = 0; k < 16; k++) A.m[k] = Tm[HF_PS(k >> 2, k & 3)] * Ecur[HF_PS(k >> 2, k & 3)];
                 m4_mul(R, Q, A);
                 Q = R;
                 m4_renorm(Q);
@@ -352,7 +357,7 @@ __global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, 
         const double* __restrict__ E0 = Es + (int64_t) slow_off[c] * 16;
         double sv = 0.0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) { v[s] = E0[s] * R->trans[4][s]; sv += v[s]; }
+        for (int s = 0; s < 4; s++) { v[s] = E0[HF_PS(0, s)] * R->trans[4][s]; sv += v[s]; }
 #pragma unroll
         for (int s = 0; s < 4; s++) v[s] /= sv;
     } else {
@@ -465,7 +470,7 @@ __global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __r
             lds_Tm(s_tab, rr[0], Tm);
             M4 A, R;
 #pragma unroll
-            for (int k = 0; k < 16; k++) A.m[k] = Tm[k] * Ecur[k];
+            for (int k = 0; k < 16; k++) A.m[k] = Tm[HF_PS(k >> 2, k & 3)] * Ecur[HF_PS(k >> 2, k & 3)];
             m4_mul(R, A, Q);
             Q = R;
             m4_renorm(Q);
@@ -505,7 +510,7 @@ __global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __r
             for (int s = 0; s < 4; s++) {
                 double acc = 0.0;
 #pragma unroll
-                for (int p = 0; p < 4; p++) acc += (f[p] * Tm[p * 4 + s] * Ecur[p * 4 + s]);
+                for (int p = 0; p < 4; p++) acc += (f[p] * Tm[HF_PS(p, s)] * Ecur[HF_PS(p, s)]);
                 nf[s] = acc;
                 sc += acc;
             }
@@ -602,7 +607,7 @@ __global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __r
 #pragma unroll
                 for (int s = 0; s < 4; s++)
 #pragma unroll
-                    for (int p = 0; p < 4; p++) nb[p] += Tm[p * 4 + s] * Er[p * 4 + s] * b[s];
+                    for (int p = 0; p < 4; p++) nb[p] += Tm[HF_PS(p, s)] * Er[HF_PS(p, s)] * b[s];
                 const double sc = scw[i];
                 if (sc < 1e-50) bad |= HF_FLAG_SCALE;                 // hmm.c:521-524
 #pragma unroll
