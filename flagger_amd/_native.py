@@ -42,6 +42,15 @@ class hf_params(C.Structure):
     ]
 
 
+
+class hfs_input(C.Structure):   # include/hmm_flagger_summary.h
+    _fields_ = [("n_windows", C.c_int64), ("n_chunks", C.c_int32), ("chunk_off", C.POINTER(C.c_int64)),
+                ("chunk_s", C.POINTER(C.c_int32)), ("chunk_e", C.POINTER(C.c_int32)), ("chunk_ctg", C.POINTER(C.c_char_p)),
+                ("window_len", C.c_int32), ("annot", C.POINTER(C.c_uint64)), ("truth", C.POINTER(C.c_int8)),
+                ("prediction", C.POINTER(C.c_int8)), ("truth_available", C.c_int32), ("prediction_available", C.c_int32),
+                ("n_labels", C.c_int32), ("n_regions", C.c_int32), ("n_annotations", C.c_int32),
+                ("annotation_names", C.POINTER(C.c_char_p))]
+
 _lib = None
 
 
@@ -107,6 +116,9 @@ def lib() -> C.CDLL:
     sig("hfm_best_collapsed_comps", C.c_int, C.POINTER(C.c_uint16), i64, C.POINTER(i32), C.c_int)
     sig("hfm_read_alpha_tsv", C.c_int, C.c_char_p, pd)
     sig("hf_em_iterate", C.c_int, vp, vp, C.c_int, C.c_int, dbl, pd, C.POINTER(C.c_int), vp)
+    # summary tables (include/hmm_flagger_summary.h)
+    sig("hfs_write_all_tables", C.c_int, C.POINTER(hfs_input), C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, dbl, C.c_int)
+    sig("hfs_last_error", C.c_char_p)
     # SQUAREM + misc model helpers
     sig("hfm_scale_initial_means", None, vp, dbl)
     sig("hfm_squarem_create", vp, vp, vp, vp)

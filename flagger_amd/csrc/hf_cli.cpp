@@ -64,7 +64,7 @@ static void usage(const char* program) {
             "         --windowLen, -W              window length in bases [preset]\n"
             "         --iterations, -n             maximum EM iterations [100]\n"
             "         --convergenceTol, -t         [0.001]\n"
-            "         --contigsList, -c            file with contig names to keep\n"
+            "         --contigsList, -c            file with contig names to keep (first token of every line)\n"
             "         --disableAdjustContigEnds, -e\n"
             "         --minReadFractionAtEnds, -f  [preset]\n"
             "         --maxHighMapqRatio, -q       [0.25]     --minHighMapqRatio   [0.75]\n"
@@ -74,8 +74,7 @@ static void usage(const char* program) {
             "         --dumpBin, -B                --accelerate, -s (SQUAREM)\n"
             "         --minimumLengths, -M         Err,Dup,Col minimum lengths [0,0,0]\n"
             "         --threads, -@                accepted for compatibility (the E-step runs on the GPU)\n"
-            "         --labelNames -l, --binArrayFile -a, --overlapRatioThreshold -v, -k: accepted; the summary tables\n"
-            "                                      (prediction_summary_*.tsv) are not produced by this build yet\n"
+            "         --labelNames -l, --binArrayFile -a, --overlapRatioThreshold -v, -k: summary tables (prediction_summary_*.tsv)\n"
             "         --device                     GPU index [0]        --algo scan|seq [scan]\n");
 }
 
@@ -108,6 +107,25 @@ struct Run {
     }
 };
 
+// writeBenchmarkingStats, hmm_flagger.c:134-162
+static int write_summary(Run& run, const std::string& dir, const std::string& suffix, const std::vector<std::string>& labelNames,
+                         const char* binArrayFilePath, double overlapRatioThreshold, int threads) {
+    const int64_t N = hfio_n_windows(run.tab);
+    std::vector<int8_t> labels((size_t) N);
+    int rc = hf_get_labels(run.ctx, labels.data());
+    if (rc != HF_OK) return rc;
+    std::vector<const char*> names;
+    for (const auto& s : labelNames) names.push_back(s.c_str());
+    const std::string path = dir + "/prediction_summary_" + suffix + ".tsv";
+    if (hfio_write_summary(run.tab, labels.data(), path.c_str(), binArrayFilePath, names.empty() ? nullptr : names.data(),
+                           (int) names.size(), overlapRatioThreshold, threads) != 0) {
+        fprintf(stderr, "[%s] %s\n", ts(), hfio_last_error());
+        exit(EXIT_FAILURE);
+    }
+    fprintf(stderr, "[%s] Writing tables to file %s is done.\n", ts(), path.c_str());
+    return HF_OK;
+}
+
 static void write_params(const hfm_model* m, const std::string& dir, const std::string& suffix) {   // hmm_flagger.c:119-132
     fprintf(stderr, "[%s] Writing transition tsv...\n", ts());
     hfm_write_transition_tsv(m, (dir + "/transition_" + suffix + ".tsv").c_str());
@@ -124,6 +142,10 @@ int main(int argc, char* argv[]) {
     double initialRandomDeviation = 0.0;
     bool adjustContigEnds = true, writeParamsPerIter = false, writePosterior = false, dumpBin = false, acceleration = false;
     int modelType = -1, device = 0, algo = HF_ALGO_SCAN;
+    const char* binArrayFilePath = nullptr;
+    bool writeBenchmarkingStatsPerIteration = false;
+    double overlapRatioThreshold = 0.4;
+    std::vector<std::string> labelNames;
     int32_t minLenPerState[4] = {0, 0, 0, 0};
     const char* program = strrchr(argv[0], '/');
     program = program ? program + 1 : argv[0];
@@ -147,7 +169,22 @@ int main(int argc, char* argv[]) {
                     return EXIT_FAILURE;
                 } else modelType = -2;
                 break;
-            case 'a': case 'k': case 'l': case 'v': break;      // summary-table options: accepted, unused
+            case 'a': binArrayFilePath = optarg; break;
+            case 'k': writeBenchmarkingStatsPerIteration = true; break;
+            case 'v': overlapRatioThreshold = atof(optarg); break;
+            case 'l': {                                          // hmm_flagger.c:721-724: names + "Unk"
+                std::string s(optarg);
+                size_t a = 0;
+                labelNames.clear();
+                while (true) {
+                    const size_t b = s.find(',', a);
+                    labelNames.push_back(s.substr(a, b == std::string::npos ? std::string::npos : b - a));
+                    if (b == std::string::npos) break;
+                    a = b + 1;
+                }
+                labelNames.push_back("Unk");
+                break;
+            }
             case 'c': contigListPath = optarg; break;
             case 'p': numberOfCollapsedComps = atoi(optarg); break;
             case '@': threads = atoi(optarg); break;
@@ -178,7 +215,6 @@ int main(int argc, char* argv[]) {
                 return 1;
         }
     }
-    (void) threads;
     const double realtimeStart = real_time();
     if (!inputPath) { fprintf(stderr, "[%s] Error: Input path cannot be NULL.\n", ts()); return EXIT_FAILURE; }
     if (convergenceTol <= 0.0 || convergenceTol > 1.0) {
@@ -217,9 +253,14 @@ int main(int argc, char* argv[]) {
     run.tab = hfio_load(inputPath, chunkLen, windowLen);
     if (!run.tab) { fprintf(stderr, "[%s] %s\n", ts(), hfio_last_error()); return EXIT_FAILURE; }
     hfio_table* tab = run.tab;
-    if (contigListPath) {
-        fprintf(stderr, "[%s] Error: --contigsList is not supported by the MI355X build yet.\n", ts());
-        return EXIT_FAILURE;
+    if (contigListPath) {                                        // hmm_flagger.c:915-921, 93-99
+        int nNames = 0;
+        char** names = hfio_read_name_list(contigListPath, &nNames);
+        if (!names) { fprintf(stderr, "[%s] %s\n", ts(), hfio_last_error()); return EXIT_FAILURE; }
+        fprintf(stderr, "[%s] Including only the chunks whose contigs match the given contig list.\n", ts());
+        hfio_subset_contigs(tab, names, nNames);
+        for (int i = 0; i < nNames; i++) free(names[i]);
+        free(names);
     }
     if (dumpBin) {
         char binPath[2200];
@@ -281,6 +322,12 @@ int main(int argc, char* argv[]) {
         passes++;
         fprintf(stderr, "[%s] [Iteration %s = %d] EM jobs are all finished.\n", ts(), acceleration ? "accelerated" : "", iter);
         fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, acceleration ? 3 * (iter - 1) : iter - 1, run.stats[0]);
+        if (writeBenchmarkingStatsPerIteration || iter == 1) {   // hmm_flagger.c:360-379
+            char suffix[64];
+            if (iter == 1) snprintf(suffix, sizeof suffix, "initial");
+            else snprintf(suffix, sizeof suffix, acceleration ? "iteration_accelerated_%d" : "iteration_%d", iter - 1);
+            if ((rc = write_summary(run, dir, suffix, labelNames, binArrayFilePath, overlapRatioThreshold, threads)) != HF_OK) return die_estep(rc);
+        }
         if (acceleration) {                                  // hmm_flagger.c:382-416
             fprintf(stderr, "[%s] [Iteration accelerated = %d] Running SQUAREM acceleration.\n", ts(), iter);
             auto estep_cb = [&](hfm_model* m, int mode, double* st) -> int {
@@ -312,6 +359,7 @@ int main(int argc, char* argv[]) {
     fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, acceleration ? 3 * (iter - 1) : iter - 1, run.stats[0]);
     fclose(llf);
     write_params(model, dir, "final");
+    if ((rc = write_summary(run, dir, "final", labelNames, binArrayFilePath, overlapRatioThreshold, threads)) != HF_OK) return die_estep(rc);
     std::vector<int8_t> labels((size_t) N);
     if ((rc = hf_get_labels(run.ctx, labels.data())) != HF_OK) return die_estep(rc);
     memcpy(hfio_prediction(tab), labels.data(), (size_t) N);

@@ -1,6 +1,7 @@
 // hf_io.cpp — window table (SoA) + the file formats either side of the hot path
 // (include/hmm_flagger_io.h).  Citations: mobinasri/flagger programs/submodules/.
 #include "../../include/hmm_flagger_io.h"
+#include "../../include/hmm_flagger_summary.h"
 #include <zlib.h>
 #include <cmath>
 #include <cstdio>
@@ -321,7 +322,77 @@ int32_t hfio_start_only(const hfio_table* t) { return t->start_only ? 1 : 0; }
 int32_t hfio_n_annotations(const hfio_table* t) { return (int32_t) t->annotation_names.size(); }
 const char* hfio_annotation_name(const hfio_table* t, int i) { return t->annotation_names[(size_t) i].c_str(); }
 const char* hfio_chunk_ctg(const hfio_table* t, int c) { return t->chunks[(size_t) c].ctg.c_str(); }
+int32_t hfio_subset_contigs(hfio_table* t, const char* const* names, int n_names) {
+    std::vector<ChunkMeta> chunks;
+    std::vector<int64_t> off{0};
+    std::vector<int32_t> cs, ce, cl;
+    std::vector<uint16_t> cov, mapq, clip;
+    std::vector<uint64_t> annot;
+    std::vector<int8_t> truth, pred;
+    for (size_t c = 0; c < t->chunks.size(); c++) {
+        bool keep = false;
+        for (int k = 0; k < n_names && !keep; k++) keep = t->chunks[c].ctg == names[k];
+        if (!keep) continue;
+        const size_t a = (size_t) t->chunk_off[c], b = (size_t) t->chunk_off[c + 1];
+        chunks.push_back(t->chunks[c]);
+        cs.push_back(t->chunk_s[c]); ce.push_back(t->chunk_e[c]); cl.push_back(t->chunk_ctg_len[c]);
+        cov.insert(cov.end(), t->cov.begin() + a, t->cov.begin() + b);
+        mapq.insert(mapq.end(), t->mapq.begin() + a, t->mapq.begin() + b);
+        clip.insert(clip.end(), t->clip.begin() + a, t->clip.begin() + b);
+        annot.insert(annot.end(), t->annot.begin() + a, t->annot.begin() + b);
+        if (!t->truth.empty()) truth.insert(truth.end(), t->truth.begin() + a, t->truth.begin() + b);
+        if (!t->prediction.empty()) pred.insert(pred.end(), t->prediction.begin() + a, t->prediction.begin() + b);
+        off.push_back((int64_t) cov.size());
+    }
+    t->chunks.swap(chunks); t->chunk_off.swap(off); t->chunk_s.swap(cs); t->chunk_e.swap(ce); t->chunk_ctg_len.swap(cl);
+    t->cov.swap(cov); t->mapq.swap(mapq); t->clip.swap(clip); t->annot.swap(annot); t->truth.swap(truth); t->prediction.swap(pred);
+    return (int32_t) t->chunks.size();
+}
+
+char** hfio_read_name_list(const char* path, int* n_names) {
+    *n_names = 0;
+    FILE* f = std::fopen(path, "r");
+    if (!f) { g_io_err = std::string("Error: Unable to open ") + path; return nullptr; }
+    std::vector<std::string> names;
+    char line[4096];
+    while (std::fgets(line, sizeof line, f)) {
+        size_t l = std::strlen(line);
+        while (l && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = '\0';
+        if (char* sp = std::strchr(line, ' ')) *sp = '\0';
+        if (line[0]) names.push_back(line);
+    }
+    std::fclose(f);
+    char** out = (char**) std::calloc(names.size() + 1, sizeof(char*));
+    for (size_t i = 0; i < names.size(); i++) out[i] = strdup(names[i].c_str());
+    *n_names = (int) names.size();
+    return out;
+}
+
 int8_t* hfio_truth(hfio_table* t) { return t->truth.data(); }
+int32_t hfio_truth_available(const hfio_table* t) { return t->truth_available ? 1 : 0; }
+int32_t hfio_n_labels(const hfio_table* t) { return t->n_labels; }
+
+int hfio_write_summary(hfio_table* t, const int8_t* labels, const char* output_path, const char* bin_array_path,
+                       const char* const* label_names_with_unknown, int n_label_names, double overlap_ratio_threshold,
+                       int threads) {
+    t->prediction_available = true;                    // hmm_flagger.c:353-354
+    t->n_labels = 4;
+    std::vector<const char*> ctg(t->chunks.size()), ann(t->annotation_names.size());
+    for (size_t c = 0; c < ctg.size(); c++) ctg[c] = t->chunks[c].ctg.c_str();
+    for (size_t a = 0; a < ann.size(); a++) ann[a] = t->annotation_names[a].c_str();
+    hfs_input in;
+    in.n_windows = (int64_t) t->cov.size(); in.n_chunks = (int32_t) t->chunks.size();
+    in.chunk_off = t->chunk_off.data(); in.chunk_s = t->chunk_s.data(); in.chunk_e = t->chunk_e.data();
+    in.chunk_ctg = ctg.data(); in.window_len = t->window_len;
+    in.annot = t->annot.data(); in.truth = t->truth.empty() ? nullptr : t->truth.data(); in.prediction = labels;
+    in.truth_available = t->truth_available; in.prediction_available = 1; in.n_labels = t->n_labels;
+    in.n_regions = (int32_t) t->region_coverages.size(); in.n_annotations = (int32_t) ann.size();
+    in.annotation_names = ann.data();
+    const int rc = hfs_write_all_tables(&in, output_path, bin_array_path, label_names_with_unknown, n_label_names,
+                                        overlap_ratio_threshold, threads);
+    if (rc) g_io_err = hfs_last_error();
+    return rc;
+}
 int8_t* hfio_prediction(hfio_table* t) { return t->prediction.data(); }
 
 void hfio_windows(const hfio_table* t, hf_windows* w) {

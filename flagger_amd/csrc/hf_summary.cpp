@@ -1,0 +1,421 @@
+// hf_summary.cpp — prediction summary tables (include/hmm_flagger_summary.h): confusion tables of reference-label
+// runs against query labels per region / annotation and per size bin, in three metrics, plus the
+// precision/recall/F1 and auN-ratio files when the truth track is present.
+//
+// What the reference does with one thread-pool job per (category type, metric, comparison, category index), each
+// walking every window through a ptBlock iterator (summary_table.c:934-1223), is done here over flat per-window
+// arrays built once; the state machine of a job follows the reference's conditions one for one, because the
+// file contents depend on their order (flush, query-run bookkeeping, reset, restart).
+#include "../../include/hmm_flagger_summary.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_sum_err;
+
+enum Metric { OVERLAP_BASED = 0, BASE_LEVEL = 1, AUN = 2 };                       // summary_table.h:24-28
+enum Category { CAT_REGION = 0, CAT_ANNOTATION = 1 };                             // summary_table.h:30-33
+enum Comparison { TRUTH_VS_PRED = 0, PRED_VS_TRUTH = 1, TRUTH_VS_TRUTH = 2, PRED_VS_PRED = 3 };   // :35-40
+const char* const kMetricName[3] = {"overlap_based", "base_level", "truth_based_auN"};
+const char* const kCategoryName[2] = {"region", "annotation"};
+const char* const kComparisonName[4] = {"TRUTH_VS_PREDICTION", "PREDICTION_VS_TRUTH", "TRUTH", "PREDICTION"};
+const int kHapIndex = 2;                                                          // summary_table.c:15
+
+struct Bins {                                                                     // IntBinArray, common.c:670-751
+    std::vector<int> starts, ends;
+    std::vector<std::string> names;
+    void indices(int value, std::vector<int>& out) const {
+        out.clear();
+        for (size_t i = 0; i < starts.size(); i++)
+            if (starts[i] <= value && value < ends[i]) out.push_back((int) i);
+    }
+};
+
+struct Table {                                                                    // SummaryTable, summary_table.c:17-92
+    int nr = 0, nc = 0;
+    std::vector<double> t, row_total;
+    double total = 0.0;
+    void init(int r, int c) { nr = r; nc = c; t.assign((size_t) r * c, 0.0); row_total.assign(r, 0.0); total = 0.0; }
+    void add(int r, int c, double v) { t[(size_t) r * nc + c] += v; row_total[r] += v; total += v; }
+    double at(int r, int c) const { return t[(size_t) r * nc + c]; }
+    // the percentages the reference refreshes at every increment end up as these functions of the final counts
+    double pct(int r, int c) const { return 0 < row_total[r] ? at(r, c) / row_total[r] * 100.0 : 0.0; }
+    double row_pct(int r) const { return 0 < total ? row_total[r] / total * 100.0 : 0.0; }
+};
+
+struct TableList {                                                                // one per (category type, metric, comparison)
+    bool present = false;
+    int n1 = 0, n2 = 0;
+    std::vector<Table> tabs;
+    void init(int c1, int c2, int rows) { present = true; n1 = c1; n2 = c2; tabs.assign((size_t) c1 * c2, Table()); for (auto& x : tabs) x.init(rows, rows); }
+    Table& get(int c1, int c2) { return tabs[(size_t) c1 * n2 + c2]; }
+    const Table& get(int c1, int c2) const { return tabs[(size_t) c1 * n2 + c2]; }
+};
+
+struct Windows {
+    int64_t n = 0;
+    std::vector<int32_t> start, end, ctg;     // ctg: index of the contig NAME (chunks of one contig share it)
+    const uint64_t* annot = nullptr;
+    const int8_t* truth = nullptr;
+    const int8_t* pred = nullptr;
+};
+
+inline bool in_category(const Windows& w, int64_t i, int cat_type, int c1) {
+    if (i < 0) return false;                                                     // no previous window (NULL CoverageInfo)
+    const uint64_t flag = w.annot[i];
+    if (cat_type == CAT_REGION) return c1 == (int) ((flag & 0xFC00000000000000ULL) >> 58);   // ptBlock.c:252-255, 294-298
+    if ((flag & ~0xFC00000000000000ULL) == 0ULL && c1 == 0) return true;         // ptBlock.c:245-250
+    const uint64_t bit = 0 < c1 ? 1ULL << (c1 - 1) : 0ULL;                       // ptBlock.c:225-228
+    return (bit & flag) != 0;
+}
+
+// convertBaseLevelToOverlapBased, summary_table.c:817-834
+void to_overlap_based(std::vector<double>& row, int block_len, double thr) {
+    bool hit = false;
+    for (double& v : row) {
+        const double ratio = v / block_len;
+        if (thr < ratio) hit = true;
+        v = thr < ratio ? 1 : 0;
+    }
+    if (!hit) row.back() = 1;
+}
+
+// SummaryTableList_updateByUpdaterArgs, summary_table.c:934-1223
+void fill_one_category(const Windows& w, const Bins& bins, int cat_type, int c1, int metric, int cmp, double thr,
+                       const TableList* aux, TableList& out, int n_rows) {
+    const bool ref_is_truth = cmp == TRUTH_VS_PRED || cmp == TRUTH_VS_TRUTH;      // summary_table.c:1279-1292
+    const bool query_is_pred = cmp == TRUTH_VS_PRED || cmp == PRED_VS_PRED;
+    const int8_t* ref_lab = ref_is_truth ? w.truth : w.pred;
+    const int8_t* qry_lab = query_is_pred ? w.pred : w.truth;
+    const int nc = n_rows;
+    std::vector<double> row(nc, 0.0);
+    std::vector<std::vector<int>> qlens(nc);
+    std::vector<int> bin_idx;
+    int ref_start = -1, qry_start = -1, pre_ref = -1, pre_qry = -1, pre_end = -1;
+    int32_t pre_ctg = -1;
+    bool have_prev = false;
+
+    auto flush = [&]() {
+        const int block_len = pre_end - ref_start + 1;
+        bins.indices(block_len, bin_idx);
+        if (metric == OVERLAP_BASED) to_overlap_based(row, block_len, thr);
+        if (metric == AUN) {
+            if (pre_qry != -1) qlens[pre_qry].push_back(pre_end - qry_start + 1);
+            for (int q = 0; q < nc; q++)
+                for (int len : qlens[q]) row[q] += (double) len * len;
+        }
+        for (int b : bin_idx) {
+            const double total_ref = metric == AUN ? aux->get(c1, b).at(pre_ref, pre_ref) : 1.0;
+            Table& tab = out.get(c1, b);
+            for (int q = 0; q < nc; q++) tab.add(pre_ref, q, row[q] / total_ref);
+        }
+    };
+
+    for (int64_t i = 0; i < w.n; i++) {
+        int ref = ref_lab ? ref_lab[i] : -1, qry = qry_lab ? qry_lab[i] : -1;
+        if (ref == -1) ref = n_rows - 1;                                          // last row / column: "Unk"
+        if (qry == -1) qry = nc - 1;
+        const bool contig_changed = have_prev && pre_ctg != w.ctg[i];
+        const bool ref_changed = ref != pre_ref, qry_changed = qry != pre_qry;
+        const bool in_cur = in_category(w, i, cat_type, c1), in_prev = have_prev && in_category(w, i - 1, cat_type, c1);
+        const bool continued = in_cur && in_prev, started = in_cur && !in_prev, ended = !in_cur && in_prev;
+        const bool pre_ref_valid = pre_ref != -1, pre_qry_valid = pre_qry != -1;
+
+        if (pre_ref_valid && ((continued && ref_changed) || (in_prev && contig_changed) || ended)) flush();
+        if (in_cur && metric == AUN && pre_qry_valid && qry_changed && (continued && !ref_changed) && !contig_changed)
+            qlens[pre_qry].push_back(pre_end - qry_start + 1);
+        if ((!in_cur && contig_changed) || ended) {
+            ref_start = -1; qry_start = -1;
+            std::fill(row.begin(), row.end(), 0.0);
+        }
+        if ((continued && ref_changed) || (in_cur && contig_changed) || started) {
+            ref_start = w.start[i];
+            std::fill(row.begin(), row.end(), 0.0);
+            for (auto& l : qlens) l.clear();
+        }
+        if ((continued && ref_changed) || (continued && qry_changed) || (in_cur && contig_changed) || started)
+            qry_start = w.start[i];
+        if (in_cur && metric != AUN) row[qry] += w.end[i] - w.start[i] + 1;
+        have_prev = true; pre_ref = ref; pre_qry = qry; pre_ctg = w.ctg[i]; pre_end = w.end[i];
+    }
+    if (have_prev && in_category(w, w.n - 1, cat_type, c1) && pre_ref != -1) flush();
+}
+
+std::string fmt2(double v) { char b[400]; std::snprintf(b, sizeof b, "%.2f", v); return b; }
+
+std::string join2(const double* a, int n) {                                       // String_joinDoubleArrayWithFormat "%.2f", '\t'
+    std::string s;
+    for (int i = 0; i < n; i++) { if (i) s += '\t'; s += fmt2(a[i]); }
+    return s;
+}
+
+struct Names {
+    std::vector<std::string> cat[2];       // region_i / annotation names
+    std::vector<std::string> labels;       // may be empty (no --labelNames)
+    std::string row_name(int r) const { return labels.empty() ? std::to_string(r) : labels[r]; }
+};
+
+void write_counts(FILE* f, const TableList& tl, const Names& nm, const Bins& bins, int cat_type, const std::string& prefix,
+                  bool total_only, bool percentage) {
+    // SummaryTableList_write{,Percentage,TotalPerRow,TotalPerRowPercentage}IntoFile, summary_table.c:393-455
+    const int nr = tl.tabs.empty() ? 0 : tl.tabs[0].nr;
+    std::vector<double> buf(nr);
+    for (int c1 = 0; c1 < tl.n1; c1++)
+        for (int c2 = 0; c2 < tl.n2; c2++) {
+            const Table& t = tl.get(c1, c2);
+            const std::string head = prefix + "\t" + nm.cat[cat_type][c1] + "\t" + bins.names[c2] + "\t";
+            if (total_only) {
+                for (int r = 0; r < nr; r++) buf[r] = percentage ? t.row_pct(r) : t.row_total[r];
+                std::fprintf(f, "%sALL_LABELS\t%s\n", head.c_str(), join2(buf.data(), nr).c_str());
+            } else {
+                for (int r = 0; r < nr; r++) {
+                    for (int c = 0; c < nr; c++) buf[c] = percentage ? t.pct(r, c) : t.at(r, c);
+                    std::fprintf(f, "%s%s\t%s\n", head.c_str(), nm.row_name(r).c_str(), join2(buf.data(), nr).c_str());
+                }
+            }
+        }
+}
+
+std::string na_or(bool ok, double v) { return ok ? fmt2(v) : std::string("NA"); }
+
+// SummaryTableList_writeFinalStatisticsIntoFile, summary_table.c:457-741
+void write_final_stats(FILE* f, const TableList& recall, const TableList& precision, const Names& nm, const Bins& bins,
+                       int cat_type, const std::string& prefix) {
+    const int n_labels = recall.tabs[0].nr - 1;
+    for (int c1 = 0; c1 < recall.n1; c1++)
+        for (int c2 = 0; c2 < recall.n2; c2++) {
+            const Table& rt = recall.get(c1, c2);
+            const Table& pt = precision.get(c1, c2);
+            const std::string head = prefix + "\t" + nm.cat[cat_type][c1] + "\t" + bins.names[c2] + "\t";
+            double tot_tp_r = 0, tot_tp_p = 0, tot_r = 0, tot_p = 0;
+            double sum_r = 0, sum_p = 0, sum_r_nh = 0, sum_p_nh = 0;
+            double rec_r = 0, rec_p = 0, rec_r_nh = 0, rec_p_nh = 0;
+            int nz_r = 0, nz_p = 0, nz_r_nh = 0, nz_p_nh = 0;
+            for (int r = 0; r < n_labels; r++) {
+                const double tp_r = rt.at(r, r), tp_p = pt.at(r, r);
+                tot_tp_r += tp_r; tot_tp_p += tp_p;
+                const double fn = rt.row_total[r] - tp_r, fp = pt.row_total[r] - tp_p;
+                tot_r += tp_r + fn; tot_p += tp_p + fp;
+                const double rec = tp_r / (tp_r + fn + 1.0e-9) * 100.0, pre = tp_p / (tp_p + fp + 1.0e-9) * 100.0;
+                const bool r_ok = 1e-9 < (tp_r + fn), p_ok = 1e-9 < (tp_p + fp);
+                nz_r += r_ok; nz_p += p_ok;
+                if (r != kHapIndex) { nz_r_nh += r_ok; nz_p_nh += p_ok; }
+                sum_r += rec; sum_p += pre;
+                if (r != kHapIndex) { sum_r_nh += rec; sum_p_nh += pre; }
+                if (r_ok) { const double v = 0.0 < rec ? 1.0 / rec : 1.0e9; rec_r += v; if (r != kHapIndex) rec_r_nh += v; }
+                if (p_ok) { const double v = 0.0 < pre ? 1.0 / pre : 1.0e9; rec_p += v; if (r != kHapIndex) rec_p_nh += v; }
+                const double f1 = 2 * pre * rec / (pre + rec + 1.0e-9);
+                std::fprintf(f, "%s%s\t%.2f\t%.2f\t%.2f\t%.2f\t%.2f\t%.2f\t%s\t%s\t%s\t%s\t%s\n", head.c_str(), nm.row_name(r).c_str(),
+                             tp_p, tp_r, fp, fn, tp_p + fp, tp_r + fn, na_or(p_ok, pre).c_str(), na_or(r_ok, rec).c_str(),
+                             na_or(r_ok && p_ok, f1).c_str(), "NA", "NA");
+            }
+            const double mac_r = 0 < nz_r ? sum_r / nz_r : 0.0, mac_p = 0 < nz_p ? sum_p / nz_p : 0.0;
+            const double mac_r_nh = 0 < nz_r_nh ? sum_r_nh / nz_r_nh : 0.0, mac_p_nh = 0 < nz_p_nh ? sum_p_nh / nz_p_nh : 0.0;
+            const double har_r = 0 < nz_r ? (double) nz_r / rec_r : 0.0, har_p = 0 < nz_p ? (double) nz_p / rec_p : 0.0;
+            const double har_r_nh = 0 < nz_r_nh ? (double) nz_r_nh / rec_r_nh : 0.0, har_p_nh = 0 < nz_p_nh ? (double) nz_p_nh / rec_p_nh : 0.0;
+            auto f1_of = [](double a, double b) { return 2 * a * b / (a + b + 1.0e-9); };
+            auto line = [&](const char* name, bool p_ok, double p, bool r_ok, double r) {
+                std::fprintf(f, "%s%s\tNA\tNA\tNA\tNA\tNA\tNA\t%s\t%s\t%s\tNA\tNA\n", head.c_str(), name, na_or(p_ok, p).c_str(),
+                             na_or(r_ok, r).c_str(), na_or(p_ok && r_ok, f1_of(r, p)).c_str());
+            };
+            line("MACRO_AVERAGE", 0 < nz_p, mac_p, 0 < nz_r, mac_r);
+            line("MACRO_AVERAGE_NO_HAP", 0 < nz_p_nh, mac_p_nh, 0 < nz_r_nh, mac_r_nh);
+            line("HARMONIC_MEAN", 0 < nz_p, har_p, 0 < nz_r, har_r);
+            line("HARMONIC_MEAN_NO_HAP", 0 < nz_p_nh, har_p_nh, 0 < nz_r_nh, har_r_nh);
+            const double acc_p = tot_tp_p / (tot_p + 1.0e-9) * 100.0, acc_r = tot_tp_r / (tot_r + 1e-9) * 100.0;
+            std::fprintf(f, "%sACCURACY\t%.2f\t%.2f\tNA\tNA\t%.2f\t%.2f\tNA\tNA\tNA\t%.2f\t%.2f\n", head.c_str(), tot_tp_p, tot_tp_r,
+                         tot_p, tot_r, acc_p, acc_r);
+        }
+}
+
+// SummaryTableList_writeFinalAunStatisticsIntoFile, summary_table.c:744-811
+void write_final_aun(FILE* f, const TableList& num, const TableList& den, const Names& nm, const Bins& bins, int cat_type,
+                     const std::string& prefix) {
+    const int n_labels = num.tabs[0].nr - 1;
+    for (int c1 = 0; c1 < num.n1; c1++)
+        for (int c2 = 0; c2 < num.n2; c2++) {
+            const Table& nt = num.get(c1, c2);
+            const Table& dt = den.get(c1, c2);
+            const std::string head = prefix + "\t" + nm.cat[cat_type][c1] + "\t" + bins.names[c2] + "\t";
+            double sum = 0.0, rec = 0.0;
+            int nz = 0;
+            for (int r = 0; r < n_labels; r++) {
+                const double d = dt.at(r, r), n = nt.at(r, r);
+                const double aun = n / (d + 1e-9);
+                nz += 0 < d ? 1 : 0;
+                sum += aun;
+                if (0 < d) rec += 0.0 < aun ? 1.0 / aun : 1.0e9;
+                std::fprintf(f, "%s%s\t%.2f\n", head.c_str(), nm.row_name(r).c_str(), aun);
+            }
+            std::fprintf(f, "%sAVERAGE\t%s\n", head.c_str(), na_or(0 < nz, 0 < nz ? sum / nz : 0.0).c_str());
+            std::fprintf(f, "%sHARMONIC_MEAN\t%s\n", head.c_str(), na_or(0 < nz, 0 < nz ? (double) nz / rec : 0.0).c_str());
+        }
+}
+
+int fail(const std::string& m) { g_sum_err = m; return -1; }
+
+}  // namespace
+
+extern "C" {
+
+const char* hfs_last_error(void) { return g_sum_err.c_str(); }
+
+int hfs_write_all_tables(const hfs_input* in, const char* output_path, const char* bin_array_path,
+                         const char* const* label_names_with_unknown, int n_label_names, double overlap_ratio_threshold,
+                         int threads) {
+    if (!in || !output_path || in->n_windows < 0 || in->n_chunks < 0) return fail("hfs_write_all_tables: bad argument");
+    const size_t plen = std::strlen(output_path);
+    if (plen < 4) return fail("hfs_write_all_tables: output path must end in .tsv");
+    // ---- size bins (summary_table.c:1672-1678) ----
+    Bins bins;
+    if (bin_array_path) {
+        FILE* bf = std::fopen(bin_array_path, "r");
+        if (!bf) return fail(std::string("Error: ") + bin_array_path + " cannot be opened.");
+        char line[4096];
+        while (std::fgets(line, sizeof line, bf)) {
+            size_t l = std::strlen(line);
+            while (l && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = '\0';
+            if (char* sp = std::strchr(line, ' ')) *sp = '\0';     // lines are read up to the first space (common.c:620-642)
+            if (line[0] == '\0' || line[0] == '#') continue;
+            char* t1 = std::strchr(line, '\t');
+            char* t2 = t1 ? std::strchr(t1 + 1, '\t') : nullptr;
+            if (!t2) { std::fclose(bf); return fail("bin array file: expected start<TAB>end<TAB>name"); }
+            *t1 = '\0'; *t2 = '\0';
+            bins.starts.push_back((int) std::atof(line));          // atof: scientific notation allowed (common.c:709-711)
+            bins.ends.push_back((int) std::atof(t1 + 1));
+            char* t3 = std::strchr(t2 + 1, '\t');
+            if (t3) *t3 = '\0';
+            bins.names.push_back(t2 + 1);
+        }
+        std::fclose(bf);
+    } else {
+        bins.starts.push_back(0); bins.ends.push_back((int) 1e9); bins.names.push_back("ALL_SIZES");
+    }
+    // ---- names ----
+    Names nm;
+    if (label_names_with_unknown && n_label_names > 0) {
+        if (n_label_names - 1 != in->n_labels) {                   // summary_table.c:1682-1689
+            char b[200];
+            std::snprintf(b, sizeof b, "Error: Number of label names %d  does not match the number of labels in the header %d.",
+                          n_label_names - 1, in->n_labels);
+            return fail(b);
+        }
+        for (int i = 0; i < n_label_names; i++) nm.labels.push_back(label_names_with_unknown[i]);
+    }
+    for (int r = 0; r < in->n_regions; r++) nm.cat[CAT_REGION].push_back("region_" + std::to_string(r));
+    for (int a = 0; a < in->n_annotations; a++) nm.cat[CAT_ANNOTATION].push_back(in->annotation_names ? in->annotation_names[a] : "NA");
+    const int n_rows = in->n_labels + 1;
+    // ---- windows in iterator order (chunk.c:915-950) ----
+    Windows w;
+    w.n = in->n_windows; w.annot = in->annot; w.truth = in->truth; w.pred = in->prediction;
+    w.start.resize((size_t) w.n); w.end.resize((size_t) w.n); w.ctg.resize((size_t) w.n);
+    {
+        std::map<std::string, int32_t> ids;
+        for (int c = 0; c < in->n_chunks; c++) {
+            const std::string name = in->chunk_ctg[c];
+            auto it = ids.find(name);
+            if (it == ids.end()) it = ids.emplace(name, (int32_t) ids.size()).first;
+            const int64_t t0 = in->chunk_off[c], T = in->chunk_off[c + 1] - t0;
+            const int s = in->chunk_s[c], e = in->chunk_e[c], W = in->window_len;
+            for (int64_t i = 0; i < T; i++) {
+                const int st = s + (int) i * W;
+                const int en0 = s + ((int) i + 1) * W - 1;
+                w.start[(size_t) (t0 + i)] = st;
+                w.end[(size_t) (t0 + i)] = en0 < e ? en0 : e;
+                w.ctg[(size_t) (t0 + i)] = it->second;
+            }
+        }
+    }
+    const bool truth = in->truth_available != 0, pred = in->prediction_available != 0;
+    // ---- the catalog: [category type][metric][comparison] (summary_table.c:1696-1737) ----
+    TableList cat[2][3][4];
+    struct Job { int cat_type, metric, cmp, c1; };
+    auto jobs_for_metric = [&](int metric, std::vector<Job>& jobs) {             // summary_table.c:1588-1661
+        for (int ct = 0; ct < 2; ct++)
+            for (int cmp = 0; cmp < 4; cmp++) {
+                const bool need_t = cmp == TRUTH_VS_PRED || cmp == PRED_VS_TRUTH || cmp == TRUTH_VS_TRUTH;
+                const bool need_p = cmp == TRUTH_VS_PRED || cmp == PRED_VS_TRUTH || cmp == PRED_VS_PRED;
+                if (!truth && need_t) continue;
+                if (!pred && need_p) continue;
+                if (metric == AUN && (cmp == PRED_VS_PRED || cmp == PRED_VS_TRUTH)) continue;
+                const int n1 = (int) nm.cat[ct].size();
+                cat[ct][metric][cmp].init(n1, (int) bins.names.size(), n_rows);
+                for (int c1 = 0; c1 < n1; c1++) jobs.push_back({ct, metric, cmp, c1});
+            }
+    };
+    auto run_jobs = [&](const std::vector<Job>& jobs) {
+        const int nt = std::max(1, std::min<int>(threads, (int) jobs.size()));
+        auto work = [&](int k) {
+            for (size_t j = (size_t) k; j < jobs.size(); j += (size_t) nt) {
+                const Job& jb = jobs[j];
+                const TableList* aux = jb.metric == AUN ? &cat[jb.cat_type][BASE_LEVEL][TRUTH_VS_TRUTH] : nullptr;
+                fill_one_category(w, bins, jb.cat_type, jb.c1, jb.metric, jb.cmp, overlap_ratio_threshold, aux,
+                                  cat[jb.cat_type][jb.metric][jb.cmp], n_rows);
+            }
+        };
+        if (nt == 1) { work(0); return; }
+        std::vector<std::thread> pool;
+        for (int k = 0; k < nt; k++) pool.emplace_back(work, k);
+        for (auto& t : pool) t.join();
+    };
+    if (truth || pred) {
+        std::vector<Job> first, second;
+        jobs_for_metric(OVERLAP_BASED, first);
+        jobs_for_metric(BASE_LEVEL, first);
+        run_jobs(first);                       // auN needs the finished base-level TRUTH tables
+        jobs_for_metric(AUN, second);
+        run_jobs(second);
+    }
+    // ---- write (SummaryTableListFullCatalog_write, summary_table.c:1403-1586) ----
+    FILE* fout = std::fopen(output_path, "w");
+    if (!fout) return fail(std::string("Error: ") + output_path + " cannot be opened.");
+    std::fprintf(fout, "#Statistic\tMetric_Type\tEntry_Type\tCategory_Type\tCategory_Name\tSize_Bin_Name\tRef_Label");
+    for (const auto& l : nm.labels) std::fprintf(fout, "\t%s", l.c_str());
+    std::fprintf(fout, "\n");
+    FILE *fstats = nullptr, *faun = nullptr;
+    if (truth && pred) {
+        const std::string prefix(output_path, plen - 4);
+        fstats = std::fopen((prefix + ".benchmarking.tsv").c_str(), "w");
+        faun = std::fopen((prefix + ".benchmarking.auN_ratio.tsv").c_str(), "w");
+        if (!fstats || !faun) {
+            if (fstats) std::fclose(fstats);
+            if (faun) std::fclose(faun);
+            std::fclose(fout);
+            return fail("Error: benchmarking tsv files cannot be opened.");
+        }
+        std::fprintf(fstats, "#Metric_Type\tCategory_Type\tCategory_Name\tSize_Bin_Name\tLabel\tTP_Prediction_Ref\tTP_Truth_Ref\tFP\tFN\t"
+                             "Total_Prediction_Ref\tTotal_Truth_Ref\tPrecision\tRecall\tF1-Score\tAccuracy_Prediction_Ref\tAccuracy_Truth_Ref\n");
+        std::fprintf(faun, "#Category_Type\tCategory_Name\tSize_Bin_Name\tLabel\tauN_Ratio\n");
+    }
+    for (int ct = 0; ct < 2; ct++) {
+        for (int metric = 0; metric < 3; metric++) {
+            for (int cmp = 0; cmp < 4; cmp++) {
+                const TableList& tl = cat[ct][metric][cmp];
+                if (!tl.present) continue;
+                const bool total_only = cmp == TRUTH_VS_TRUTH || cmp == PRED_VS_PRED;
+                const std::string base = std::string(kComparisonName[cmp]) + "\t" + kMetricName[metric];
+                write_counts(fout, tl, nm, bins, ct, base + "\tcount\t" + kCategoryName[ct], total_only, false);
+                write_counts(fout, tl, nm, bins, ct, base + "\tpercentage\t" + kCategoryName[ct], total_only, true);
+            }
+            if (truth && pred && metric != AUN)
+                write_final_stats(fstats, cat[ct][metric][TRUTH_VS_PRED], cat[ct][metric][PRED_VS_TRUTH], nm, bins, ct,
+                                  std::string(kMetricName[metric]) + "\t" + kCategoryName[ct]);
+        }
+        if (truth && pred)
+            write_final_aun(faun, cat[ct][AUN][TRUTH_VS_PRED], cat[ct][AUN][TRUTH_VS_TRUTH], nm, bins, ct, kCategoryName[ct]);
+    }
+    std::fclose(fout);
+    if (fstats) std::fclose(fstats);
+    if (faun) std::fclose(faun);
+    return 0;
+}
+
+}  // extern "C"

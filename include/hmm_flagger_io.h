@@ -39,6 +39,12 @@ int32_t hfio_start_only(const hfio_table *t);
 int32_t hfio_n_annotations(const hfio_table *t);
 const char *hfio_annotation_name(const hfio_table *t, int i);
 const char *hfio_chunk_ctg(const hfio_table *t, int c);
+/* --contigsList: keep only the chunks whose contig is named (ChunksCreator_subsetChunksToContigs, chunk.c:218-237);
+ * chunk order is preserved.  Returns the number of chunks kept. */
+int32_t hfio_subset_contigs(hfio_table *t, const char *const *names, int n_names);
+/* first space-delimited token of every line (Splitter_parseLinesIntoList, common.c:620-642); NULL-terminated
+ * array owned by the caller (free each entry and the array). */
+char **hfio_read_name_list(const char *path, int *n_names);
 int8_t *hfio_truth(hfio_table *t);          /* [n_windows] */
 int8_t *hfio_prediction(hfio_table *t);     /* [n_windows], -1 until set */
 
@@ -52,6 +58,14 @@ int hfio_write_bin(const hfio_table *t, const char *path);
 int hfio_write_final_bed(const hfio_table *t, const int8_t *labels, const char *path, const char *track_name,
                          const int32_t *min_len_per_state);
 /* posterior: [n_windows][4] */
+/* prediction_summary_<suffix>.tsv (+ .benchmarking.tsv / .benchmarking.auN_ratio.tsv when the truth track is
+ * present) for the table's windows with `labels` as the prediction: writeBenchmarkingStats, hmm_flagger.c:134-162.
+ * Marks the prediction as available with 4 labels, as hmm_flagger.c:353-354 does.  See hmm_flagger_summary.h. */
+int hfio_write_summary(hfio_table *t, const int8_t *labels, const char *output_path, const char *bin_array_path,
+                       const char *const *label_names_with_unknown, int n_label_names, double overlap_ratio_threshold,
+                       int threads);
+int32_t hfio_truth_available(const hfio_table *t);
+int32_t hfio_n_labels(const hfio_table *t);
 int hfio_write_posterior_bed(const hfio_table *t, const double *posterior, const int8_t *labels, const char *path);
 
 #ifdef __cplusplus

@@ -106,3 +106,53 @@ def test_bench_single_gpu_and_distributed_code_paths_agree():
         outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]))   # RCCL prints a banner too
     assert outs[0]["loglikelihood_after_last_step"] == outs[1]["loglikelihood_after_last_step"]
     assert outs[1]["n_gpus"] == 1 and outs[1]["value"] > 0
+
+
+def test_cli_summary_tables_and_contig_list(tmp_path):
+    """prediction_summary_{initial,final}.tsv + benchmarking files of the command line equal the literal
+    restatement of summary_table.c (oracle/summary_tables.py) applied to the windows and the labels of the final BED;
+    --contigsList keeps only the named contigs."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import summary_tables as oracle_tables
+    from flagger_amd.io import Table
+    cov = os.path.join(GOLD, "sim_gaussian_30k.cov.gz")
+    keep = tmp_path / "contigs.txt"
+    keep.write_text("TEST_CONTIG_1 this text after the space is ignored\n")
+    bins = tmp_path / "bins.tsv"
+    bins.write_text("#start\tend\tname\n0\t50\tshort\n50\t1e9\tlong\n")
+    for name, extra in (("all", []), ("one", ["--contigsList", str(keep)])):
+        out = tmp_path / name
+        _run(CLI, ["-i", cov, "--modelType", "gaussian", "--chunkLen", "1000", "--windowLen", "1", "--collapsedComps", "4",
+                   "--minHighMapqRatio", "0", "-e", "-n", "3", "--labelNames", "Err,Dup,Hap,Col", "--binArrayFile", str(bins),
+                   "--overlapRatioThreshold", "0.3", "-k"] + extra, out)
+        for f in ("prediction_summary_initial.tsv", "prediction_summary_iteration_1.tsv", "prediction_summary_final.tsv",
+                  "prediction_summary_final.benchmarking.tsv", "prediction_summary_final.benchmarking.auN_ratio.tsv"):
+            assert (out / f).exists(), f
+        st = Table(cov, 1000, 1).store()
+        if extra:
+            st = st.subset_chunks([c for c in range(st.n_chunks) if st.chunk_ctg[c] == "TEST_CONTIG_1"])
+        # labels of the windows from the final BED (window length 1: one base per window)
+        code = {"Err": 0, "Dup": 1, "Hap": 2, "Col": 3}
+        blocks = {}
+        for line in (out / "final_flagger_prediction.bed").read_text().splitlines()[1:]:
+            t = line.split("\t")
+            blocks.setdefault(t[0], []).append((int(t[1]), int(t[2]), code[t[3]]))
+        assert set(blocks) == set(st.chunk_ctg)
+        pred = np.full(st.n_windows, -1, dtype=np.int8)
+        for c in range(st.n_chunks):
+            t0, t1 = int(st.chunk_off[c]), int(st.chunk_off[c + 1])
+            for s, e, lab in blocks[st.chunk_ctg[c]]:
+                lo, hi = max(s, int(st.chunk_s[c])), min(e, int(st.chunk_e[c]) + 1)
+                if lo < hi:
+                    pred[t0 + lo - int(st.chunk_s[c]):t0 + hi - int(st.chunk_s[c])] = lab
+        assert (pred >= 0).all()
+        inp = dict(chunk_off=[int(v) for v in st.chunk_off], chunk_s=[int(v) for v in st.chunk_s], chunk_e=[int(v) for v in st.chunk_e],
+                   chunk_ctg=list(st.chunk_ctg), window_len=1, annot=st.annot, truth=st.truth, prediction=pred, truth_available=1,
+                   prediction_available=1, n_labels=4, n_regions=st.n_regions, annotation_names=list(st.annotation_names))
+        ref = tmp_path / (name + "_ref")
+        ref.mkdir()
+        oracle_tables.write_all_tables(inp, str(ref / "prediction_summary_final.tsv"), str(bins), ["Err", "Dup", "Hap", "Col", "Unk"], 0.3)
+        for f in ("prediction_summary_final.tsv", "prediction_summary_final.benchmarking.tsv",
+                  "prediction_summary_final.benchmarking.auN_ratio.tsv"):
+            assert (out / f).read_text() == (ref / f).read_text(), f
