@@ -12,7 +12,7 @@ HF_NSTATES = 4
 HF_MAXCOMP = 16
 HF_MAXREGIONS = 64
 HF_NKERNELS = 10
-HF_MODEL_TRUNC_EXP_GAUSSIAN, HF_MODEL_GAUSSIAN = 0, 1
+HF_MODEL_TRUNC_EXP_GAUSSIAN, HF_MODEL_GAUSSIAN, HF_MODEL_NEGATIVE_BINOMIAL = 0, 1, 2
 HF_MODE_FULL, HF_MODE_FORWARD_ONLY = 0, 1
 HF_ALGO_SCAN, HF_ALGO_SEQ = 0, 1
 HF_OK, HF_E_ARG, HF_E_HIP, HF_E_SCALE, HF_E_NAN, HF_E_REGION, HF_E_NOGPU = 0, -1, -2, -3, -4, -5, -6
@@ -39,6 +39,8 @@ class hf_params(C.Structure):
         ("alpha", (C.c_double * 4) * 4),
         ("trans", C.POINTER(C.c_double)), ("lambda_", C.POINTER(C.c_double)), ("trunc_point", C.POINTER(C.c_double)),
         ("mean", C.POINTER(C.c_double)), ("var", C.POINTER(C.c_double)), ("weight", C.POINTER(C.c_double)),
+        ("nb_E", C.POINTER(C.c_double)), ("nb_P", C.POINTER(C.c_double)), ("nb_dig", C.POINTER(C.c_double)),
+        ("nb_r", C.POINTER(C.c_double)), ("nb_beta", C.POINTER(C.c_double)),
     ]
 
 

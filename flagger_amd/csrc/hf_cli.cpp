@@ -58,7 +58,7 @@ static void usage(const char* program) {
             "         --input, -i                  cov / cov.gz / bin input\n"
             "         --preset, -x                 hifi | ont-r9 | ont-r10 [hifi]\n"
             "         --outputDir, -o              existing directory for the output files\n"
-            "         --modelType, -m              gaussian | trunc_exp_gaussian [preset]\n"
+            "         --modelType, -m              gaussian | trunc_exp_gaussian | negative_binomial [trunc_exp_gaussian]\n"
             "         --trackName, -N              track name of the final BED [final_hmm_flagger]\n"
             "         --chunkLen, -C               chunk length in bases [20000000]\n"
             "         --windowLen, -W              window length in bases [preset]\n"
@@ -164,10 +164,8 @@ int main(int argc, char* argv[]) {
                 if (!strcmp(optarg, "gaussian")) modelType = HF_MODEL_GAUSSIAN;
                 else if (!strcmp(optarg, "trunc_exp_gaussian") || !strcmp(optarg, "truncated_exponential_gaussian"))
                     modelType = HF_MODEL_TRUNC_EXP_GAUSSIAN;
-                else if (!strcmp(optarg, "nb") || !strcmp(optarg, "negative_binomial")) {
-                    fprintf(stderr, "[%s] Error: the negative_binomial model is not supported by the MI355X build.\n", ts());
-                    return EXIT_FAILURE;
-                } else modelType = -2;
+                else if (!strcmp(optarg, "nb") || !strcmp(optarg, "negative_binomial")) modelType = HF_MODEL_NEGATIVE_BINOMIAL;
+                else modelType = -2;
                 break;
             case 'a': binArrayFilePath = optarg; break;
             case 'k': writeBenchmarkingStatsPerIteration = true; break;

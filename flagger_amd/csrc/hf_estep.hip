@@ -68,6 +68,8 @@ struct hf_ctx {
     // slow = chunk-first and contig-end windows (beta != beta_star), ascending; slow_off[c] = chunk c's first entry
     int M = 1; double* d_lutE = nullptr; double* d_lutC = nullptr;
     int n_keys = 0; int32_t* d_keys = nullptr;
+    // negative_binomial model: device copies of hf_params.nb_* and the per-tile count data (allocated on first use)
+    double *d_nbE = nullptr, *d_nbP = nullptr, *d_nbDig = nullptr, *d_nbR = nullptr, *d_nbBeta = nullptr, *d_tile_hist = nullptr;
     int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_Es = nullptr; double* d_Cs = nullptr;
 };
 
@@ -160,8 +162,8 @@ __device__ __forceinline__ void load_T(const DevParams* __restrict__ P, uint32_t
 // HF_ALGO_SEQ: emission row of every window by direct evaluation, E[t][16] (A8-A10); chunk-first windows hold
 // e_s(x_0; alpha=0, preX=0) in row pre=0 (hmm.c:338-352)
 __global__ void __launch_bounds__(256) k_emit_rows(int64_t N, const uint32_t* __restrict__ rec, const double* __restrict__ beta,
-                                                   const DevParams* __restrict__ P, double* __restrict__ E,
-                                                   unsigned* __restrict__ flags) {
+                                                   const DevParams* __restrict__ P, const double* __restrict__ nbE,
+                                                   double* __restrict__ E, unsigned* __restrict__ flags) {
     const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= N) return;
     const uint32_t r = rec[t];
@@ -169,6 +171,13 @@ __global__ void __launch_bounds__(256) k_emit_rows(int64_t N, const uint32_t* __
     const double x = (double) REC_X(r), px = first ? 0.0 : (double) REC_X(rec[t - 1]);
     unsigned nan = 0;
     double out[16];
+    if (nbE) {   // negative_binomial: e_s(x) from the caller's table (hf_params.nb_E), the same in every row
+        for (int s = 0; s < 4; s++) {
+            const double e = nbE[((int64_t) REC_REGION(r) * 4 + s) * (HF_NB_MAX_COVERAGE + 1) + REC_X(r)];
+            if (e != e) nan |= HF_FLAG_NAN;
+            for (int p = 0; p < 4; p++) out[p * 4 + s] = (first && p != 0) ? 0.0 : e;
+        }
+    } else
     hf_emit_values<false>(P, &P->reg[REC_REGION(r)], x, px, first, beta[t], out, &nan);
     double2* dst = reinterpret_cast<double2*>(E) + t * 8;
 #pragma unroll
@@ -261,6 +270,7 @@ __device__ __forceinline__ int posterior_label(const double f[4], const double b
 }
 
 #include "hf_scan.h"
+#include "hf_nb.h"
 
 __global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
                                                 const uint32_t* __restrict__ rec,
@@ -792,6 +802,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); hipFree(ctx->d_chunk_stats);
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
+    hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
     hipFree(ctx->d_Es); hipFree(ctx->d_Cs); hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
@@ -877,9 +888,31 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
         const size_t tab_bytes = (size_t) ctx->R * HF_TAB_STRIDE * 8;   // LDS transition tables
         const RowSrc S = row_src(ctx);
         const bool full = mode == HF_MODE_FULL;
+        const bool nbm = p->model_type == HF_MODEL_NEGATIVE_BINOMIAL;
+        if (nbm) {   // the caller's per-x tables go up with the parameters
+            if (!p->nb_E || !p->nb_P || !p->nb_dig || !p->nb_r || !p->nb_beta)
+                return set_err(HF_E_ARG, "hf_estep: negative_binomial needs hf_params.nb_E/nb_P/nb_dig/nb_r/nb_beta");
+            const size_t nE = (size_t) ctx->R * 4 * HF_NB_NX * 8, nP = (size_t) ctx->R * 4 * ctx->K * HF_NB_NX * 8,
+                         nR = (size_t) ctx->R * 4 * ctx->K * 8;
+            if (!ctx->d_nbE) {
+                HIPCHK(hipMalloc((void**) &ctx->d_nbE, nE)); HIPCHK(hipMalloc((void**) &ctx->d_nbP, nP));
+                HIPCHK(hipMalloc((void**) &ctx->d_nbDig, nP)); HIPCHK(hipMalloc((void**) &ctx->d_nbR, nR));
+                HIPCHK(hipMalloc((void**) &ctx->d_nbBeta, nR));
+                HIPCHK(hipMalloc((void**) &ctx->d_tile_hist, ((size_t) ctx->ntiles * ctx->R * HF_NB_TILE_VEC + 1) * 8));
+            }
+            HIPCHK(hipMemcpyAsync(ctx->d_nbE, p->nb_E, nE, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(ctx->d_nbP, p->nb_P, nP, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(ctx->d_nbDig, p->nb_dig, nP, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(ctx->d_nbR, p->nb_r, nR, hipMemcpyHostToDevice, st));
+            HIPCHK(hipMemcpyAsync(ctx->d_nbBeta, p->nb_beta, nR, hipMemcpyHostToDevice, st));
+        }
         {   // also clears the flag word: first kernel of every pass
             KTimer t(ctx, st, HF_K_TABLES);
             const int jobs = ctx->n_keys + ctx->n_slow;
+            if (nbm)
+                hipLaunchKernelGGL(k_tables_nb, dim3((unsigned) (jobs / 256 + 1)), dim3(256), 0, st, ctx->n_keys, ctx->d_keys, ctx->n_slow,
+                                   ctx->d_slow_w, ctx->d_rec, ctx->M, ctx->d_nbE, ctx->d_lutE, ctx->d_Es, ctx->d_flags);
+            else
             hipLaunchKernelGGL(k_tables, dim3((unsigned) (jobs / HF_TABLE_JOBS_PER_BLOCK + 1)), dim3(256), 0, st, ctx->n_keys, ctx->d_keys, ctx->n_slow,
                                ctx->d_slow_w, ctx->d_rec, ctx->d_beta, ctx->M, ctx->K, ctx->d_params, ctx->d_lutE, ctx->d_lutC,
                                ctx->d_Es, ctx->d_Cs, ctx->d_flags);
@@ -889,7 +922,7 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
                 {
                     KTimer t(ctx, st, HF_K_EMIT_ROWS);
                     hipLaunchKernelGGL(k_emit_rows, dim3((unsigned) ((ctx->N + 255) / 256)), dim3(256), 0, st, ctx->N, ctx->d_rec,
-                                       ctx->d_beta, ctx->d_params, ctx->d_E, ctx->d_flags);
+                                       ctx->d_beta, ctx->d_params, nbm ? ctx->d_nbE : (const double*) nullptr, ctx->d_E, ctx->d_flags);
                 }
                 {
                     KTimer t(ctx, st, HF_K_FWD_SEQ);
@@ -925,7 +958,20 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
         }
         const int kc = p->ncomp[3];
         const int fl = full && ctx->ntiles > 0;
-        if (kc <= 4) launch_stats<4>(ctx, st, fl, kc);
+        if (nbm) {
+            if (fl) {
+                KTimer t(ctx, st, HF_K_STATS_TILE);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile_nb<HF_SCAN_L>), dim3(tb), dim3(256),
+                                   ((size_t) ctx->R * HF_TAB_STRIDE + 4 * (64 * 16 + 64 + 16 * 64)) * 8, st, ctx->ntiles, ctx->d_tile_desc,
+                                   ctx->d_rec, S, ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_hist);
+            }
+            NbTables nt;
+            nt.E = ctx->d_nbE; nt.P = ctx->d_nbP; nt.dig = ctx->d_nbDig; nt.r = ctx->d_nbR; nt.beta = ctx->d_nbBeta;
+            KTimer t(ctx, st, HF_K_CHUNK_STATS);
+            hipLaunchKernelGGL(k_chunk_stats_nb, dim3((unsigned) ctx->C), dim3(256), 0, st, ctx->d_chunk_tile0, ctx->d_regmask,
+                               ctx->d_tile_hist, ctx->d_tile_ll, ctx->d_params, nt, ctx->d_chunk_stats, ctx->V, ctx->K, fl);
+        }
+        else if (kc <= 4) launch_stats<4>(ctx, st, fl, kc);
         else if (kc <= 8) launch_stats<8>(ctx, st, fl, kc);
         else launch_stats<16>(ctx, st, fl, kc);
     }

@@ -19,6 +19,48 @@ constexpr double kErrBinding = 0.1;         // hmm_utils.h:14
 constexpr double kTermination = 1e-4;       // hmm_utils.c:2112
 constexpr double kDiagProb = 0.99;          // hmm.c:15
 constexpr double kPseudoCount = 0.001;      // hmm.c:16
+constexpr int kMaxCov = HF_NB_MAX_COVERAGE; // hmm_utils.h:15 MAX_COVERAGE_VALUE
+
+// digamma/digamma.c:27-117 — digamma in long double: reflection below 0, recurrence below 1, exact values at 1, 2, 3,
+// duplication formula above 3, and on (1,3) the Chebyshev expansion of R. J. Mathar, arXiv:math.CA/0403344 app. E
+// (J. Wimp, Math. Comp. 15 (1961) 174, table 1); the coefficients are the published table.
+long double digammal_(long double x) {
+    static const long double euler = 0.5772156649015328606065120900824024L;
+    static const long double ln2 = 0.6931471805599453094172321214581766L;
+    static const long double pi = 3.1415926535897932384626433832795029L;
+    static const long double K[] = {
+        .30459198558715155634315638246624251L, .72037977439182833573548891941219706L,
+        -.12454959243861367729528855995001087L, .27769457331927827002810119567456810e-1L,
+        -.67762371439822456447373550186163070e-2L, .17238755142247705209823876688592170e-2L,
+        -.44817699064252933515310345718960928e-3L, .11793660000155572716272710617753373e-3L,
+        -.31253894280980134452125172274246963e-4L, .83173997012173283398932708991137488e-5L,
+        -.22191427643780045431149221890172210e-5L, .59302266729329346291029599913617915e-6L,
+        -.15863051191470655433559920279603632e-6L, .42459203983193603241777510648681429e-7L,
+        -.11369129616951114238848106591780146e-7L, .304502217295931698401459168423403510e-8L,
+        -.81568455080753152802915013641723686e-9L, .21852324749975455125936715817306383e-9L,
+        -.58546491441689515680751900276454407e-10L, .15686348450871204869813586459513648e-10L,
+        -.42029496273143231373796179302482033e-11L, .11261435719264907097227520956710754e-11L,
+        -.30174353636860279765375177200637590e-12L, .80850955256389526647406571868193768e-13L,
+        -.21663779809421233144009565199997351e-13L, .58047634271339391495076374966835526e-14L,
+        -.15553767189204733561108869588173845e-14L, .41676108598040807753707828039353330e-15L,
+        -.11167065064221317094734023242188463e-15L };
+    if (x < 0.0L) return digammal_(1.0L - x) + pi / tanl(pi * (1.0L - x));
+    if (x < 1.0L) return digammal_(1.0L + x) - 1.0L / x;
+    if (x == 1.0L) return -euler;
+    if (x == 2.0L) return 1.0L - euler;
+    if (x == 3.0L) return 1.5L - euler;
+    if (x > 3.0L) return 0.5L * (digammal_(x / 2.0L) + digammal_((x + 1.0L) / 2.0L)) + ln2;
+    long double t0 = 1.0L, t1 = x - 2.0L;
+    long double res = K[0] + K[1] * t1;
+    x -= 2.0L;
+    for (size_t n = 2; n < sizeof(K) / sizeof(K[0]); n++) {
+        const long double t2 = 2.0L * x * t1 - t0;
+        res += K[n] * t2;
+        t0 = t1;
+        t1 = t2;
+    }
+    return res;
+}
 }
 
 struct hfm_model {
@@ -29,7 +71,10 @@ struct hfm_model {
     double loglik = 0.0;
     std::vector<double> trans;     // [R][5][5]
     std::vector<double> lambda, trunc;  // [R]
-    std::vector<double> mean, var, weight; // [R][4][KM]
+    std::vector<double> mean, var, weight; // [R][4][KM]; negative_binomial model: mean = theta, var = lambda (hmm_utils.h NegativeBinomial)
+    // negative_binomial: per-iteration tables handed to the E-step (rebuilt by hfm_params)
+    mutable std::vector<double> nb_E, nb_P, nb_dig, nb_r, nb_beta;
+    bool nb() const { return model_type == HF_MODEL_NEGATIVE_BINOMIAL; }
     double& M(int r, int s, int c) { return mean[((size_t) r * S + s) * KM + c]; }
     double& Vr(int r, int s, int c) { return var[((size_t) r * S + s) * KM + c]; }
     double& W(int r, int s, int c) { return weight[((size_t) r * S + s) * KM + c]; }
@@ -42,7 +87,8 @@ extern "C" {
 hfm_model* hfm_create(int model_type, int n_collapsed, const int32_t* region_coverages, int n_regions,
                       int start_only, int avg_alignment_len, int window_len, const double* alpha16,
                       double max_high_mapq_ratio, double min_high_mapq_ratio) {
-    if ((model_type != HF_MODEL_TRUNC_EXP_GAUSSIAN && model_type != HF_MODEL_GAUSSIAN) || n_collapsed < 1 ||
+    if ((model_type != HF_MODEL_TRUNC_EXP_GAUSSIAN && model_type != HF_MODEL_GAUSSIAN &&
+         model_type != HF_MODEL_NEGATIVE_BINOMIAL) || n_collapsed < 1 ||
         n_collapsed > KM || n_regions < 1 || n_regions > HF_MAXREGIONS || !region_coverages)
         return nullptr;
     hfm_model* m = new hfm_model();
@@ -71,6 +117,13 @@ hfm_model* hfm_create(int model_type, int n_collapsed, const int32_t* region_cov
                 m->M(r, s, c) = mu;
                 m->Vr(r, s, c) = mu * 1.0;
                 m->W(r, s, c) = 1.0 / m->ncomp[s];
+                if (model_type == HF_MODEL_NEGATIVE_BINOMIAL) {  // NegativeBinomial_constructByMean(mean, 1.5), hmm_utils.c:428-457, 1635-1639
+                    const double var = mu * 1.5;
+                    const double theta = mu / var;
+                    const double rr = std::pow(mu, 2) / (var - mu);
+                    m->M(r, s, c) = theta;
+                    m->Vr(r, s, c) = -1 * rr * std::log(mu / var);
+                }
             }
         for (int i = 0; i < 5; i++)                              // hmm_utils.c:2109-2128
             for (int j = 0; j < 5; j++)
@@ -98,6 +151,45 @@ void hfm_params(const hfm_model* m, hf_params* out) {
     std::memcpy(out->alpha, m->alpha, sizeof(out->alpha));
     out->trans = m->trans.data(); out->lambda = m->lambda.data(); out->trunc_point = m->trunc.data();
     out->mean = m->mean.data(); out->var = m->var.data(); out->weight = m->weight.data();
+    out->nb_E = out->nb_P = out->nb_dig = out->nb_r = out->nb_beta = nullptr;
+    if (!m->nb()) return;
+    // negative_binomial: everything that depends on x only is tabulated here with the host libm, exactly as the
+    // reference evaluates it (lgamma/exp/log of glibc, digamma in long double): emission value E[r][s][x]
+    // (hmm_utils.c:480-520), component probabilities P[r][s][c][x], digamma table (:394-408), r and beta (:545-547)
+    const int NX = kMaxCov + 1, K = m->K;
+    hfm_model* mm = const_cast<hfm_model*>(m);
+    m->nb_E.assign((size_t) m->R * S * NX, 0.0);
+    m->nb_P.assign((size_t) m->R * S * K * NX, 0.0);
+    m->nb_dig.assign((size_t) m->R * S * K * NX, 0.0);
+    m->nb_r.assign((size_t) m->R * S * K, 0.0);
+    m->nb_beta.assign((size_t) m->R * S * K, 0.0);
+    for (int r = 0; r < m->R; r++)
+        for (int s = 0; s < S; s++)
+            for (int c = 0; c < m->ncomp[s]; c++) {
+                const double theta = mm->M(r, s, c), lambda = mm->Vr(r, s, c), w = mm->W(r, s, c);
+                const double rr = -1 * lambda / std::log(theta);
+                const size_t pc = ((size_t) r * S + s) * K + c;
+                m->nb_r[pc] = rr;
+                m->nb_beta[pc] = -1 * theta / (1 - theta) - 1 / std::log(theta);
+                double* P = &m->nb_P[pc * NX];
+                double* D = &m->nb_dig[pc * NX];
+                for (int x = 0; x < NX; x++) {
+                    double p = w * std::exp(lgamma(rr + x) - lgamma(rr) - lgamma(x + 1) + rr * std::log(theta) + (double) x * std::log(1 - theta));
+                    if (!(p != p) && p < 1e-40) p = 1e-40;       // NaN is kept: the E-step reports it if the value is used
+                    P[x] = p;
+                }
+                D[0] = (double) digammal_(rr);
+                for (int x = 1; x < NX; x++) D[x] = D[x - 1] + 1.0 / (rr + x - 1);
+            }
+    for (int r = 0; r < m->R; r++)
+        for (int s = 0; s < S; s++)
+            for (int x = 0; x < NX; x++) {
+                double tot = 0.0;                                 // Double_sum1DArray, component order
+                for (int c = 0; c < m->ncomp[s]; c++) tot += m->nb_P[((((size_t) r * S + s) * K + c)) * NX + x];
+                m->nb_E[((size_t) r * S + s) * NX + x] = tot;
+            }
+    out->nb_E = m->nb_E.data(); out->nb_P = m->nb_P.data(); out->nb_dig = m->nb_dig.data();
+    out->nb_r = m->nb_r.data(); out->nb_beta = m->nb_beta.data();
 }
 
 // hmm_utils.c:949-956
@@ -127,8 +219,9 @@ static double estimate_lambda(double trunc_point, double num, double den, double
 }
 
 // binding factor of (state, parameter, component): hmm_utils.c:191-238, 290-304, 143-157
-static double binding(int s, int p, int c) {
+static double binding(int s, int p, int c, bool nb = false) {
     if (p == 2) return 0.0;
+    if (nb && p == 0) return 1.0;            // theta is bound across every state and component (hmm_utils.c:240-288)
     if (s == 0) return kErrBinding;
     if (s == 1) return 0.5;
     if (s == 2) return 1.0;
@@ -150,7 +243,7 @@ int hfm_estimate(hfm_model* m, const double* stats, double tol) {
             for (int s = 0; s < S; s++) {
                 if (!m->gaussian_state(s)) continue;
                 for (int c = 0; c < m->ncomp[s]; c++) {
-                    const double f = binding(s, p, c);
+                    const double f = binding(s, p, c, m->nb());
                     if (0.0 < f) { bnum += num(s, p, c) / f; bden += den(s, p, c); }
                 }
             }
@@ -158,7 +251,7 @@ int hfm_estimate(hfm_model* m, const double* stats, double tol) {
             for (int s = 0; s < S; s++) {
                 if (!m->gaussian_state(s)) continue;
                 for (int c = 0; c < m->ncomp[s]; c++) {
-                    const double f = binding(s, p, c);
+                    const double f = binding(s, p, c, m->nb());
                     double est, count;
                     if (0.0 < f) { est = bound * f; count = bden; }
                     else { count = den(s, p, c); est = count == 0 ? 0.0 : num(s, p, c) / den(s, p, c); }
@@ -233,11 +326,17 @@ int hfm_write_emission_tsv(const hfm_model* mc, const char* path) {
         const int np = te ? 2 : 3;                                // hmm_utils.c:1539-1575
         for (int p = 0; p < np; p++) {
             const char* pname = te ? (p == 0 ? "Mean" : "Trunc_Point") : (p == 0 ? "Mean" : p == 1 ? "Var" : "Weight");
-            std::fprintf(f, "%s\t%s\t%d\t%s", kStateNames[s], te ? "Truncated Exponential" : "Gaussian",
+            std::fprintf(f, "%s\t%s\t%d\t%s", kStateNames[s], te ? "Truncated Exponential" : m->nb() ? "Negative Binomial" : "Gaussian",
                          te ? 1 : m->ncomp[s], pname);
             for (int r = 0; r < m->R; r++) {
                 std::fprintf(f, "\t");
                 if (te) std::fprintf(f, "%.5e", p == 0 ? 1.0 / m->lambda[r] : m->trunc[r]);  // :1056-1069
+                else if (m->nb() && p < 2)                       // logged as mean and variance, hmm_utils.c:463-473, 1560-1570
+                    for (int c = 0; c < m->ncomp[s]; c++) {
+                        const double theta = m->M(r, s, c), lambda = m->Vr(r, s, c);
+                        const double rr = -1 * lambda / std::log(theta);
+                        std::fprintf(f, c ? ",%.5e" : "%.5e", p == 0 ? rr * (1 - theta) / theta : rr * (1 - theta) / std::pow(theta, 2));
+                    }
                 else
                     for (int c = 0; c < m->ncomp[s]; c++)
                         std::fprintf(f, c ? ",%.5e" : "%.5e", p == 0 ? m->M(r, s, c) : p == 1 ? m->Vr(r, s, c) : m->W(r, s, c));
@@ -278,6 +377,13 @@ void hfm_scale_initial_means(hfm_model* m, double f) {
         for (int s = 0; s < S; s++)
             for (int c = 0; c < m->ncomp[s]; c++) {
                 const double g = s == 3 ? f * f : f;
+                if (m->nb()) {                                       // re-derive theta, lambda from the scaled mean
+                    const double theta = m->M(r, s, c), rr0 = -1 * m->Vr(r, s, c) / std::log(theta);
+                    const double mu = rr0 * (1 - theta) / theta * g, var = mu * 1.5;
+                    m->M(r, s, c) = mu / var;
+                    m->Vr(r, s, c) = -1 * (std::pow(mu, 2) / (var - mu)) * std::log(mu / var);
+                    continue;
+                }
                 m->M(r, s, c) *= g;
                 m->Vr(r, s, c) = m->M(r, s, c) * 1.0;
             }
@@ -294,6 +400,7 @@ int hfm_is_feasible(const hfm_model* mc) {
             if (!m->gaussian_state(s)) { ok &= 0 < m->lambda[r]; ok &= 0 < m->trunc[r]; continue; }
             for (int c = 0; c < m->ncomp[s]; c++) {
                 ok &= 0 < m->M(r, s, c);
+                if (m->nb()) ok &= m->M(r, s, c) < 1;                 // 0 < theta < 1, hmm_utils.c:367-376
                 ok &= 0 < m->Vr(r, s, c);
                 ok &= (0 <= m->W(r, s, c)) && (m->W(r, s, c) <= 1);
             }

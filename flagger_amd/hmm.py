@@ -26,6 +26,7 @@ from .synth import WindowStore
 
 MODEL_TRUNC_EXP_GAUSSIAN = N.HF_MODEL_TRUNC_EXP_GAUSSIAN
 MODEL_GAUSSIAN = N.HF_MODEL_GAUSSIAN
+MODEL_NEGATIVE_BINOMIAL = N.HF_MODEL_NEGATIVE_BINOMIAL
 STATE_NAMES = ("Err", "Dup", "Hap", "Col")
 
 

@@ -29,7 +29,8 @@ extern "C" {
 #define HF_MAXCOMP 16     /* per-state mixture components (reference clamps K to 2..10) */
 #define HF_MAXREGIONS 64  /* 6 region bits — ptBlock.c:294-304 */
 
-enum { HF_MODEL_TRUNC_EXP_GAUSSIAN = 0, HF_MODEL_GAUSSIAN = 1 };       /* hmm_utils.h:43-48 */
+enum { HF_MODEL_TRUNC_EXP_GAUSSIAN = 0, HF_MODEL_GAUSSIAN = 1, HF_MODEL_NEGATIVE_BINOMIAL = 2 };   /* hmm_utils.h:43-48 */
+#define HF_NB_MAX_COVERAGE 250   /* MAX_COVERAGE_VALUE, hmm_utils.h:15: count data has bins 0..249, tables 0..250 */
 enum { HF_MODE_FULL = 0,          /* EM_runOneIterationForList */
        HF_MODE_FORWARD_ONLY = 1   /* EM_runForwardForList */ };
 enum { HF_ALGO_SCAN = 0,          /* in-chunk parallel prefix scan (default) */
@@ -81,6 +82,14 @@ typedef struct hf_params {
     const double *mean;              /* [n_regions][4][HF_MAXCOMP] */
     const double *var;               /* [n_regions][4][HF_MAXCOMP] */
     const double *weight;            /* [n_regions][4][HF_MAXCOMP] */
+    /* HF_MODEL_NEGATIVE_BINOMIAL only (NULL otherwise); mean = theta, var = lambda of the NegativeBinomial struct.
+     * Every quantity of that model depends on the coverage x alone (no alpha, no beta), so the caller tabulates it
+     * with its own libm, K = the max_comps given to hf_create, NX = HF_NB_MAX_COVERAGE + 1:
+     *   nb_E[r][s][x]        emission value, NegativeBinomial_getProb                      hmm_utils.c:480-485
+     *   nb_P[r][s][c][x]     component probabilities (weights and 1e-40 floor applied)     hmm_utils.c:497-520
+     *   nb_dig[r][s][c][x]   NegativeBinomial.digammaTable                                 hmm_utils.c:394-408
+     *   nb_r, nb_beta[r][s][c]   r = -lambda/log(theta), beta = -theta/(1-theta) - 1/log(theta)   :458-461, 547 */
+    const double *nb_E, *nb_P, *nb_dig, *nb_r, *nb_beta;
 } hf_params;
 
 /* Layout of one statistics vector (doubles):

@@ -32,9 +32,12 @@ extern "C" {
 #define OHF_PI 3.14159           /* common.h:15 (sic) */
 #define OHF_TERMINATION_PROB 1e-4 /* hmm_utils.c:2112 */
 
-enum { OHF_MODEL_TRUNC_EXP_GAUSSIAN = 0, OHF_MODEL_GAUSSIAN = 1 }; /* hmm_utils.h:43-48 */
+#define OHF_MAX_COVERAGE_VALUE 250 /* hmm_utils.h:15 */
+
+enum { OHF_MODEL_TRUNC_EXP_GAUSSIAN = 0, OHF_MODEL_GAUSSIAN = 1, OHF_MODEL_NEGATIVE_BINOMIAL = 2 }; /* hmm_utils.h:43-48 */
 enum { OHF_STATE_ERR = 0, OHF_STATE_DUP = 1, OHF_STATE_HAP = 2, OHF_STATE_COL = 3 };
 enum { OHF_P_MEAN = 0, OHF_P_VAR = 1, OHF_P_WEIGHT = 2 };          /* hmm_utils.h:50-54 */
+enum { OHF_P_NB_THETA = 0, OHF_P_NB_LAMBDA = 1 };                  /* hmm_utils.h:56-62 (weight = 2 as well) */
 
 /* numerator/denominator accumulators of one emission distribution (hmm_utils.h:93-107);
  * trunc-exp uses [0][0] only (lambda estimator, hmm_utils.c:1310). */
@@ -54,6 +57,9 @@ typedef struct {
     double mean[OHF_NSTATES][OHF_MAXCOMP];
     double var[OHF_NSTATES][OHF_MAXCOMP];
     double weight[OHF_NSTATES][OHF_MAXCOMP];
+    /* negative_binomial model: theta, lambda per component (weights above), hmm_utils.h NegativeBinomial */
+    double theta[OHF_NSTATES][OHF_MAXCOMP];
+    double nb_lambda[OHF_NSTATES][OHF_MAXCOMP];
     ohf_estimator est[OHF_NSTATES];
 } ohf_region;
 
@@ -128,6 +134,20 @@ bool ohf_estimate_parameters(ohf_model *m, double tol);   /* HMM_estimateParamet
 void ohf_reset_estimators(ohf_model *m);                  /* HMM_resetEstimators */
 int ohf_best_collapsed_comps(const ohf_chunks *cc);       /* hmm_flagger.c:105-111,1012-1013 */
 double ohf_estimate_lambda(double trunc_point, double num, double den, double tol);
+
+/* ---- negative_binomial model (ohf_nb.c) ---- */
+long double ohf_digammal(long double x);
+double ohf_nb_r(double theta, double lambda);
+double ohf_nb_mean(double theta, double lambda);
+double ohf_nb_var(double theta, double lambda);
+void ohf_nb_init(ohf_region *g, int s, const double *mean, int ncomp);
+int ohf_nb_comp_probs(const ohf_region *g, int s, int ncomp, uint8_t x, double *probs);
+void ohf_nb_digamma_table(const ohf_region *g, int s, int ncomp, double table[][OHF_MAX_COVERAGE_VALUE + 1]);
+int ohf_nb_update(ohf_estimator *est, const ohf_region *g, int s, int ncomp,
+                  double table[][OHF_MAX_COVERAGE_VALUE + 1], uint8_t x, double count);
+int ohf_nb_update_from_counts(ohf_region *acc, const ohf_region *g, const int *ncomp,
+                              double counts[OHF_NSTATES][OHF_MAX_COVERAGE_VALUE]);
+bool ohf_nb_estimate(const ohf_model *m, ohf_region *g, double tol);
 
 /* ---- I/O (ohf_io.c) ---- */
 ohf_chunks *ohf_read_bin(const char *path);

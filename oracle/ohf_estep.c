@@ -64,6 +64,12 @@ double ohf_emission(const ohf_model *m, int region, int state, uint8_t x, uint8_
     if (state == OHF_STATE_ERR && m->model_type == OHF_MODEL_TRUNC_EXP_GAUSSIAN)
         return trunc_exp_prob(r->lambda, r->trunc_point, x, beta);
     double probs[OHF_MAXCOMP];
+    if (m->model_type == OHF_MODEL_NEGATIVE_BINOMIAL) { /* hmm_utils.c:1414-1415 -> 480-485: x only */
+        if (ohf_nb_comp_probs(r, state, m->ncomp[state], x, probs) < 0) { if (err) *err = -2; return NAN; }
+        double totnb = 0.0;
+        for (int c = 0; c < m->ncomp[state]; c++) totnb += probs[c];
+        return totnb;
+    }
     if (gaussian_comp_probs(r->mean[state], r->var[state], r->weight[state], m->ncomp[state],
                             x, pre_x, alpha, beta, probs) < 0) {
         if (err) *err = -2;
@@ -209,6 +215,9 @@ int ohf_chunk_update_estimators(ohf_chunk *ch, const ohf_model *m, ohf_region *a
                                 const ohf_run_opts *o) {
     int T = ch->n, err = 0;
     const double *f = ch->f, *b = ch->b;
+    const bool nb = m->model_type == OHF_MODEL_NEGATIVE_BINOMIAL;
+    /* count data of the chunk's private model copy: zero at the start of every pass (hmm.c:288-298, hmm_utils.c:1701) */
+    double (*counts)[OHF_NSTATES][OHF_MAX_COVERAGE_VALUE] = nb ? calloc((size_t) m->n_regions, sizeof(*counts)) : NULL;
     for (int i = 1; i < T; i++) {
         if (i == T - 1) continue; /* hmm.c:564-566 */
         double beta = ohf_beta(ch, window_len, i + 1, o);
@@ -227,7 +236,9 @@ int ohf_chunk_update_estimators(ohf_chunk *ch, const ohf_model *m, ohf_region *a
                 else t = ohf_trans_cond(m, region, p, s, ch->cov[i + 1], ch->mapq[i + 1], ch->clip[i + 1]);
                 double count = f[4 * i + p] * t * e * b[4 * (i + 1) + s];
                 double adjusted = count / OHF_TERMINATION_PROB; /* hmm.c:614 */
-                if (s == OHF_STATE_ERR && m->model_type == OHF_MODEL_TRUNC_EXP_GAUSSIAN) {
+                if (nb) { /* hmm.c:615-617, count_data.c:49-57 */
+                    counts[region][s][x < OHF_MAX_COVERAGE_VALUE ? x : OHF_MAX_COVERAGE_VALUE - 1] += adjusted;
+                } else if (s == OHF_STATE_ERR && m->model_type == OHF_MODEL_TRUNC_EXP_GAUSSIAN) {
                     a->est[s].num[0][0] += adjusted * x; /* hmm_utils.c:1027-1034 */
                     a->est[s].den[0][0] += adjusted;
                 } else {
@@ -237,9 +248,14 @@ int ohf_chunk_update_estimators(ohf_chunk *ch, const ohf_model *m, ohf_region *a
                 a->count[p][s] += adjusted; /* hmm_utils.c:2010-2015 */
             }
         }
-        if (err) return err;
+        if (err) { free(counts); return err; }
     }
-    return 0;
+    if (nb) { /* hmm.c:644-649 */
+        for (int region = 0; region < m->n_regions && !err; region++)
+            if (ohf_nb_update_from_counts(&acc[region], &m->regions[region], m->ncomp, counts[region]) < 0) err = -2;
+        free(counts);
+    }
+    return err;
 }
 
 /* hmm.c:671-685 EM_getPosterior */

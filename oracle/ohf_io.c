@@ -155,8 +155,9 @@ void ohf_write_emission_tsv(const ohf_model *m, FILE *f) {
         int np = te ? 2 : 3; /* hmm_utils.c:1539-1575 */
         static const char *TE_NAMES[2] = {"Mean", "Trunc_Point"};
         static const char *G_NAMES[3] = {"Mean", "Var", "Weight"};
+        const bool nb = m->model_type == OHF_MODEL_NEGATIVE_BINOMIAL; /* logged as Mean, Var, Weight (hmm_utils.c:1560-1570) */
         for (int p = 0; p < np; p++) {
-            fprintf(f, "%s\t%s\t%d\t%s", STATE_NAMES[s], te ? "Truncated Exponential" : "Gaussian",
+            fprintf(f, "%s\t%s\t%d\t%s", STATE_NAMES[s], te ? "Truncated Exponential" : nb ? "Negative Binomial" : "Gaussian",
                     te ? 1 : m->ncomp[s], te ? TE_NAMES[p] : G_NAMES[p]);
             for (int r = 0; r < m->n_regions; r++) {
                 const ohf_region *g = &m->regions[r];
@@ -164,6 +165,11 @@ void ohf_write_emission_tsv(const ohf_model *m, FILE *f) {
                 if (te) {
                     double v = p == 0 ? 1.0 / g->lambda : g->trunc_point; /* hmm_utils.c:1056-1069 */
                     join_vals(f, &v, 1);
+                } else if (nb && p < 2) { /* hmm_utils.c:589-608, 463-473 */
+                    double v[OHF_MAXCOMP];
+                    for (int c = 0; c < m->ncomp[s]; c++)
+                        v[c] = p == 0 ? ohf_nb_mean(g->theta[s][c], g->nb_lambda[s][c]) : ohf_nb_var(g->theta[s][c], g->nb_lambda[s][c]);
+                    join_vals(f, v, m->ncomp[s]);
                 } else {
                     join_vals(f, p == 0 ? g->mean[s] : p == 1 ? g->var[s] : g->weight[s], m->ncomp[s]);
                 }

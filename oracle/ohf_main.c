@@ -57,6 +57,8 @@ int main(int argc, char **argv) {
                 if (!strcmp(optarg, "gaussian")) modelType = OHF_MODEL_GAUSSIAN;
                 else if (!strcmp(optarg, "trunc_exp_gaussian") || !strcmp(optarg, "truncated_exponential_gaussian"))
                     modelType = OHF_MODEL_TRUNC_EXP_GAUSSIAN;
+                else if (!strcmp(optarg, "nb") || !strcmp(optarg, "negative_binomial")) /* hmm_utils.c:18-29 */
+                    modelType = OHF_MODEL_NEGATIVE_BINOMIAL;
                 else { fprintf(stderr, "oracle: unsupported model type %s\n", optarg); return 1; }
                 break;
             case 'q': maxHighMapq = atof(optarg); break;

@@ -58,6 +58,8 @@ ohf_model *ohf_model_create(int model_type, int n_collapsed, const int32_t *regi
                 g->var[s][c] = mr[s][c] * 1.0;
                 g->weight[s][c] = 1.0 / m->ncomp[s];
             }
+        if (model_type == OHF_MODEL_NEGATIVE_BINOMIAL) /* hmm_utils.c:1635-1639 */
+            for (int s = 0; s < OHF_NSTATES; s++) ohf_nb_init(g, s, mr[s], m->ncomp[s]);
         /* hmm_utils.c:2109-2128 Transition_constructSymmetricBiased(4, 0.99) */
         double term = OHF_TERMINATION_PROB;
         for (int i = 0; i < 5; i++)
@@ -203,6 +205,7 @@ static bool estimate_gaussian_param(const ohf_model *m, ohf_region *g, int p, do
 /* hmm_utils.c:1860-1903 EmissionDistSeries_estimateParameters */
 static bool estimate_emissions(const ohf_model *m, ohf_region *g, double tol) {
     bool converged = true;
+    if (m->model_type == OHF_MODEL_NEGATIVE_BINOMIAL) return ohf_nb_estimate(m, g, tol); /* hmm_utils.c:1885-1900 */
     for (int p = 0; p < 3; p++) converged &= estimate_gaussian_param(m, g, p, tol);
     if (m->model_type == OHF_MODEL_TRUNC_EXP_GAUSSIAN) {
         /* binding coefficient 0 => own estimator; golden-section with the OLD trunc point */

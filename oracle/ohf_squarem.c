@@ -32,6 +32,10 @@ static int collect(ohf_model *m, double **slots) {
         ohf_region *g = &m->regions[r];
         for (int s = 0; s < OHF_NSTATES; s++) {
             if (s == OHF_STATE_ERR && m->model_type == OHF_MODEL_TRUNC_EXP_GAUSSIAN) { slots[n++] = &g->lambda; continue; }
+            if (m->model_type == OHF_MODEL_NEGATIVE_BINOMIAL) { /* theta, lambda, weight (hmm_utils.c:1122-1131) */
+                for (int c = 0; c < m->ncomp[s]; c++) { slots[n++] = &g->theta[s][c]; slots[n++] = &g->nb_lambda[s][c]; slots[n++] = &g->weight[s][c]; }
+                continue;
+            }
             for (int c = 0; c < m->ncomp[s]; c++) { slots[n++] = &g->mean[s][c]; slots[n++] = &g->var[s][c]; slots[n++] = &g->weight[s][c]; }
         }
         for (int i = 0; i < OHF_NSTATES; i++) for (int j = 0; j < OHF_NSTATES; j++) slots[n++] = &g->trans[i][j];
@@ -45,6 +49,14 @@ static bool feasible(const ohf_model *m) { /* hmm.c:80-87; hmm_utils.c:685-694, 
         const ohf_region *g = &m->regions[r];
         for (int s = 0; s < OHF_NSTATES; s++) {
             if (s == OHF_STATE_ERR && m->model_type == OHF_MODEL_TRUNC_EXP_GAUSSIAN) { ok &= 0 < g->lambda; ok &= 0 < g->trunc_point; continue; }
+            if (m->model_type == OHF_MODEL_NEGATIVE_BINOMIAL) { /* hmm_utils.c:367-376 */
+                for (int c = 0; c < m->ncomp[s]; c++) {
+                    ok &= (0 < g->theta[s][c]) && (g->theta[s][c] < 1);
+                    ok &= (0 < g->nb_lambda[s][c]);
+                    ok &= (0 <= g->weight[s][c]) && (g->weight[s][c] <= 1);
+                }
+                continue;
+            }
             for (int c = 0; c < m->ncomp[s]; c++) {
                 ok &= (0 < g->mean[s][c]); ok &= (0 < g->var[s][c]);
                 ok &= (0 <= g->weight[s][c]) && (g->weight[s][c] <= 1);

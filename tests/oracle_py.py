@@ -21,6 +21,7 @@ class ORegion(C.Structure):
     _fields_ = [("trans", (C.c_double * 5) * 5), ("pseudo", (C.c_double * 5) * 5), ("count", (C.c_double * 5) * 5),
                 ("lambda_", C.c_double), ("trunc_point", C.c_double),
                 ("mean", (C.c_double * MAXC) * 4), ("var", (C.c_double * MAXC) * 4), ("weight", (C.c_double * MAXC) * 4),
+                ("theta", (C.c_double * MAXC) * 4), ("nb_lambda", (C.c_double * MAXC) * 4),
                 ("est", OEst * 4)]
 
 
@@ -140,6 +141,10 @@ class Oracle:
         except Exception:
             pass
 
+    def _param_fields(self):
+        # negative_binomial: the product keeps theta / lambda in the mean / var slots of its vector
+        return ("theta", "nb_lambda", "weight") if self.model_type == 2 else ("mean", "var", "weight")
+
     # ---- parameters <-> the product's flat vector layout (hfm_get_param_vector) ----
     def param_vector(self) -> np.ndarray:
         R = self.m.contents.n_regions
@@ -148,7 +153,7 @@ class Oracle:
             g = self.m.contents.regions[r]
             out.append(np.ctypeslib.as_array(g.trans).ravel().copy())
             out.append(np.array([g.lambda_, g.trunc_point]))
-            for name in ("mean", "var", "weight"):
+            for name in self._param_fields():
                 out.append(np.ctypeslib.as_array(getattr(g, name)).ravel().copy())
         return np.concatenate(out)
 
@@ -160,7 +165,7 @@ class Oracle:
             np.ctypeslib.as_array(g.trans)[:] = v[r, :25].reshape(5, 5)
             g.lambda_, g.trunc_point = float(v[r, 25]), float(v[r, 26])
             o = 27
-            for name in ("mean", "var", "weight"):
+            for name in self._param_fields():
                 np.ctypeslib.as_array(getattr(g, name))[:] = v[r, o:o + 4 * MAXC].reshape(4, MAXC)
                 o += 4 * MAXC
 

@@ -63,6 +63,18 @@ def test_cli_on_simulated_cov_gz_matches_oracle_cli(extra, tmp_path):
     assert (tmp_path / "gpu" / "final_flagger_prediction.bed").read_text().startswith("track name=gaussian_30k ")
 
 
+@pytest.mark.parametrize("extra", [[], ["--accelerate"]], ids=["em", "squarem"])
+def test_cli_negative_binomial_model_matches_oracle_cli(extra, tmp_path):
+    cov = os.path.join(GOLD, "sim_gaussian_30k.cov.gz")
+    common = ["-i", cov, "--modelType", "negative_binomial", "--chunkLen", "1000", "--windowLen", "1", "--collapsedComps", "4",
+              "--minHighMapqRatio", "0", "-e", "-n", "6", "-w"] + extra
+    _run(CLI, common, tmp_path / "gpu")
+    _run(ORACLE, common, tmp_path / "cpu")
+    suffix = "iteration_accelerated_2" if extra else "iteration_2"
+    _same_files(tmp_path / "gpu", tmp_path / "cpu", OUTPUTS + [f"emission_{suffix}.tsv", f"transition_{suffix}.tsv"])
+    assert "Negative Binomial" in (tmp_path / "gpu" / "emission_final.tsv").read_text()
+
+
 def test_cli_diploid_em_with_minimum_lengths(tmp_path):
     store = synth.config(2, scale=0.01)
     binp = tmp_path / "d.bin"

@@ -73,6 +73,25 @@ def test_small_diploid(algo, model_type, alpha_name):
 
 
 @pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("K", [2, 6, 16])
+def test_negative_binomial_model(algo, K):
+    """--modelType negative_binomial: emission depends on x only, statistics through per-state count
+    data and the digamma table; theta bound across all states, lambda bound with the mean factors."""
+    store = synth.config(2, scale=0.004)
+    _check_pass(store, hmm.MODEL_NEGATIVE_BINOMIAL, K, np.zeros((4, 4)), algo, n_iter=3)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_negative_binomial_regions_ragged_chunks_and_extreme_coverage(algo):
+    store = synth.synthesize([300_000, 5_000, 9_000, 64_000, 65_000, 1_000], 1000, 40_000, [20, 30, 12], seed=77,
+                             region_run_bases=(5_000, 60_000))
+    store.cov[::97] = 250          # folded into count-data bin 249 (count_data.c:49-57)
+    store.cov[5::89] = 0
+    store.mapq[:] = store.cov      # keep the collapsed state valid where coverage is high
+    _check_pass(store, hmm.MODEL_NEGATIVE_BINOMIAL, 5, synth.HIFI_ALPHA, algo, n_iter=2, min_mapq=0.0)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("K", [2, 5, 10, 16])
 def test_collapsed_components(algo, K):
     store = synth.config(2, scale=0.004)
