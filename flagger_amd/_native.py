@@ -96,6 +96,7 @@ def lib() -> C.CDLL:
     sig("hf_last_kernel_ms", C.c_int, vp, C.POINTER(C.c_float))
     sig("hf_set_profiling", C.c_int, vp, C.c_uint)
     sig("hf_kernel_times", C.c_int, vp, C.POINTER(C.c_float))
+    sig("hf_kernel_time_sums", C.c_int, vp, pd, C.POINTER(C.c_int64))
     sig("hf_kernel_name", C.c_char_p, C.c_int)
     # host model
     sig("hfm_create", vp, C.c_int, C.c_int, C.POINTER(i32), C.c_int, C.c_int, C.c_int, C.c_int, pd, dbl, dbl)

@@ -382,32 +382,39 @@ __global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, 
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
             if (wave == 0) {
+                // the chain carries the vector renormalised by a power of two (exact, no division on the dependent
+                // path); what a tile starts from is that vector divided by its sum (the reference's f sums to 1)
                 for (int k = 0; k < n; k++) {
-                    so[k * 4 + 0] = v[0]; so[k * 4 + 1] = v[1]; so[k * 4 + 2] = v[2]; so[k * 4 + 3] = v[3];
+                    const double sv = v[0] + v[1] + v[2] + v[3];
+                    so[k * 4 + 0] = v[0] / sv; so[k * 4 + 1] = v[1] / sv; so[k * 4 + 2] = v[2] / sv; so[k * 4 + 3] = v[3] / sv;
                     const double* __restrict__ M = sp + k * 16;
-                    double u[4], su = 0.0;
+                    double u[4];
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         double s = v[0] * M[j];
                         s = fma(v[1], M[4 + j], s); s = fma(v[2], M[8 + j], s); s = fma(v[3], M[12 + j], s);
-                        u[j] = s; su += s;
+                        u[j] = s;
                     }
+                    int e;
+                    (void) frexp(fmax(fmax(u[0], u[1]), fmax(u[2], u[3])), &e);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] = u[j] / su;
+                    for (int j = 0; j < 4; j++) v[j] = ldexp(u[j], -e);
                 }
             } else {
-                for (int k = n - 1; k >= 0; k--) {
+                for (int k = n - 1; k >= 0; k--) {        // only the direction of b is used: power-of-two renormalisation
                     so[k * 4 + 0] = v[0]; so[k * 4 + 1] = v[1]; so[k * 4 + 2] = v[2]; so[k * 4 + 3] = v[3];
                     const double* __restrict__ M = sp + k * 16;
-                    double u[4], su = 0.0;
+                    double u[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
                         double s = M[i * 4] * v[0];
                         s = fma(M[i * 4 + 1], v[1], s); s = fma(M[i * 4 + 2], v[2], s); s = fma(M[i * 4 + 3], v[3], s);
-                        u[i] = s; su += s;
+                        u[i] = s;
                     }
+                    int e;
+                    (void) frexp(fmax(fmax(u[0], u[1]), fmax(u[2], u[3])), &e);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] = u[i] / su;
+                    for (int i = 0; i < 4; i++) v[i] = ldexp(u[i], -e);
                 }
             }
         }

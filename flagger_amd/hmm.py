@@ -244,6 +244,13 @@ class EMList:
         N.check(self._L.hf_kernel_times(self._h, ms), "hf_kernel_times")
         return {self._L.hf_kernel_name(i).decode(): float(ms[i]) for i in range(N.HF_NKERNELS)}
 
+    def kernel_time_sums(self) -> dict:
+        """{kernel: (total ms, launches)} accumulated by the library since set_profiling (HIP events on the launch stream)."""
+        sums = (C.c_double * N.HF_NKERNELS)()
+        cnt = (C.c_int64 * N.HF_NKERNELS)()
+        N.check(self._L.hf_kernel_time_sums(self._h, sums, cnt), "hf_kernel_time_sums")
+        return {self._L.hf_kernel_name(i).decode(): (float(sums[i]), int(cnt[i])) for i in range(N.HF_NKERNELS)}
+
     # --- results ---
     def labels(self) -> np.ndarray:
         out = np.empty(self.store.n_windows, dtype=np.int8)

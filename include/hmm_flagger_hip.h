@@ -158,6 +158,9 @@ enum { HF_K_TABLES = 0, HF_K_PROD_TILE, HF_K_CARRY, HF_K_FB_TILE, HF_K_STATS_TIL
        HF_K_EMIT_ROWS, HF_K_FWD_SEQ, HF_K_BWD_SEQ };
 int hf_set_profiling(hf_ctx *ctx, unsigned kernel_mask);
 int hf_kernel_times(hf_ctx *ctx, float ms[HF_NKERNELS]);
+/* Sum of the durations (ms) and number of timed launches of every selected kernel over all passes finished by
+ * hf_finish / hf_em_iterate since the last hf_set_profiling: one call after a timed loop instead of one per pass. */
+int hf_kernel_time_sums(hf_ctx *ctx, double sum_ms[HF_NKERNELS], int64_t launches[HF_NKERNELS]);
 const char *hf_kernel_name(int k);   /* "k_tables", "k_prod_tile", ... as they appear in a rocprofv3 kernel trace */
 
 #ifdef __cplusplus
