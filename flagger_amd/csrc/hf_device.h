@@ -34,6 +34,19 @@
 // slow0 = position in the slow list of the tile's first slow window
 struct TileDesc { long long t0; int T; int base; int chunk; int slow0; };
 
+// Layout of the forward / backward arrays f, b (double2 units): tile-major, lane-minor —
+//   slot(tile, lane, j, h) = ((tile*L + j)*2 + h)*64 + lane     window = tile base + lane*L + j, h: states (0,1) / (2,3)
+// so that the 64 lanes of the wavefront that owns a tile read / write 1 KiB contiguous per instruction.
+template <int L>
+__device__ __forceinline__ int64_t fb_slot(int64_t tile, int lane, int j, int h) { return ((tile * L + j) * 2 + h) * 64 + lane; }
+// the same for window w (index inside its chunk) of a chunk whose first tile is tile0
+template <int L>
+__device__ __forceinline__ int64_t fb_slot_w(int tile0, int64_t w, int h) {
+    const int64_t TW = 64 * L;
+    const int rem = (int) (w % TW);
+    return fb_slot<L>(tile0 + w / TW, rem / L, rem % L, h);
+}
+
 struct DevRegion {
     double trans[5][5];                 // Transition.matrix (row 4 Start, column 4 End)
     double tcond[8][16];                // Transition_getProbConditional per validity mask, [pre*4+s]

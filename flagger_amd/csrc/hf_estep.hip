@@ -20,6 +20,7 @@
 #define HF_SCAN_L 4   // consecutive windows per lane in the scan kernels
 #endif
 #include <string>
+#include <algorithm>
 #include <vector>
 #include <cstring>
 #include <cstdio>
@@ -43,8 +44,9 @@ struct hf_ctx {
     uint64_t* d_regmask = nullptr; // [C] bit r set if region r occurs in the chunk
     // per-pass work arrays
     double* d_E = nullptr;         // [N][16] emission rows, HF_ALGO_SEQ only
-    double* d_f = nullptr;         // [N][4]
-    double* d_b = nullptr;         // [N][4]
+    double* d_f = nullptr;         // [ntiles][L][2][64] double2: tile-major, lane-minor (hf_scan.h fb_slot)
+    double* d_b = nullptr;         // same layout
+    std::vector<int64_t> h_off; std::vector<int32_t> h_tile0;   // host copies for hf_get_forward_backward
     double* d_scale = nullptr;     // [N]
     int8_t* d_label = nullptr;     // [N]
     double* d_chunk_stats = nullptr; // [C][V]
@@ -248,8 +250,8 @@ __global__ void __launch_bounds__(64) k_fwd_seq(const int64_t* __restrict__ off,
         __syncthreads();
         if (lane < n) {
             const int64_t t = t0 + base + lane;
-            reinterpret_cast<double2*>(F + t * 4)[0] = make_double2(Fs[lane][0], Fs[lane][1]);
-            reinterpret_cast<double2*>(F + t * 4)[1] = make_double2(Fs[lane][2], Fs[lane][3]);
+            reinterpret_cast<double2*>(F)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], base + lane, 0)] = make_double2(Fs[lane][0], Fs[lane][1]);
+            reinterpret_cast<double2*>(F)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], base + lane, 1)] = make_double2(Fs[lane][2], Fs[lane][3]);
             scale[t] = Fs[lane][4];
         }
         __syncthreads();
@@ -297,10 +299,15 @@ __global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off,
         const DevRegion* __restrict__ R = &P->reg[REC_REGION(rec[t])];
         const double sc = scale[t];
         double f[4];
-#pragma unroll
-        for (int s = 0; s < 4; s++) { b[s] = R->trans[s][4] / sc; f[s] = F[t * 4 + s]; }
+        {
+            const double2* __restrict__ F2 = reinterpret_cast<const double2*>(F);
+            const double2 f01 = F2[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], T - 1, 0)], f23 = F2[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], T - 1, 1)];
+            f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
+        }
+        for (int s = 0; s < 4; s++) b[s] = R->trans[s][4] / sc;
         if (lane == 0) {
-            B[t * 4 + 0] = b[0]; B[t * 4 + 1] = b[1]; B[t * 4 + 2] = b[2]; B[t * 4 + 3] = b[3];
+            reinterpret_cast<double2*>(B)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], T - 1, 0)] = make_double2(b[0], b[1]);
+            reinterpret_cast<double2*>(B)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], T - 1, 1)] = make_double2(b[2], b[3]);
             label[t] = (int8_t) posterior_label(f, b, sc);
         }
     }
@@ -312,8 +319,11 @@ __global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off,
             const int64_t t = t0 + lo + lane; // window i
             rs[lane] = rec[t + 1];
             load_E_window(E, t + 1, &Es[lane][0]);
-#pragma unroll
-            for (int s = 0; s < 4; s++) Fs[lane][s] = F[t * 4 + s];
+            {
+                const double2* __restrict__ F2 = reinterpret_cast<const double2*>(F);
+                const double2 f01 = F2[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], lo + lane, 0)], f23 = F2[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], lo + lane, 1)];
+                Fs[lane][0] = f01.x; Fs[lane][1] = f01.y; Fs[lane][2] = f23.x; Fs[lane][3] = f23.y;
+            }
             Fs[lane][4] = scale[t];
         }
         __syncthreads();
@@ -336,8 +346,8 @@ __global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off,
         __syncthreads();
         if (lane < n) {
             const int64_t t = t0 + lo + lane;
-            reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(Bs[lane][0], Bs[lane][1]);
-            reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(Bs[lane][2], Bs[lane][3]);
+            reinterpret_cast<double2*>(B)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], lo + lane, 0)] = make_double2(Bs[lane][0], Bs[lane][1]);
+            reinterpret_cast<double2*>(B)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], lo + lane, 1)] = make_double2(Bs[lane][2], Bs[lane][3]);
             label[t] = Ls[lane];
         }
         __syncthreads();
@@ -432,12 +442,14 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
 #pragma unroll 1
         for (int j = 0; j < L; j++) {
             if (!(ok[j] && (int) REC_REGION(rr[j + 1]) == r)) continue;
-            const int64_t t = t0 + a0 + j - 1;                // pair (t, t+1)
             double Ev[16], Tm[16], f[4], b1[4];
             load_row(row_ptr(S, rr[j + 1], rr[j], sidx[j]), Ev);
-            const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + t * 4);
-            const double2* __restrict__ bp = reinterpret_cast<const double2*>(B + (t + 1) * 4);
-            const double2 f01 = fp[0], f23 = fp[1], b01 = bp[0], b23 = bp[1];
+            // f of the window before (the previous lane's last one for j == 0), b of the window itself (hf_scan.h fb_slot)
+            const int64_t fs = j > 0 ? fb_slot<L>(tile, lane, j - 1, 0)
+                                     : (lane > 0 ? fb_slot<L>(tile, lane - 1, L - 1, 0) : fb_slot<L>(tile - 1, 63, L - 1, 0));
+            const int64_t bs = fb_slot<L>(tile, lane, j, 0);
+            const double2 f01 = reinterpret_cast<const double2*>(F)[fs], f23 = reinterpret_cast<const double2*>(F)[fs + 64];
+            const double2 b01 = reinterpret_cast<const double2*>(B)[bs], b23 = reinterpret_cast<const double2*>(B)[bs + 64];
             const unsigned xw = REC_X(rr[j + 1]), xp = REC_X(rr[j]);
             const double2* __restrict__ crow = crow_ptr(S, rr[j + 1], rr[j], sidx[j]);
             lds_Tm(s_tab, rr[j + 1], Tm);
@@ -708,7 +720,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
 #define DMALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void**) &(p), (bytes) ? (bytes) : 8); \
     if (e_ != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e_)); } } while (0)
     DMALLOC(ctx->d_rec, N * 4); DMALLOC(ctx->d_beta, N * 8); DMALLOC(ctx->d_regmask, C * 8);
-    DMALLOC(ctx->d_f, N * 4 * 8); DMALLOC(ctx->d_b, N * 4 * 8);
+
     if (algo == HF_ALGO_SEQ) DMALLOC(ctx->d_E, N * 16 * 8);
     DMALLOC(ctx->d_scale, N * 8); DMALLOC(ctx->d_label, N);
     DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, ((size_t) ctx->V + 1) * 8);
@@ -793,6 +805,9 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         DMALLOC(ctx->d_Pt, nt * 16 * 8); DMALLOC(ctx->d_cf, nt * 4 * 8); DMALLOC(ctx->d_cb, nt * 4 * 8);
         DMALLOC(ctx->d_tile_ll, nt * 8);
         DMALLOC(ctx->d_Qs, nt * 64 * 16 * 8);
+        DMALLOC(ctx->d_f, nt * 64 * HF_SCAN_L * 4 * 8); DMALLOC(ctx->d_b, nt * 64 * HF_SCAN_L * 4 * 8);   // tile-major, lane-minor (hf_scan.h fb_slot)
+        ctx->h_off.assign(w->chunk_off, w->chunk_off + C + 1);
+        ctx->h_tile0 = ctile0;
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
     }
     *out = ctx;
@@ -1161,9 +1176,37 @@ int hf_get_labels(hf_ctx* ctx, int8_t* labels_host) {
 int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_host, double* b_host, double* scales_host) {
     if (!ctx || first < 0 || n < 0 || first + n > ctx->N) return set_err(HF_E_ARG, "hf_get_forward_backward: bad range");
     HIPCHK(hipSetDevice(ctx->device));
-    if (f_host) HIPCHK(hipMemcpy(f_host, ctx->d_f + first * 4, (size_t) n * 32, hipMemcpyDeviceToHost));
-    if (b_host) HIPCHK(hipMemcpy(b_host, ctx->d_b + first * 4, (size_t) n * 32, hipMemcpyDeviceToHost));
-    if (scales_host) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
+    if (scales_host && n) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
+    if ((!f_host && !b_host) || n == 0) return HF_OK;
+    // f and b live tile-major / lane-minor on the device (hf_scan.h fb_slot): fetch the tiles that cover the range and
+    // put every window's four values back in window order
+    constexpr int64_t L = HF_SCAN_L, TW = 64 * L;
+    auto locate = [&](int64_t t, int64_t* tile, int* lane, int* j) {
+        size_t c = (size_t) (std::upper_bound(ctx->h_off.begin(), ctx->h_off.end(), t) - ctx->h_off.begin()) - 1;
+        const int64_t w = t - ctx->h_off[c];
+        *tile = ctx->h_tile0[c] + w / TW;
+        const int rem = (int) (w % TW);
+        *lane = rem / (int) L; *j = rem % (int) L;
+    };
+    int64_t tile_lo, tile_hi; int lane, j;
+    locate(first, &tile_lo, &lane, &j);
+    locate(first + n - 1, &tile_hi, &lane, &j);
+    const size_t tile_doubles = (size_t) TW * 4;
+    std::vector<double> buf((size_t) (tile_hi - tile_lo + 1) * tile_doubles);
+    for (int which = 0; which < 2; which++) {
+        double* dst = which == 0 ? f_host : b_host;
+        if (!dst) continue;
+        const double* src = which == 0 ? ctx->d_f : ctx->d_b;
+        HIPCHK(hipMemcpy(buf.data(), src + (size_t) tile_lo * tile_doubles, buf.size() * 8, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) {
+            int64_t tile;
+            locate(first + i, &tile, &lane, &j);
+            for (int h = 0; h < 2; h++) {
+                const size_t slot = (size_t) ((((tile - tile_lo) * L + j) * 2 + h) * 64 + lane);
+                dst[i * 4 + 2 * h] = buf[slot * 2]; dst[i * 4 + 2 * h + 1] = buf[slot * 2 + 1];
+            }
+        }
+    }
     return HF_OK;
 }
 

@@ -109,12 +109,14 @@ __global__ void __launch_bounds__(256) k_stats_tile_nb(int ntiles, const TileDes
 #pragma unroll
             for (int k = 0; k < 16; k++) adj[k] = 0.0;
             if (mine) {
-                const int64_t t = t0 + a0 + j - 1;            // pair (t, t+1)
                 double Ev[16], Tm[16];
                 load_row(row_ptr(S, rr[j + 1], rr[j], sidx[j]), Ev);
-                const double2* __restrict__ fp = reinterpret_cast<const double2*>(F + t * 4);
-                const double2* __restrict__ bp = reinterpret_cast<const double2*>(B + (t + 1) * 4);
-                const double2 f01 = fp[0], f23 = fp[1], b01 = bp[0], b23 = bp[1];
+                // f of the window before (the previous lane's last one for j == 0), b of the window itself
+                const int64_t fs = j > 0 ? fb_slot<L>(tile, lane, j - 1, 0)
+                                         : (lane > 0 ? fb_slot<L>(tile, lane - 1, L - 1, 0) : fb_slot<L>(tile - 1, 63, L - 1, 0));
+                const int64_t bs = fb_slot<L>(tile, lane, j, 0);
+                const double2 f01 = reinterpret_cast<const double2*>(F)[fs], f23 = reinterpret_cast<const double2*>(F)[fs + 64];
+                const double2 b01 = reinterpret_cast<const double2*>(B)[bs], b23 = reinterpret_cast<const double2*>(B)[bs + 64];
                 lds_Tm(s_tab, rr[j + 1], Tm);
                 const double f[4] = {f01.x, f01.y, f23.x, f23.y};
                 const double b1[4] = {b01.x, b01.y, b23.x, b23.y};

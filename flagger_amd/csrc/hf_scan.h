@@ -303,10 +303,15 @@ __global__ void __launch_bounds__(256) k_prod_tile(int ntiles, const TileDesc* _
             for (int k = 0; k < 16; k++) Ecur[k] = Enext[k];
         }
     }
-    {
+    {   // lane-minor: the 64 lanes of a wavefront write / read 1 KiB contiguous per instruction
+#ifdef HF_QS_ROWMAJOR
         double2* dst = reinterpret_cast<double2*>(Qs + ((int64_t) tile * 64 + lane) * 16);
-#pragma unroll
         for (int k = 0; k < 8; k++) dst[k] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
+#else
+        double2* dst = reinterpret_cast<double2*>(Qs) + (int64_t) tile * 8 * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[k * 64] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
+#endif
     }
     // ordered tree product over lanes: after step d, lane l (l % 2d == 0) holds the product of lanes l..l+2d-1
 #pragma unroll
@@ -324,9 +329,14 @@ __global__ void __launch_bounds__(256) k_prod_tile(int ntiles, const TileDesc* _
 }
 
 __device__ __forceinline__ void load_lane_product(M4& Q, const double* __restrict__ Qs, int tile, int lane) {
+#ifdef HF_QS_ROWMAJOR
     const double2* __restrict__ src = reinterpret_cast<const double2*>(Qs + ((int64_t) tile * 64 + lane) * 16);
-#pragma unroll
     for (int k = 0; k < 8; k++) { const double2 v = src[k]; Q.m[2 * k] = v.x; Q.m[2 * k + 1] = v.y; }
+#else
+    const double2* __restrict__ src = reinterpret_cast<const double2*>(Qs) + (int64_t) tile * 8 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const double2 v = src[k * 64]; Q.m[2 * k] = v.x; Q.m[2 * k + 1] = v.y; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -525,8 +535,8 @@ __global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __r
 #pragma unroll
             for (int s = 0; s < 4; s++) f[s] = nf[s] / sc;
             ll += log(sc);                                            // hmm.c:428
-            reinterpret_cast<double2*>(F + t * 4)[0] = make_double2(f[0], f[1]);
-            reinterpret_cast<double2*>(F + t * 4)[1] = make_double2(f[2], f[3]);
+            reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 0)] = make_double2(f[0], f[1]);
+            reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 1)] = make_double2(f[2], f[3]);
             scale[t] = sc;
 #pragma unroll
             for (int s = 0; s < 4; s++) fw[i][s] = f[s];
@@ -596,8 +606,11 @@ __global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __r
             }
             {
                 const int64_t t = t0 + a + jl;
-                reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(b[0], b[1]);
-                reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(b[2], b[3]);
+                {   // jl is wave-divergent only in a chunk's last tile
+                    const int64_t s0 = fb_slot<L>(tile, lane, jl, 0);
+                    reinterpret_cast<double2*>(B)[s0] = make_double2(b[0], b[1]);
+                    reinterpret_cast<double2*>(B)[s0 + 64] = make_double2(b[2], b[3]);
+                }
                 label[t] = (int8_t) posterior_label(fl, b, scl);
             }
         }
@@ -619,8 +632,8 @@ __global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __r
                 if (sc < 1e-50) bad |= HF_FLAG_SCALE;                 // hmm.c:521-524
 #pragma unroll
                 for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
-                reinterpret_cast<double2*>(B + t * 4)[0] = make_double2(b[0], b[1]);
-                reinterpret_cast<double2*>(B + t * 4)[1] = make_double2(b[2], b[3]);
+                reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 0)] = make_double2(b[0], b[1]);
+                reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 1)] = make_double2(b[2], b[3]);
                 label[t] = (int8_t) posterior_label(fw[i], b, sc);
             }
             if (i >= 1) {
