@@ -72,7 +72,7 @@ struct hf_ctx {
     double beta_star = 1.0;
     // per-iteration emission rows (k_tables): keys = occurring (region, x, x_prev) of interior windows,
     // slow = chunk-first and contig-end windows (beta != beta_star), ascending; slow_off[c] = chunk c's first entry
-    int M = 1; double* d_lutE = nullptr; double* d_lutC = nullptr;
+    int M = 1; double* d_lutE = nullptr; double* d_lutC = nullptr; int64_t n_lut = 0;
     int n_keys = 0; int32_t* d_keys = nullptr;
     // negative_binomial model: device copies of hf_params.nb_* and the per-tile count data (allocated on first use)
     double *d_nbE = nullptr, *d_nbP = nullptr, *d_nbDig = nullptr, *d_nbR = nullptr, *d_nbBeta = nullptr, *d_tile_hist = nullptr;
@@ -651,7 +651,7 @@ struct KTimer {
 
 static RowSrc row_src(const hf_ctx* ctx) {
     RowSrc S;
-    S.lutE = ctx->d_lutE; S.lutC = ctx->d_lutC; S.Es = ctx->d_Es; S.Cs = ctx->d_Cs; S.M = ctx->M; S.K = ctx->K;
+    S.lutE = ctx->d_lutE; S.lutC = ctx->d_lutC; S.Es = ctx->d_Es; S.Cs = ctx->d_Cs; S.M = ctx->M; S.K = ctx->K; S.n_lut = (int) ctx->n_lut;
     return S;
 }
 
@@ -754,8 +754,6 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         for (size_t t = 0; t < N; t++) { const unsigned x = w->cov[t] & 0xffu; if (x > maxx) maxx = x; }
         ctx->M = (int) maxx + 1;
         const size_t MM = (size_t) ctx->M * ctx->M;
-        DMALLOC(ctx->d_lutE, (size_t) n_regions * MM * 16 * 8);
-        DMALLOC(ctx->d_lutC, (size_t) n_regions * MM * 4 * (size_t) max_comps * 8);
         // slow windows: chunk-first, or beta differs from beta_star (the same test as k_setup's REC_SLOW bit)
         std::vector<double> hb(N);
         if (N) { hipError_t e2 = hipMemcpy(hb.data(), ctx->d_beta, N * 8, hipMemcpyDeviceToHost);
@@ -780,8 +778,13 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         TRY(dev_upload(&ctx->d_slow_w, slow.data(), slow.size()));
         TRY(dev_upload(&ctx->d_slow_off, soff.data(), soff.size()));
         TRY(dev_upload(&ctx->d_keys, keys.data(), keys.size()));
-        DMALLOC(ctx->d_Es, slow.size() * 16 * 8);
-        DMALLOC(ctx->d_Cs, slow.size() * 4 * (size_t) max_comps * 8);
+        // one buffer per table: rows of the (region, x, x_prev) keys first, then the private rows of the slow windows
+        // (a row index fits 32 bits; + 1 row of padding)
+        ctx->n_lut = (int64_t) n_regions * (int64_t) MM;
+        DMALLOC(ctx->d_lutE, ((size_t) ctx->n_lut + slow.size() + 1) * 16 * 8);
+        DMALLOC(ctx->d_lutC, ((size_t) ctx->n_lut + slow.size() + 1) * 4 * (size_t) max_comps * 8);
+        ctx->d_Es = ctx->d_lutE + (size_t) ctx->n_lut * 16;
+        ctx->d_Cs = ctx->d_lutC + (size_t) ctx->n_lut * 4 * (size_t) max_comps;
         // tiles of 64*HF_SCAN_L windows, enumerated chunk by chunk
         std::vector<int32_t> ctile0(C + 1, 0);
         std::vector<TileDesc> desc;
@@ -822,7 +825,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
-    hipFree(ctx->d_Es); hipFree(ctx->d_Cs); hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
+    hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
@@ -953,7 +956,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
             } else {
                 {
                     KTimer t(ctx, st, HF_K_PROD_TILE);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_tile<HF_SCAN_L>), dim3(tb), dim3(256), tab_bytes, st, ctx->ntiles,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_tile<HF_SCAN_L>), dim3(tb), dim3(256), tab_bytes + 4 * 8192, st, ctx->ntiles,
                                        ctx->d_tile_desc, ctx->d_rec, ctx->d_params, S, ctx->d_Qs, ctx->d_Pt, ctx->d_flags);
                 }
                 {
@@ -962,12 +965,17 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                                        ctx->d_Es, ctx->d_slow_off, ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb);
                 }
                 KTimer t(ctx, st, HF_K_FB_TILE);
+#ifdef HF_FB_LDS
+                const size_t fb_bytes = tab_bytes + 4 * (size_t) HF_SCAN_L * 5 * 64 * 8;
+#else
+                const size_t fb_bytes = tab_bytes;
+#endif
                 if (full)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true>), dim3(tb), dim3(256), tab_bytes, st, ctx->ntiles,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true>), dim3(tb), dim3(256), fb_bytes, st, ctx->ntiles,
                                        ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_f,
                                        ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
                 else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, false>), dim3(tb), dim3(256), tab_bytes, st, ctx->ntiles,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, false>), dim3(tb), dim3(256), fb_bytes, st, ctx->ntiles,
                                        ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_f,
                                        ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
             }

@@ -107,6 +107,7 @@ struct RowSrc {
     const double* Es;     // [n_slow][16]
     const double* Cs;     // [n_slow][K][4]
     int M, K;
+    int n_lut;            // R*M*M: Es / Cs are the rows n_lut.. of the same buffers as lutE / lutC
 };
 
 __device__ __forceinline__ int64_t row_key(const RowSrc& S, uint32_t r, uint32_t rprev) {
@@ -141,6 +142,38 @@ __device__ __forceinline__ const double2* row_ptr(const RowSrc& S, uint32_t r, u
 __device__ __forceinline__ const double2* crow_ptr(const RowSrc& S, uint32_t r, uint32_t rprev, int sidx) {
     return reinterpret_cast<const double2*>(REC_SLOW(r) ? S.Cs + ((int64_t) sidx * 4) * S.K
                                                          : S.lutC + (row_key(S, r, rprev) * 4) * S.K);
+}
+
+__device__ __forceinline__ int32_t row_index(const RowSrc& S, uint32_t r, uint32_t rprev, int sidx) {
+    return REC_SLOW(r) ? (int32_t) (S.n_lut + sidx) : (int32_t) row_key(S, r, rprev);
+}
+
+// Cooperative row fetch: every lane needs the 128-byte row `ridx` of `rows`.  A lane reading its own row touches 64
+// different cache lines per load instruction; here instruction q fetches rows q*8..q*8+7 with 8 lanes x 16 B each
+// (coalesced), and the 16 values of a lane's own row come back through a swizzled, conflict-free LDS transposition.
+// ALL 64 lanes must call both halves (lanes without a window pass any valid row, e.g. 0).
+//   coop_rows_issue: the global loads (can be issued a whole loop iteration early)
+//   coop_rows_finish: LDS round trip through the wave-private buffer xp (64*8 double2 = 8 KiB)
+__device__ __forceinline__ void coop_rows_issue(const double* __restrict__ rows, int32_t ridx, int lane, double2 v[8]) {
+    const int part = lane & 7, sub = lane >> 3;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int32_t idx = __shfl(ridx, q * 8 + sub);
+        v[q] = reinterpret_cast<const double2*>(rows)[(int64_t) idx * 8 + part];
+    }
+}
+__device__ __forceinline__ void coop_rows_finish(const double2 v[8], int lane, double2* __restrict__ xp, double Ev[16]) {
+    const int part = lane & 7, sub = lane >> 3;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { const int src = q * 8 + sub; xp[src * 8 + (part ^ (src & 7))] = v[q]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const double2 d = xp[lane * 8 + (k ^ (lane & 7))]; Ev[2 * k] = d.x; Ev[2 * k + 1] = d.y; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ void load_row(const double2* __restrict__ src, double Ev[16]) {
@@ -276,6 +309,37 @@ __global__ void __launch_bounds__(256) k_prod_tile(int ntiles, const TileDesc* _
     const uint32_t rp = load_recs<L>(rec, t0, T, a, lane, rr);
     int sidx[L];
     tile_slow_index<L>(rr, lane, d.slow0, sidx);
+#ifndef HF_NO_COOP_ROWS
+    // rows through the cooperative fetch: window i+1's loads are in flight while window i is multiplied in
+    double2* __restrict__ xp = reinterpret_cast<double2*>(s_tab + P->n_regions * HF_TAB_STRIDE) + (threadIdx.x >> 6) * 512;
+    int32_t ridx[L];
+#pragma unroll
+    for (int i = 0; i < L; i++) ridx[i] = (a + i < T) ? row_index(S, rr[i], i == 0 ? rp : rr[i - 1], sidx[i]) : 0;
+    double2 vq[8];
+    coop_rows_issue(S.lutE, ridx[0], lane, vq);
+    unsigned nan = 0;
+    M4 Q;
+    m4_identity(Q);
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+        double Ecur[16];
+        coop_rows_finish(vq, lane, xp, Ecur);
+        if (i + 1 < L) coop_rows_issue(S.lutE, ridx[i + 1], lane, vq);
+        if (a + i < T) {
+            if (row_has_nan(Ecur)) nan |= HF_FLAG_NAN;
+            if (!REC_FIRST(rr[i])) {
+                double Tm[16];
+                lds_Tm(s_tab, rr[i], Tm);
+                M4 A, R;
+#pragma unroll
+                for (int k = 0; k < 16; k++) A.m[k] = Tm[HF_PS(k >> 2, k & 3)] * Ecur[HF_PS(k >> 2, k & 3)];
+                m4_mul(R, Q, A);
+                Q = R;
+                m4_renorm(Q);
+            }
+        }
+    }
+#else
     double Ecur[16];
     if (a < T) load_row(row_ptr(S, rr[0], rp, sidx[0]), Ecur);
     unsigned nan = 0;
@@ -303,6 +367,7 @@ __global__ void __launch_bounds__(256) k_prod_tile(int ntiles, const TileDesc* _
             for (int k = 0; k < 16; k++) Ecur[k] = Enext[k];
         }
     }
+#endif
     {   // lane-minor: the 64 lanes of a wavefront write / read 1 KiB contiguous per instruction
 #ifdef HF_QS_ROWMAJOR
         double2* dst = reinterpret_cast<double2*>(Qs + ((int64_t) tile * 64 + lane) * 16);
@@ -446,8 +511,16 @@ __global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, 
 // products after it)·cb[tile], magnitude from sum_s f·b·scale = terminationProb with the lane's own f and scale;
 // the chunk's last window is b_{T-1}[s] = M[s][End] / scale_{T-1} (hmm.c:452-467).
 // ------------------------------------------------------------------------------------------
+// f and scale of a lane's windows wait for the backward half in LDS (not in 40 VGPRs): 165 VGPRs, 3 blocks per CU
+// (measured 77 -> 68 us against 190 VGPRs / 2 blocks; at 4 blocks the kernel spills)
+#ifndef HF_FB_BLOCKS
+#define HF_FB_BLOCKS 3
+#endif
+#ifndef HF_FB_REGS
+#define HF_FB_LDS 1
+#endif
 template <int L, bool BWD>
-__global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __restrict__ td,
+__global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const TileDesc* __restrict__ td,
                                                  const uint32_t* __restrict__ rec, const RowSrc S,
                                                  const double* __restrict__ Qs, const DevParams* __restrict__ P,
                                                  const double* __restrict__ cf, const double* __restrict__ cb,
@@ -511,7 +584,16 @@ __global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __r
         for (int j = 0; j < 4; j++) f[j] = (lane == 0) ? carry[j] : u[j] / su;
     }
     // replay this lane's windows in the reference's operation order (hmm.c:333-420); f and scale stay in registers
+#ifdef HF_FB_LDS
+    // f and scale of the lane's windows wait for the backward half in wave-private LDS, lane-minor (conflict-free)
+    double* __restrict__ s_fw = s_tab + P->n_regions * HF_TAB_STRIDE + (threadIdx.x >> 6) * (L * 5 * 64) + lane;
+#define FW(i, s) s_fw[((i) * 5 + (s)) * 64]
+#define SCW(i) s_fw[((i) * 5 + 4) * 64]
+#else
     double fw[L][4], scw[L];
+#define FW(i, s) fw[i][s]
+#define SCW(i) scw[i]
+#endif
     double ll = 0.0;
 #pragma unroll
     for (int i = 0; i < L; i++) {
@@ -539,12 +621,12 @@ __global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __r
             reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 1)] = make_double2(f[2], f[3]);
             scale[t] = sc;
 #pragma unroll
-            for (int s = 0; s < 4; s++) fw[i][s] = f[s];
-            scw[i] = sc;
+            for (int s = 0; s < 4; s++) FW(i, s) = f[s];
+            SCW(i) = sc;
         } else {
 #pragma unroll
-            for (int s = 0; s < 4; s++) fw[i][s] = 0.0;
-            scw[i] = 1.0;
+            for (int s = 0; s < 4; s++) FW(i, s) = 0.0;
+            SCW(i) = 1.0;
         }
         if (i + 1 < L) {
 #pragma unroll
@@ -589,8 +671,8 @@ __global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __r
             for (int i = 0; i < L; i++)
                 if (i == jl) {
 #pragma unroll
-                    for (int s = 0; s < 4; s++) fl[s] = fw[i][s];
-                    scl = scw[i];
+                    for (int s = 0; s < 4; s++) fl[s] = FW(i, s);
+                    scl = SCW(i);
                 }
             if (a + jl == Tm1) {   // hmm.c:452-467
 #pragma unroll
@@ -628,13 +710,16 @@ __global__ void __launch_bounds__(256) k_fb_tile(int ntiles, const TileDesc* __r
                 for (int s = 0; s < 4; s++)
 #pragma unroll
                     for (int p = 0; p < 4; p++) nb[p] += Tm[HF_PS(p, s)] * Er[HF_PS(p, s)] * b[s];
-                const double sc = scw[i];
+                const double sc = SCW(i);
                 if (sc < 1e-50) bad |= HF_FLAG_SCALE;                 // hmm.c:521-524
 #pragma unroll
                 for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
                 reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 0)] = make_double2(b[0], b[1]);
                 reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 1)] = make_double2(b[2], b[3]);
-                label[t] = (int8_t) posterior_label(fw[i], b, sc);
+                {
+                    const double fi[4] = {FW(i, 0), FW(i, 1), FW(i, 2), FW(i, 3)};
+                    label[t] = (int8_t) posterior_label(fi, b, sc);
+                }
             }
             if (i >= 1) {
 #pragma unroll
