@@ -425,7 +425,6 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
     for (int o = 32; o > 0; o >>= 1) present |= __shfl_xor(present, o);
     const unsigned long long in_chunk = regmask[d.chunk];
     double xa[4], om[4];
-    int um[4];
     for (int r = 0; r < nreg; r++) {
         if (!((in_chunk >> r) & 1ull)) continue;   // k_chunk_stats never reads this slot
         double* __restrict__ dst = tile_stats + ((int64_t) tile * nreg + r) * NA;
@@ -496,7 +495,6 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
                 const double alpha = P->alpha[p * 4 + 3];
                 xa[p] = (x - alpha * px) / (1.0 - alpha);
                 om[p] = 1.0 - alpha;
-                um[p] = P->umap[p * 4 + 3];
             }
 #pragma unroll 1
             for (int cc = 0; cc < ncol; cc++) {
@@ -505,7 +503,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
                 double mnum = s_acc[cc * RS], vnum = s_acc[(ncol + cc) * RS], den = s_acc[(2 * ncol + cc) * RS];
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
-                    const double pc = um[p] == 0 ? u01.x : um[p] == 1 ? u01.y : um[p] == 2 ? u23.x : u23.y;
+                    const double pc = p == 0 ? u01.x : p == 1 ? u01.y : p == 2 ? u23.x : u23.y;   // [component][previous state]
                     const double w = adj3[p] * pc / Ev[HF_PS(p, 3)];
                     mnum += w * xa[p];
                     const double z = (xa[p] - mu) * om[p];

@@ -103,7 +103,7 @@ __device__ __forceinline__ void m4_shfl_down(M4& dst, const M4& src, int d) {
 // ------------------------------------------------------------------------------------------
 struct RowSrc {
     const double* lutE;   // [R*M*M][16]
-    const double* lutC;   // [R*M*M][K][4]
+    const double* lutC;   // [R*M*M][K][4]: component probability of the collapsed state, [component][previous state]
     const double* Es;     // [n_slow][16]
     const double* Cs;     // [n_slow][K][4]
     int M, K;
@@ -203,7 +203,7 @@ __device__ __forceinline__ uint32_t load_recs(const uint32_t* __restrict__ rec, 
 // k_tables: this iteration's emission rows.
 //   job < n_keys            key = (region*M + x)*M + x_prev of an interior window (beta == beta_star):
 //                           lutE[key][16] = E[pre][s], lutC[key][K][4] = component probabilities of the collapsed
-//                           state, [component][u-th distinct alpha] — the per-iteration constants apply
+//                           state, [component][previous state] — the per-iteration constants apply
 //   job - n_keys < n_slow   the slow window slow_w[k]: the same two rows with the window's own beta (or the
 //                           chunk-first row, hmm.c:338-352), in Es[k] / Cs[k]
 // 32 threads per job: thread `slot` evaluates one unit — a single-component state (slot 0..2: Err, Dup, Hap) or
@@ -267,9 +267,12 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) vals[jl][slot][u] = v[u];
-        if (slot >= 3) {
+        if (slot >= 3) {   // component probabilities per PREVIOUS STATE (the value of its alpha): no select in the consumer
 #pragma unroll
-            for (int u = 0; u < 4; u++) dstC[c * 4 + u] = first ? 0.0 : v[u];
+            for (int pre = 0; pre < 4; pre++) {
+                const int u = P->umap[pre * 4 + 3];
+                dstC[c * 4 + pre] = first ? 0.0 : (u == 0 ? v[0] : u == 1 ? v[1] : u == 2 ? v[2] : v[3]);
+            }
         }
     }
     __syncthreads();
