@@ -66,6 +66,8 @@ struct hf_ctx {
     unsigned prof_mask = 0;        // bit k: kernel k (HF_K_*) is bracketed by kev[2k], kev[2k+1]
     hipEvent_t kev[2 * HF_NKERNELS] = {}; bool kran[HF_NKERNELS] = {};
     bool have_full = false;
+    size_t lds_max = 64 * 1024;    // LDS one workgroup may use (hipDeviceAttributeMaxSharedMemoryPerBlock)
+    bool launch_failed = false;
     struct GraphSlot { int key = 0; hipGraphExec_t exec = nullptr; };   // key 0: not captured yet, -1: capture unavailable
     GraphSlot graphs[2];           // HF_MODE_FULL, HF_MODE_FORWARD_ONLY
     hipStream_t gstream = nullptr; // capture stream
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     fill_tab(P, s_tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + wave;   // 4 wavefronts per block unless LDS forces fewer
     if (tile >= ntiles) return;
     // per-wave accumulator rows [row][lane], row stride 65 doubles: lane-minor accesses and the column sums at the
     // end of a region are both bank-conflict free.  Rows 0..3*ncol-1: component accumulators (q*ncol + cc).
@@ -647,6 +649,27 @@ struct KTimer {
     ~KTimer() { if (on) { hipEventRecord(c->kev[2 * k + 1], st); c->kran[k] = true; } }
 };
 
+// Launch geometry of a one-wavefront-per-tile kernel: 4 wavefronts per block, fewer when the per-region transition
+// tables (1088 B per region) plus the per-wavefront LDS do not fit (many regions / components); dynamic LDS above the
+// default 64 KiB is requested explicitly.
+struct TileGeom { unsigned blocks = 0, threads = 256; size_t lds = 0; bool ok = false; };
+template <class Kern>
+static TileGeom tile_geom(const hf_ctx* ctx, Kern kernel, size_t per_wave_bytes) {
+    TileGeom g;
+    const size_t tab = (size_t) ctx->R * HF_TAB_STRIDE * 8;
+    int w = 4;
+    while (w >= 1 && tab + (size_t) w * per_wave_bytes > ctx->lds_max) w--;
+    if (w < 1) return g;
+    g.threads = 64u * (unsigned) w;
+    g.blocks = (unsigned) ((ctx->ntiles + w - 1) / w);
+    g.lds = tab + (size_t) w * per_wave_bytes;
+    g.ok = true;
+    if (g.lds > 64 * 1024)
+        g.ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) g.lds) == hipSuccess;
+    return g;
+}
+#define TILE_GEOM_OR_FAIL(g) do { if (!(g).ok) { set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup"); ctx->launch_failed = true; return; } } while (0)
+
 static RowSrc row_src(const hf_ctx* ctx) {
     RowSrc S;
     S.lutE = ctx->d_lutE; S.lutC = ctx->d_lutC; S.Es = ctx->d_Es; S.Cs = ctx->d_Cs; S.M = ctx->M; S.K = ctx->K; S.n_lut = (int) ctx->n_lut;
@@ -657,8 +680,9 @@ template <int KT>
 static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
     if (full) {
         KTimer t(ctx, st, HF_K_STATS_TILE);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3((unsigned) ((ctx->ntiles + 3) / 4)), dim3(256),
-                           ((size_t) ctx->R * HF_TAB_STRIDE + 4 * (size_t) (3 * ncol > 28 ? 3 * ncol : 28) * 65) * 8, st, ctx->ntiles,
+        const TileGeom g = tile_geom(ctx, k_stats_tile<KT>, (size_t) (3 * ncol > 28 ? 3 * ncol : 28) * 65 * 8);
+        TILE_GEOM_OR_FAIL(g);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
                            ctx->d_tile_desc, ctx->d_rec, row_src(ctx), ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask,
                            ctx->d_tile_stats);
     }
@@ -688,6 +712,10 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     HIPCHK(hipSetDevice(device));
     hf_ctx* ctx = new hf_ctx();
     ctx->device = device; ctx->algo = algo;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) ctx->lds_max = (size_t) v;
+    }
     ctx->N = w->n_windows; ctx->C = w->n_chunks; ctx->R = n_regions; ctx->K = max_comps;
     ctx->V = hf_stats_len(n_regions, max_comps);
     ctx->meta = *w;
@@ -901,8 +929,6 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
     for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
     if (ctx->C == 0) HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
     if (ctx->C > 0) {
-        const unsigned tb = (unsigned) ((ctx->ntiles + 3) / 4);
-        const size_t tab_bytes = (size_t) ctx->R * HF_TAB_STRIDE * 8;   // LDS transition tables
         const RowSrc S = row_src(ctx);
         const bool full = mode == HF_MODE_FULL;
         const bool nbm = p->model_type == HF_MODEL_NEGATIVE_BINOMIAL;
@@ -954,7 +980,9 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
             } else {
                 {
                     KTimer t(ctx, st, HF_K_PROD_TILE);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_tile<HF_SCAN_L>), dim3(tb), dim3(256), tab_bytes + 4 * 8192, st, ctx->ntiles,
+                    const TileGeom g = tile_geom(ctx, k_prod_tile<HF_SCAN_L>, 8192);
+                    if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_tile<HF_SCAN_L>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
                                        ctx->d_tile_desc, ctx->d_rec, ctx->d_params, S, ctx->d_Qs, ctx->d_Pt, ctx->d_flags);
                 }
                 {
@@ -964,16 +992,18 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 }
                 KTimer t(ctx, st, HF_K_FB_TILE);
 #ifdef HF_FB_LDS
-                const size_t fb_bytes = tab_bytes + 4 * (size_t) HF_SCAN_L * 5 * 64 * 8;
+                const size_t fb_wave = (size_t) HF_SCAN_L * 5 * 64 * 8;
 #else
-                const size_t fb_bytes = tab_bytes;
+                const size_t fb_wave = 0;
 #endif
+                const TileGeom g = full ? tile_geom(ctx, k_fb_tile<HF_SCAN_L, true>, fb_wave) : tile_geom(ctx, k_fb_tile<HF_SCAN_L, false>, fb_wave);
+                if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
                 if (full)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true>), dim3(tb), dim3(256), fb_bytes, st, ctx->ntiles,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
                                        ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_f,
                                        ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
                 else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, false>), dim3(tb), dim3(256), fb_bytes, st, ctx->ntiles,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, false>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
                                        ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_f,
                                        ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
             }
@@ -983,8 +1013,9 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         if (nbm) {
             if (fl) {
                 KTimer t(ctx, st, HF_K_STATS_TILE);
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile_nb<HF_SCAN_L>), dim3(tb), dim3(256),
-                                   ((size_t) ctx->R * HF_TAB_STRIDE + 4 * (64 * 16 + 64 + 16 * 64)) * 8, st, ctx->ntiles, ctx->d_tile_desc,
+                const TileGeom g = tile_geom(ctx, k_stats_tile_nb<HF_SCAN_L>, (size_t) (64 * 16 + 64 + 16 * 64) * 8);
+                if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile_nb<HF_SCAN_L>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles, ctx->d_tile_desc,
                                    ctx->d_rec, S, ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_hist);
             }
             NbTables nt;
@@ -996,6 +1027,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         else if (kc <= 4) launch_stats<4>(ctx, st, fl, kc);
         else if (kc <= 8) launch_stats<8>(ctx, st, fl, kc);
         else launch_stats<16>(ctx, st, fl, kc);
+        if (ctx->launch_failed) { ctx->launch_failed = false; return HF_E_ARG; }
     }
     HIPCHK(hipGetLastError());
     return HF_OK;

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) k_stats_tile_nb(int ntiles, const TileDes
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     fill_tab(P, s_tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + wave;   // 4 wavefronts per block unless LDS forces fewer
     if (tile >= ntiles) return;
     // per wave: records [64][16], bins of the records [64] (as doubles), histogram [4 states][4 bins][64 lanes]
     double* __restrict__ s_rec = s_tab + P->n_regions * HF_TAB_STRIDE + wave * (64 * 16 + 64 + 16 * 64);

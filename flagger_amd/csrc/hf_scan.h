@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) k_prod_tile(int ntiles, const TileDesc* _
                                                    unsigned* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     fill_tab(P, s_tab);
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
     const TileDesc d = td[tile];
     const int64_t t0 = d.t0, T = d.T, base = d.base;
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
                                                  double* __restrict__ tile_ll, unsigned* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     fill_tab(P, s_tab);
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (tile >= ntiles) return;
     const TileDesc d = td[tile];
     const int64_t t0 = d.t0, T = d.T, base = d.base;

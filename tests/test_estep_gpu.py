@@ -108,6 +108,17 @@ def test_multi_region_ont(algo):
 
 
 @pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("model_type", [hmm.MODEL_TRUNC_EXP_GAUSSIAN, hmm.MODEL_NEGATIVE_BINOMIAL])
+def test_maximum_number_of_regions_and_components(algo, model_type):
+    """All 64 region classes the 6 region bits allow (ptBlock.c:294-304) with 16 collapsed components: the per-region
+    tables no longer fit the default LDS budget of the tile kernels."""
+    store = synth.synthesize([600_000, 90_000], 1000, 100_000, [20 + (i % 7) for i in range(64)], seed=5,
+                             region_run_bases=(3_000, 20_000))
+    assert len(np.unique(store.annot >> np.uint64(58))) > 12 and int((store.annot >> np.uint64(58)).max()) > 60
+    _check_pass(store, model_type, 16, synth.HIFI_ALPHA, algo, n_iter=1)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("adjust,avg_len", [(False, 15000), (True, 0), (True, 15000), (True, 200000)])
 def test_contig_end_adjustment(algo, adjust, avg_len):
     """beta: disabled (-e), missing #avg_alignment_len (=> 0.25 everywhere, Q4), normal, reads longer than chunks."""
