@@ -108,6 +108,30 @@ def test_multi_region_ont(algo):
 
 
 @pytest.mark.parametrize("algo", ALGOS)
+def test_empty_chunk_list(algo):
+    """No chunk at all (e.g. --contigsList that matches nothing): log-likelihood 0, all-zero statistics, no labels."""
+    full = synth.synthesize([50_000], 1000, 20_000, [20], seed=2)
+    store = full.subset_chunks([])
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 3, full, synth.HIFI_ALPHA)
+    em = hmm.EMList(store, model, algo=algo)
+    hmm.EM_runOneIterationForList(em, model)
+    assert model.loglikelihood == 0.0 and not np.any(model.estimators)
+    assert em.labels().size == 0
+    hmm.EM_runForwardForList(em, model)
+    assert model.loglikelihood == 0.0
+    em.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_one_long_chunk_spanning_many_tiles(algo):
+    """A 45 000-window chunk = 176 tiles: the carry sweep of a chunk goes through more than one LDS batch of tile
+    products (HF_CARRY_BATCH = 128), next to a chunk of exactly one tile and one of exactly 128 tiles."""
+    store = synth.synthesize([45_000_000, 256_000, 32_768_000], 1000, 60_000_000, [20], seed=21)
+    assert sorted(np.diff(store.chunk_off).tolist()) == [256, 32768, 45000]
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, synth.HIFI_ALPHA, algo, n_iter=1)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
 @pytest.mark.parametrize("model_type", [hmm.MODEL_TRUNC_EXP_GAUSSIAN, hmm.MODEL_NEGATIVE_BINOMIAL])
 def test_maximum_number_of_regions_and_components(algo, model_type):
     """All 64 region classes the 6 region bits allow (ptBlock.c:294-304) with 16 collapsed components: the per-region
