@@ -51,6 +51,7 @@ struct hf_ctx {
     int8_t* d_label = nullptr;     // [N]
     double* d_chunk_stats = nullptr; // [C][V]
     double* d_total = nullptr;     // [V]
+    double* d_total_host = nullptr; // device address of the pinned h_total: k_reduce writes the result straight to the host
     // scan algorithm: tile tables and per-tile work arrays
     TileDesc* d_tile_desc = nullptr;
     int ntiles = 0; int32_t* d_chunk_tile0 = nullptr;
@@ -758,6 +759,11 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         hipHostMalloc((void**) &ctx->h_total, ((size_t) ctx->V + 1) * 8) != hipSuccess) {
         hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed");
     }
+    {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, ctx->h_total, 0) == hipSuccess) ctx->d_total_host = (double*) dp;
+        else (void) hipGetLastError();
+    }
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     hipMemset(ctx->d_flags, 0, 4);
     hipMemset(ctx->d_label, 0xff, N ? N : 1);
@@ -1072,7 +1078,8 @@ int hf_reduce_chunks_indexed(hf_ctx* ctx, const double* chunk_stats_dev, const i
     {
         KTimer t(ctx, (hipStream_t) stream, HF_K_REDUCE);
         hipLaunchKernelGGL(k_reduce, dim3((unsigned) (ctx->V + 1)), dim3(64), 0, (hipStream_t) stream, chunk_stats_dev, row_index_dev,
-                           n_chunks, ctx->V, out_dev, out_dev == ctx->d_total ? ctx->d_flags : (const unsigned*) nullptr);
+                           n_chunks, ctx->V, out_dev,
+                           (out_dev == ctx->d_total || out_dev == ctx->d_total_host) ? ctx->d_flags : (const unsigned*) nullptr);
     }
     ctx->prof_mask = keep;
     HIPCHK(hipGetLastError());
@@ -1113,10 +1120,19 @@ int hf_check(hf_ctx* ctx, void* stream) {
 int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
     if (!ctx || !stats_host) return set_err(HF_E_ARG, "hf_finish: bad argument");
     hipStream_t st = (hipStream_t) stream;
+#ifndef HF_NO_DIRECT_OUT
+    // the reduction writes the V+1 doubles into pinned host memory over PCIe: no device-to-host copy afterwards
+    int rc = hf_reduce_chunks(ctx, ctx->d_chunk_stats, ctx->C, ctx->d_total_host ? ctx->d_total_host : ctx->d_total, stream);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ctx->ev1, st));
+    if (!ctx->d_total_host)
+        HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
+#else
     int rc = hf_reduce_chunks(ctx, ctx->d_chunk_stats, ctx->C, ctx->d_total, stream);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev1, st));
     HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
+#endif
     HIPCHK(hipStreamSynchronize(st));
     accumulate_kernel_times(ctx);
     std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
