@@ -98,6 +98,7 @@ def lib() -> C.CDLL:
     sig("hf_kernel_times", C.c_int, vp, C.POINTER(C.c_float))
     sig("hf_kernel_time_sums", C.c_int, vp, pd, C.POINTER(C.c_int64))
     sig("hf_kernel_name", C.c_char_p, C.c_int)
+    sig("hf_selftest_division", C.c_int, C.c_int, i64, pd, pd, pd, pd, C.POINTER(C.c_int32))
     # host model
     sig("hfm_create", vp, C.c_int, C.c_int, C.POINTER(i32), C.c_int, C.c_int, C.c_int, C.c_int, pd, dbl, dbl)
     sig("hfm_copy", vp, vp)

@@ -47,6 +47,35 @@ __device__ __forceinline__ int64_t fb_slot_w(int tile0, int64_t w, int h) {
     return fb_slot<L>(tile0 + w / TW, rem / L, rem % L, h);
 }
 
+// ---- divisions that share a denominator ---------------------------------------------------------------------
+// a / d as the compiler emits it for fp64 (LowerFDIV64: v_div_scale x2, v_rcp_f64, two Newton steps, quotient,
+// residual, v_div_fmas, v_div_fixup) spends most of its instructions on the denominator.  When many numerators
+// meet the same denominator, the reciprocal refinement is done once (prediv) and each quotient costs a multiply and
+// two FMAs (divp) — the SAME operations in the same order, so the result is bit-identical to a / d whenever
+// v_div_scale would not rescale and v_div_fixup would not intervene: d and a normal, far from the exponent limits.
+// div_operand_safe() is the guard on EACH operand (0 or 2^-380 <= v <= 2^380, v >= 0): then the exponents differ by
+// less than the 768 at which v_div_scale steps in and the quotient stays normal; callers fall back to a / d otherwise.
+struct PreDiv { double d, r; };
+__device__ __forceinline__ PreDiv prediv(double d) {
+    const double r0 = __builtin_amdgcn_rcp(d);
+    const double e0 = fma(-d, r0, 1.0);
+    const double r1 = fma(r0, e0, r0);
+    const double e1 = fma(-d, r1, 1.0);
+    PreDiv p;
+    p.d = d;
+    p.r = fma(r1, e1, r1);
+    return p;
+}
+__device__ __forceinline__ double divp(double a, const PreDiv& p) {
+    const double q0 = a * p.r;
+    const double res = fma(-p.d, q0, a);
+    return fma(res, p.r, q0);
+}
+__device__ __forceinline__ bool div_operand_safe(double v) {
+    const unsigned h = (unsigned) __double2hiint(v);
+    return v == 0.0 || (h - 0x28300000u) <= (0x57B00000u - 0x28300000u);
+}
+
 struct DevRegion {
     double trans[5][5];                 // Transition.matrix (row 4 Start, column 4 End)
     double tcond[8][16];                // Transition_getProbConditional per validity mask, [pre*4+s]

@@ -428,6 +428,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
     for (int o = 32; o > 0; o >>= 1) present |= __shfl_xor(present, o);
     const unsigned long long in_chunk = regmask[d.chunk];
     double xa[4], om[4];
+    const PreDiv term_div = prediv(HF_TERMINATION_PROB);
     for (int r = 0; r < nreg; r++) {
         if (!((in_chunk >> r) & 1ull)) continue;   // k_chunk_stats never reads this slot
         double* __restrict__ dst = tile_stats + ((int64_t) tile * nreg + r) * NA;
@@ -461,16 +462,32 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
             // one state (column) at a time, with a scheduling barrier after each: keeps the live set small;
             // state outer / pre inner is also the order of the reference (hmm.c:588-589)
             double adj3[4];
+            bool col_fast = false;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 double adj[4];
+                bool okc = true;
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const int k = HF_PS(p, s);                // rows and tables are state-major
-                    const double count = f[p] * Tm[k] * Ev[k] * b1[s];
-                    adj[p] = count / HF_TERMINATION_PROB;     // hmm.c:613-614
-                    a.trans[p * 4 + s] += adj[p];             // hmm_utils.c:2010-2015
+                    adj[p] = f[p] * Tm[k] * Ev[k] * b1[s];    // count, hmm.c:612
+                    okc &= div_operand_safe(adj[p]);
                 }
+                if (s == 3) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++) okc &= Ev[HF_PS(p, 3)] != 0.0 && div_operand_safe(Ev[HF_PS(p, 3)]);
+                }
+                // count / terminationProb (hmm.c:613-614): the shared-denominator form when every operand is in range
+                if (__all(okc)) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++) adj[p] = divp(adj[p], term_div);
+                    if (s == 3) col_fast = true;
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; p++) adj[p] = adj[p] / HF_TERMINATION_PROB;
+                }
+#pragma unroll
+                for (int p = 0; p < 4; p++) a.trans[p * 4 + s] += adj[p];   // hmm_utils.c:2010-2015
                 if (s == 3) {
 #pragma unroll
                     for (int p = 0; p < 4; p++) adj3[p] = adj[p];
@@ -482,7 +499,8 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
                     for (int p = 0; p < 4; p++) {
                         const int k = HF_PS(p, s);
                         const double alpha = P->alpha[p * 4 + s];
-                        const double x_adj = (x - alpha * px) / (1.0 - alpha);
+                        // alpha == 0 (wave-uniform): (x - 0*px) / (1 - 0) is x itself
+                        const double x_adj = alpha == 0.0 ? x : (x - alpha * px) / (1.0 - alpha);
                         const double w = adj[p] * Ev[k] / Ev[k];
                         a.g_mnum[s] += w * x_adj;
                         const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
@@ -496,25 +514,48 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const double alpha = P->alpha[p * 4 + 3];
-                xa[p] = (x - alpha * px) / (1.0 - alpha);
+                xa[p] = alpha == 0.0 ? x : (x - alpha * px) / (1.0 - alpha);
                 om[p] = 1.0 - alpha;
             }
-#pragma unroll 1
-            for (int cc = 0; cc < ncol; cc++) {
-                const double2 u01 = crow[cc * 2], u23 = crow[cc * 2 + 1];
-                const double mu = R->mean[3][cc];
-                double mnum = s_acc[cc * RS], vnum = s_acc[(ncol + cc) * RS], den = s_acc[(2 * ncol + cc) * RS];
+            if (col_fast) {   // w = adj3 * pc / E3 with the four reciprocals of E3 prepared once for all components
+                PreDiv e3[4];
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const double pc = p == 0 ? u01.x : p == 1 ? u01.y : p == 2 ? u23.x : u23.y;   // [component][previous state]
-                    const double w = adj3[p] * pc / Ev[HF_PS(p, 3)];
-                    mnum += w * xa[p];
-                    const double z = (xa[p] - mu) * om[p];
-                    vnum += w * z * z;
-                    den += w;
-                    c_wden += w;
+                for (int p = 0; p < 4; p++) e3[p] = prediv(Ev[HF_PS(p, 3)]);
+#pragma unroll 1
+                for (int cc = 0; cc < ncol; cc++) {
+                    const double2 u01 = crow[cc * 2], u23 = crow[cc * 2 + 1];
+                    const double mu = R->mean[3][cc];
+                    double mnum = s_acc[cc * RS], vnum = s_acc[(ncol + cc) * RS], den = s_acc[(2 * ncol + cc) * RS];
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const double pc = p == 0 ? u01.x : p == 1 ? u01.y : p == 2 ? u23.x : u23.y;   // [component][previous state]
+                        const double w = divp(adj3[p] * pc, e3[p]);
+                        mnum += w * xa[p];
+                        const double z = (xa[p] - mu) * om[p];
+                        vnum += w * z * z;
+                        den += w;
+                        c_wden += w;
+                    }
+                    s_acc[cc * RS] = mnum; s_acc[(ncol + cc) * RS] = vnum; s_acc[(2 * ncol + cc) * RS] = den;
                 }
-                s_acc[cc * RS] = mnum; s_acc[(ncol + cc) * RS] = vnum; s_acc[(2 * ncol + cc) * RS] = den;
+            } else {
+#pragma unroll 1
+                for (int cc = 0; cc < ncol; cc++) {
+                    const double2 u01 = crow[cc * 2], u23 = crow[cc * 2 + 1];
+                    const double mu = R->mean[3][cc];
+                    double mnum = s_acc[cc * RS], vnum = s_acc[(ncol + cc) * RS], den = s_acc[(2 * ncol + cc) * RS];
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const double pc = p == 0 ? u01.x : p == 1 ? u01.y : p == 2 ? u23.x : u23.y;
+                        const double w = adj3[p] * pc / Ev[HF_PS(p, 3)];
+                        mnum += w * xa[p];
+                        const double z = (xa[p] - mu) * om[p];
+                        vnum += w * z * z;
+                        den += w;
+                        c_wden += w;
+                    }
+                    s_acc[cc * RS] = mnum; s_acc[(ncol + cc) * RS] = vnum; s_acc[(2 * ncol + cc) * RS] = den;
+                }
             }
         }
         // sum over the 64 lanes in lane order: accumulator i is summed by lane i out of its LDS row (fixed order),
@@ -1305,6 +1346,32 @@ const char* hf_kernel_name(int k) {
     static const char* names[HF_NKERNELS] = {"k_tables", "k_prod_tile", "k_carry", "k_fb_tile", "k_stats_tile", "k_chunk_stats",
                                              "k_reduce", "k_emit_rows", "k_fwd_seq", "k_bwd_seq"};
     return k >= 0 && k < HF_NKERNELS ? names[k] : "?";
+}
+
+// self-test hook (tests/test_estep_gpu.py): quotient through prediv/divp next to the plain a / d, element-wise
+__global__ void k_selftest_div(int64_t n, const double* __restrict__ a, const double* __restrict__ d,
+                               double* __restrict__ fast, double* __restrict__ exact, int32_t* __restrict__ safe) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fast[i] = divp(a[i], prediv(d[i]));
+    exact[i] = a[i] / d[i];
+    safe[i] = (div_operand_safe(a[i]) && d[i] != 0.0 && div_operand_safe(d[i])) ? 1 : 0;
+}
+
+int hf_selftest_division(int device, int64_t n, const double* a, const double* d, double* fast, double* exact, int32_t* safe) {
+    if (n < 0 || !a || !d || !fast || !exact || !safe) return set_err(HF_E_ARG, "hf_selftest_division: bad argument");
+    if (hf_device_count() <= 0) return set_err(HF_E_NOGPU, "hf_selftest_division: no HIP device");
+    HIPCHK(hipSetDevice(device));
+    double *da = nullptr, *dd = nullptr, *df = nullptr, *de = nullptr; int32_t* ds = nullptr;
+    const size_t b = (size_t) (n ? n : 1) * 8;
+    HIPCHK(hipMalloc((void**) &da, b)); HIPCHK(hipMalloc((void**) &dd, b)); HIPCHK(hipMalloc((void**) &df, b));
+    HIPCHK(hipMalloc((void**) &de, b)); HIPCHK(hipMalloc((void**) &ds, b));
+    HIPCHK(hipMemcpy(da, a, (size_t) n * 8, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(dd, d, (size_t) n * 8, hipMemcpyHostToDevice));
+    if (n) hipLaunchKernelGGL(k_selftest_div, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, n, da, dd, df, de, ds);
+    HIPCHK(hipMemcpy(fast, df, (size_t) n * 8, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(exact, de, (size_t) n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(safe, ds, (size_t) n * 4, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(dd); hipFree(df); hipFree(de); hipFree(ds);
+    return HF_OK;
 }
 
 int hf_last_kernel_ms(hf_ctx* ctx, float* ms) {

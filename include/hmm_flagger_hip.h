@@ -163,6 +163,11 @@ int hf_kernel_times(hf_ctx *ctx, float ms[HF_NKERNELS]);
 int hf_kernel_time_sums(hf_ctx *ctx, double sum_ms[HF_NKERNELS], int64_t launches[HF_NKERNELS]);
 const char *hf_kernel_name(int k);   /* "k_tables", "k_prod_tile", ... as they appear in a rocprofv3 kernel trace */
 
+/* Self-test hook: fast[i] = a[i] / d[i] through the shared-denominator form the statistics kernel uses (hf_device.h
+ * prediv / divp), exact[i] = the plain division, safe[i] = whether the kernel's guard would take the fast form.
+ * fast must equal exact bit for bit wherever safe is set. */
+int hf_selftest_division(int device, int64_t n, const double *a, const double *d, double *fast, double *exact, int32_t *safe);
+
 #ifdef __cplusplus
 }
 #endif

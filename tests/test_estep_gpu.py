@@ -285,3 +285,31 @@ def test_full_size_cfg2_one_pass_and_invariants():
     assert np.allclose((f * b).sum(axis=1) * sc, 1e-4, rtol=1e-9)     # the scaling invariant used by the scan
     em.close()
     orc.close()
+
+
+def test_shared_denominator_division_is_bit_identical_where_the_guard_allows_it():
+    """k_stats_tile divides many numerators by the same denominator through one refined reciprocal (hf_device.h
+    prediv / divp).  Wherever its guard admits the operands the quotient must be the correctly rounded a / d,
+    bit for bit; outside (zero / denormal / huge operands) the kernel falls back to the plain division."""
+    import ctypes as C
+    rng = np.random.default_rng(99)
+    n = 2_000_000
+    ea, ed = rng.uniform(-400, 400, n), rng.uniform(-400, 400, n)      # the guard admits 2^-380 .. 2^380
+    a = rng.uniform(1.0, 2.0, n) * np.exp2(np.floor(ea))
+    d = rng.uniform(1.0, 2.0, n) * np.exp2(np.floor(ed))
+    a[:1000] = 0.0
+    d[1000:2000] = 1e-4                      # terminationProb
+    a[2000:3000] = np.nextafter(a[2000:3000], np.inf)
+    d[3000:4000] = a[3000:4000]              # quotient exactly 1
+    a[4000:4100] = 5e-324                    # denormal: must be rejected by the guard
+    d[4100:4200] = 0.0
+    fast, exact, safe = np.empty(n), np.empty(n), np.empty(n, dtype=np.int32)
+    L = N.lib()
+    pd = C.POINTER(C.c_double)
+    N.check(L.hf_selftest_division(0, n, a.ctypes.data_as(pd), d.ctypes.data_as(pd), fast.ctypes.data_as(pd),
+                                   exact.ctypes.data_as(pd), safe.ctypes.data_as(C.POINTER(C.c_int32))), "hf_selftest_division")
+    ok = safe.astype(bool)
+    assert ok.sum() > 0.85 * n and not ok[4000:4200].any() and ok[:1000].sum() > 900   # zero numerators are admitted
+    bad = ok & (fast.view(np.uint64) != exact.view(np.uint64))
+    assert not bad.any(), (int(bad.sum()), np.log2(a[bad][:8]), np.log2(d[bad][:8]), fast[bad][:4], exact[bad][:4])
+    assert np.array_equal(exact[ok], a[ok] / d[ok])          # and both are the IEEE quotient
