@@ -139,14 +139,6 @@ __device__ __forceinline__ double hf_gauss_comp_star(double m1, double gvar, dou
     return p;
 }
 
-__device__ __forceinline__ double hf_gauss_sum_star(const DevRegion* __restrict__ R, int s, int u, int ncomp, double x,
-                                                    double pre_x, double alpha, double beta, unsigned* nan) {
-    double tot = 0.0;
-    for (int c = 0; c < ncomp; c++)
-        tot += hf_gauss_comp_star(R->m1[s][u][c], R->gvar[s][c], R->gnorm[s][c], x, pre_x, alpha, beta, nan);
-    return tot;
-}
-
 __device__ __forceinline__ double hf_trunc_exp_star(const DevRegion* __restrict__ R, double x) {
     if (R->trunc_point < x) return 0.0;
     return R->te_lam * exp(-R->te_lam * x) / R->te_den;
@@ -163,8 +155,8 @@ __device__ __forceinline__ double hf_gauss_sum(const DevRegion* __restrict__ R, 
 
 // E[pre][s] = e_s(x | px, alpha[pre][s], bt) for region parameters R (A8-A10), evaluated once per distinct alpha
 // of a column; Err as trunc-exp ignores alpha.  `first` = chunk-first window: e_s(x; alpha = 0, preX = 0) in row
-// pre = 0 and zeros elsewhere (hmm.c:338-352).  STAR = true: bt == P->beta_star, per-iteration constants apply.
-template <bool STAR>
+// pre = 0 and zeros elsewhere (hmm.c:338-352).  Direct per-window evaluation (HF_ALGO_SEQ); the scan path builds the
+// same values per table row in k_tables.
 __device__ __forceinline__ void hf_emit_values(const DevParams* __restrict__ P, const DevRegion* __restrict__ R, double x,
                                                double px, bool first, double bt, double out[16], unsigned* nan) {
     const bool te = hf_err_is_truncexp(P);
@@ -178,7 +170,7 @@ __device__ __forceinline__ void hf_emit_values(const DevParams* __restrict__ P, 
         for (int s = 0; s < 4; s++) {
             double val[4];
             if (s == 0 && te) {
-                const double v = STAR ? hf_trunc_exp_star(R, x) : hf_trunc_exp(R->lambda, R->trunc_point, x, bt);
+                const double v = hf_trunc_exp(R->lambda, R->trunc_point, x, bt);
                 val[0] = v; val[1] = v; val[2] = v; val[3] = v;
             } else {
                 const int nu = P->nuniq[s], nc = P->ncomp[s];
@@ -186,8 +178,7 @@ __device__ __forceinline__ void hf_emit_values(const DevParams* __restrict__ P, 
 #pragma unroll
                 for (int u = 0; u < 4; u++)
                     if (u < nu)
-                        val[u] = STAR ? hf_gauss_sum_star(R, s, u, nc, x, px, P->ualpha[s][u], bt, nan)
-                                      : hf_gauss_sum(R, s, nc, x, px, P->ualpha[s][u], bt, nan);
+                        val[u] = hf_gauss_sum(R, s, nc, x, px, P->ualpha[s][u], bt, nan);
             }
 #pragma unroll
             for (int pre = 0; pre < 4; pre++) {

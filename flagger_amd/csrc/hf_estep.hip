@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) k_emit_rows(int64_t N, const uint32_t* __
             for (int p = 0; p < 4; p++) out[p * 4 + s] = (first && p != 0) ? 0.0 : e;
         }
     } else
-    hf_emit_values<false>(P, &P->reg[REC_REGION(r)], x, px, first, beta[t], out, &nan);
+    hf_emit_values(P, &P->reg[REC_REGION(r)], x, px, first, beta[t], out, &nan);
     double2* dst = reinterpret_cast<double2*>(E) + t * 8;
 #pragma unroll
     for (int k = 0; k < 8; k++) dst[k] = make_double2(out[2 * k], out[2 * k + 1]);
