@@ -89,6 +89,45 @@ class WindowStore:
             chunk_s=self.chunk_s[idx], chunk_e=self.chunk_e[idx])
 
     # ---- reference `.bin` format (chunk.c:596-709 / 713-828) ----
+    def write_cov(self, path: str) -> None:
+        """Text coverage file (.cov or .cov.gz) with one run per window: header lines as the reference's simulator
+        writes them (programs/src/simulate_coverage_data.py:146-168), then `>ctg len` and 1-based inclusive rows
+        `start end cov mapq clip annotation_indices region [truth]`."""
+        import gzip
+        import io
+        opener = gzip.open if path.endswith(".gz") else open
+        with opener(path, "wt", **({"compresslevel": 1} if path.endswith(".gz") else {})) as f:
+            f.write(f"#annotation:len:{len(self.annotation_names)}\n")
+            for i, n in enumerate(self.annotation_names):
+                f.write(f"#annotation:name:{i}:{n}\n")
+            f.write(f"#region:len:{self.n_regions}\n")
+            for i, c in enumerate(self.region_coverages):
+                f.write(f"#region:coverage:{i}:{c}\n")
+            if self.truth_available:
+                f.write(f"#label:len:{self.n_labels}\n#truth:true\n#prediction:false\n")
+            f.write(f"#avg_alignment_len:{self.avg_alignment_len}\n#start-only:{'true' if self.start_only else 'false'}\n")
+            region = (self.annot >> np.uint64(58)).astype(np.int64)
+            bits = self.annot & np.uint64(0x03FFFFFFFFFFFFFF)
+            W = self.window_len
+            prev_ctg = None
+            for c in range(self.n_chunks):
+                if self.chunk_ctg[c] != prev_ctg:
+                    f.write(f">{self.chunk_ctg[c]} {int(self.chunk_ctg_len[c])}\n")
+                    prev_ctg = self.chunk_ctg[c]
+                t0, t1 = int(self.chunk_off[c]), int(self.chunk_off[c + 1])
+                s0, e0 = int(self.chunk_s[c]), int(self.chunk_e[c])
+                buf = io.StringIO()
+                for i in range(t1 - t0):
+                    t = t0 + i
+                    st, en = s0 + i * W + 1, min(s0 + (i + 1) * W, e0 + 1)
+                    b = int(bits[t])
+                    ann = ",".join(str(k + 1) for k in range(58) if (b >> k) & 1) or "0"
+                    row = f"{st}\t{en}\t{int(self.cov[t])}\t{int(self.mapq[t])}\t{int(self.clip[t])}\t{ann}\t{int(region[t])}"
+                    if self.truth_available:
+                        row += f"\t{int(self.truth[t])}"
+                    buf.write(row + "\n")
+                f.write(buf.getvalue())
+
     def write_bin(self, path: str) -> None:
         with open(path, "wb") as f:
             f.write(struct.pack("<i", len(self.annotation_names)))
