@@ -117,3 +117,29 @@ def test_final_bed_and_posterior_bed_match_oracle_writers(min_len, tmp_path):
     orc.write_final_bed(str(theirs), "trk", min_len)
     assert mine.read_text() == theirs.read_text()
     orc.close()
+
+
+@pytest.mark.parametrize("ext", ["cov", "cov.gz"])
+def test_synthetic_store_written_as_cov_loads_back_identically(ext, tmp_path):
+    """WindowStore.write_cov (one run per window, the simulator's header layout) -> product loader and oracle loader:
+    the same windows, chunks, regions, annotations and truth labels as the store; --contigsList subsetting."""
+    st = synth.synthesize([250_000, 61_000, 1_000], 1000, 100_000, [20, 33], seed=9, region_run_bases=(4_000, 30_000))
+    path = str(tmp_path / f"s.{ext}")
+    st.write_cov(path)
+    tab = fio.Table(path, 100_000, 1000)
+    got = tab.store()
+    for name in ("cov", "mapq", "clip", "annot", "truth", "chunk_off", "chunk_s", "chunk_e", "chunk_ctg_len"):
+        assert np.array_equal(getattr(got, name), getattr(st, name)), name
+    assert list(got.chunk_ctg) == list(st.chunk_ctg) and got.region_coverages == st.region_coverages
+    ref = _oracle_load_cov(path, 100_000, 1000, tmp_path)
+    assert np.array_equal(ref.cov, st.cov) and np.array_equal(ref.annot, st.annot) and np.array_equal(ref.chunk_off, st.chunk_off)
+    # keep two of the three contigs (hfio_subset_contigs, chunk.c:218-237)
+    import ctypes as C
+    L = tab._L
+    L.hfio_subset_contigs.restype = C.c_int32
+    L.hfio_subset_contigs.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_int]
+    names = (C.c_char_p * 2)(b"ctg2", b"ctg0")
+    kept = L.hfio_subset_contigs(tab._h, names, 2)
+    sub = tab.store()
+    want = st.subset_chunks([c for c in range(st.n_chunks) if st.chunk_ctg[c] in ("ctg0", "ctg2")])
+    assert kept == want.n_chunks and np.array_equal(sub.cov, want.cov) and list(sub.chunk_ctg) == list(want.chunk_ctg)
