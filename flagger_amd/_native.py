@@ -89,6 +89,7 @@ def lib() -> C.CDLL:
     sig("hf_reduce_chunks", C.c_int, vp, vp, i64, vp, vp)
     sig("hf_reduce_chunks_indexed", C.c_int, vp, vp, vp, i64, vp, vp)
     sig("hf_finish", C.c_int, vp, pd, vp)
+    sig("hf_finish_gathered", C.c_int, vp, vp, vp, i64, pd, vp)
     sig("hf_check", C.c_int, vp, vp)
     sig("hf_get_labels", C.c_int, vp, C.POINTER(C.c_int8))
     sig("hf_get_posterior", C.c_int, vp, i64, i64, pd)

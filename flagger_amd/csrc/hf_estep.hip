@@ -1180,6 +1180,25 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
     return flags_to_code((unsigned) ctx->h_total[ctx->V]);
 }
 
+// Multi-GPU counterpart of hf_finish: the rows of ALL chunks are in `rows_dev` (all-gathered, row_index_dev maps list
+// position -> row); reduce them in the fixed order straight into pinned host memory, wait, translate the flags of
+// THIS rank's pass.  One synchronisation per EM step.
+int hf_finish_gathered(hf_ctx* ctx, const double* rows_dev, const int32_t* row_index_dev, int64_t n_chunks, double* stats_host,
+                       void* stream) {
+    if (!ctx || !rows_dev || !stats_host || n_chunks < 0) return set_err(HF_E_ARG, "hf_finish_gathered: bad argument");
+    hipStream_t st = (hipStream_t) stream;
+    double* out = ctx->d_total_host ? ctx->d_total_host : ctx->d_total;
+    int rc = hf_reduce_chunks_indexed(ctx, rows_dev, row_index_dev, n_chunks, out, stream);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ctx->ev1, st));
+    if (!ctx->d_total_host)
+        HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    accumulate_kernel_times(ctx);
+    std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
+    return flags_to_code((unsigned) ctx->h_total[ctx->V]);
+}
+
 // One EM step in one call: E-step with the model's current parameters, reduced statistics back on the host,
 // then (do_mstep) HMM_estimateParameters.  What runHMMFlagger repeats (hmm_flagger.c:337-445) without going back
 // to the caller between the two halves.

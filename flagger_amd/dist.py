@@ -73,7 +73,10 @@ class ShardedEMList:
         else:
             self.local.chunk_stats_into(self.recv[0])
         # every rank sums ALL chunks in global list order straight out of the gathered buffer
-        self.local.reduce_into(self.recv.view(self.world * self.maxc, self.V), self.row_index, self.n_chunks_total, self.total)
+        rows = self.recv.view(self.world * self.maxc, self.V)
+        if hasattr(self.local, "finish_gathered"):        # HIP backend: sum into pinned host memory, one sync, flags checked
+            return self.local.finish_gathered(rows, self.row_index, self.n_chunks_total).copy()
+        self.local.reduce_into(rows, self.row_index, self.n_chunks_total, self.total)
         stats = self.total.cpu().numpy().copy()           # device->host copy synchronises the stream
         self.local.check()
         return stats
@@ -113,6 +116,9 @@ class HipLocal:
 
     def reduce_into(self, rows, row_index, n_chunks, total):
         self.em.reduce_chunks_indexed(rows.data_ptr(), row_index.data_ptr(), n_chunks, total.data_ptr())
+
+    def finish_gathered(self, rows, row_index, n_chunks):
+        return self.em.finish_gathered(rows.data_ptr(), row_index.data_ptr(), n_chunks)
 
     def check(self):
         self.em.check()

@@ -200,6 +200,14 @@ class EMList:
     def copy_chunk_stats(self, dst_dev_ptr: int) -> None:
         N.check(self._L.hf_copy_chunk_stats(self._h, C.c_void_p(dst_dev_ptr), self.stream), "hf_copy_chunk_stats")
 
+    def finish_gathered(self, rows_dev_ptr: int, row_index_dev_ptr: int, n_chunks: int) -> np.ndarray:
+        """Fixed-order sum of the all-gathered per-chunk vectors into host memory + flag check: one sync (hf_finish_gathered)."""
+        if not hasattr(self, "_stats_buf"):
+            self._stats_buf = np.empty(self.stats_len, dtype=np.float64)
+        N.check(self._L.hf_finish_gathered(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr), n_chunks,
+                                           _dptr(self._stats_buf), self.stream), "hf_finish_gathered")
+        return self._stats_buf
+
     def reduce_chunks_indexed(self, rows_dev_ptr: int, row_index_dev_ptr: int, n_chunks: int, dst_dev_ptr: int) -> None:
         N.check(self._L.hf_reduce_chunks_indexed(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr), n_chunks,
                                                  C.c_void_p(dst_dev_ptr), self.stream), "hf_reduce_chunks_indexed")

@@ -135,6 +135,12 @@ int hf_reduce_chunks(hf_ctx *ctx, const double *chunk_stats_dev, int64_t n_chunk
 int hf_reduce_chunks_indexed(hf_ctx *ctx, const double *rows_dev, const int32_t *row_index_dev, int64_t n_chunks,
                              double *out_dev, void *stream);
 
+/* Multi-GPU counterpart of hf_finish: `rows_dev` holds the per-chunk vectors of ALL ranks (all-gathered; row_index_dev[c]
+ * = row of list position c, or NULL when packed), summed in the fixed order into `stats_host`; waits for the stream
+ * and translates the device error flags of this rank's pass.  Every rank gets identical bits. */
+int hf_finish_gathered(hf_ctx *ctx, const double *rows_dev, const int32_t *row_index_dev, int64_t n_chunks,
+                       double *stats_host, void *stream);
+
 /* Single-GPU convenience: reduce this context's chunks, copy the vector to `stats_host`,
  * wait for the stream and translate the device error flags (HF_E_SCALE / HF_E_NAN / ...). */
 int hf_finish(hf_ctx *ctx, double *stats_host, void *stream);
