@@ -296,8 +296,11 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
 // gives the tile product Pt.  Chunk-first windows are excluded from Q_l and Pt.  Every row a pass uses goes
 // through here once: this is where a NaN row raises HF_E_NAN (hmm_utils.c:783-786).
 // ------------------------------------------------------------------------------------------
+#ifndef HF_PROD_BLOCKS
+#define HF_PROD_BLOCKS 3
+#endif
 template <int L>
-__global__ void __launch_bounds__(256) k_prod_tile(int ntiles, const TileDesc* __restrict__ td,
+__global__ void __launch_bounds__(256, HF_PROD_BLOCKS) k_prod_tile(int ntiles, const TileDesc* __restrict__ td,
                                                    const uint32_t* __restrict__ rec, const DevParams* __restrict__ P,
                                                    const RowSrc S, double* __restrict__ Qs, double* __restrict__ Pt,
                                                    unsigned* __restrict__ flags) {
