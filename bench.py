@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink contig lengths (testing only; 1.0 = BASELINE workload)")
     ap.add_argument("--algo", choices=["scan", "seq"], default="scan")
+    ap.add_argument("--config", type=int, choices=[2, 4], default=2,
+                    help="BASELINE.json configs[n]: 2 = the headline workload (default); 4 = ONT-R10 preset, 7 bias regions, 8 kb windows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events inside the timed region (the pass then runs as one HIP graph); the dominant kernel's "
@@ -95,9 +97,9 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node <gpus>"
 
     # ---- workload: BASELINE.json configs[2] (= configs[3] when sharded over 8 GPUs) ----
-    store = synth.config(2, scale=args.scale)
+    store = synth.config(args.config, scale=args.scale)
     K = hmm.getBestNumberOfCollapsedComps(store)
-    alpha = synth.HIFI_ALPHA
+    alpha = synth.HIFI_ALPHA if args.config == 2 else synth.ONT_R10_ALPHA
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
     algo = N.HF_ALGO_SCAN if args.algo == "scan" else N.HF_ALGO_SEQ
     torch.cuda.set_device(local_rank)
@@ -162,7 +164,7 @@ def main():
         # made by profiles/pmc_summary.py on this same command; FETCH_SIZE x2 on gfx950): full workload, 1 GPU only
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and world == 1 and args.scale == 1.0:
+        if os.path.exists(pmc) and world == 1 and args.scale == 1.0 and args.config == 2:
             try:
                 for k, v in json.load(open(pmc)).items():
                     if k.split("<")[0] == dom:
@@ -175,9 +177,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: synthetic 2x3.03 Gb diploid HiFi-like coverage, "
-                                   "4 kb windows, 20 Mb chunks, trunc_exp_gaussian, HiFi v1.1.0 alpha, full EM step "
-                                   "(E-step+decode on GPU, M-step on host)" + ("" if args.scale == 1.0 else f" [scale {args.scale}]"),
+            "config": {"workload": ("BASELINE.json configs[2]: synthetic 2x3.03 Gb diploid HiFi-like coverage, "
+                                    "4 kb windows, 20 Mb chunks, trunc_exp_gaussian, HiFi v1.1.0 alpha, full EM step "
+                                    "(E-step+decode on GPU, M-step on host)" if args.config == 2 else
+                                    "BASELINE.json configs[4]: synthetic 2x3.03 Gb diploid, ONT-R10 preset (8 kb windows), 7 bias "
+                                    "regions with their own emission parameters, ONT-R10 v1.1.0 alpha, full EM step")
+                                   + ("" if args.scale == 1.0 else f" [scale {args.scale}]"),
                        "n_windows": n_windows, "n_chunks": store.n_chunks, "collapsed_comps": K,
                        "algo": args.algo, "parallelism": f"chunks sharded over {world} GPU(s), all-gather of per-chunk statistics"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
