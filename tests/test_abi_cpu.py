@@ -43,3 +43,20 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
     with pytest.raises(N.HFError) as ei:
         hmm.EMList(store, model)
     assert ei.value.code == N.HF_E_NOGPU
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under flagger_amd/ may import, link or execute it, and the shared
+    library must not depend on liboracle_hf.so."""
+    import re
+    import subprocess
+    pkg = os.path.join(ROOT, "flagger_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+\S*oracle", text, re.M), f
+                assert "liboracle" not in text and "ohf_" not in text and "oracle/" not in text, f
+    so = os.path.join(pkg, "csrc", "libhmmflagger_hip.so")
+    needed = subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout
+    assert "oracle" not in needed
