@@ -628,7 +628,15 @@ __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__
         if (!((present >> r) & 1ull)) continue;
         if (tid < NA) {
             double v = 0.0;
-            for (int k = 0; k < nt; k++) v += tile_stats[((int64_t) (k0 + k) * nreg + r) * NA + tid];
+            int k = 0;
+            for (; k + 8 <= nt; k += 8) {   // 8 loads in flight, adds stay in tile order
+                double xk[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) xk[u] = tile_stats[((int64_t) (k0 + k + u) * nreg + r) * NA + tid];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v += xk[u];
+            }
+            for (; k < nt; k++) v += tile_stats[((int64_t) (k0 + k) * nreg + r) * NA + tid];
             red[tid] = v;
         }
         __syncthreads();
@@ -1060,7 +1068,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         if (nbm) {
             if (fl) {
                 KTimer t(ctx, st, HF_K_STATS_TILE);
-                const TileGeom g = tile_geom(ctx, k_stats_tile_nb<HF_SCAN_L>, (size_t) (64 * 16 + 64 + 16 * 64) * 8);
+                const TileGeom g = tile_geom(ctx, k_stats_tile_nb<HF_SCAN_L>, (size_t) HF_NB_WAVE_LDS * 8);
                 if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile_nb<HF_SCAN_L>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles, ctx->d_tile_desc,
                                    ctx->d_rec, S, ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_hist);

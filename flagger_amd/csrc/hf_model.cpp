@@ -158,6 +158,9 @@ void hfm_params(const hfm_model* m, hf_params* out) {
     // (hmm_utils.c:480-520), component probabilities P[r][s][c][x], digamma table (:394-408), r and beta (:545-547)
     const int NX = kMaxCov + 1, K = m->K;
     hfm_model* mm = const_cast<hfm_model*>(m);
+    static double lgx1[kMaxCov + 1];                       // lgamma(x + 1), x = 0..250
+    static bool lgx1_ready = false;
+    if (!lgx1_ready) { for (int x = 0; x < NX; x++) lgx1[x] = lgamma(x + 1); lgx1_ready = true; }
     m->nb_E.assign((size_t) m->R * S * NX, 0.0);
     m->nb_P.assign((size_t) m->R * S * K * NX, 0.0);
     m->nb_dig.assign((size_t) m->R * S * K * NX, 0.0);
@@ -173,8 +176,10 @@ void hfm_params(const hfm_model* m, hf_params* out) {
                 m->nb_beta[pc] = -1 * theta / (1 - theta) - 1 / std::log(theta);
                 double* P = &m->nb_P[pc * NX];
                 double* D = &m->nb_dig[pc * NX];
+                // the x-independent terms once per component (pure functions of the same arguments: same doubles)
+                const double lg_r = lgamma(rr), r_log_theta = rr * std::log(theta), log_1m_theta = std::log(1 - theta);
                 for (int x = 0; x < NX; x++) {
-                    double p = w * std::exp(lgamma(rr + x) - lgamma(rr) - lgamma(x + 1) + rr * std::log(theta) + (double) x * std::log(1 - theta));
+                    double p = w * std::exp(lgamma(rr + x) - lg_r - lgx1[x] + r_log_theta + (double) x * log_1m_theta);
                     if (!(p != p) && p < 1e-40) p = 1e-40;       // NaN is kept: the E-step reports it if the value is used
                     P[x] = p;
                 }

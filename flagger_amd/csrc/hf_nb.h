@@ -55,10 +55,13 @@ __global__ void __launch_bounds__(256) k_tables_nb(int n_keys, const int32_t* __
     }
 }
 
-// One wavefront per tile.  Per step j every lane computes the 16 xi values of the pair ending at its j-th window and
-// parks them in LDS; lanes 0..15 add the 64 records' values to their transition accumulator, and the lane that owns
-// bin min(x,249) (owner = bin % 64) adds the record to its count-data bins — records are visited in a fixed order, so
-// the sums are reproducible.
+// One wavefront per tile, lane l owns the pairs that end at its L windows.  The 16 xi values of a pair go to the lane's
+// transition accumulators (registers) and to the wave-private count data hist[state][min(x,249)] in LDS.  Lanes whose
+// pairs fall into the same bin are serialised in ascending lane order: every pending lane bids for its bin with an LDS
+// atomic MIN of its lane number (the result does not depend on the order of the bids), the winner adds its four
+// values per state (state outer / pre inner, hmm.c:588-589) and retires; rounds repeat until no lane is pending — as
+// many rounds as the most crowded bin has pairs.  A fixed order, so the sums are reproducible.
+#define HF_NB_WAVE_LDS (16 * 65 + 4 * 256 + 128)     // doubles per wavefront: lane-sum rows, count data, bids (256 x u32)
 template <int L>
 __global__ void __launch_bounds__(256) k_stats_tile_nb(int ntiles, const TileDesc* __restrict__ td,
                                                        const uint32_t* __restrict__ rec, const RowSrc S,
@@ -70,10 +73,9 @@ __global__ void __launch_bounds__(256) k_stats_tile_nb(int ntiles, const TileDes
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (blockDim.x >> 6) + wave;   // 4 wavefronts per block unless LDS forces fewer
     if (tile >= ntiles) return;
-    // per wave: records [64][16], bins of the records [64] (as doubles), histogram [4 states][4 bins][64 lanes]
-    double* __restrict__ s_rec = s_tab + P->n_regions * HF_TAB_STRIDE + wave * (64 * 16 + 64 + 16 * 64);
-    double* __restrict__ s_bin = s_rec + 64 * 16;
-    double* __restrict__ s_hist = s_bin + 64;
+    double* __restrict__ s_row = s_tab + P->n_regions * HF_TAB_STRIDE + wave * HF_NB_WAVE_LDS;   // [16][65]
+    double* __restrict__ s_hist = s_row + 16 * 65;                                                // [4][256]
+    unsigned* __restrict__ s_bid = reinterpret_cast<unsigned*>(s_hist + 4 * 256);                 // [256]
     const TileDesc d = td[tile];
     const int64_t t0 = d.t0, T = d.T, base = d.base;
     const int nreg = P->n_regions;
@@ -92,6 +94,7 @@ __global__ void __launch_bounds__(256) k_stats_tile_nb(int ntiles, const TileDes
     }
     for (int o = 32; o > 0; o >>= 1) present |= __shfl_xor(present, o);
     const unsigned long long in_chunk = regmask[d.chunk];
+    for (int i = lane; i < 256; i += 64) s_bid[i] = 0xffffffffu;
     for (int r = 0; r < nreg; r++) {
         if (!((in_chunk >> r) & 1ull)) continue;
         double* __restrict__ dst = tile_hist + ((int64_t) tile * nreg + r) * HF_NB_TILE_VEC;
@@ -99,13 +102,18 @@ __global__ void __launch_bounds__(256) k_stats_tile_nb(int ntiles, const TileDes
             for (int i = lane; i < HF_NB_TILE_VEC; i += 64) dst[i] = 0.0;
             continue;
         }
-        double trans_acc = 0.0;                              // lanes 0..15: entry pre*4+s = lane
+        double tr[16];                                        // transition counts of this lane's pairs, [pre*4 + s]
 #pragma unroll
-        for (int i = 0; i < 16; i++) s_hist[i * 64 + lane] = 0.0;
+        for (int k = 0; k < 16; k++) tr[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) s_hist[i * 64 + lane] = 0.0;   // hist[s][bin]: s*256 + bin
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll 1
         for (int j = 0; j < L; j++) {
             const bool mine = ok[j] && (int) REC_REGION(rr[j + 1]) == r;
-            double adj[16];
+            double adj[16];                                   // state-major: [s*4 + pre]
 #pragma unroll
             for (int k = 0; k < 16; k++) adj[k] = 0.0;
             if (mine) {
@@ -126,45 +134,52 @@ __global__ void __launch_bounds__(256) k_stats_tile_nb(int ntiles, const TileDes
                     for (int p = 0; p < 4; p++) {
                         const double count = f[p] * Tm[HF_PS(p, s)] * Ev[HF_PS(p, s)] * b1[s];
                         adj[s * 4 + p] = count / HF_TERMINATION_PROB;     // hmm.c:613-614
+                        tr[p * 4 + s] += adj[s * 4 + p];                  // hmm_utils.c:2010-2015
                     }
             }
+            const unsigned x = REC_X(rr[j + 1]);
+            const int bin = (int) (x < HF_NB_MAX_COVERAGE ? x : HF_NB_MAX_COVERAGE - 1);          // count_data.c:49-57
+            bool pending = mine;
+            while (__any(pending)) {
+                if (pending) atomicMin(&s_bid[bin], (unsigned) lane);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const bool win = pending && s_bid[bin] == (unsigned) lane;
+                if (win) {
 #pragma unroll
-            for (int k = 0; k < 16; k++) s_rec[lane * 16 + k] = adj[k];   // state-major: [s*4 + pre]
-            {
-                const unsigned x = REC_X(rr[j + 1]);
-                s_bin[lane] = mine ? (double) (x < HF_NB_MAX_COVERAGE ? x : HF_NB_MAX_COVERAGE - 1) : -1.0;   // count_data.c:49-57
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < 16) {                                  // hmm_utils.c:2010-2015; lane = pre*4 + s reads record entry s*4 + pre
-                const int e = (lane & 3) * 4 + (lane >> 2);
-#pragma unroll 8
-                for (int k = 0; k < 64; k++) trans_acc += s_rec[k * 16 + e];
-            }
-#pragma unroll 1
-            for (int k = 0; k < 64; k++) {
-                const int xb = (int) s_bin[k];
-                if (xb >= 0 && (xb & 63) == lane) {
-                    const int bin = xb >> 6;
+                    for (int s = 0; s < 4; s++) {
+                        double h = s_hist[s * 256 + bin];
 #pragma unroll
-                    for (int s = 0; s < 4; s++) {             // state outer, pre inner: the reference's order (hmm.c:588-589)
-                        double h = s_hist[(s * 4 + bin) * 64 + lane];
-#pragma unroll
-                        for (int p = 0; p < 4; p++) h += s_rec[k * 16 + s * 4 + p];
-                        s_hist[(s * 4 + bin) * 64 + lane] = h;
+                        for (int p = 0; p < 4; p++) h += adj[s * 4 + p];
+                        s_hist[s * 256 + bin] = h;
                     }
+                    s_bid[bin] = 0xffffffffu;
+                    pending = false;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        if (lane < 16) dst[lane] = trans_acc;
+        // transition counts: sums over the 64 lanes through LDS rows, one lane per entry, lane order
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int k = 0; k < 16; k++) s_row[k * 65 + lane] = tr[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 16) {
+            const double* __restrict__ row = s_row + lane * 65;
+            double v = 0.0;
+#pragma unroll 8
+            for (int l = 0; l < 64; l++) v += row[l];
+            dst[lane] = v;
+        }
 #pragma unroll
-            for (int b = 0; b < 4; b++) dst[16 + s * 256 + b * 64 + lane] = s_hist[(s * 4 + b) * 64 + lane];
+        for (int i = 0; i < 16; i++) dst[16 + i * 64 + lane] = s_hist[i * 64 + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -196,7 +211,15 @@ __global__ void __launch_bounds__(256) k_chunk_stats_nb(const int32_t* __restric
         double* __restrict__ dst = vec + 1 + r * rstride;
         for (int i = tid; i < HF_NB_TILE_VEC; i += blockDim.x) {
             double v = 0.0;
-            for (int k = 0; k < nt; k++) v += tile_hist[((int64_t) (k0 + k) * nreg + r) * HF_NB_TILE_VEC + i];
+            int k = 0;
+            for (; k + 8 <= nt; k += 8) {   // 8 loads in flight, adds stay in tile order
+                double xk[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) xk[u] = tile_hist[((int64_t) (k0 + k + u) * nreg + r) * HF_NB_TILE_VEC + i];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v += xk[u];
+            }
+            for (; k < nt; k++) v += tile_hist[((int64_t) (k0 + k) * nreg + r) * HF_NB_TILE_VEC + i];
             if (i < 16) dst[24 * K + i] = v;
             else counts[(i - 16) >> 8][(i - 16) & 255] = v;
         }
@@ -224,17 +247,13 @@ __global__ void __launch_bounds__(256) k_chunk_stats_nb(const int32_t* __restric
             dst[((s * 3 + 1) * 2 + 0) * K + cc] = la_num; dst[((s * 3 + 1) * 2 + 1) * K + cc] = la_den;
             dst[((s * 3 + 2) * 2 + 0) * K + cc] = w_num;
         }
-        // thread 64 + s: the weight estimator's denominator, shared by all components of state s (hmm_utils.c:66-74):
-        // every w of every component, x outer / component inner
+        // the weight estimator's denominator is shared by all components of a state (hmm_utils.c:66-74): the sum of every
+        // component's w — taken here as the sum over components (index order) of their own sums over x
+        __syncthreads();
         if (tid >= 64 && tid < 68) {
             const int s2 = tid - 64, nc = P->ncomp[s2];
-            const double* __restrict__ Ex = nb.E + ((int64_t) r * 4 + s2) * HF_NB_NX;
             double den = 0.0;
-            for (int x = 0; x < HF_NB_MAX_COVERAGE; x++) {
-                const double count = counts[s2][x];
-                if (0 < count)
-                    for (int c2 = 0; c2 < nc; c2++) den += count * nb.P[(((int64_t) r * 4 + s2) * K + c2) * HF_NB_NX + x] / Ex[x];
-            }
+            for (int c2 = 0; c2 < nc; c2++) den += dst[((s2 * 3 + 2) * 2 + 0) * K + c2];
             for (int c2 = 0; c2 < nc; c2++) dst[((s2 * 3 + 2) * 2 + 1) * K + c2] = den;
         }
         __syncthreads();
