@@ -33,6 +33,8 @@
 // of dependent loads
 // slow0 = position in the slow list of the tile's first slow window
 struct TileDesc { long long t0; int T; int base; int chunk; int slow0; };
+// per chunk, for k_carry: first tile, number of tiles, first slow row, region of the first / last window (one 32-byte load)
+struct CarryDesc { int32_t k0, nt, slow0, reg_first, reg_last, pad0, pad1, pad2; };
 
 // Layout of the forward / backward arrays f, b (double2 units): tile-major, lane-minor —
 //   slot(tile, lane, j, h) = ((tile*L + j)*2 + h)*64 + lane     window = tile base + lane*L + j, h: states (0,1) / (2,3)

@@ -54,7 +54,7 @@ struct hf_ctx {
     double* d_total_host = nullptr; // device address of the pinned h_total: k_reduce writes the result straight to the host
     // scan algorithm: tile tables and per-tile work arrays
     TileDesc* d_tile_desc = nullptr;
-    int ntiles = 0; int32_t* d_chunk_tile0 = nullptr;
+    int ntiles = 0; int32_t* d_chunk_tile0 = nullptr; CarryDesc* d_carry_desc = nullptr;
     double* d_Pt = nullptr; double* d_cf = nullptr; double* d_cb = nullptr; double* d_tile_ll = nullptr;
     double* d_tile_stats = nullptr; // [ntiles][R][NA(16)]
     double* d_Qs = nullptr;         // [ntiles][64][16] lane products
@@ -885,6 +885,15 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         ctx->ntiles = (int) desc.size();
         TRY(dev_upload(&ctx->d_tile_desc, desc.data(), desc.size()));
         TRY(dev_upload(&ctx->d_chunk_tile0, ctile0.data(), ctile0.size()));
+        std::vector<CarryDesc> cdesc(C);
+        for (size_t c = 0; c < C; c++) {
+            const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+            CarryDesc d = {ctile0[c], ctile0[c + 1] - ctile0[c], soff[c], 0, 0, 0, 0, 0};
+            if (T > 0) { d.reg_first = (int32_t) ((w->annot[t0] & 0xFC00000000000000ULL) >> 58);
+                         d.reg_last = (int32_t) ((w->annot[t0 + T - 1] & 0xFC00000000000000ULL) >> 58); }
+            cdesc[c] = d;
+        }
+        TRY(dev_upload(&ctx->d_carry_desc, cdesc.data(), cdesc.size()));
         const size_t nt = (size_t) ctx->ntiles;
         DMALLOC(ctx->d_Pt, nt * 16 * 8); DMALLOC(ctx->d_cf, nt * 4 * 8); DMALLOC(ctx->d_cb, nt * 4 * 8);
         DMALLOC(ctx->d_tile_ll, nt * 8);
@@ -906,7 +915,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
-    hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_Pt);
+    hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_carry_desc); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
@@ -1042,8 +1051,8 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 }
                 {
                     KTimer t(ctx, st, HF_K_CARRY);
-                    hipLaunchKernelGGL(k_carry, dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
-                                       ctx->d_Es, ctx->d_slow_off, ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb);
+                    hipLaunchKernelGGL(k_carry, dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_carry_desc, ctx->d_Es,
+                                       ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb);
                 }
                 KTimer t(ctx, st, HF_K_FB_TILE);
 #ifdef HF_FB_LDS

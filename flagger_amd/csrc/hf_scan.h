@@ -418,31 +418,28 @@ __device__ __forceinline__ void load_lane_product(M4& Q, const double* __restric
 // HF_CARRY_BATCH tiles (coalesced loads by all 64 lanes), then lane 0 runs the dependent chain out of LDS.
 // ------------------------------------------------------------------------------------------
 #define HF_CARRY_BATCH 128
-__global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
-                                               const uint32_t* __restrict__ rec, const double* __restrict__ Es,
-                                               const int32_t* __restrict__ slow_off,
+__global__ void __launch_bounds__(128) k_carry(const CarryDesc* __restrict__ cdesc, const double* __restrict__ Es,
                                                const DevParams* __restrict__ P, const double* __restrict__ Pt,
                                                double* __restrict__ cf, double* __restrict__ cb) {
     __shared__ __attribute__((aligned(16))) double s_pt[2][HF_CARRY_BATCH * 16];
-    __shared__ double s_out[2][HF_CARRY_BATCH * 4];
-    const int c = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t t0 = off[c], T = off[c + 1] - t0;
-    if (T <= 0) return;
-    const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
+    __shared__ __attribute__((aligned(16))) double s_out[2][HF_CARRY_BATCH * 4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const CarryDesc D = cdesc[blockIdx.x];
+    const int k0 = D.k0, nt = D.nt;
+    if (nt <= 0) return;
     double* __restrict__ sp = s_pt[wave];
     double* __restrict__ so = s_out[wave];
     double v[4];
     if (wave == 0) {   // start∘e of the chunk's first window (its row is the chunk's first entry of the slow list)
-        const uint32_t r0 = rec[t0];
-        const DevRegion* __restrict__ R = &P->reg[REC_REGION(r0)];
-        const double* __restrict__ E0 = Es + (int64_t) slow_off[c] * 16;
+        const DevRegion* __restrict__ R = &P->reg[D.reg_first];
+        const double* __restrict__ E0 = Es + (int64_t) D.slow0 * 16;
         double sv = 0.0;
 #pragma unroll
         for (int s = 0; s < 4; s++) { v[s] = E0[HF_PS(0, s)] * R->trans[4][s]; sv += v[s]; }
 #pragma unroll
         for (int s = 0; s < 4; s++) v[s] /= sv;
     } else {
-        const DevRegion* __restrict__ R = &P->reg[REC_REGION(rec[t0 + T - 1])];
+        const DevRegion* __restrict__ R = &P->reg[D.reg_last];
         double sw = 0.0;
 #pragma unroll
         for (int s = 0; s < 4; s++) { v[s] = R->trans[s][4]; sw += v[s]; }
@@ -462,12 +459,11 @@ __global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, 
         __builtin_amdgcn_s_waitcnt(0);   // the wave's own LDS stores have landed (one wave per half: no block barrier)
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) {
+            // the chain carries the vector renormalised by a power of two (exact, and nothing else on the dependent
+            // path: one lane of one wavefront per SIMD pays the full latency of every instruction)
             if (wave == 0) {
-                // the chain carries the vector renormalised by a power of two (exact, no division on the dependent
-                // path); what a tile starts from is that vector divided by its sum (the reference's f sums to 1)
                 for (int k = 0; k < n; k++) {
-                    const double sv = v[0] + v[1] + v[2] + v[3];
-                    so[k * 4 + 0] = v[0] / sv; so[k * 4 + 1] = v[1] / sv; so[k * 4 + 2] = v[2] / sv; so[k * 4 + 3] = v[3] / sv;
+                    so[k * 4 + 0] = v[0]; so[k * 4 + 1] = v[1]; so[k * 4 + 2] = v[2]; so[k * 4 + 3] = v[3];
                     const double* __restrict__ M = sp + k * 16;
                     double u[4];
 #pragma unroll
@@ -482,7 +478,7 @@ __global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, 
                     for (int j = 0; j < 4; j++) v[j] = ldexp(u[j], -e);
                 }
             } else {
-                for (int k = n - 1; k >= 0; k--) {        // only the direction of b is used: power-of-two renormalisation
+                for (int k = n - 1; k >= 0; k--) {        // only the direction of b is used
                     so[k * 4 + 0] = v[0]; so[k * 4 + 1] = v[1]; so[k * 4 + 2] = v[2]; so[k * 4 + 3] = v[3];
                     const double* __restrict__ M = sp + k * 16;
                     double u[4];
@@ -501,8 +497,18 @@ __global__ void __launch_bounds__(128) k_carry(const int64_t* __restrict__ off, 
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        {
-            double* __restrict__ dst = (wave == 0 ? cf : cb) + (int64_t) (k0 + b0) * 4;
+        if (wave == 0) {
+            // what a tile starts from is the carried vector divided by its sum (the reference's f sums to 1): one tile
+            // per lane, off the chain
+            double2* __restrict__ dst = reinterpret_cast<double2*>(cf + (int64_t) (k0 + b0) * 4);
+            const double2* __restrict__ so2 = reinterpret_cast<const double2*>(so);
+            for (int k = lane; k < n; k += 64) {
+                const double2 a = so2[k * 2], b = so2[k * 2 + 1];
+                const double sv = a.x + a.y + b.x + b.y;
+                dst[k * 2] = make_double2(a.x / sv, a.y / sv); dst[k * 2 + 1] = make_double2(b.x / sv, b.y / sv);
+            }
+        } else {
+            double* __restrict__ dst = cb + (int64_t) (k0 + b0) * 4;
             for (int i = lane; i < n * 4; i += 64) dst[i] = so[i];
         }
         __builtin_amdgcn_s_waitcnt(0);
