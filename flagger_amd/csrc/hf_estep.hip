@@ -25,6 +25,8 @@
 #include <cstring>
 #include <cstdio>
 #include <cmath>
+#include <chrono>
+#include <cstdlib>
 
 static thread_local std::string g_err;
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
@@ -55,6 +57,7 @@ struct hf_ctx {
     // scan algorithm: tile tables and per-tile work arrays
     TileDesc* d_tile_desc = nullptr;
     int ntiles = 0; int32_t* d_chunk_tile0 = nullptr; CarryDesc* d_carry_desc = nullptr;
+    bool host_trace = false; double ht[5] = {0, 0, 0, 0, 0}; long ht_n = 0;   // HF_HOST_TRACE=1: where an EM step's host time goes
     double* d_Pt = nullptr; double* d_cf = nullptr; double* d_cb = nullptr; double* d_tile_ll = nullptr;
     double* d_tile_stats = nullptr; // [ntiles][R][NA(16)]
     double* d_Qs = nullptr;         // [ntiles][64][16] lane products
@@ -903,6 +906,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         ctx->h_tile0 = ctile0;
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
     }
+    { const char* e = std::getenv("HF_HOST_TRACE"); ctx->host_trace = e && e[0] == '1'; }
     *out = ctx;
     return HF_OK;
 }
@@ -910,6 +914,9 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
 void hf_destroy(hf_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->host_trace && ctx->ht_n)
+        std::fprintf(stderr, "[hf host trace] %ld EM steps: enqueue %.1f us, wait %.1f us, m-step %.1f us, gpu span (first launch .. reduction) %.1f us\n",
+                     ctx->ht_n, ctx->ht[0] / ctx->ht_n, ctx->ht[1] / ctx->ht_n, ctx->ht[2] / ctx->ht_n, ctx->ht[3] / ctx->ht_n);
     hipFree(ctx->d_off); hipFree(ctx->d_rec); hipFree(ctx->d_beta); hipFree(ctx->d_regmask); hipFree(ctx->d_E);
     hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); hipFree(ctx->d_chunk_stats);
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
@@ -1284,15 +1291,27 @@ int hf_em_iterate(hf_ctx* ctx, hfm_model* model, int mode, int do_mstep, double 
             ctx->graphs[0].key = ctx->graphs[1].key = -1;   // capture is not available here: plain launches from now on
         }
     }
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    auto t1 = t0, t2 = t0;
     if (!done) {
         rc = hf_estep(ctx, &p, mode, stream);
+        t1 = clk::now();
         if (rc == HF_OK) rc = hf_finish(ctx, stats_host, stream);
+        t2 = clk::now();
     }
     if (rc != HF_OK) return rc;
     hfm_set_loglikelihood(model, stats_host[0]);
     if (do_mstep && mode == HF_MODE_FULL) {
         const int cv = hfm_estimate(model, stats_host, tol);
         if (converged) *converged = cv;
+    }
+    if (ctx->host_trace && !done) {
+        const auto t3 = clk::now();
+        float gpu_ms = 0.f;
+        (void) hipEventElapsedTime(&gpu_ms, ctx->ev0, ctx->ev1);
+        auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        ctx->ht[0] += us(t0, t1); ctx->ht[1] += us(t1, t2); ctx->ht[2] += us(t2, t3); ctx->ht[3] += gpu_ms * 1e3; ctx->ht_n++;
     }
     return HF_OK;
 }
