@@ -105,6 +105,8 @@ def main():
     torch.cuda.set_device(local_rank)
     sharded = fdist.make_sharded_hip(store, model, rank, world, local_rank, True, 0.95, algo)
     em = sharded.local.em
+    if not dist_path:                      # one GPU, no exchange: statistics by emission row (the library's default)
+        em.set_stats_mode(N.HF_STATS_ROWS)
     em.set_profiling(True)                 # warm-up passes time every kernel to find the dominant one
     n_windows = store.n_windows
 
@@ -184,7 +186,9 @@ def main():
                                     "regions with their own emission parameters, ONT-R10 v1.1.0 alpha, full EM step")
                                    + ("" if args.scale == 1.0 else f" [scale {args.scale}]"),
                        "n_windows": n_windows, "n_chunks": store.n_chunks, "collapsed_comps": K,
-                       "algo": args.algo, "parallelism": f"chunks sharded over {world} GPU(s), all-gather of per-chunk statistics"},
+                       "algo": args.algo,
+                       "statistics": "per chunk, ordered reduction" if em.stats_mode == N.HF_STATS_CHUNKS else "by emission row",
+                       "parallelism": f"chunks sharded over {world} GPU(s), all-gather of per-chunk statistics"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                          "kernel_ms_timed": dom_ms, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_WINDOW * local_windows,

@@ -11,10 +11,11 @@ import os
 HF_NSTATES = 4
 HF_MAXCOMP = 16
 HF_MAXREGIONS = 64
-HF_NKERNELS = 10
+HF_NKERNELS = 13
 HF_MODEL_TRUNC_EXP_GAUSSIAN, HF_MODEL_GAUSSIAN, HF_MODEL_NEGATIVE_BINOMIAL = 0, 1, 2
 HF_MODE_FULL, HF_MODE_FORWARD_ONLY = 0, 1
 HF_ALGO_SCAN, HF_ALGO_SEQ = 0, 1
+HF_STATS_CHUNKS, HF_STATS_ROWS = 0, 1
 HF_OK, HF_E_ARG, HF_E_HIP, HF_E_SCALE, HF_E_NAN, HF_E_REGION, HF_E_NOGPU = 0, -1, -2, -3, -4, -5, -6
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhmmflagger_hip.so")
@@ -99,6 +100,8 @@ def lib() -> C.CDLL:
     sig("hf_kernel_times", C.c_int, vp, C.POINTER(C.c_float))
     sig("hf_kernel_time_sums", C.c_int, vp, pd, C.POINTER(C.c_int64))
     sig("hf_kernel_name", C.c_char_p, C.c_int)
+    sig("hf_set_stats_mode", C.c_int, vp, C.c_int)
+    sig("hf_get_stats_mode", C.c_int, vp)
     sig("hf_selftest_division", C.c_int, C.c_int, i64, pd, pd, pd, pd, C.POINTER(C.c_int32))
     # host model
     sig("hfm_create", vp, C.c_int, C.c_int, C.POINTER(i32), C.c_int, C.c_int, C.c_int, C.c_int, pd, dbl, dbl)

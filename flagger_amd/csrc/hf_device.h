@@ -35,6 +35,9 @@
 struct TileDesc { long long t0; int T; int base; int chunk; int slow0; };
 // per chunk, for k_carry: first tile, number of tiles, first slow row, region of the first / last window (one 32-byte load)
 struct CarryDesc { int32_t k0, nt, slow0, reg_first, reg_last, pad0, pad1, pad2; };
+// statistics by emission row (hf_rows.h): one pair (t-1, t) of the plan, one row slot
+struct PairIdx { int32_t t; uint32_t rec; };                     // global window t of the pair (t-1, t) (< 0: empty slot), its record
+struct RowSlot { int32_t row, g0, ng, xpx; };                    // row < 0: padding; xpx = x | x_prev << 8
 
 // Layout of the forward / backward arrays f, b (double2 units): tile-major, lane-minor —
 //   slot(tile, lane, j, h) = ((tile*L + j)*2 + h)*64 + lane     window = tile base + lane*L + j, h: states (0,1) / (2,3)

@@ -82,6 +82,14 @@ struct hf_ctx {
     int n_keys = 0; int32_t* d_keys = nullptr;
     // negative_binomial model: device copies of hf_params.nb_* and the per-tile count data (allocated on first use)
     double *d_nbE = nullptr, *d_nbP = nullptr, *d_nbDig = nullptr, *d_nbR = nullptr, *d_nbBeta = nullptr, *d_tile_hist = nullptr;
+    // statistics by emission row (hf_rows.h): the static plan and its work arrays
+    int stats_mode = HF_STATS_CHUNKS; bool rows_ready = false, pass_rows = false; int pass_kc = 0;
+    int n_groups = 0, n_rowwaves = 0;
+    double* d_chunk_ll = nullptr;  // [C] log-likelihood per chunk (rows mode)
+    double* d_recs = nullptr;      // [N+1] pair records { f_{t-1}, b_t } (k_fb_tile RECS); fb_recs: the last full pass wrote them
+    bool fb_recs = false;
+    PairIdx* d_pairs = nullptr; int32_t* d_grp_row = nullptr; double* d_grp_sums = nullptr;
+    RowSlot* d_rowslots = nullptr; int32_t* d_rw_region = nullptr; int32_t* d_rw_off = nullptr; double* d_rw_stats = nullptr;
     int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_Es = nullptr; double* d_Cs = nullptr;
 };
 
@@ -449,7 +457,12 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
         for (int j = 0; j < L; j++) {
             if (!(ok[j] && (int) REC_REGION(rr[j + 1]) == r)) continue;
             double Ev[16], Tm[16], f[4], b1[4];
+#ifdef HF_PROBE_SAMEROW   // timing probe (wrong results): every lane reads lane 0's rows — one cache line per load instruction
+            const int32_t probe_idx = __shfl(row_index(S, rr[j + 1], rr[j], sidx[j]), 0);
+            load_row(reinterpret_cast<const double2*>(S.lutE) + (int64_t) probe_idx * 8, Ev);
+#else
             load_row(row_ptr(S, rr[j + 1], rr[j], sidx[j]), Ev);
+#endif
             // f of the window before (the previous lane's last one for j == 0), b of the window itself (hf_scan.h fb_slot)
             const int64_t fs = j > 0 ? fb_slot<L>(tile, lane, j - 1, 0)
                                      : (lane > 0 ? fb_slot<L>(tile, lane - 1, L - 1, 0) : fb_slot<L>(tile - 1, 63, L - 1, 0));
@@ -457,7 +470,11 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
             const double2 f01 = reinterpret_cast<const double2*>(F)[fs], f23 = reinterpret_cast<const double2*>(F)[fs + 64];
             const double2 b01 = reinterpret_cast<const double2*>(B)[bs], b23 = reinterpret_cast<const double2*>(B)[bs + 64];
             const unsigned xw = REC_X(rr[j + 1]), xp = REC_X(rr[j]);
+#ifdef HF_PROBE_SAMEROW
+            const double2* __restrict__ crow = reinterpret_cast<const double2*>(S.lutC + ((int64_t) probe_idx * 4) * S.K);
+#else
             const double2* __restrict__ crow = crow_ptr(S, rr[j + 1], rr[j], sidx[j]);
+#endif
             lds_Tm(s_tab, rr[j + 1], Tm);
             f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
             b1[0] = b01.x; b1[1] = b01.y; b1[2] = b23.x; b1[3] = b23.y;
@@ -683,6 +700,8 @@ __global__ void __launch_bounds__(64) k_reduce(const double* __restrict__ chunk_
     if (lane == 0) out[v] = acc;
 }
 
+#include "hf_rows.h"
+
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ------------------------------------------------------------------------------------------
@@ -707,9 +726,9 @@ struct KTimer {
 // default 64 KiB is requested explicitly.
 struct TileGeom { unsigned blocks = 0, threads = 256; size_t lds = 0; bool ok = false; };
 template <class Kern>
-static TileGeom tile_geom(const hf_ctx* ctx, Kern kernel, size_t per_wave_bytes) {
+static TileGeom tile_geom(const hf_ctx* ctx, Kern kernel, size_t per_wave_bytes, bool with_tab = true) {
     TileGeom g;
-    const size_t tab = (size_t) ctx->R * HF_TAB_STRIDE * 8;
+    const size_t tab = with_tab ? (size_t) ctx->R * HF_TAB_STRIDE * 8 : 0;
     int w = 4;
     while (w >= 1 && tab + (size_t) w * per_wave_bytes > ctx->lds_max) w--;
     if (w < 1) return g;
@@ -729,8 +748,33 @@ static RowSrc row_src(const hf_ctx* ctx) {
     return S;
 }
 
+// does a full pass of the Gaussian models take the statistics-by-row path?
+static bool rows_pass(const hf_ctx* ctx) { return ctx->stats_mode == HF_STATS_ROWS && ctx->rows_ready && ctx->algo == HF_ALGO_SCAN; }
+
 template <int KT>
 static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
+    ctx->pass_rows = false;
+    if (full && rows_pass(ctx)) {
+        // statistics by emission row (hf_rows.h); hf_finish launches k_rows_total
+        {
+            KTimer t(ctx, st, HF_K_PAIR_SUMS);
+            const TileGeom g = tile_geom(ctx, k_pair_sums, 0);
+            TILE_GEOM_OR_FAIL(g);
+            hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) (((int64_t) ctx->n_groups * 16 + 255) / 256)), dim3(256), g.lds, st, ctx->n_groups,
+                               ctx->d_pairs, ctx->d_grp_row, ctx->d_lutE, ctx->d_params, ctx->d_recs, ctx->d_grp_sums);
+        }
+        KTimer t(ctx, st, HF_K_ROW_STATS);
+        const TileGeom g = tile_geom(ctx, k_row_stats<KT>, (size_t) (3 * ncol > 28 ? 3 * ncol : 28) * 65 * 8, false);
+        TILE_GEOM_OR_FAIL(g);
+        const int wpb = (int) g.threads / 64;
+        const int n_rw_blocks = (ctx->n_rowwaves + wpb - 1) / wpb, n_ll_blocks = (ctx->C + wpb - 1) / wpb;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_stats<KT>), dim3((unsigned) (n_rw_blocks + n_ll_blocks)), dim3(g.threads), g.lds, st,
+                           ctx->n_rowwaves, n_rw_blocks, ctx->d_rw_region, ctx->d_rowslots, ctx->d_grp_sums, row_src(ctx), ctx->d_params,
+                           ctx->d_rw_stats, ctx->C, ctx->d_chunk_tile0, ctx->d_tile_ll, ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll);
+        ctx->pass_rows = true;
+        ctx->pass_kc = ncol;
+        return;
+    }
     if (full) {
         KTimer t(ctx, st, HF_K_STATS_TILE);
         const TileGeom g = tile_geom(ctx, k_stats_tile<KT>, (size_t) (3 * ncol > 28 ? 3 * ncol : 28) * 65 * 8);
@@ -743,6 +787,18 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_chunk_tile0,
                        ctx->d_regmask, ctx->d_tile_stats, ctx->d_tile_ll, ctx->d_params, ctx->d_chunk_stats, ctx->V, ctx->K,
                        full);
+}
+
+// the last kernel of a pass in HF_STATS_ROWS mode: total vector (+ flag word) into `out`
+static int launch_rows_total(hf_ctx* ctx, hipStream_t st, double* out) {
+    KTimer t(ctx, st, HF_K_ROWS_TOTAL);
+    const int kc = ctx->pass_kc;
+#define ROWS_TOTAL(KT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_total<KT>), dim3(1), dim3(1024), 0, st, ctx->d_rw_off, ctx->d_rw_stats, \
+        ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, ctx->d_total, out, ctx->d_flags)
+    if (kc <= 4) ROWS_TOTAL(4); else if (kc <= 8) ROWS_TOTAL(8); else ROWS_TOTAL(16);
+#undef ROWS_TOTAL
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 extern "C" {
@@ -905,8 +961,101 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         ctx->h_off.assign(w->chunk_off, w->chunk_off + C + 1);
         ctx->h_tile0 = ctile0;
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
+        // ---- plan of the statistics by emission row (hf_rows.h) ----
+        if (N > 0 && C > 0) {
+            std::vector<uint32_t> hrec(N);
+            if (hipMemcpy(hrec.data(), ctx->d_rec, N * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                hf_destroy(ctx); return set_err(HF_E_HIP, "record download failed");
+            }
+            const size_t n_rows_all = (size_t) ctx->n_lut + slow.size();
+            std::vector<int32_t> cnt(n_rows_all + 1, 0);
+            std::vector<int32_t> prow; std::vector<PairIdx> pidx;
+            prow.reserve(N); pidx.reserve(N);
+            size_t sp = 0;
+            for (size_t c = 0; c < C; c++) {
+                const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                for (int64_t x = 2; x < T; x++) {          // pairs (x-1, x), x = 2..T-1 (hmm.c:638-642)
+                    const size_t t = (size_t) (t0 + x);
+                    int64_t row;
+                    if (hb[t] != ctx->beta_star) {
+                        while (sp < slow.size() && (size_t) slow[sp] < t) sp++;
+                        row = ctx->n_lut + (int64_t) sp;
+                    } else {
+                        const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
+                        row = (int64_t) ((reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu));
+                    }
+                    PairIdx q; q.t = (int32_t) t; q.rec = hrec[t];
+                    prow.push_back((int32_t) row); pidx.push_back(q);
+                    cnt[(size_t) row]++;
+                }
+            }
+            if (!pidx.empty() && ctx->n_lut + (int64_t) slow.size() < INT32_MAX && N < (size_t) INT32_MAX) {
+                // counting sort by row (pairs of a row stay in window order)
+                std::vector<int64_t> start(n_rows_all + 1, 0);
+                for (size_t r = 0; r < n_rows_all; r++) start[r + 1] = start[r] + cnt[r];
+                std::vector<PairIdx> sorted(pidx.size());
+                {
+                    std::vector<int64_t> fill(start.begin(), start.end() - 1);
+                    for (size_t i = 0; i < pidx.size(); i++) sorted[(size_t) fill[(size_t) prow[i]]++] = pidx[i];
+                }
+                // occurring rows ordered by (region, row)
+                struct OccRow { int32_t region, row; };
+                std::vector<OccRow> occ;
+                for (size_t r = 0; r < n_rows_all; r++) {
+                    if (!cnt[r]) continue;
+                    int32_t reg;
+                    if ((int64_t) r < ctx->n_lut) reg = (int32_t) (r / ((size_t) ctx->M * ctx->M));
+                    else reg = (int32_t) ((w->annot[(size_t) slow[r - (size_t) ctx->n_lut]] & 0xFC00000000000000ULL) >> 58);
+                    occ.push_back({reg, (int32_t) r});
+                }
+                std::stable_sort(occ.begin(), occ.end(), [](const OccRow& a, const OccRow& b) { return a.region < b.region; });
+                std::vector<PairIdx> gp; std::vector<int32_t> grow;
+                std::vector<RowSlot> rslots; std::vector<int32_t> rwreg, rwoff((size_t) n_regions + 1, 0);
+                const PairIdx empty = {-1, 0u};
+                size_t oi = 0;
+                for (int reg = 0; reg < n_regions; reg++) {
+                    rwoff[(size_t) reg] = (int32_t) (rslots.size() / 64);
+                    for (; oi < occ.size() && occ[oi].region == reg; oi++) {
+                        const size_t r = (size_t) occ[oi].row;
+                        const int64_t n = cnt[r], s0 = start[r];
+                        const int32_t g_first = (int32_t) grow.size();
+                        for (int64_t b = 0; b < n; b += HF_GRP_PAIRS) {
+                            for (int64_t i = 0; i < HF_GRP_PAIRS; i++) gp.push_back(b + i < n ? sorted[(size_t) (s0 + b + i)] : empty);
+                            grow.push_back((int32_t) r);
+                        }
+                        const int32_t ng_all = (int32_t) grow.size() - g_first;
+                        int32_t xpx;
+                        if ((int64_t) r < ctx->n_lut) xpx = (int32_t) ((r / (size_t) ctx->M) % (size_t) ctx->M) | ((int32_t) (r % (size_t) ctx->M) << 8);
+                        else { const size_t t = (size_t) slow[r - (size_t) ctx->n_lut]; xpx = (int32_t) (w->cov[t] & 0xffu) | ((int32_t) (w->cov[t - 1] & 0xffu) << 8); }
+                        for (int32_t g = 0; g < ng_all; g += HF_ROWSLOT_GROUPS) {
+                            RowSlot sl; sl.row = (int32_t) r; sl.g0 = g_first + g;
+                            sl.ng = ng_all - g < HF_ROWSLOT_GROUPS ? ng_all - g : HF_ROWSLOT_GROUPS; sl.xpx = xpx;
+                            rslots.push_back(sl);
+                        }
+                    }
+                    while (rslots.size() % 64) rslots.push_back({-1, 0, 0, 0});
+                    for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / 64; k++) rwreg.push_back(reg);
+                }
+                rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / 64);
+                ctx->n_groups = (int) grow.size(); ctx->n_rowwaves = (int) (rslots.size() / 64);
+                TRY(dev_upload(&ctx->d_pairs, gp.data(), gp.size()));
+                TRY(dev_upload(&ctx->d_grp_row, grow.data(), grow.size()));
+                TRY(dev_upload(&ctx->d_rowslots, rslots.data(), rslots.size()));
+                TRY(dev_upload(&ctx->d_rw_region, rwreg.data(), rwreg.size()));
+                TRY(dev_upload(&ctx->d_rw_off, rwoff.data(), rwoff.size()));
+                DMALLOC(ctx->d_grp_sums, (size_t) ctx->n_groups * 16 * 8);
+                DMALLOC(ctx->d_recs, (N + 1) * 64);
+                DMALLOC(ctx->d_chunk_ll, C * 8);
+                DMALLOC(ctx->d_rw_stats, (size_t) ctx->n_rowwaves * (16 + 9 + 2 + 3 * 16 + 1) * 8);
+                ctx->rows_ready = true;
+            }
+        }
     }
     { const char* e = std::getenv("HF_HOST_TRACE"); ctx->host_trace = e && e[0] == '1'; }
+    {
+        const char* e = std::getenv("HF_STATS");
+        ctx->stats_mode = (e && std::strcmp(e, "chunks") == 0) ? HF_STATS_CHUNKS : HF_STATS_ROWS;
+    }
     *out = ctx;
     return HF_OK;
 }
@@ -922,7 +1071,9 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
-    hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_carry_desc); hipFree(ctx->d_Pt);
+    hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_carry_desc);
+    hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
+    hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
@@ -998,6 +1149,7 @@ static int pack_params(hf_ctx* ctx, const hf_params* p) {
 static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t st) {
     HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
     for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
+    ctx->pass_rows = false;
     if (ctx->C == 0) HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
     if (ctx->C > 0) {
         const RowSrc S = row_src(ctx);
@@ -1063,13 +1215,19 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 }
                 KTimer t(ctx, st, HF_K_FB_TILE);
 #ifdef HF_FB_LDS
-                const size_t fb_wave = (size_t) HF_SCAN_L * 5 * 64 * 8;
+                const size_t fb_wave = (size_t) HF_SCAN_L * 5 * HF_FW_STRIDE * 8;
 #else
                 const size_t fb_wave = 0;
 #endif
                 const TileGeom g = full ? tile_geom(ctx, k_fb_tile<HF_SCAN_L, true>, fb_wave) : tile_geom(ctx, k_fb_tile<HF_SCAN_L, false>, fb_wave);
                 if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
-                if (full)
+                const bool recs = full && !nbm && rows_pass(ctx);
+                if (full) ctx->fb_recs = recs;
+                if (recs)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true, true>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
+                                       ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_recs,
+                                       ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
+                else if (full)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
                                        ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_f,
                                        ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
@@ -1125,8 +1283,18 @@ int64_t hf_chunk_stats_len(const hf_ctx* ctx) { return ctx ? ctx->V : 0; }
 double* hf_chunk_stats_dev(hf_ctx* ctx) { return ctx ? ctx->d_chunk_stats : nullptr; }
 int8_t* hf_labels_dev(hf_ctx* ctx) { return ctx ? ctx->d_label : nullptr; }
 
+int hf_set_stats_mode(hf_ctx* ctx, int mode) {
+    if (!ctx || (mode != HF_STATS_CHUNKS && mode != HF_STATS_ROWS)) return set_err(HF_E_ARG, "hf_set_stats_mode: bad argument");
+    ctx->stats_mode = mode;
+    return HF_OK;
+}
+int hf_get_stats_mode(const hf_ctx* ctx) {
+    return ctx && ctx->stats_mode == HF_STATS_ROWS && ctx->rows_ready && ctx->algo == HF_ALGO_SCAN ? HF_STATS_ROWS : HF_STATS_CHUNKS;
+}
+
 int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
     if (!ctx || !dst_dev) return set_err(HF_E_ARG, "hf_copy_chunk_stats: bad argument");
+    if (ctx->pass_rows) return set_err(HF_E_ARG, "hf_copy_chunk_stats: the last pass ran in HF_STATS_ROWS mode (no per-chunk vectors)");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(dst_dev, ctx->d_chunk_stats, (size_t) ctx->C * ctx->V * 8, hipMemcpyDeviceToDevice,
                           (hipStream_t) stream));
@@ -1187,7 +1355,12 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
     hipStream_t st = (hipStream_t) stream;
 #ifndef HF_NO_DIRECT_OUT
     // the reduction writes the V+1 doubles into pinned host memory over PCIe: no device-to-host copy afterwards
-    int rc = hf_reduce_chunks(ctx, ctx->d_chunk_stats, ctx->C, ctx->d_total_host ? ctx->d_total_host : ctx->d_total, stream);
+    int rc;
+    if (ctx->pass_rows) {
+        HIPCHK(hipSetDevice(ctx->device));
+        rc = launch_rows_total(ctx, st, ctx->d_total_host ? ctx->d_total_host : ctx->d_total);
+    } else
+        rc = hf_reduce_chunks(ctx, ctx->d_chunk_stats, ctx->C, ctx->d_total_host ? ctx->d_total_host : ctx->d_total, stream);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev1, st));
     if (!ctx->d_total_host)
@@ -1210,6 +1383,7 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
 int hf_finish_gathered(hf_ctx* ctx, const double* rows_dev, const int32_t* row_index_dev, int64_t n_chunks, double* stats_host,
                        void* stream) {
     if (!ctx || !rows_dev || !stats_host || n_chunks < 0) return set_err(HF_E_ARG, "hf_finish_gathered: bad argument");
+    if (ctx->pass_rows) return set_err(HF_E_ARG, "hf_finish_gathered: the last pass ran in HF_STATS_ROWS mode (no per-chunk vectors)");
     hipStream_t st = (hipStream_t) stream;
     double* out = ctx->d_total_host ? ctx->d_total_host : ctx->d_total;
     int rc = hf_reduce_chunks_indexed(ctx, rows_dev, row_index_dev, n_chunks, out, stream);
@@ -1237,7 +1411,7 @@ using GraphSlot = hf_ctx::GraphSlot;
 static bool graph_eligible(const hf_ctx* ctx, const hf_params* p) {
     static const bool enabled = std::getenv("HF_USE_GRAPH") != nullptr;
     return enabled && ctx->prof_mask == 0 && ctx->C > 0 && ctx->ntiles > 0 && p->model_type != HF_MODEL_NEGATIVE_BINOMIAL &&
-           ctx->graphs[0].key != -1;
+           ctx->graphs[0].key != -1 && !(ctx->stats_mode == HF_STATS_ROWS && ctx->rows_ready);
 }
 
 static int graph_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t st) {
@@ -1328,6 +1502,16 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
     HIPCHK(hipSetDevice(ctx->device));
     if (scales_host && n) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
     if ((!f_host && !b_host) || n == 0) return HF_OK;
+    if (ctx->fb_recs) {   // pair records (k_fb_tile RECS): f_t is the first half of record t+1, b_t the second half of record t
+        std::vector<double> buf((size_t) (n + 1) * 8);
+        HIPCHK(hipMemcpy(buf.data(), ctx->d_recs + (size_t) first * 8, buf.size() * 8, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++)
+            for (int s = 0; s < 4; s++) {
+                if (f_host) f_host[i * 4 + s] = buf[(size_t) (i + 1) * 8 + s];
+                if (b_host) b_host[i * 4 + s] = buf[(size_t) i * 8 + 4 + s];
+            }
+        return HF_OK;
+    }
     // f and b live tile-major / lane-minor on the device (hf_scan.h fb_slot): fetch the tiles that cover the range and
     // put every window's four values back in window order
     constexpr int64_t L = HF_SCAN_L, TW = 64 * L;
@@ -1399,7 +1583,8 @@ int hf_kernel_times(hf_ctx* ctx, float ms[HF_NKERNELS]) {
 
 const char* hf_kernel_name(int k) {
     static const char* names[HF_NKERNELS] = {"k_tables", "k_prod_tile", "k_carry", "k_fb_tile", "k_stats_tile", "k_chunk_stats",
-                                             "k_reduce", "k_emit_rows", "k_fwd_seq", "k_bwd_seq"};
+                                             "k_reduce", "k_emit_rows", "k_fwd_seq", "k_bwd_seq", "k_pair_sums", "k_row_stats",
+                                             "k_rows_total"};
     return k >= 0 && k < HF_NKERNELS ? names[k] : "?";
 }
 

@@ -531,7 +531,11 @@ __global__ void __launch_bounds__(128) k_carry(const CarryDesc* __restrict__ cde
 #ifndef HF_FB_REGS
 #define HF_FB_LDS 1
 #endif
-template <int L, bool BWD>
+// RECS (with BWD): instead of the lane-minor arrays F, B the pass writes one 64-byte PAIR RECORD per window into F —
+// record t = { f_{t-1}[4], b_t[4] } (window-major, N+1 records) — what the statistics by emission row read (hf_rows.h);
+// the halves are written out of LDS by neighbouring lanes (16 cache lines per store instruction instead of 64).
+#define HF_FW_STRIDE 65   // doubles between the rows of the wave-private f / scale block: conflict-free both ways
+template <int L, bool BWD, bool RECS = false>
 __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const TileDesc* __restrict__ td,
                                                  const uint32_t* __restrict__ rec, const RowSrc S,
                                                  const double* __restrict__ Qs, const DevParams* __restrict__ P,
@@ -553,6 +557,16 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
     const double2* rowp[L];
 #pragma unroll
     for (int i = 0; i < L; i++) rowp[i] = row_ptr(S, rr[i], i == 0 ? rp : rr[i - 1], sidx[i]);
+#ifdef HF_PROBE_SAMEROW   // timing probe (wrong results): every lane reads lane 0's row — one cache line per load instruction
+#pragma unroll
+    for (int i = 0; i < L; i++)
+        rowp[i] = reinterpret_cast<const double2*>(S.lutE) + (int64_t) __shfl(row_index(S, rr[i], i == 0 ? rp : rr[i - 1], sidx[i]), 0) * 8;
+#endif
+#ifdef HF_PROBE_NODIV     // timing probe (wrong results): the replay's divisions become multiplications
+#define HF_PDIV(x, y) ((x) * (y))
+#else
+#define HF_PDIV(x, y) ((x) / (y))
+#endif
     double Ecur[16];
     if (a < T) load_row(rowp[0], Ecur);           // in flight during the scan
     double carry[4];
@@ -598,9 +612,9 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
     // replay this lane's windows in the reference's operation order (hmm.c:333-420); f and scale stay in registers
 #ifdef HF_FB_LDS
     // f and scale of the lane's windows wait for the backward half in wave-private LDS, lane-minor (conflict-free)
-    double* __restrict__ s_fw = s_tab + P->n_regions * HF_TAB_STRIDE + (threadIdx.x >> 6) * (L * 5 * 64) + lane;
-#define FW(i, s) s_fw[((i) * 5 + (s)) * 64]
-#define SCW(i) s_fw[((i) * 5 + 4) * 64]
+    double* __restrict__ s_fw = s_tab + P->n_regions * HF_TAB_STRIDE + (threadIdx.x >> 6) * (L * 5 * HF_FW_STRIDE) + lane;
+#define FW(i, s) s_fw[((i) * 5 + (s)) * HF_FW_STRIDE]
+#define SCW(i) s_fw[((i) * 5 + 4) * HF_FW_STRIDE]
 #else
     double fw[L][4], scw[L];
 #define FW(i, s) fw[i][s]
@@ -627,10 +641,17 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
             }
             if (!REC_FIRST(r) && sc < 1e-50) bad |= HF_FLAG_SCALE;   // hmm.c:412-415
 #pragma unroll
-            for (int s = 0; s < 4; s++) f[s] = nf[s] / sc;
+            for (int s = 0; s < 4; s++) f[s] = HF_PDIV(nf[s], sc);
             ll += log(sc);                                            // hmm.c:428
-            reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 0)] = make_double2(f[0], f[1]);
-            reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 1)] = make_double2(f[2], f[3]);
+#ifdef HF_PROBE_RECS   // timing probe (wrong results for the statistics): window-major 32-byte records, lane stride 128 B
+            reinterpret_cast<double2*>(F)[(t0 + a + i) * 2] = make_double2(f[0], f[1]);
+            reinterpret_cast<double2*>(F)[(t0 + a + i) * 2 + 1] = make_double2(f[2], f[3]);
+#else
+            if (!RECS) {
+                reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 0)] = make_double2(f[0], f[1]);
+                reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 1)] = make_double2(f[2], f[3]);
+            }
+#endif
             scale[t] = sc;
 #pragma unroll
             for (int s = 0; s < 4; s++) FW(i, s) = f[s];
@@ -647,6 +668,32 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
     }
     for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
     if (lane == 0) tile_ll[tile] = ll;
+#ifdef HF_FB_LDS
+    // pair records: window k of the tile is written by lanes 2k', 2k'+1 (16 bytes each) out of the wave's LDS block
+    // (wave-uniform record base in scalar registers, one 32-bit lane offset: no 64-bit address arithmetic per store)
+#define HF_COOP_HALF(DST_OFF, REC_SHIFT)                                                                               \
+    {                                                                                                                   \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                          \
+        __builtin_amdgcn_wave_barrier();                                                                                \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                          \
+        const double* __restrict__ s_w = s_fw - lane;                                                                   \
+        const int64_t rec0 = t0 + base;                                                                                 \
+        const int64_t rec0u = ((int64_t) __builtin_amdgcn_readfirstlane((int) (rec0 >> 32)) << 32) |                    \
+                              (uint32_t) __builtin_amdgcn_readfirstlane((int) rec0);                                    \
+        double2* __restrict__ Pw = reinterpret_cast<double2*>(F) + rec0u * 4;                                           \
+        const int nvalid = __builtin_amdgcn_readfirstlane((int) (T - base < 64 * L ? T - base : 64 * L));               \
+        const int sh = lane & 1, kl = lane >> 1;                                                                        \
+        _Pragma("unroll") for (int q = 0; q < (64 * L) / 32; q++) {                                                     \
+            const int k = 32 * q + kl, owner = k / L, i = k % L;                                                        \
+            if (k < nvalid) {                                                                                           \
+                const double2 v = make_double2(s_w[(i * 5 + 2 * sh) * HF_FW_STRIDE + owner],                            \
+                                               s_w[(i * 5 + 2 * sh + 1) * HF_FW_STRIDE + owner]);                       \
+                Pw[(k + (REC_SHIFT)) * 4 + (DST_OFF) + sh] = v;                                                         \
+            }                                                                                                           \
+        }                                                                                                               \
+    }
+    if (RECS) HF_COOP_HALF(0, 1)      // f_t goes into record t+1
+#endif
     if (BWD) {
         // ---- backward: exclusive SUFFIX product over lanes ----
         const int64_t Tm1 = T - 1;
@@ -701,11 +748,28 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
             {
                 const int64_t t = t0 + a + jl;
                 {   // jl is wave-divergent only in a chunk's last tile
-                    const int64_t s0 = fb_slot<L>(tile, lane, jl, 0);
-                    reinterpret_cast<double2*>(B)[s0] = make_double2(b[0], b[1]);
-                    reinterpret_cast<double2*>(B)[s0 + 64] = make_double2(b[2], b[3]);
+#ifdef HF_PROBE_RECS
+                    reinterpret_cast<double2*>(B)[t * 2] = make_double2(b[0], b[1]);
+                    reinterpret_cast<double2*>(B)[t * 2 + 1] = make_double2(b[2], b[3]);
+#else
+                    if (!RECS) {
+                        const int64_t s0 = fb_slot<L>(tile, lane, jl, 0);
+                        reinterpret_cast<double2*>(B)[s0] = make_double2(b[0], b[1]);
+                        reinterpret_cast<double2*>(B)[s0 + 64] = make_double2(b[2], b[3]);
+                    }
+#endif
                 }
                 label[t] = (int8_t) posterior_label(fl, b, scl);
+#ifdef HF_FB_LDS
+                if (RECS) {   // f of this window is not needed any more: its LDS slots take b for the record write
+#pragma unroll
+                    for (int i = 0; i < L; i++)
+                        if (i == jl) {
+#pragma unroll
+                            for (int s = 0; s < 4; s++) FW(i, s) = b[s];
+                        }
+                }
+#endif
             }
         }
         // replay the other windows (decreasing) in the reference's operation order: window i uses the row of i+1
@@ -725,13 +789,26 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
                 const double sc = SCW(i);
                 if (sc < 1e-50) bad |= HF_FLAG_SCALE;                 // hmm.c:521-524
 #pragma unroll
-                for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
-                reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 0)] = make_double2(b[0], b[1]);
-                reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 1)] = make_double2(b[2], b[3]);
+                for (int s = 0; s < 4; s++) b[s] = HF_PDIV(nb[s], sc);
+#ifdef HF_PROBE_RECS
+                reinterpret_cast<double2*>(B)[t * 2] = make_double2(b[0], b[1]);
+                reinterpret_cast<double2*>(B)[t * 2 + 1] = make_double2(b[2], b[3]);
+#else
+                if (!RECS) {
+                    reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 0)] = make_double2(b[0], b[1]);
+                    reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 1)] = make_double2(b[2], b[3]);
+                }
+#endif
                 {
                     const double fi[4] = {FW(i, 0), FW(i, 1), FW(i, 2), FW(i, 3)};
                     label[t] = (int8_t) posterior_label(fi, b, sc);
                 }
+#ifdef HF_FB_LDS
+                if (RECS) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) FW(i, s) = b[s];
+                }
+#endif
             }
             if (i >= 1) {
 #pragma unroll
@@ -739,5 +816,9 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
             }
         }
     }
+#ifdef HF_FB_LDS
+    if (BWD && RECS) HF_COOP_HALF(2, 0)   // b_t goes into record t
+#undef HF_COOP_HALF
+#endif
     if (bad) atomicOr(flags, bad);
 }

@@ -107,6 +107,7 @@ class HipLocal:
 
     def __init__(self, emlist):
         self.em = emlist
+        self.em.set_stats_mode(N.HF_STATS_CHUNKS)   # the exchange is made of per-chunk vectors
 
     def launch(self, model, mode):
         self.em.launch(model, mode)

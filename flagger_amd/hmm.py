@@ -184,6 +184,14 @@ class EMList:
     def __del__(self):
         self.close()
 
+    def set_stats_mode(self, mode: int) -> None:
+        """N.HF_STATS_ROWS (default where it applies) or N.HF_STATS_CHUNKS (per-chunk vectors, needed by the multi-GPU exchange)."""
+        N.check(self._L.hf_set_stats_mode(self._h, int(mode)), "hf_set_stats_mode")
+
+    @property
+    def stats_mode(self) -> int:
+        return int(self._L.hf_get_stats_mode(self._h))
+
     # --- E-step pieces (used directly by the multi-GPU path in dist.py) ---
     def launch(self, model: HMM, mode: int = N.HF_MODE_FULL) -> None:
         p = model.params()

@@ -147,6 +147,21 @@ int hf_finish(hf_ctx *ctx, double *stats_host, void *stream);
 /* Only wait + error flags (multi-GPU callers reduce the gathered vectors themselves). */
 int hf_check(hf_ctx *ctx, void *stream);
 
+/* How a HF_MODE_FULL pass of HF_ALGO_SCAN produces the statistics (Gaussian / trunc-exp models):
+ *   HF_STATS_CHUNKS  one estimator vector per chunk (EM_runOneIterationForList's per-chunk EM objects, hmm.c:739-763),
+ *                    reduced over the chunk list in list order: hf_chunk_stats_dev / hf_copy_chunk_stats /
+ *                    hf_reduce_chunks* / hf_finish_gathered work on these vectors, and the result does not depend on how
+ *                    the chunk list is sharded over GPUs (bit for bit).
+ *   HF_STATS_ROWS    the pair counts are summed per emission row first and the estimator updates run once per row
+ *                    (flagger_amd/csrc/hf_rows.h); hf_finish returns the same vector up to the rounding of a different
+ *                    summation order (fixed by the plan of hf_create: reproducible), ~2.5x less statistics time.  The
+ *                    per-chunk vectors are NOT produced (only element 0, the chunk's log-likelihood).
+ * Default: HF_STATS_ROWS where it applies (else HF_STATS_CHUNKS is used silently); environment HF_STATS=chunks|rows
+ * overrides the default at hf_create. */
+enum { HF_STATS_CHUNKS = 0, HF_STATS_ROWS = 1 };
+int hf_set_stats_mode(hf_ctx *ctx, int mode);
+int hf_get_stats_mode(const hf_ctx *ctx);          /* the mode the NEXT full pass will use */
+
 /* Results of the last HF_MODE_FULL pass. */
 int hf_get_labels(hf_ctx *ctx, int8_t *labels_host);                                   /* hmm.c:730-736 */
 int hf_get_posterior(hf_ctx *ctx, int64_t first, int64_t n, double *post_host);        /* [n][4] hmm.c:671-685 */
@@ -159,9 +174,9 @@ int hf_last_kernel_ms(hf_ctx *ctx, float *ms);
  * by a pair of HIP events on the launch stream; hf_kernel_times returns the duration of each selected kernel in
  * the LAST pass in milliseconds (0 for kernels not selected or not run).  Call after hf_finish/hf_check.
  * Each selected kernel adds two event packets to the stream, so select only what is being measured. */
-#define HF_NKERNELS 10
+#define HF_NKERNELS 13
 enum { HF_K_TABLES = 0, HF_K_PROD_TILE, HF_K_CARRY, HF_K_FB_TILE, HF_K_STATS_TILE, HF_K_CHUNK_STATS, HF_K_REDUCE,
-       HF_K_EMIT_ROWS, HF_K_FWD_SEQ, HF_K_BWD_SEQ };
+       HF_K_EMIT_ROWS, HF_K_FWD_SEQ, HF_K_BWD_SEQ, HF_K_PAIR_SUMS, HF_K_ROW_STATS, HF_K_ROWS_TOTAL };
 int hf_set_profiling(hf_ctx *ctx, unsigned kernel_mask);
 int hf_kernel_times(hf_ctx *ctx, float ms[HF_NKERNELS]);
 /* Sum of the durations (ms) and number of timed launches of every selected kernel over all passes finished by

@@ -106,7 +106,7 @@ def test_cli_argument_errors(tmp_path):
 
 def test_bench_single_gpu_and_distributed_code_paths_agree():
     """bench.py --dist-path runs the multi-GPU code path (RCCL process group of one rank, all-gather of the
-    per-chunk vectors, indexed fixed-order reduction): identical log-likelihood trajectory to the direct path."""
+    per-chunk vectors, indexed fixed-order reduction): the log-likelihood trajectory of the direct path."""
     import json
     import sys
     outs = []
@@ -116,7 +116,9 @@ def test_bench_single_gpu_and_distributed_code_paths_agree():
                            env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1]))   # RCCL prints a banner too
-    assert outs[0]["loglikelihood_after_last_step"] == outs[1]["loglikelihood_after_last_step"]
+    # the direct path sums the statistics by emission row, the exchange path per chunk: the same numbers up to rounding
+    assert outs[0]["config"]["statistics"] == "by emission row" and outs[1]["config"]["statistics"].startswith("per chunk")
+    assert outs[0]["loglikelihood_after_last_step"] == pytest.approx(outs[1]["loglikelihood_after_last_step"], rel=1e-10)
     assert outs[1]["n_gpus"] == 1 and outs[1]["value"] > 0
 
 

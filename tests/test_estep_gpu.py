@@ -17,9 +17,21 @@ LL_RTOL = 1e-9      # north_star asks for 1e-6
 STAT_RTOL = 1e-9
 
 
+SCAN_CHUNKS = 100 + N.HF_ALGO_SCAN
+
+
+def make_em(store, model, *args, algo=N.HF_ALGO_SCAN, **kw):
+    """EMList for an ALGOS parameter."""
+    em = hmm.EMList(store, model, *args, algo=algo % 100, **kw)
+    if algo >= 100:
+        em.set_stats_mode(N.HF_STATS_CHUNKS)
+        assert em.stats_mode == N.HF_STATS_CHUNKS
+    return em
+
+
 def _check_pass(store, model_type, K, alpha, algo, adjust=True, frac=0.95, n_iter=2, max_mapq=0.25, min_mapq=0.75):
     model = hmm.createModel(model_type, K, store, alpha, max_mapq, min_mapq)
-    em = hmm.EMList(store, model, adjust, frac, device=0, algo=algo)
+    em = make_em(store, model, adjust, frac, device=0, algo=algo)
     orc = Oracle(store, model_type, K, alpha, max_mapq, min_mapq, adjust, frac, threads=8)
     try:
         assert np.array_equal(model.param_vector(), orc.param_vector())
@@ -50,7 +62,9 @@ def _check_pass(store, model_type, K, alpha, algo, adjust=True, frac=0.95, n_ite
         orc.close()
 
 
-ALGOS = [pytest.param(N.HF_ALGO_SEQ, id="seq"), pytest.param(N.HF_ALGO_SCAN, id="scan")]
+# "scan" takes the library default (statistics by emission row where it applies), "scan-chunks" the per-chunk vectors
+ALGOS = [pytest.param(N.HF_ALGO_SEQ, id="seq"), pytest.param(N.HF_ALGO_SCAN, id="scan"),
+         pytest.param(SCAN_CHUNKS, id="scan-chunks")]
 
 
 @pytest.mark.parametrize("algo", ALGOS)
@@ -113,7 +127,7 @@ def test_empty_chunk_list(algo):
     full = synth.synthesize([50_000], 1000, 20_000, [20], seed=2)
     store = full.subset_chunks([])
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 3, full, synth.HIFI_ALPHA)
-    em = hmm.EMList(store, model, algo=algo)
+    em = make_em(store, model, algo=algo)
     hmm.EM_runOneIterationForList(em, model)
     assert model.loglikelihood == 0.0 and not np.any(model.estimators)
     assert em.labels().size == 0
@@ -180,7 +194,7 @@ def test_forward_only_mode(algo):
     store = synth.config(2, scale=0.004)
     K = 4
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
-    em = hmm.EMList(store, model, algo=algo)
+    em = make_em(store, model, algo=algo)
     orc = Oracle(store, 0, K, synth.HIFI_ALPHA)
     hmm.EM_runForwardForList(em, model)
     assert orc.run_iteration(forward_only=True) == 0
@@ -197,7 +211,7 @@ def test_full_em_against_oracle(algo, tmp_path):
     store = synth.config(2, scale=0.01)
     K = hmm.getBestNumberOfCollapsedComps(store)
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
-    em = hmm.EMList(store, model, algo=algo)
+    em = make_em(store, model, algo=algo)
     out = tmp_path / "gpu"
     out.mkdir()
     lls = hmm.runHMMFlagger(em, model, 12, 1e-3, str(out))
@@ -228,7 +242,7 @@ def test_scale_underflow_is_reported():
         t[:4, :4] = 1e-30
         t[:4, 0] = 1.0 - 1e-4
         model.set_param_vector(v.ravel())
-        em = hmm.EMList(store, model, algo=algo)
+        em = make_em(store, model, algo=algo)
         orc = Oracle(store, 0, 2, np.zeros((4, 4)))
         orc.set_param_vector(model.param_vector())
         assert orc.run_iteration() == -1
@@ -313,3 +327,31 @@ def test_shared_denominator_division_is_bit_identical_where_the_guard_allows_it(
     bad = ok & (fast.view(np.uint64) != exact.view(np.uint64))
     assert not bad.any(), (int(bad.sum()), np.log2(a[bad][:8]), np.log2(d[bad][:8]), fast[bad][:4], exact[bad][:4])
     assert np.array_equal(exact[ok], a[ok] / d[ok])          # and both are the IEEE quotient
+
+
+def test_statistics_by_row_agree_with_per_chunk_statistics():
+    """HF_STATS_ROWS (hf_rows.h) against HF_STATS_CHUNKS on the same pass: same log-likelihood bits, statistics to
+    rounding (a different order of the same additions), same labels / forward / backward; multi-region input with
+    contig ends (private rows) and region changes; the mode is reported and can be switched between passes."""
+    store = synth.config(4, scale=0.02)
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.ONT_R10_ALPHA)
+    em = hmm.EMList(store, model, True, 0.8)
+    try:
+        assert em.stats_mode == N.HF_STATS_ROWS
+        em.launch(model); rows = em.finish()
+        lab_r = em.labels(); f_r, b_r, sc_r = em.forward_backward()
+        em.set_stats_mode(N.HF_STATS_CHUNKS)
+        em.launch(model); chunks = em.finish()
+        lab_c = em.labels(); f_c, b_c, sc_c = em.forward_backward()
+        assert rows[0] == chunks[0]
+        scale = np.maximum(np.abs(chunks), 1e-9 * np.abs(chunks).max())
+        assert np.all(np.abs(rows - chunks) <= 1e-12 * scale), np.max(np.abs(rows - chunks) / scale)
+        assert np.array_equal(rows == 0.0, chunks == 0.0)
+        assert np.array_equal(lab_r, lab_c) and np.array_equal(sc_r, sc_c)
+        assert np.array_equal(f_r, f_c) and np.array_equal(b_r, b_c)      # pair records vs lane-minor arrays: the same values
+        em.set_stats_mode(N.HF_STATS_ROWS)
+        em.launch(model); again = em.finish()
+        assert np.array_equal(again, rows)                                 # fixed plan: reproducible bit for bit
+    finally:
+        em.close()
