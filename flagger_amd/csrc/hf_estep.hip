@@ -83,7 +83,7 @@ struct hf_ctx {
     // negative_binomial model: device copies of hf_params.nb_* and the per-tile count data (allocated on first use)
     double *d_nbE = nullptr, *d_nbP = nullptr, *d_nbDig = nullptr, *d_nbR = nullptr, *d_nbBeta = nullptr, *d_tile_hist = nullptr;
     // statistics by emission row (hf_rows.h): the static plan and its work arrays
-    int stats_mode = HF_STATS_CHUNKS; bool rows_ready = false, pass_rows = false; int pass_kc = 0;
+    int stats_mode = HF_STATS_CHUNKS; bool rows_ready = false, pass_rows = false; int pass_kc = 0, pass_wpb = 4;
     int n_groups = 0, n_rowwaves = 0;
     double* d_chunk_ll = nullptr;  // [C] log-likelihood per chunk (rows mode)
     double* d_recs = nullptr;      // [N+1] pair records { f_{t-1}, b_t } (k_fb_tile RECS); fb_recs: the last full pass wrote them
@@ -764,13 +764,16 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
                                ctx->d_pairs, ctx->d_grp_row, ctx->d_lutE, ctx->d_params, ctx->d_recs, ctx->d_grp_sums);
         }
         KTimer t(ctx, st, HF_K_ROW_STATS);
-        const TileGeom g = tile_geom(ctx, k_row_stats<KT>, (size_t) (3 * ncol > 28 ? 3 * ncol : 28) * 65 * 8, false);
+        constexpr size_t NA = 16 + 9 + 2 + 3 * KT + 1;
+        TileGeom g = tile_geom(ctx, k_row_stats<KT>, (size_t) (3 * ncol > 28 ? 3 * ncol : 28) * 65 * 8 + NA * 8, false);
         TILE_GEOM_OR_FAIL(g);
+        if (g.threads == 192) { g.threads = 128; g.lds = g.lds / 3 * 2; }   // 4, 2 or 1 wavefronts: a block stays inside one region
         const int wpb = (int) g.threads / 64;
         const int n_rw_blocks = (ctx->n_rowwaves + wpb - 1) / wpb, n_ll_blocks = (ctx->C + wpb - 1) / wpb;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_stats<KT>), dim3((unsigned) (n_rw_blocks + n_ll_blocks)), dim3(g.threads), g.lds, st,
                            ctx->n_rowwaves, n_rw_blocks, ctx->d_rw_region, ctx->d_rowslots, ctx->d_grp_sums, row_src(ctx), ctx->d_params,
                            ctx->d_rw_stats, ctx->C, ctx->d_chunk_tile0, ctx->d_tile_ll, ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll);
+        ctx->pass_wpb = wpb;
         ctx->pass_rows = true;
         ctx->pass_kc = ncol;
         return;
@@ -793,8 +796,8 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
 static int launch_rows_total(hf_ctx* ctx, hipStream_t st, double* out) {
     KTimer t(ctx, st, HF_K_ROWS_TOTAL);
     const int kc = ctx->pass_kc;
-#define ROWS_TOTAL(KT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_total<KT>), dim3(1), dim3(1024), 0, st, ctx->d_rw_off, ctx->d_rw_stats, \
-        ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, ctx->d_total, out, ctx->d_flags)
+#define ROWS_TOTAL(KT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_total<KT>), dim3(1), dim3(1024), 0, st, ctx->d_rw_off, ctx->pass_wpb, ctx->d_rw_stats, \
+        ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out, ctx->d_flags)
     if (kc <= 4) ROWS_TOTAL(4); else if (kc <= 8) ROWS_TOTAL(8); else ROWS_TOTAL(16);
 #undef ROWS_TOTAL
     HIPCHK(hipGetLastError());
@@ -1014,7 +1017,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 const PairIdx empty = {-1, 0u};
                 size_t oi = 0;
                 for (int reg = 0; reg < n_regions; reg++) {
-                    rwoff[(size_t) reg] = (int32_t) (rslots.size() / 64);
+                    rwoff[(size_t) reg] = (int32_t) (rslots.size() / 16);
                     for (; oi < occ.size() && occ[oi].region == reg; oi++) {
                         const size_t r = (size_t) occ[oi].row;
                         const int64_t n = cnt[r], s0 = start[r];
@@ -1034,10 +1037,10 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         }
                     }
                     while (rslots.size() % 64) rslots.push_back({-1, 0, 0, 0});
-                    for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / 64; k++) rwreg.push_back(reg);
+                    for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / 16; k++) rwreg.push_back(reg);
                 }
-                rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / 64);
-                ctx->n_groups = (int) grow.size(); ctx->n_rowwaves = (int) (rslots.size() / 64);
+                rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / 16);
+                ctx->n_groups = (int) grow.size(); ctx->n_rowwaves = (int) (rslots.size() / 16);   // 16 slots per wavefront, 64 per region pad
                 TRY(dev_upload(&ctx->d_pairs, gp.data(), gp.size()));
                 TRY(dev_upload(&ctx->d_grp_row, grow.data(), grow.size()));
                 TRY(dev_upload(&ctx->d_rowslots, rslots.data(), rslots.size()));

@@ -13,8 +13,8 @@
 //
 // Plan (static, hf_create): the pairs (t-1, t), t = 2..T-1 of every chunk, sorted by (region, row, t); a GROUP is up to 64
 // consecutive pairs of one row, worked on by 16 lanes; a ROW SLOT is up to 4 consecutive groups of one row (a
-// popular row has many slots: linearity again), worked on by one lane of k_row_stats; row slots are padded to whole
-// wavefronts per region.
+// popular row has many slots: linearity again), worked on by four lanes of k_row_stats; row slots are padded to 64 per
+// region (four wavefronts of 16 slots: the wavefronts of a block always belong to one region).
 #pragma once
 #include "hf_scan.h"
 
@@ -104,16 +104,17 @@ __global__ void __launch_bounds__(256) k_pair_sums(int n_groups, const PairIdx* 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_row_stats: one lane per row slot, one wavefront per 64 row slots of ONE region; the estimator updates of
-// k_stats_tile with the slot's summed counts in the place of one window's counts.  Output: one partial vector per
-// wavefront in StatAcc<KT> order (the format k_stats_tile writes per tile).
+// k_row_stats: FOUR lanes per row slot — lane p takes the previous state p: its row of the transition counts and its
+// term of every estimator update of k_stats_tile (hmm_utils.c:812-839, 1027-1034), with the slot's summed counts in the
+// place of one window's counts — 16 row slots of ONE region per wavefront.  The 64 lanes are summed in lane order out of
+// LDS (as k_stats_tile does), the wavefronts of a block in wave order: one partial vector per BLOCK, StatAcc<KT> order.
 // The blocks after the first n_rw_blocks do a second job that has to happen once per pass anyway: the log-likelihood of
 // every chunk (one wavefront per chunk, the same sum as k_chunk_stats) into element 0 of the chunk's vector.
 // ------------------------------------------------------------------------------------------
 template <int KT>
 __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_blocks, const int32_t* __restrict__ rw_region,
                                                       const RowSlot* __restrict__ slots, const double* __restrict__ grp_sums,
-                                                      const RowSrc S, const DevParams* __restrict__ P, double* __restrict__ rw_stats,
+                                                      const RowSrc S, const DevParams* __restrict__ P, double* __restrict__ blk_stats,
                                                       int C, const int32_t* __restrict__ chunk_tile0,
                                                       const double* __restrict__ tile_ll, double* __restrict__ chunk_stats, int64_t V,
                                                       double* __restrict__ chunk_ll) {
@@ -133,100 +134,74 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
         return;
     }
     const int rw = (int) blockIdx.x * wpb + wave;
-    if (rw >= n_rowwaves) return;
     const int ncol = P->ncomp[3];
     const bool te = hf_err_is_truncexp(P);
     const int nrows = 3 * ncol > NS + 1 ? 3 * ncol : NS + 1;
     double* __restrict__ s_row = s_rows + wave * (nrows * RS);
     double* __restrict__ s_acc = s_row + lane;
-    const DevRegion* __restrict__ R = &P->reg[rw_region[rw]];
-    const RowSlot sl = slots[(int64_t) rw * 64 + lane];
-    StatAccSmall a;
-#pragma unroll
-    for (int i = 0; i < NS; i++) reinterpret_cast<double*>(&a)[i] = 0.0;
-    double c_wden = 0.0;
+    double* __restrict__ s_blk = s_rows + wpb * (nrows * RS);       // [wpb][NA] wave sums
+    const int p = lane & 3;
+    RowSlot sl; sl.row = -1; sl.g0 = 0; sl.ng = 0; sl.xpx = 0;
+    if (rw < n_rowwaves) sl = slots[(int64_t) rw * 16 + (lane >> 2)];
+    const DevRegion* __restrict__ R = &P->reg[rw < n_rowwaves ? rw_region[rw] : 0];
+    double tr[4] = {0.0, 0.0, 0.0, 0.0};                  // trans[p][s]
+    double g_mnum[3] = {0.0, 0.0, 0.0}, g_vnum[3] = {0.0, 0.0, 0.0}, g_den[3] = {0.0, 0.0, 0.0};
+    double te_num = 0.0, te_den = 0.0, c_wden = 0.0;
     for (int i = 0; i < 3 * ncol; i++) s_acc[i * RS] = 0.0;
     if (sl.row >= 0) {
-        double cnt[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) cnt[k] = 0.0;
-        const double2* __restrict__ gs = reinterpret_cast<const double2*>(grp_sums) + (int64_t) sl.g0 * 8;
-        double2 gv[HF_ROWSLOT_GROUPS][8];          // all loads first, then the additions in plan order
+        // the slot's counts of this lane's previous state: entries (p, s) of every group sum (state-major: s*4 + p)
+        const double* __restrict__ gs = grp_sums + (int64_t) sl.g0 * 16 + p;
+        double gv[HF_ROWSLOT_GROUPS][4];
 #pragma unroll
         for (int g = 0; g < HF_ROWSLOT_GROUPS; g++)
 #pragma unroll
-            for (int k = 0; k < 8; k++) gv[g][k] = gs[(int64_t) (g < sl.ng ? g : 0) * 8 + k];
+            for (int s4 = 0; s4 < 4; s4++) gv[g][s4] = gs[(int64_t) (g < sl.ng ? g : 0) * 16 + s4 * 4];
+        const double* __restrict__ er = S.lutE + (int64_t) sl.row * 16 + p;
+        double Ev[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) Ev[s4] = er[s4 * 4];
+        const double* __restrict__ crow = S.lutC + ((int64_t) sl.row * 4) * S.K + p;   // [component][previous state]
+        double pcv[KT];
+#pragma unroll
+        for (int cc = 0; cc < KT; cc++) pcv[cc] = cc < ncol ? crow[cc * 4] : 0.0;
+        double cnt[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int g = 0; g < HF_ROWSLOT_GROUPS; g++)
             if (g < sl.ng) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) { cnt[2 * k] += gv[g][k].x; cnt[2 * k + 1] += gv[g][k].y; }
+                for (int s4 = 0; s4 < 4; s4++) cnt[s4] += gv[g][s4];   // groups in plan order
             }
-        double Ev[16];
-        load_row(reinterpret_cast<const double2*>(S.lutE) + (int64_t) sl.row * 8, Ev);
-        const double2* __restrict__ crow = reinterpret_cast<const double2*>(S.lutC + ((int64_t) sl.row * 4) * S.K);
         const double x = (double) (sl.xpx & 0xff), px = (double) ((sl.xpx >> 8) & 0xff);
-        double adj3[4];
+        double adj3 = 0.0;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            double adj[4];
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                adj[p] = cnt[HF_PS(p, s)] / HF_TERMINATION_PROB;      // hmm.c:613-614
-                a.trans[p * 4 + s] += adj[p];                         // hmm_utils.c:2010-2015
-            }
-            if (s == 3) {
-#pragma unroll
-                for (int p = 0; p < 4; p++) adj3[p] = adj[p];
-            } else if (s == 0 && te) {                                // hmm_utils.c:1027-1034
-#pragma unroll
-                for (int p = 0; p < 4; p++) { a.te_num += adj[p] * x; a.te_den += adj[p]; }
-            } else {                                                  // hmm_utils.c:812-839, one component
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const int k = HF_PS(p, s);
-                    const double alpha = P->alpha[p * 4 + s];
-                    const double x_adj = alpha == 0.0 ? x : (x - alpha * px) / (1.0 - alpha);
-                    const double w = adj[p] * Ev[k] / Ev[k];
-                    a.g_mnum[s] += w * x_adj;
-                    const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
-                    a.g_vnum[s] += w * z * z;
-                    a.g_den[s] += w;
-                }
+            const double adj = cnt[s] / HF_TERMINATION_PROB;          // hmm.c:613-614
+            tr[s] = adj;                                              // hmm_utils.c:2010-2015
+            if (s == 3) adj3 = adj;
+            else if (s == 0 && te) { te_num = adj * x; te_den = adj; }   // hmm_utils.c:1027-1034
+            else {                                                    // hmm_utils.c:812-839, one component
+                const double alpha = P->alpha[p * 4 + s];
+                const double x_adj = alpha == 0.0 ? x : (x - alpha * px) / (1.0 - alpha);
+                const double w = adj * Ev[s] / Ev[s];
+                g_mnum[s] = w * x_adj;
+                const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
+                g_vnum[s] = w * z * z;
+                g_den[s] = w;
             }
         }
-        double xa[4], om[4];
+        const double alpha3 = P->alpha[p * 4 + 3];
+        const double xa = alpha3 == 0.0 ? x : (x - alpha3 * px) / (1.0 - alpha3), om = 1.0 - alpha3;
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const double alpha = P->alpha[p * 4 + 3];
-            xa[p] = alpha == 0.0 ? x : (x - alpha * px) / (1.0 - alpha);
-            om[p] = 1.0 - alpha;
-        }
-        double2 cu[KT][2];                        // every component's probabilities first: no load on the loop's path
-#pragma unroll
-        for (int cc = 0; cc < KT; cc++)
-            if (cc < ncol) { cu[cc][0] = crow[cc * 2]; cu[cc][1] = crow[cc * 2 + 1]; }
-#pragma unroll
-        for (int cc = 0; cc < KT; cc++) {         // collapsed state, [component][previous state]
+        for (int cc = 0; cc < KT; cc++) {         // collapsed state
             if (cc >= ncol) continue;
-            const double2 u01 = cu[cc][0], u23 = cu[cc][1];
-            const double mu = R->mean[3][cc];
-            double mnum = 0.0, vnum = 0.0, den = 0.0;
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const double pc = p == 0 ? u01.x : p == 1 ? u01.y : p == 2 ? u23.x : u23.y;
-                const double w = adj3[p] * pc / Ev[HF_PS(p, 3)];
-                mnum += w * xa[p];
-                const double z = (xa[p] - mu) * om[p];
-                vnum += w * z * z;
-                den += w;
-                c_wden += w;
-            }
-            s_acc[cc * RS] = mnum; s_acc[(ncol + cc) * RS] = vnum; s_acc[(2 * ncol + cc) * RS] = den;
+            const double w = adj3 * pcv[cc] / Ev[3];
+            const double z = (xa - R->mean[3][cc]) * om;
+            s_acc[cc * RS] = w * xa; s_acc[(ncol + cc) * RS] = w * z * z; s_acc[(2 * ncol + cc) * RS] = w;
+            c_wden += w;
         }
     }
-    // sums over the 64 lanes in lane order, as k_stats_tile: accumulator i is summed by lane i out of its LDS row
-    double* __restrict__ dst = rw_stats + (int64_t) rw * NA;
+    // sums over the 64 lanes in lane order: accumulator i is summed by lane i out of its LDS row
+    double* __restrict__ wsum = s_blk + wave * NA;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -237,16 +212,20 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
 #pragma unroll 8
             for (int l = 0; l < 64; l++) v += row[l];
         }
-        for (int i = lane; i < 3 * KT; i += 64) dst[NS + i] = 0.0;
+        for (int i = lane; i < 3 * KT; i += 64) wsum[NS + i] = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane < 3 * ncol) dst[NS + (lane / ncol) * KT + (lane % ncol)] = v;
+        if (lane < 3 * ncol) wsum[NS + (lane / ncol) * KT + (lane % ncol)] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // StatAccSmall order: trans[16] (row p*4 + s: only this lane's previous state), g_mnum[3], g_vnum[3], g_den[3], te_num, te_den
 #pragma unroll
-    for (int i = 0; i < NS; i++) s_acc[i * RS] = reinterpret_cast<double*>(&a)[i];
+    for (int i = 0; i < 16; i++) s_acc[i * RS] = (i >> 2) == p ? tr[i & 3] : 0.0;
+#pragma unroll
+    for (int s = 0; s < 3; s++) { s_acc[(16 + s) * RS] = g_mnum[s]; s_acc[(19 + s) * RS] = g_vnum[s]; s_acc[(22 + s) * RS] = g_den[s]; }
+    s_acc[25 * RS] = te_num; s_acc[26 * RS] = te_den;
     s_acc[NS * RS] = c_wden;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -256,27 +235,34 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
         double v = 0.0;
 #pragma unroll 8
         for (int l = 0; l < 64; l++) v += row[l];
-        dst[lane < NS ? lane : NS + 3 * KT] = v;
+        wsum[lane < NS ? lane : NS + 3 * KT] = v;
+    }
+    __syncthreads();
+    if ((int) threadIdx.x < NA) {   // the block's wavefronts in wave order
+        double v = 0.0;
+        for (int w = 0; w < wpb; w++) v += s_blk[w * NA + threadIdx.x];
+        blk_stats[(int64_t) blockIdx.x * NA + threadIdx.x] = v;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rows_total: one block.  Element 0 = sum of the chunks' log-likelihoods (k_row_stats) in k_reduce's order (the same bits as the
-// per-chunk path); per region, the wavefront partials of k_row_stats summed in plan order by 1024/NA interleaved
+// k_rows_total: one block.  Element 0 = sum of the chunks' log-likelihoods (k_row_stats) in k_reduce's order (the same
+// bits as the per-chunk path); per region, the block partials of k_row_stats summed in plan order by 960/NA interleaved
 // accumulators per element (fixed), expanded into the estimator layout of include/hmm_flagger_hip.h exactly as
-// k_chunk_stats does; the vector is assembled in device memory and then copied to `out` (the pinned host block).
+// k_chunk_stats does; a region's block of the vector is assembled in LDS and written to `out` (the pinned host block) once.
+// blk_off[r]..blk_off[r+1]: the partials of region r.
 // ------------------------------------------------------------------------------------------
 template <int KT>
-__global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__ rw_off, const double* __restrict__ rw_stats,
-                                                    const DevParams* __restrict__ P, const double* __restrict__ chunk_ll, int64_t C,
-                                                    int64_t V, int Kctx, double* __restrict__ total, double* __restrict__ out,
-                                                    const unsigned* __restrict__ flags) {
+__global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_stats,
+                                                     const DevParams* __restrict__ P, const double* __restrict__ chunk_ll, int64_t C,
+                                                     int64_t V, int Kctx, double* __restrict__ out, const unsigned* __restrict__ flags) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
-    const int tid = threadIdx.x;
     constexpr int NQ = 960 / NA;                  // interleaved accumulators per element (the last wavefront sums the log-likelihoods)
+    const int tid = threadIdx.x;
     __shared__ double part[NQ][NA];
     __shared__ double red[NA];
-    for (int64_t v = 1 + tid; v < V; v += 1024) total[v] = 0.0;
+    __shared__ double blockv[24 * HF_MAXCOMP + 16];   // one region's block of the vector, assembled in LDS
+    const unsigned fl = (tid == 0 && flags) ? *flags : 0u;
     if (tid >= 960) {   // k_reduce's order over the chunk list
         const int lane = tid - 960;
         double acc = 0.0;
@@ -287,27 +273,26 @@ __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__
         }
         for (; c < C; c += 64) acc += chunk_ll[c];
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-        if (lane == 0) total[0] = acc;
+        if (lane == 0) out[0] = acc;
     }
-    __syncthreads();
     const int nreg = P->n_regions, ncol = P->ncomp[3];
     const bool te = hf_err_is_truncexp(P);
-    const int64_t rstride = 24 * (int64_t) Kctx + 16;
+    const int rstride = 24 * Kctx + 16;
     for (int r = 0; r < nreg; r++) {
-        const int w0 = rw_off[r], w1 = rw_off[r + 1];
-        if (w1 == w0) continue;
+        const int w0 = rw_off[r] / wpb, w1 = rw_off[r + 1] / wpb;   // rw_off counts wavefronts, a multiple of 4 per region
+        for (int v = tid; v < rstride; v += 1024) blockv[v] = 0.0;
         const int q = tid / NA, i = tid % NA;
         if (q < NQ) {
             double v = 0.0;
             int k = w0 + q;
-            for (; k + NQ * 3 < w1; k += NQ * 4) {   // 4 loads in flight, adds in plan order
-                double xk[4];
+            for (; k + NQ * 7 < w1; k += NQ * 8) {   // 8 loads in flight, adds in plan order
+                double xk[8];
 #pragma unroll
-                for (int u = 0; u < 4; u++) xk[u] = rw_stats[(int64_t) (k + NQ * u) * NA + i];
+                for (int u = 0; u < 8; u++) xk[u] = blk_stats[(int64_t) (k + NQ * u) * NA + i];
 #pragma unroll
-                for (int u = 0; u < 4; u++) v += xk[u];
+                for (int u = 0; u < 8; u++) v += xk[u];
             }
-            for (; k < w1; k += NQ) v += rw_stats[(int64_t) k * NA + i];
+            for (; k < w1; k += NQ) v += blk_stats[(int64_t) k * NA + i];
             part[q][i] = v;
         }
         __syncthreads();
@@ -318,31 +303,31 @@ __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__
             red[tid] = v;
         }
         __syncthreads();
-        double* __restrict__ dst = total + 1 + r * rstride;
-        const StatAcc<KT>* __restrict__ Sa = reinterpret_cast<const StatAcc<KT>*>(red);
-        if (tid < 16) dst[24 * Kctx + tid] = Sa->trans[tid];
-        if (tid == 32 && te) { dst[(0 * 2 + 0) * Kctx] = Sa->te_num; dst[(0 * 2 + 1) * Kctx] = Sa->te_den; }
-        if (tid >= 64 && tid < 67) {
-            const int s = tid - 64;
-            if (!(s == 0 && te)) {
-                double* dd = dst + (int64_t) (s * 3) * 2 * Kctx;
-                dd[(0 * 2 + 0) * Kctx] = Sa->g_mnum[s]; dd[(0 * 2 + 1) * Kctx] = Sa->g_den[s];
-                dd[(1 * 2 + 0) * Kctx] = Sa->g_vnum[s]; dd[(1 * 2 + 1) * Kctx] = Sa->g_den[s];
-                dd[(2 * 2 + 0) * Kctx] = Sa->g_den[s];  dd[(2 * 2 + 1) * Kctx] = Sa->g_den[s];
+        if (w1 > w0) {
+            double* __restrict__ dst = blockv;
+            const StatAcc<KT>* __restrict__ Sa = reinterpret_cast<const StatAcc<KT>*>(red);
+            if (tid < 16) dst[24 * Kctx + tid] = Sa->trans[tid];
+            if (tid == 32 && te) { dst[(0 * 2 + 0) * Kctx] = Sa->te_num; dst[(0 * 2 + 1) * Kctx] = Sa->te_den; }
+            if (tid >= 64 && tid < 67) {
+                const int s = tid - 64;
+                if (!(s == 0 && te)) {
+                    double* dd = dst + (s * 3) * 2 * Kctx;
+                    dd[(0 * 2 + 0) * Kctx] = Sa->g_mnum[s]; dd[(0 * 2 + 1) * Kctx] = Sa->g_den[s];
+                    dd[(1 * 2 + 0) * Kctx] = Sa->g_vnum[s]; dd[(1 * 2 + 1) * Kctx] = Sa->g_den[s];
+                    dd[(2 * 2 + 0) * Kctx] = Sa->g_den[s];  dd[(2 * 2 + 1) * Kctx] = Sa->g_den[s];
+                }
+            }
+            if (tid >= 96 && tid < 96 + KT && (tid - 96) < ncol) {
+                const int cc = tid - 96;
+                double* dd = dst + (3 * 3) * 2 * Kctx;
+                dd[(0 * 2 + 0) * Kctx + cc] = Sa->c_mnum[cc]; dd[(0 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
+                dd[(1 * 2 + 0) * Kctx + cc] = Sa->c_vnum[cc]; dd[(1 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
+                dd[(2 * 2 + 0) * Kctx + cc] = Sa->c_den[cc];  dd[(2 * 2 + 1) * Kctx + cc] = Sa->c_wden;
             }
         }
-        if (tid >= 96 && tid < 96 + KT && (tid - 96) < ncol) {
-            const int cc = tid - 96;
-            double* dd = dst + (int64_t) (3 * 3) * 2 * Kctx;
-            dd[(0 * 2 + 0) * Kctx + cc] = Sa->c_mnum[cc]; dd[(0 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
-            dd[(1 * 2 + 0) * Kctx + cc] = Sa->c_vnum[cc]; dd[(1 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
-            dd[(2 * 2 + 0) * Kctx + cc] = Sa->c_den[cc];  dd[(2 * 2 + 1) * Kctx + cc] = Sa->c_wden;
-        }
+        __syncthreads();
+        for (int v = tid; v < rstride; v += 1024) out[1 + (int64_t) r * rstride + v] = blockv[v];
         __syncthreads();
     }
-    __threadfence();
-    __syncthreads();
-    if (out != total)
-        for (int64_t v = tid; v < V; v += 1024) out[v] = total[v];
-    if (tid == 0 && flags) out[V] = (double) *flags;
+    if (tid == 0 && flags) out[V] = (double) fl;
 }
