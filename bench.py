@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events inside the timed region (the pass then runs as one HIP graph); the dominant kernel's "
                          "duration comes from the untimed passes that follow — for comparing launch paths, not the default")
+    ap.add_argument("--exchange", choices=["ranks", "chunks"], default="ranks",
+                    help="multi-GPU exchange: one statistics vector per rank, summed in rank order (default), or the per-chunk "
+                         "vectors summed in chunk-list order (bit-identical to a one-GPU run of the per-chunk statistics)")
     ap.add_argument("--dist-path", action="store_true",
                     help="take the multi-GPU code path (process group, all-gather, indexed reduction) even with one GPU")
     args = ap.parse_args()
@@ -103,7 +106,7 @@ def main():
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
     algo = N.HF_ALGO_SCAN if args.algo == "scan" else N.HF_ALGO_SEQ
     torch.cuda.set_device(local_rank)
-    sharded = fdist.make_sharded_hip(store, model, rank, world, local_rank, True, 0.95, algo)
+    sharded = fdist.make_sharded_hip(store, model, rank, world, local_rank, True, 0.95, algo, exchange=args.exchange)
     em = sharded.local.em
     if not dist_path:                      # one GPU, no exchange: statistics by emission row (the library's default)
         em.set_stats_mode(N.HF_STATS_ROWS)
@@ -188,7 +191,9 @@ def main():
                        "n_windows": n_windows, "n_chunks": store.n_chunks, "collapsed_comps": K,
                        "algo": args.algo,
                        "statistics": "per chunk, ordered reduction" if em.stats_mode == N.HF_STATS_CHUNKS else "by emission row",
-                       "parallelism": f"chunks sharded over {world} GPU(s), all-gather of per-chunk statistics"},
+                       "parallelism": (f"chunks sharded over {world} GPU(s), " + ("no exchange" if not dist_path else
+                                       "all-gather of one statistics vector per rank" if args.exchange == "ranks" else
+                                       "all-gather of per-chunk statistics"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
                          "kernel_ms_timed": dom_ms, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_WINDOW * local_windows,

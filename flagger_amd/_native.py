@@ -101,6 +101,7 @@ def lib() -> C.CDLL:
     sig("hf_kernel_time_sums", C.c_int, vp, pd, C.POINTER(C.c_int64))
     sig("hf_kernel_name", C.c_char_p, C.c_int)
     sig("hf_set_stats_mode", C.c_int, vp, C.c_int)
+    sig("hf_rank_total", C.c_int, vp, vp, vp)
     sig("hf_get_stats_mode", C.c_int, vp)
     sig("hf_selftest_division", C.c_int, C.c_int, i64, pd, pd, pd, pd, C.POINTER(C.c_int32))
     # host model

@@ -793,11 +793,11 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
 }
 
 // the last kernel of a pass in HF_STATS_ROWS mode: total vector (+ flag word) into `out`
-static int launch_rows_total(hf_ctx* ctx, hipStream_t st, double* out) {
+static int launch_rows_total(hf_ctx* ctx, hipStream_t st, double* out, bool with_flags = true) {
     KTimer t(ctx, st, HF_K_ROWS_TOTAL);
     const int kc = ctx->pass_kc;
 #define ROWS_TOTAL(KT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_total<KT>), dim3(1), dim3(1024), 0, st, ctx->d_rw_off, ctx->pass_wpb, ctx->d_rw_stats, \
-        ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out, ctx->d_flags)
+        ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out, with_flags ? ctx->d_flags : (const unsigned*) nullptr)
     if (kc <= 4) ROWS_TOTAL(4); else if (kc <= 8) ROWS_TOTAL(8); else ROWS_TOTAL(16);
 #undef ROWS_TOTAL
     HIPCHK(hipGetLastError());
@@ -1304,6 +1304,13 @@ int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
     return HF_OK;
 }
 
+int hf_rank_total(hf_ctx* ctx, double* out_dev, void* stream) {
+    if (!ctx || !out_dev) return set_err(HF_E_ARG, "hf_rank_total: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->pass_rows) return launch_rows_total(ctx, (hipStream_t) stream, out_dev, false);
+    return hf_reduce_chunks_indexed(ctx, ctx->d_chunk_stats, nullptr, ctx->C, out_dev, stream);
+}
+
 int hf_reduce_chunks_indexed(hf_ctx* ctx, const double* chunk_stats_dev, const int32_t* row_index_dev, int64_t n_chunks,
                              double* out_dev, void* stream) {
     if (!ctx || !chunk_stats_dev || !out_dev || n_chunks < 0) return set_err(HF_E_ARG, "hf_reduce_chunks: bad argument");
@@ -1386,7 +1393,6 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
 int hf_finish_gathered(hf_ctx* ctx, const double* rows_dev, const int32_t* row_index_dev, int64_t n_chunks, double* stats_host,
                        void* stream) {
     if (!ctx || !rows_dev || !stats_host || n_chunks < 0) return set_err(HF_E_ARG, "hf_finish_gathered: bad argument");
-    if (ctx->pass_rows) return set_err(HF_E_ARG, "hf_finish_gathered: the last pass ran in HF_STATS_ROWS mode (no per-chunk vectors)");
     hipStream_t st = (hipStream_t) stream;
     double* out = ctx->d_total_host ? ctx->d_total_host : ctx->d_total;
     int rc = hf_reduce_chunks_indexed(ctx, rows_dev, row_index_dev, n_chunks, out, stream);

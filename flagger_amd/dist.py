@@ -41,7 +41,7 @@ class ShardedEMList:
     object; the product passes an `hmm.EMList` factory, the CPU/gloo tests pass an oracle-backed one."""
 
     def __init__(self, store: WindowStore, rank: int, world: int, make_local: Callable, stats_len: int,
-                 device=None, group=None):
+                 device=None, group=None, exchange: str = "chunks"):
         import torch
         self.torch = torch
         self.rank, self.world, self.group = rank, world, group
@@ -60,6 +60,17 @@ class ShardedEMList:
         # row of global chunk c inside recv viewed as [world*maxc, V]: rank-major, padded to maxc rows per rank
         rows = [r * self.maxc + k for r in range(world) for k in range(self.counts[r])]
         self.row_index = torch.tensor(rows if rows else [0], dtype=torch.int32, device=self.device)
+        # exchange "chunks": all-gather the per-chunk vectors, sum in global list order (bit-identical to one GPU);
+        # "ranks": every rank sums its own chunks (hf_rank_total, statistics by emission row on the HIP backend), one
+        # vector per rank is all-gathered and summed in rank order (the same numbers up to the rounding of the order)
+        if exchange not in ("chunks", "ranks"):
+            raise ValueError("exchange must be 'chunks' or 'ranks'")
+        self.exchange = exchange
+        if exchange == "ranks":
+            self.local.use_rank_totals()
+            self.rsend = torch.zeros((self.V,), dtype=torch.float64, device=self.device)
+            self.rrecv = torch.zeros((world, self.V), dtype=torch.float64, device=self.device)
+            self.rank_rows = torch.arange(world, dtype=torch.int32, device=self.device)
         self.force_collective = False      # run the collective even with world == 1 (exercises the RCCL path on one GPU)
         self.total = torch.zeros((self.V,), dtype=torch.float64, device=self.device)
 
@@ -67,6 +78,18 @@ class ShardedEMList:
         torch = self.torch
         import torch.distributed as dist
         self.local.launch(model, mode)
+        if self.exchange == "ranks":
+            self.local.rank_total_into(self.rsend)
+            if self.world > 1 or self.force_collective:
+                dist.all_gather_into_tensor(self.rrecv.view(-1), self.rsend, group=self.group)
+            else:
+                self.rrecv[0].copy_(self.rsend)
+            if hasattr(self.local, "finish_gathered"):    # HIP backend: rank-order sum into pinned host memory, one sync
+                return self.local.finish_gathered(self.rrecv, None, self.world).copy()
+            self.local.reduce_into(self.rrecv, self.rank_rows, self.world, self.total)
+            stats = self.total.cpu().numpy().copy()
+            self.local.check()
+            return stats
         if self.world > 1 or self.force_collective:
             self.local.chunk_stats_into(self.send)        # [maxc, V] rows of this rank, device-to-device
             dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group)
@@ -115,11 +138,17 @@ class HipLocal:
     def chunk_stats_into(self, send):
         self.em.copy_chunk_stats(send.data_ptr())
 
+    def use_rank_totals(self):
+        self.em.set_stats_mode(N.HF_STATS_ROWS)     # no per-chunk vectors needed: statistics by emission row
+
+    def rank_total_into(self, send):
+        self.em.rank_total(send.data_ptr())
+
     def reduce_into(self, rows, row_index, n_chunks, total):
         self.em.reduce_chunks_indexed(rows.data_ptr(), row_index.data_ptr(), n_chunks, total.data_ptr())
 
     def finish_gathered(self, rows, row_index, n_chunks):
-        return self.em.finish_gathered(rows.data_ptr(), row_index.data_ptr(), n_chunks)
+        return self.em.finish_gathered(rows.data_ptr(), row_index.data_ptr() if row_index is not None else 0, n_chunks)
 
     def check(self):
         self.em.check()
@@ -129,7 +158,7 @@ class HipLocal:
 
 
 def make_sharded_hip(store: WindowStore, model, rank: int, world: int, local_rank: int, adjust=True, frac=0.95,
-                     algo: int = N.HF_ALGO_SCAN, group=None):
+                     algo: int = N.HF_ALGO_SCAN, group=None, exchange: str = "chunks"):
     """One process per GPU: this rank's chunks live on cuda:<local_rank>; kernels and the collective share
     torch's current stream so no extra synchronisation is needed."""
     import torch
@@ -141,4 +170,4 @@ def make_sharded_hip(store: WindowStore, model, rank: int, world: int, local_ran
     def factory(sub):
         return HipLocal(hmm.EMList(sub, model, adjust, frac, device=local_rank, algo=algo, stream=stream))
     V = N.stats_len(model.numberOfRegions, model.maxNumberOfComps)
-    return ShardedEMList(store, rank, world, factory, V, device=dev, group=group)
+    return ShardedEMList(store, rank, world, factory, V, device=dev, group=group, exchange=exchange)

@@ -205,6 +205,10 @@ class EMList:
     def check(self) -> None:
         N.check(self._L.hf_check(self._h, self.stream), "hf_check")
 
+    def rank_total(self, dst_dev_ptr: int) -> None:
+        """This context's statistics vector (either statistics mode) into device memory."""
+        N.check(self._L.hf_rank_total(self._h, C.c_void_p(dst_dev_ptr), self.stream), "hf_rank_total")
+
     def copy_chunk_stats(self, dst_dev_ptr: int) -> None:
         N.check(self._L.hf_copy_chunk_stats(self._h, C.c_void_p(dst_dev_ptr), self.stream), "hf_copy_chunk_stats")
 
@@ -212,12 +216,12 @@ class EMList:
         """Fixed-order sum of the all-gathered per-chunk vectors into host memory + flag check: one sync (hf_finish_gathered)."""
         if not hasattr(self, "_stats_buf"):
             self._stats_buf = np.empty(self.stats_len, dtype=np.float64)
-        N.check(self._L.hf_finish_gathered(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr), n_chunks,
+        N.check(self._L.hf_finish_gathered(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr) if row_index_dev_ptr else None, n_chunks,
                                            _dptr(self._stats_buf), self.stream), "hf_finish_gathered")
         return self._stats_buf
 
     def reduce_chunks_indexed(self, rows_dev_ptr: int, row_index_dev_ptr: int, n_chunks: int, dst_dev_ptr: int) -> None:
-        N.check(self._L.hf_reduce_chunks_indexed(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr), n_chunks,
+        N.check(self._L.hf_reduce_chunks_indexed(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr) if row_index_dev_ptr else None, n_chunks,
                                                  C.c_void_p(dst_dev_ptr), self.stream), "hf_reduce_chunks_indexed")
 
     def reduce_chunks(self, src_dev_ptr: int, n_chunks: int, dst_dev_ptr: int) -> None:

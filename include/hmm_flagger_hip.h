@@ -160,6 +160,10 @@ int hf_check(hf_ctx *ctx, void *stream);
  * overrides the default at hf_create. */
 enum { HF_STATS_CHUNKS = 0, HF_STATS_ROWS = 1 };
 int hf_set_stats_mode(hf_ctx *ctx, int mode);
+/* The statistics vector of THIS context's chunks after a pass, in either mode, into device memory (hf_chunk_stats_len
+ * doubles): what ranks exchange when the per-chunk vectors are not needed — all-gather one vector per rank, then
+ * hf_finish_gathered(rows = the gathered vectors, row_index = NULL, n = world size) sums them in rank order. */
+int hf_rank_total(hf_ctx *ctx, double *out_dev, void *stream);
 int hf_get_stats_mode(const hf_ctx *ctx);          /* the mode the NEXT full pass will use */
 
 /* Results of the last HF_MODE_FULL pass. */

@@ -110,7 +110,7 @@ def test_bench_single_gpu_and_distributed_code_paths_agree():
     import json
     import sys
     outs = []
-    for extra in ([], ["--dist-path"]):
+    for extra in ([], ["--dist-path", "--exchange", "chunks"], ["--dist-path", "--exchange", "ranks"]):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "0.02", "--steps", "3", "--warmup", "1",
                             "--no-cpu-baseline"] + extra, capture_output=True, text=True,
                            env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533"))
@@ -119,6 +119,9 @@ def test_bench_single_gpu_and_distributed_code_paths_agree():
     # the direct path sums the statistics by emission row, the exchange path per chunk: the same numbers up to rounding
     assert outs[0]["config"]["statistics"] == "by emission row" and outs[1]["config"]["statistics"].startswith("per chunk")
     assert outs[0]["loglikelihood_after_last_step"] == pytest.approx(outs[1]["loglikelihood_after_last_step"], rel=1e-10)
+    # one vector per rank: with one rank this is the direct path's vector passed through the collective
+    assert outs[2]["config"]["statistics"] == "by emission row"
+    assert outs[2]["loglikelihood_after_last_step"] == outs[0]["loglikelihood_after_last_step"]
     assert outs[1]["n_gpus"] == 1 and outs[1]["value"] > 0
 
 

@@ -53,6 +53,15 @@ class OracleLocal:
             acc = acc + p[idx[c]]
         total.copy_(torch.from_numpy(acc))
 
+    def use_rank_totals(self):
+        pass
+
+    def rank_total_into(self, send):
+        acc = np.zeros(send.shape[0])
+        for o in self.orcs:            # this rank's chunks in list order
+            acc = acc + o.stats_vector(K)
+        send.copy_(torch.from_numpy(acc))
+
     def check(self):
         pass
 
@@ -60,14 +69,14 @@ class OracleLocal:
         return np.concatenate([o.labels() for o in self.orcs]) if self.orcs else np.zeros(0, np.int8)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange="chunks"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     tdist.init_process_group("gloo", rank=rank, world_size=world)
     store = _store()
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, ALPHA)
     V = N.stats_len(model.numberOfRegions, K)
-    sh = fdist.ShardedEMList(store, rank, world, OracleLocal, V)
+    sh = fdist.ShardedEMList(store, rank, world, OracleLocal, V, exchange=exchange)
     trace = []
     for _ in range(3):
         hmm.EM_runOneIterationForList(sh, model)
@@ -143,3 +152,31 @@ def test_shard_bounds_balance_and_edge_cases():
         assert max(per) <= sizes.sum() / world + sizes.max()
     assert fdist.shard_bounds([], 4) == [0, 0, 0, 0, 0]
     assert fdist.shard_bounds([5], 3)[-1] == 1
+
+
+def test_rank_total_exchange_matches_to_rounding():
+    """exchange="ranks": every rank sums its own chunks, one vector per rank is all-gathered and summed in rank order —
+    the per-chunk result up to the rounding of a different summation order; every rank holds the same bits."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "ranks")) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    store = _store()
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, ALPHA)
+    orc = Oracle(store, 0, K, ALPHA, threads=2)
+    orc.set_param_vector(model.param_vector())
+    assert orc.run_iteration() == 0
+    ref = orc.stats_vector(K)
+    for rank, trace, pv, labels, ll, bounds in res:
+        got = trace[0]
+        scale = np.maximum(np.abs(ref), 1e-9 * np.abs(ref).max())
+        assert np.all(np.abs(got - ref) <= 1e-12 * scale)
+        assert np.array_equal(trace[0], res[0][1][0]) and np.array_equal(pv, res[0][2])     # replicas agree bit for bit
+    orc.close()
