@@ -84,6 +84,8 @@ struct hf_ctx {
     double *d_nbE = nullptr, *d_nbP = nullptr, *d_nbDig = nullptr, *d_nbR = nullptr, *d_nbBeta = nullptr, *d_tile_hist = nullptr;
     // statistics by emission row (hf_rows.h): the static plan and its work arrays
     int stats_mode = HF_STATS_CHUNKS; bool rows_ready = false, pass_rows = false; int pass_kc = 0, pass_wpb = 4;
+    double poll_seq = 0.0;         // completion stamp of the last polled pass (hf_finish)
+    unsigned* d_done = nullptr;    // k_reduce: blocks finished (the last one stamps the host block)
     int n_groups = 0, n_rowwaves = 0;
     double* d_chunk_ll = nullptr;  // [C] log-likelihood per chunk (rows mode)
     double* d_recs = nullptr;      // [N+1] pair records { f_{t-1}, b_t } (k_fb_tile RECS); fb_recs: the last full pass wrote them
@@ -687,17 +689,24 @@ __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__
 // sum over chunks (hmm.c:759-763) in a fixed order that depends only on the chunk list: one wavefront per vector
 // element, lane l adds chunks l, l+64, ... in list order, then a fixed shuffle tree over the lanes.  The same
 // kernel reduces the local chunk list on one GPU and the all-gathered list on N GPUs => identical bits.
+// seq != 0: `out` is the pinned host block and the host polls out[V+1]: the block that finishes last stamps it.
 __global__ void __launch_bounds__(64) k_reduce(const double* __restrict__ chunk_stats, const int32_t* __restrict__ row_index,
                                                int64_t n_chunks, int64_t V, double* __restrict__ out,
-                                               const unsigned* __restrict__ flags) {
+                                               const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done) {
     const int64_t v = blockIdx.x;
     const int lane = threadIdx.x;
-    if (v == V) { if (flags && lane == 0) out[V] = (double) *flags; return; }   // error flags ride along with the vector
-    double acc = 0.0;
-    // row_index (multi-GPU): row of global chunk c inside the all-gathered, per-rank padded buffer
-    for (int64_t c = lane; c < n_chunks; c += 64) acc += chunk_stats[(row_index ? (int64_t) row_index[c] : c) * V + v];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if (lane == 0) out[v] = acc;
+    if (v == V) { if (flags && lane == 0) out[V] = (double) *flags; }   // error flags ride along with the vector
+    else {
+        double acc = 0.0;
+        // row_index (multi-GPU): row of global chunk c inside the all-gathered, per-rank padded buffer
+        for (int64_t c = lane; c < n_chunks; c += 64) acc += chunk_stats[(row_index ? (int64_t) row_index[c] : c) * V + v];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        if (lane == 0) out[v] = acc;
+    }
+    if (seq != 0.0 && lane == 0) {
+        __threadfence_system();
+        if (atomicAdd(done, 1u) == gridDim.x - 1) { *done = 0u; out[V + 1] = seq; __threadfence_system(); }
+    }
 }
 
 #include "hf_rows.h"
@@ -793,11 +802,11 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
 }
 
 // the last kernel of a pass in HF_STATS_ROWS mode: total vector (+ flag word) into `out`
-static int launch_rows_total(hf_ctx* ctx, hipStream_t st, double* out, bool with_flags = true) {
+static int launch_rows_total(hf_ctx* ctx, hipStream_t st, double* out, bool with_flags = true, double seq = 0.0) {
     KTimer t(ctx, st, HF_K_ROWS_TOTAL);
     const int kc = ctx->pass_kc;
 #define ROWS_TOTAL(KT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_total<KT>), dim3(1), dim3(1024), 0, st, ctx->d_rw_off, ctx->pass_wpb, ctx->d_rw_stats, \
-        ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out, with_flags ? ctx->d_flags : (const unsigned*) nullptr)
+        ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out, with_flags ? ctx->d_flags : (const unsigned*) nullptr, seq)
     if (kc <= 4) ROWS_TOTAL(4); else if (kc <= 8) ROWS_TOTAL(8); else ROWS_TOTAL(16);
 #undef ROWS_TOTAL
     HIPCHK(hipGetLastError());
@@ -863,11 +872,13 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     DMALLOC(ctx->d_scale, N * 8); DMALLOC(ctx->d_label, N);
     DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, ((size_t) ctx->V + 1) * 8);
     DMALLOC(ctx->d_flags, 4);
+    DMALLOC(ctx->d_done, 4);
+    hipMemset(ctx->d_done, 0, 4);
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
     DMALLOC(ctx->d_params, ctx->params_bytes);
     if (hipHostMalloc((void**) &ctx->h_params, ctx->params_bytes) != hipSuccess ||
         hipHostMalloc((void**) &ctx->h_flags, 4) != hipSuccess ||
-        hipHostMalloc((void**) &ctx->h_total, ((size_t) ctx->V + 1) * 8) != hipSuccess) {
+        hipHostMalloc((void**) &ctx->h_total, ((size_t) ctx->V + 2) * 8) != hipSuccess) {
         hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed");
     }
     {
@@ -1075,7 +1086,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_carry_desc);
-    hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
+    hipFree(ctx->d_done); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
@@ -1311,8 +1322,8 @@ int hf_rank_total(hf_ctx* ctx, double* out_dev, void* stream) {
     return hf_reduce_chunks_indexed(ctx, ctx->d_chunk_stats, nullptr, ctx->C, out_dev, stream);
 }
 
-int hf_reduce_chunks_indexed(hf_ctx* ctx, const double* chunk_stats_dev, const int32_t* row_index_dev, int64_t n_chunks,
-                             double* out_dev, void* stream) {
+static int reduce_chunks_seq(hf_ctx* ctx, const double* chunk_stats_dev, const int32_t* row_index_dev, int64_t n_chunks,
+                             double* out_dev, void* stream, double seq) {
     if (!ctx || !chunk_stats_dev || !out_dev || n_chunks < 0) return set_err(HF_E_ARG, "hf_reduce_chunks: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
     const bool own = chunk_stats_dev == ctx->d_chunk_stats;
@@ -1322,11 +1333,16 @@ int hf_reduce_chunks_indexed(hf_ctx* ctx, const double* chunk_stats_dev, const i
         KTimer t(ctx, (hipStream_t) stream, HF_K_REDUCE);
         hipLaunchKernelGGL(k_reduce, dim3((unsigned) (ctx->V + 1)), dim3(64), 0, (hipStream_t) stream, chunk_stats_dev, row_index_dev,
                            n_chunks, ctx->V, out_dev,
-                           (out_dev == ctx->d_total || out_dev == ctx->d_total_host) ? ctx->d_flags : (const unsigned*) nullptr);
+                           (out_dev == ctx->d_total || out_dev == ctx->d_total_host) ? ctx->d_flags : (const unsigned*) nullptr,
+                           seq, ctx->d_done);
     }
     ctx->prof_mask = keep;
     HIPCHK(hipGetLastError());
     return HF_OK;
+}
+int hf_reduce_chunks_indexed(hf_ctx* ctx, const double* chunk_stats_dev, const int32_t* row_index_dev, int64_t n_chunks,
+                             double* out_dev, void* stream) {
+    return reduce_chunks_seq(ctx, chunk_stats_dev, row_index_dev, n_chunks, out_dev, stream, 0.0);
 }
 
 int hf_reduce_chunks(hf_ctx* ctx, const double* chunk_stats_dev, int64_t n_chunks, double* out_dev, void* stream) {
@@ -1360,31 +1376,49 @@ int hf_check(hf_ctx* ctx, void* stream) {
     return flags_to_code(*ctx->h_flags);
 }
 
+// Polled completion: the last kernel of a pass writes the statistics into the pinned host block and then a stamp; the host
+// spins on the stamp instead of waiting for the stream's completion signal (≈ 12 us less per EM step).  Not used while
+// the last kernel itself is being timed with events, nor with the host trace (both need the stream drained).
+static bool poll_ok(const hf_ctx* ctx, int last_kernel) {
+#ifdef HF_NO_POLL
+    return false;
+#else
+    return ctx->d_total_host && !((ctx->prof_mask >> last_kernel) & 1u) && !ctx->host_trace;
+#endif
+}
+static double next_stamp(hf_ctx* ctx) { ctx->poll_seq += 1.0; ctx->h_total[ctx->V + 1] = 0.0; return ctx->poll_seq; }
+static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_host) {
+    bool seen = false;
+    if (polled) {
+        volatile double* stamp = ctx->h_total + ctx->V + 1;
+        const auto t0 = std::chrono::steady_clock::now();
+        long spins = 0;
+        while (!(seen = (*stamp == ctx->poll_seq))) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;   // let the stream report
+        }
+    }
+    if (!seen) HIPCHK(hipStreamSynchronize(st));
+    accumulate_kernel_times(ctx);   // events of the kernels before the last one have completed
+    std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
+    return flags_to_code((unsigned) ctx->h_total[ctx->V]);
+}
+
 int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
     if (!ctx || !stats_host) return set_err(HF_E_ARG, "hf_finish: bad argument");
     hipStream_t st = (hipStream_t) stream;
-#ifndef HF_NO_DIRECT_OUT
+    HIPCHK(hipSetDevice(ctx->device));
     // the reduction writes the V+1 doubles into pinned host memory over PCIe: no device-to-host copy afterwards
-    int rc;
-    if (ctx->pass_rows) {
-        HIPCHK(hipSetDevice(ctx->device));
-        rc = launch_rows_total(ctx, st, ctx->d_total_host ? ctx->d_total_host : ctx->d_total);
-    } else
-        rc = hf_reduce_chunks(ctx, ctx->d_chunk_stats, ctx->C, ctx->d_total_host ? ctx->d_total_host : ctx->d_total, stream);
+    double* out = ctx->d_total_host ? ctx->d_total_host : ctx->d_total;
+    const bool polled = poll_ok(ctx, ctx->pass_rows ? HF_K_ROWS_TOTAL : HF_K_REDUCE);
+    const double seq = polled ? next_stamp(ctx) : 0.0;
+    int rc = ctx->pass_rows ? launch_rows_total(ctx, st, out, true, seq)
+                            : reduce_chunks_seq(ctx, ctx->d_chunk_stats, nullptr, ctx->C, out, stream, seq);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev1, st));
     if (!ctx->d_total_host)
         HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
-#else
-    int rc = hf_reduce_chunks(ctx, ctx->d_chunk_stats, ctx->C, ctx->d_total, stream);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(ctx->ev1, st));
-    HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
-#endif
-    HIPCHK(hipStreamSynchronize(st));
-    accumulate_kernel_times(ctx);
-    std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
-    return flags_to_code((unsigned) ctx->h_total[ctx->V]);
+    return wait_total(ctx, st, polled, stats_host);
 }
 
 // Multi-GPU counterpart of hf_finish: the rows of ALL chunks are in `rows_dev` (all-gathered, row_index_dev maps list
@@ -1395,15 +1429,14 @@ int hf_finish_gathered(hf_ctx* ctx, const double* rows_dev, const int32_t* row_i
     if (!ctx || !rows_dev || !stats_host || n_chunks < 0) return set_err(HF_E_ARG, "hf_finish_gathered: bad argument");
     hipStream_t st = (hipStream_t) stream;
     double* out = ctx->d_total_host ? ctx->d_total_host : ctx->d_total;
-    int rc = hf_reduce_chunks_indexed(ctx, rows_dev, row_index_dev, n_chunks, out, stream);
+    const bool polled = poll_ok(ctx, HF_K_REDUCE);
+    const double seq = polled ? next_stamp(ctx) : 0.0;
+    int rc = reduce_chunks_seq(ctx, rows_dev, row_index_dev, n_chunks, out, stream, seq);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev1, st));
     if (!ctx->d_total_host)
         HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    accumulate_kernel_times(ctx);
-    std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
-    return flags_to_code((unsigned) ctx->h_total[ctx->V]);
+    return wait_total(ctx, st, polled, stats_host);
 }
 
 // One EM step in one call: E-step with the model's current parameters, reduced statistics back on the host,

@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
 template <int KT>
 __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_stats,
                                                      const DevParams* __restrict__ P, const double* __restrict__ chunk_ll, int64_t C,
-                                                     int64_t V, int Kctx, double* __restrict__ out, const unsigned* __restrict__ flags) {
+                                                     int64_t V, int Kctx, double* __restrict__ out, const unsigned* __restrict__ flags, double seq) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NQ = 960 / NA;                  // interleaved accumulators per element (the last wavefront sums the log-likelihoods)
     const int tid = threadIdx.x;
@@ -330,4 +330,9 @@ __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__
         __syncthreads();
     }
     if (tid == 0 && flags) out[V] = (double) fl;
+    if (seq != 0.0) {   // completion stamp for a host that polls the pinned block: after every write above is visible
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) { out[V + 1] = seq; __threadfence_system(); }
+    }
 }
