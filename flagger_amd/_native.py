@@ -16,6 +16,7 @@ HF_MODEL_TRUNC_EXP_GAUSSIAN, HF_MODEL_GAUSSIAN, HF_MODEL_NEGATIVE_BINOMIAL = 0, 
 HF_MODE_FULL, HF_MODE_FORWARD_ONLY = 0, 1
 HF_ALGO_SCAN, HF_ALGO_SEQ = 0, 1
 HF_STATS_CHUNKS, HF_STATS_ROWS = 0, 1
+HF_PROF_PASS = 0x80000000
 HF_OK, HF_E_ARG, HF_E_HIP, HF_E_SCALE, HF_E_NAN, HF_E_REGION, HF_E_NOGPU = 0, -1, -2, -3, -4, -5, -6
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhmmflagger_hip.so")

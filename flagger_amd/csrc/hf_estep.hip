@@ -714,6 +714,15 @@ __global__ void __launch_bounds__(64) k_reduce(const double* __restrict__ chunk_
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ------------------------------------------------------------------------------------------
+// the event pair around a whole pass (hf_last_kernel_ms) costs two extra packets per step: only while profiling is on
+static bool pass_events(const hf_ctx* ctx) {
+#ifdef HF_ALWAYS_EVENTS
+    return true;
+#else
+    return (ctx->prof_mask & HF_PROF_PASS) != 0 || ctx->host_trace;
+#endif
+}
+
 template <typename T>
 static int dev_upload(T** dst, const T* src, size_t n) {
     HIPCHK(hipMalloc((void**) dst, (n ? n : 1) * sizeof(T)));
@@ -1282,11 +1291,11 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
     HIPCHK(hipSetDevice(ctx->device));
     int rc = pack_params(ctx, p);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(ctx->ev0, st));
+    if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev0, st));
     rc = enqueue_pass(ctx, p, mode, st);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(ctx->ev1, st));
-    ctx->ev_valid = true;
+    if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev1, st));
+    ctx->ev_valid = pass_events(ctx);
     ctx->have_full = (mode == HF_MODE_FULL);
     return HF_OK;
 }
@@ -1383,7 +1392,7 @@ static bool poll_ok(const hf_ctx* ctx, int last_kernel) {
 #ifdef HF_NO_POLL
     return false;
 #else
-    return ctx->d_total_host && !((ctx->prof_mask >> last_kernel) & 1u) && !ctx->host_trace;
+    return ctx->d_total_host && !((ctx->prof_mask >> last_kernel) & 1u) && !(ctx->prof_mask & HF_PROF_PASS) && !ctx->host_trace;
 #endif
 }
 static double next_stamp(hf_ctx* ctx) { ctx->poll_seq += 1.0; ctx->h_total[ctx->V + 1] = 0.0; return ctx->poll_seq; }
@@ -1415,7 +1424,7 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
     int rc = ctx->pass_rows ? launch_rows_total(ctx, st, out, true, seq)
                             : reduce_chunks_seq(ctx, ctx->d_chunk_stats, nullptr, ctx->C, out, stream, seq);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(ctx->ev1, st));
+    if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev1, st));
     if (!ctx->d_total_host)
         HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
     return wait_total(ctx, st, polled, stats_host);
@@ -1433,7 +1442,7 @@ int hf_finish_gathered(hf_ctx* ctx, const double* rows_dev, const int32_t* row_i
     const double seq = polled ? next_stamp(ctx) : 0.0;
     int rc = reduce_chunks_seq(ctx, rows_dev, row_index_dev, n_chunks, out, stream, seq);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(ctx->ev1, st));
+    if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev1, st));
     if (!ctx->d_total_host)
         HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
     return wait_total(ctx, st, polled, stats_host);
@@ -1603,7 +1612,7 @@ int hf_set_profiling(hf_ctx* ctx, unsigned kernel_mask) {
     if (!ctx) return set_err(HF_E_ARG, "hf_set_profiling: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
     if (kernel_mask && !ctx->kev[0]) for (int i = 0; i < 2 * HF_NKERNELS; i++) HIPCHK(hipEventCreate(&ctx->kev[i]));
-    ctx->prof_mask = kernel_mask & ((1u << HF_NKERNELS) - 1u);
+    ctx->prof_mask = kernel_mask & (((1u << HF_NKERNELS) - 1u) | HF_PROF_PASS);
     for (int i = 0; i < HF_NKERNELS; i++) { ctx->kran[i] = false; ctx->ksum[i] = 0.0; ctx->kcount[i] = 0; }
     return HF_OK;
 }

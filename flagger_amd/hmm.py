@@ -249,7 +249,7 @@ class EMList:
         """True/False: all kernels / none; or an iterable of kernel names (hf_kernel_name) to bracket with events."""
         names = [self._L.hf_kernel_name(i).decode() for i in range(N.HF_NKERNELS)]
         if kernels is True:
-            mask = (1 << N.HF_NKERNELS) - 1
+            mask = ((1 << N.HF_NKERNELS) - 1) | N.HF_PROF_PASS      # every kernel + the whole pass (kernel_ms)
         elif not kernels:
             mask = 0
         else:

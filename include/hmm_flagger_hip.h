@@ -171,7 +171,8 @@ int hf_get_labels(hf_ctx *ctx, int8_t *labels_host);                            
 int hf_get_posterior(hf_ctx *ctx, int64_t first, int64_t n, double *post_host);        /* [n][4] hmm.c:671-685 */
 int hf_get_forward_backward(hf_ctx *ctx, int64_t first, int64_t n, double *f_host, double *b_host,
                             double *scales_host);                                      /* EM.f/.b/.scales */
-/* kernel time of the last hf_estep + reduce in milliseconds (HIP events on the stream used) */
+/* kernel time of the last hf_estep + reduce in milliseconds (HIP events on the stream used); recorded only while
+ * hf_set_profiling's mask carries HF_PROF_PASS (two extra stream packets per pass) */
 int hf_last_kernel_ms(hf_ctx *ctx, float *ms);
 
 /* Per-kernel timing (bench.py's roofline leg): every kernel k whose bit is set in kernel_mask is bracketed
@@ -181,6 +182,7 @@ int hf_last_kernel_ms(hf_ctx *ctx, float *ms);
 #define HF_NKERNELS 13
 enum { HF_K_TABLES = 0, HF_K_PROD_TILE, HF_K_CARRY, HF_K_FB_TILE, HF_K_STATS_TILE, HF_K_CHUNK_STATS, HF_K_REDUCE,
        HF_K_EMIT_ROWS, HF_K_FWD_SEQ, HF_K_BWD_SEQ, HF_K_PAIR_SUMS, HF_K_ROW_STATS, HF_K_ROWS_TOTAL };
+#define HF_PROF_PASS 0x80000000u   /* in kernel_mask: also bracket the whole pass (hf_last_kernel_ms) */
 int hf_set_profiling(hf_ctx *ctx, unsigned kernel_mask);
 int hf_kernel_times(hf_ctx *ctx, float ms[HF_NKERNELS]);
 /* Sum of the durations (ms) and number of timed launches of every selected kernel over all passes finished by
