@@ -643,15 +643,10 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
 #pragma unroll
             for (int s = 0; s < 4; s++) f[s] = HF_PDIV(nf[s], sc);
             ll += log(sc);                                            // hmm.c:428
-#ifdef HF_PROBE_RECS   // timing probe (wrong results for the statistics): window-major 32-byte records, lane stride 128 B
-            reinterpret_cast<double2*>(F)[(t0 + a + i) * 2] = make_double2(f[0], f[1]);
-            reinterpret_cast<double2*>(F)[(t0 + a + i) * 2 + 1] = make_double2(f[2], f[3]);
-#else
             if (!RECS) {
                 reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 0)] = make_double2(f[0], f[1]);
                 reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 1)] = make_double2(f[2], f[3]);
             }
-#endif
             scale[t] = sc;
 #pragma unroll
             for (int s = 0; s < 4; s++) FW(i, s) = f[s];
@@ -748,16 +743,11 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
             {
                 const int64_t t = t0 + a + jl;
                 {   // jl is wave-divergent only in a chunk's last tile
-#ifdef HF_PROBE_RECS
-                    reinterpret_cast<double2*>(B)[t * 2] = make_double2(b[0], b[1]);
-                    reinterpret_cast<double2*>(B)[t * 2 + 1] = make_double2(b[2], b[3]);
-#else
                     if (!RECS) {
                         const int64_t s0 = fb_slot<L>(tile, lane, jl, 0);
                         reinterpret_cast<double2*>(B)[s0] = make_double2(b[0], b[1]);
                         reinterpret_cast<double2*>(B)[s0 + 64] = make_double2(b[2], b[3]);
                     }
-#endif
                 }
                 label[t] = (int8_t) posterior_label(fl, b, scl);
 #ifdef HF_FB_LDS
@@ -790,15 +780,10 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
                 if (sc < 1e-50) bad |= HF_FLAG_SCALE;                 // hmm.c:521-524
 #pragma unroll
                 for (int s = 0; s < 4; s++) b[s] = HF_PDIV(nb[s], sc);
-#ifdef HF_PROBE_RECS
-                reinterpret_cast<double2*>(B)[t * 2] = make_double2(b[0], b[1]);
-                reinterpret_cast<double2*>(B)[t * 2 + 1] = make_double2(b[2], b[3]);
-#else
                 if (!RECS) {
                     reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 0)] = make_double2(b[0], b[1]);
                     reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 1)] = make_double2(b[2], b[3]);
                 }
-#endif
                 {
                     const double fi[4] = {FW(i, 0), FW(i, 1), FW(i, 2), FW(i, 3)};
                     label[t] = (int8_t) posterior_label(fi, b, sc);
