@@ -15,7 +15,7 @@ em = hmm.EMList(store, model)
 em.set_profiling(True)
 for _ in range(30):
     try:
-        em.em_iterate(model, False, 1e-3)
+        em.em_iterate(model, False, 1e-3, mode=int(os.environ.get("PROBE_MODE", "0")))   # 1: forward-only passes
     except N.HFError:
         pass
 ks = {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in em.kernel_time_sums().items() if v[1]}
