@@ -355,3 +355,39 @@ def test_statistics_by_row_agree_with_per_chunk_statistics():
         assert np.array_equal(again, rows)                                 # fixed plan: reproducible bit for bit
     finally:
         em.close()
+
+
+def test_partial_range_getters_and_rank_total_in_both_statistics_modes():
+    """hf_get_forward_backward / hf_get_posterior on a sub-range (pair records in the statistics-by-row mode, lane-minor
+    arrays otherwise) equal the slices of the full range; hf_rank_total (what ranks exchange) equals hf_finish's vector;
+    hf_last_kernel_ms needs the HF_PROF_PASS bit."""
+    store = synth.config(2, scale=0.004)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, store, synth.HIFI_ALPHA)
+    em = hmm.EMList(store, model)
+    other = hmm.EMList(store, model)            # only lends a device buffer: its per-chunk array is the "exchange buffer"
+    scratch = other._L.hf_chunk_stats_dev(other._h)
+    try:
+        for mode in (N.HF_STATS_ROWS, N.HF_STATS_CHUNKS):
+            em.set_stats_mode(mode)
+            em.launch(model)
+            em.rank_total(scratch)
+            got = em.finish_gathered(scratch, 0, 1).copy()     # the exchange of a world of one rank
+            total = em.finish()
+            assert np.array_equal(got, total)
+            f, b, sc = em.forward_backward()
+            n = store.n_windows
+            for first, cnt in ((0, 1), (n - 1, 1), (n // 3, 257), (5, 64)):
+                f1, b1, s1 = em.forward_backward(first, cnt)
+                assert np.array_equal(f1, f[first:first + cnt]) and np.array_equal(b1, b[first:first + cnt])
+                assert np.array_equal(s1, sc[first:first + cnt])
+            post = em.posterior()
+            assert np.allclose(post.sum(axis=1), 1.0, rtol=0, atol=1e-12)
+            assert np.array_equal(em.posterior(7, 30), post[7:37])
+        with pytest.raises(N.HFError):
+            em.kernel_ms()                     # no pass-level event pair unless profiling asks for it
+        em.set_profiling(True)
+        em.launch(model); em.finish()
+        assert em.kernel_ms() > 0.0
+    finally:
+        em.close()
+        other.close()
