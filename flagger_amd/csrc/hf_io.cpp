@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -111,6 +114,133 @@ const char* field_after(const char* line, int n_colons) {         // pointer jus
     return p;
 }
 
+
+// ---- reading: a second thread inflates 4 MiB blocks ahead of the parser; lines are handed out in place ----
+class LineReader {
+  public:
+    explicit LineReader(gzFile f) : f_(f) {
+        for (auto& b : buf_) b.resize(kCap + 1);
+        th_ = std::thread([this] { produce(); });
+    }
+    ~LineReader() {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_free_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    // next line, NUL-terminated, without its '\n', in writable memory that stays valid until the next call
+    bool next(char*& line, size_t& len) {
+        if (have_ && pos_ == len_[cur_]) release();     // the previous call's line lived in this block until now
+        for (;;) {
+            if (!have_ && !acquire()) {                 // end of file: a last line without '\n'
+                if (carry_.empty()) return false;
+                carry_.push_back('\0');
+                out_.swap(carry_); carry_.clear();
+                line = out_.data(); len = out_.size() - 1;
+                return true;
+            }
+            char* base = buf_[cur_].data();
+            char* p = base + pos_;
+            char* end = base + len_[cur_];
+            char* nl = (char*) std::memchr(p, '\n', (size_t) (end - p));
+            if (!nl) {                                  // the line continues in the next block
+                carry_.insert(carry_.end(), p, end);
+                release();
+                continue;
+            }
+            pos_ = (size_t) (nl - base) + 1;
+            if (!carry_.empty()) {
+                carry_.insert(carry_.end(), p, nl);
+                carry_.push_back('\0');
+                out_.swap(carry_); carry_.clear();
+                line = out_.data(); len = out_.size() - 1;
+            } else {
+                *nl = '\0';
+                line = p; len = (size_t) (nl - p);
+            }
+            return true;
+        }
+    }
+
+  private:
+    static constexpr size_t kCap = 4u << 20;
+    static constexpr int kN = 3;
+    void produce() {
+        for (int i = 0;; i = (i + 1) % kN) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_free_.wait(g, [this] { return stop_ || filled_ < kN; });
+                if (stop_) return;
+            }
+            size_t got = 0;
+            while (got < kCap) {                        // gzread returns short counts only at the end of the stream
+                const int r = gzread(f_, buf_[i].data() + got, (unsigned) (kCap - got));
+                if (r <= 0) break;
+                got += (size_t) r;
+            }
+            {
+                std::lock_guard<std::mutex> g(m_);
+                len_[i] = got; filled_++;
+            }
+            cv_full_.notify_all();
+            if (got == 0) return;
+        }
+    }
+    bool acquire() {                                    // wait for the next filled block
+        std::unique_lock<std::mutex> g(m_);
+        cv_full_.wait(g, [this] { return filled_ > 0; });
+        if (len_[next_] == 0) return false;             // the empty block that marks the end
+        cur_ = next_; next_ = (next_ + 1) % kN; pos_ = 0; have_ = true;
+        return true;
+    }
+    void release() { have_ = false; release_slot(); }
+    void release_slot() {
+        { std::lock_guard<std::mutex> g(m_); filled_--; }
+        cv_free_.notify_all();
+    }
+    gzFile f_;
+    std::vector<char> buf_[kN];
+    size_t len_[kN] = {0, 0, 0};
+    std::vector<char> carry_, out_;
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_free_, cv_full_;
+    int filled_ = 0, cur_ = 0, next_ = 0;
+    size_t pos_ = 0;
+    bool have_ = false, stop_ = false;
+};
+
+// atoi / atof of a field for the shapes that occur in coverage files, with the library calls as the fallback.
+// An integer of at most 15 digits divided by an exact power of ten is correctly rounded, i.e. it is strtod's result.
+inline int fast_atoi(const char* p) {
+    const char* q = p;
+    bool neg = false;
+    if (*q == '-') { neg = true; q++; } else if (*q == '+') q++;
+    if (*q < '0' || *q > '9') return std::atoi(p);
+    long v = 0;
+    int nd = 0;
+    while (*q >= '0' && *q <= '9' && nd < 10) { v = v * 10 + (*q - '0'); q++; nd++; }
+    if (*q >= '0' && *q <= '9') return std::atoi(p);     // very long: let the library decide
+    if (v > 2147483647L) return std::atoi(p);
+    return (int) (neg ? -v : v);
+}
+inline double fast_atof(const char* p) {
+    static const double p10[16] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15};
+    const char* q = p;
+    bool neg = false;
+    if (*q == '-') { neg = true; q++; } else if (*q == '+') q++;
+    if (*q < '0' || *q > '9') return std::atof(p);
+    unsigned long long m = 0;
+    int nd = 0, frac = 0;
+    while (*q >= '0' && *q <= '9') { if (++nd > 15) return std::atof(p); m = m * 10 + (unsigned) (*q - '0'); q++; }
+    if (*q == '.') {
+        q++;
+        while (*q >= '0' && *q <= '9') { if (++nd > 15) return std::atof(p); m = m * 10 + (unsigned) (*q - '0'); q++; frac++; }
+    }
+    if (*q != '\0') return std::atof(p);                 // exponent, inf, nan, trailing text: the library's rules
+    const double v = frac ? (double) m / p10[frac] : (double) m;
+    return neg ? -v : v;
+}
+
 // ---- .cov / .cov.gz: header (track_reader.c:48-457), rows (:751-818), chunks (chunk.c:240-294), windows ----
 hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
     if (chunk_len <= 0 || window_len <= 0) { g_io_err = "chunkLen/windowLen must be > 0"; return nullptr; }
@@ -119,7 +249,7 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
     gzbuffer(f, 1 << 20);
     hfio_table* t = new hfio_table();
     t->chunk_len = chunk_len; t->window_len = window_len;
-    std::vector<char> buf(8192);                                    // LINE_MAX_SIZE
+    LineReader* reader = new LineReader(f);
     bool have_ann = false, have_reg = false, have_lab = false, have_avg = false;
     int n_ann = 0, n_reg = 0, parsed_cov = 0;
     std::string ctg;
@@ -128,7 +258,7 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
     ChunkMeta cur{};
     WindowAcc acc;
     int next_pos = 0;                                               // next base expected in the current contig
-    auto fail = [&](const std::string& m) { g_io_err = m; gzclose(f); delete t; return (hfio_table*) nullptr; };
+    auto fail = [&](const std::string& m) { g_io_err = m; delete reader; gzclose(f); delete t; return (hfio_table*) nullptr; };
     auto first_chunk = [&]() {
         cur.ctg = ctg; cur.ctg_len = ctg_len; cur.s = 0;
         cur.e = ctg_len < 2 * chunk_len ? ctg_len - 1 : chunk_len - 1;   // chunk.c:262
@@ -138,10 +268,10 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
         cur.s = pe + 1;
         cur.e = ctg_len < pe + 2 * chunk_len ? ctg_len - 1 : pe + chunk_len;   // chunk.c:274-277
     };
-    while (gzgets(f, buf.data(), (int) buf.size())) {
-        char* line = buf.data();
-        size_t L = std::strlen(line);
-        if (L && line[L - 1] == '\n') line[--L] = '\0';
+    char* line = nullptr;
+    size_t L = 0;
+    while (reader->next(line, L)) {
+        if (L && line[L - 1] == '\r') line[--L] = '\0';
         if (L == 0) continue;
         if (line[0] == '#') {
             if (starts_with(line, "#annotation:len") && !have_ann) {
@@ -194,12 +324,12 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
             *q = '\0'; p = q + 1;
         }
         if (nf < 7) return fail("Error: a coverage row has fewer than 7 columns");
-        const int s = std::atoi(fld[0]) - 1, e = std::atoi(fld[1]) - 1;          // 1-based inclusive -> 0-based
-        const double v_cov = std::atof(fld[2]), v_mapq = std::atof(fld[3]), v_clip = std::atof(fld[4]);
+        const int s = fast_atoi(fld[0]) - 1, e = fast_atoi(fld[1]) - 1;          // 1-based inclusive -> 0-based
+        const double v_cov = fast_atof(fld[2]), v_mapq = fast_atof(fld[3]), v_clip = fast_atof(fld[4]);
         const uint64_t flag = annot_flag_of(fld[5]);
-        const int region = clampi(std::atoi(fld[6]), 0, 100);
-        const int truth = clampi((nf >= 8 ? std::atoi(fld[7]) : -1), -1, 10) + 1;
-        const int pred = clampi((nf >= 9 ? std::atoi(fld[8]) : -1), -1, 10) + 1;
+        const int region = clampi(fast_atoi(fld[6]), 0, 100);
+        const int truth = clampi((nf >= 8 ? fast_atoi(fld[7]) : -1), -1, 10) + 1;
+        const int pred = clampi((nf >= 9 ? fast_atoi(fld[8]) : -1), -1, 10) + 1;
         if (s != next_pos || e < s) return fail("Error: coverage rows must tile each contig without gaps (chunk.c:451)");
         int pos = s;
         while (pos <= e && pos <= ctg_len - 1) {
@@ -216,6 +346,7 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
         }
         next_pos = e + 1;
     }
+    delete reader;
     gzclose(f);
     if (in_contig) { t->push_window(acc); t->close_chunk(cur); }
     if (!have_ann || !have_reg) { g_io_err = "Error: missing '#annotation:len:' / '#region:len:' header"; delete t; return nullptr; }

@@ -143,3 +143,36 @@ def test_synthetic_store_written_as_cov_loads_back_identically(ext, tmp_path):
     sub = tab.store()
     want = st.subset_chunks([c for c in range(st.n_chunks) if st.chunk_ctg[c] in ("ctg0", "ctg2")])
     assert kept == want.n_chunks and np.array_equal(sub.cov, want.cov) and list(sub.chunk_ctg) == list(want.chunk_ctg)
+
+
+def test_loader_number_shapes_line_endings_and_block_boundaries(tmp_path):
+    """The block reader (a second thread inflates 4 MiB blocks ahead of the parser) and the fast field parser against the
+    oracle's gzgets + atoi/atof: every number shape falls back to the library where the fast path does not apply; lines
+    that straddle block boundaries; a last line without newline; CRLF line endings."""
+    header = ["#annotation:len:2", "#annotation:name:0:no_annotation", "#annotation:name:1:whole_genome", "#region:len:1",
+              "#region:coverage:0:20", "#label:len:4", "#truth:true", "#avg_alignment_len:9000", "#start-only:false"]
+    shapes = ["12", "12.", "012.50", "1e1", "1.5E+1", "+7", ".5", "  8", "3.141592653589793238", "0.1", "7.25", "1234567.125",
+              "0", "00", "249.99", "250.5", "1e-3", "123456789012345", "1234567890123456", "9.999999999999999", "nan"]
+    rng = np.random.default_rng(11)
+    lines = list(header) + [">c0 400000"]
+    for i in range(400_000):                       # one base per row: ~9 MB of text, two block boundaries
+        v = shapes[i % len(shapes)] if i % 7 == 0 and shapes[i % len(shapes)] != "nan" else str(int(rng.integers(0, 60)))
+        lines.append(f"{i + 1}\t{i + 1}\t{v}\t{int(rng.integers(0, 30))}.5\t{int(rng.integers(0, 5))}\t1\t0\t{int(rng.integers(-1, 4))}")
+    text = "\n".join(lines) + "\n"
+    assert len(text) > 2 * (4 << 20)
+    p = tmp_path / "shapes.cov"
+    p.write_text(text)
+    ref = _oracle_load_cov(str(p), 50_000, 100, tmp_path)
+    mine = fio.Table(str(p), 50_000, 100).store()
+    _same_store(mine, ref)
+    (tmp_path / "nonl.cov").write_text(text[:-1])                      # no newline after the last row
+    _same_store(fio.Table(str(tmp_path / "nonl.cov"), 50_000, 100).store(), ref)
+    (tmp_path / "crlf.cov").write_text(text.replace("\n", "\r\n"))
+    _same_store(fio.Table(str(tmp_path / "crlf.cov"), 50_000, 100).store(), ref)
+    import gzip
+    with gzip.open(tmp_path / "z.cov.gz", "wt") as f:
+        f.write(text)
+    _same_store(fio.Table(str(tmp_path / "z.cov.gz"), 50_000, 100).store(), ref)
+    (tmp_path / "empty.cov").write_text("")
+    with pytest.raises(Exception):
+        fio.Table(str(tmp_path / "empty.cov"), 50_000, 100)
