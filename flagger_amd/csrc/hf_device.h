@@ -193,3 +193,28 @@ __device__ __forceinline__ void hf_emit_values(const DevParams* __restrict__ P, 
         }
     }
 }
+
+// transition row table for one window: region change => 1/(S+1) (hmm.c:398-400)
+__device__ __forceinline__ void load_T(const DevParams* __restrict__ P, uint32_t r, double Tm[16]) {
+    if (REC_REGCHG(r)) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) Tm[k] = 1.0 / (HF_NSTATES + 1);
+    } else {
+        const double* __restrict__ src = P->reg[REC_REGION(r)].tcond[REC_VMASK(r)];
+#pragma unroll
+        for (int k = 0; k < 16; k++) Tm[k] = src[k];
+    }
+}
+
+__device__ __forceinline__ int posterior_label(const double f[4], const double b[4], double sc) {
+    // hmm.c:671-692 + common.c:292-304 (strict >, first maximum wins)
+    double p[4], total = 0.0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) { p[s] = f[s] * b[s] * sc; total += p[s]; }
+#pragma unroll
+    for (int s = 0; s < 4; s++) p[s] /= total;
+    double mx = p[0]; int idx = 0;
+#pragma unroll
+    for (int s = 0; s < 4; s++) if (mx < p[s]) { mx = p[s]; idx = s; }
+    return idx;
+}

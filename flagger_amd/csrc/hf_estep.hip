@@ -1,18 +1,21 @@
-// hf_estep.hip — MI355X (gfx950) E-step of HMM-Flagger: kernels + C ABI (include/hmm_flagger_hip.h).
+// hf_estep.hip — MI355X (gfx950) E-step of HMM-Flagger: the host side of the C ABI (include/hmm_flagger_hip.h), the
+// context, the one-time set-up kernels and the launch sequence of a pass; the kernels of a pass live in the headers below.
 //
 // Replaces EM_runOneIterationForList / EM_runForwardForList (programs/submodules/hmm/hmm.c:739,790).
-// Pipeline of one pass (per EM iteration), HF_ALGO_SCAN (hf_scan.h):
-//   k_tables      emission rows of this iteration (per occurring (region, x, x_prev) + per contig-end window)
+// One pass (per EM iteration), HF_ALGO_SCAN:
+//   hf_scan.h    k_tables      emission rows of this iteration (per occurring (region, x, x_prev) + per contig-end window)
 //                                                                        (hmm_utils.c:753-793, 941-947)
-//   k_prod_tile   lane / tile products of A_t = T_t∘E_t
-//   k_carry       per chunk: carried-in forward vector / backward direction of every tile
-//   k_fb_tile     scaled forward + log-likelihood, scaled backward + posterior argmax
+//                k_prod_tile   lane / tile products of A_t = T_t∘E_t
+//                k_carry       per chunk: carried-in forward vector / backward direction of every tile
+//                k_fb_tile     scaled forward + log-likelihood, scaled backward + posterior argmax
 //                                                                        (hmm.c:333-434, 452-545, 671-692)
-//   k_stats_tile  xi sufficient statistics per tile                      (hmm.c:563-650, hmm_utils.c:812-839)
-//   k_chunk_stats per chunk: tile partials -> estimator layout, chunk log-likelihood
-//   k_reduce      sum over chunks in a fixed order                       (hmm.c:759-763)
-// HF_ALGO_SEQ keeps the first formulation as an independent check: k_emit_rows (direct evaluation of every
-// window's row), k_fwd_seq / k_bwd_seq (one wavefront per chunk, sequential recurrences), then the same statistics.
+//   hf_rows.h    k_pair_sums, k_row_stats, k_rows_total: xi sufficient statistics summed by emission row (default)
+//                                                                        (hmm.c:563-650, hmm_utils.c:812-839, 1027-1034)
+//   hf_chunks.h  k_stats_tile, k_chunk_stats, k_reduce: the same statistics as one vector per chunk, summed in chunk-list
+//                order (hmm.c:759-763) — HF_STATS_CHUNKS, the per-chunk multi-GPU exchange, HF_ALGO_SEQ
+//   hf_nb.h      the negative_binomial model's tables and count data
+//   hf_seq.h     HF_ALGO_SEQ, an independent on-device check: k_emit_rows (direct evaluation of every window's row),
+//                k_fwd_seq / k_bwd_seq (one wavefront per chunk, sequential recurrences)
 // There is no CPU fallback: without a HIP device hf_create fails with HF_E_NOGPU.
 #include "hf_device.h"
 #include "../../include/hmm_flagger_model.h"
@@ -164,552 +167,12 @@ __global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __res
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// k_emit: E_t[pre][s] = e_s(x_t | x_{t-1}, alpha[pre][s], beta_t) for every window (A8-A10).
-// Chunk-first windows hold e_s(x_0; alpha=0, preX=0) in row pre=0 (hmm.c:338-352).
-// Evaluated once per distinct alpha of a column; Err (trunc-exp) ignores alpha.
-// ------------------------------------------------------------------------------------------
-// transition row table for one window: region change => 1/(S+1) (hmm.c:398-400)
-__device__ __forceinline__ void load_T(const DevParams* __restrict__ P, uint32_t r, double Tm[16]) {
-    if (REC_REGCHG(r)) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) Tm[k] = 1.0 / (HF_NSTATES + 1);
-    } else {
-        const double* __restrict__ src = P->reg[REC_REGION(r)].tcond[REC_VMASK(r)];
-#pragma unroll
-        for (int k = 0; k < 16; k++) Tm[k] = src[k];
-    }
-}
-
-// HF_ALGO_SEQ: emission row of every window by direct evaluation, E[t][16] (A8-A10); chunk-first windows hold
-// e_s(x_0; alpha=0, preX=0) in row pre=0 (hmm.c:338-352)
-__global__ void __launch_bounds__(256) k_emit_rows(int64_t N, const uint32_t* __restrict__ rec, const double* __restrict__ beta,
-                                                   const DevParams* __restrict__ P, const double* __restrict__ nbE,
-                                                   double* __restrict__ E, unsigned* __restrict__ flags) {
-    const int64_t t = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= N) return;
-    const uint32_t r = rec[t];
-    const bool first = REC_FIRST(r) != 0;
-    const double x = (double) REC_X(r), px = first ? 0.0 : (double) REC_X(rec[t - 1]);
-    unsigned nan = 0;
-    double out[16];
-    if (nbE) {   // negative_binomial: e_s(x) from the caller's table (hf_params.nb_E), the same in every row
-        for (int s = 0; s < 4; s++) {
-            const double e = nbE[((int64_t) REC_REGION(r) * 4 + s) * (HF_NB_MAX_COVERAGE + 1) + REC_X(r)];
-            if (e != e) nan |= HF_FLAG_NAN;
-            for (int p = 0; p < 4; p++) out[p * 4 + s] = (first && p != 0) ? 0.0 : e;
-        }
-    } else
-    hf_emit_values(P, &P->reg[REC_REGION(r)], x, px, first, beta[t], out, &nan);
-    double2* dst = reinterpret_cast<double2*>(E) + t * 8;
-#pragma unroll
-    for (int k = 0; k < 8; k++) dst[k] = make_double2(out[2 * k], out[2 * k + 1]);
-    if (nan) atomicOr(flags, nan);
-}
-
-__device__ __forceinline__ void load_E_window(const double* __restrict__ E, int64_t t, double* Ev) {
-    const double2* __restrict__ src = reinterpret_cast<const double2*>(E) + t * 8;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const double2 v = src[k]; Ev[2 * k] = v.x; Ev[2 * k + 1] = v.y; }
-}
-
-// ------------------------------------------------------------------------------------------
-// HF_ALGO_SEQ: one wavefront per chunk, windows visited in order with the reference's exact
-// operation order; tiles of 64 windows are staged through LDS with coalesced loads/stores.
-// ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_fwd_seq(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
-                                                const uint32_t* __restrict__ rec,
-                                                const double* __restrict__ E, const DevParams* __restrict__ P,
-                                                double* __restrict__ F, double* __restrict__ scale,
-                                                double* __restrict__ tile_ll, unsigned* __restrict__ flags) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int64_t t0 = off[c], T = off[c + 1] - t0;
-    __shared__ double Es[64][17];
-    __shared__ double Fs[64][5];
-    __shared__ uint32_t rs[64];
-    double f[4] = {0.0, 0.0, 0.0, 0.0};
-    double ll = 0.0;
-    unsigned bad = 0;
-    for (int64_t base = 0; base < T; base += 64) {
-        const int n = (int) ((T - base) < 64 ? (T - base) : 64);
-        if (lane < n) {
-            const int64_t t = t0 + base + lane;
-            rs[lane] = rec[t];
-            load_E_window(E, t, &Es[lane][0]);
-        }
-        __syncthreads();
-        for (int j = 0; j < n; j++) {
-            const uint32_t r = rs[j];
-            double nf[4], sc = 0.0;
-            if (base + j == 0) { // hmm.c:333-364
-                const DevRegion* __restrict__ R = &P->reg[REC_REGION(r)];
-#pragma unroll
-                for (int s = 0; s < 4; s++) { nf[s] = Es[j][s] * R->trans[4][s]; sc += nf[s]; }
-            } else {             // hmm.c:366-420
-                double Tm[16];
-                load_T(P, r, Tm);
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    double acc = 0.0;
-#pragma unroll
-                    for (int p = 0; p < 4; p++) acc += (f[p] * Tm[p * 4 + s] * Es[j][p * 4 + s]);
-                    nf[s] = acc;
-                    sc += acc;
-                }
-                if (sc < 1e-50) bad |= HF_FLAG_SCALE;
-            }
-#pragma unroll
-            for (int s = 0; s < 4; s++) { f[s] = nf[s] / sc; }
-            ll += log(sc);
-            if (lane == 0) { Fs[j][0] = f[0]; Fs[j][1] = f[1]; Fs[j][2] = f[2]; Fs[j][3] = f[3]; Fs[j][4] = sc; }
-        }
-        __syncthreads();
-        if (lane < n) {
-            const int64_t t = t0 + base + lane;
-            reinterpret_cast<double2*>(F)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], base + lane, 0)] = make_double2(Fs[lane][0], Fs[lane][1]);
-            reinterpret_cast<double2*>(F)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], base + lane, 1)] = make_double2(Fs[lane][2], Fs[lane][3]);
-            scale[t] = Fs[lane][4];
-        }
-        __syncthreads();
-    }
-    // the chunk's log-likelihood goes through the same per-tile slots as the scan path (k_chunk_stats sums them)
-    const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
-    for (int k = lane; k < nt; k += 64) tile_ll[k0 + k] = k == 0 ? ll : 0.0;
-    if (lane == 0 && bad) atomicOr(flags, bad);
-}
-
-__device__ __forceinline__ int posterior_label(const double f[4], const double b[4], double sc) {
-    // hmm.c:671-692 + common.c:292-304 (strict >, first maximum wins)
-    double p[4], total = 0.0;
-#pragma unroll
-    for (int s = 0; s < 4; s++) { p[s] = f[s] * b[s] * sc; total += p[s]; }
-#pragma unroll
-    for (int s = 0; s < 4; s++) p[s] /= total;
-    double mx = p[0]; int idx = 0;
-#pragma unroll
-    for (int s = 0; s < 4; s++) if (mx < p[s]) { mx = p[s]; idx = s; }
-    return idx;
-}
-
 #include "hf_scan.h"
+#include "hf_seq.h"
 #include "hf_nb.h"
-
-__global__ void __launch_bounds__(64) k_bwd_seq(const int64_t* __restrict__ off, const int32_t* __restrict__ chunk_tile0,
-                                                const uint32_t* __restrict__ rec,
-                                                const double* __restrict__ E, const DevParams* __restrict__ P,
-                                                const double* __restrict__ F, const double* __restrict__ scale,
-                                                double* __restrict__ B, int8_t* __restrict__ label,
-                                                unsigned* __restrict__ flags) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int64_t t0 = off[c], T = off[c + 1] - t0;
-    if (T <= 0) return;
-    __shared__ double Es[64][17];   // E of window i+1
-    __shared__ double Fs[64][5];    // f_i[0..3], scale_i
-    __shared__ double Bs[64][4];
-    __shared__ uint32_t rs[64];     // rec of window i+1
-    __shared__ int8_t Ls[64];
-    double b[4];
-    unsigned bad = 0;
-    { // last column, hmm.c:452-467
-        const int64_t t = t0 + T - 1;
-        const DevRegion* __restrict__ R = &P->reg[REC_REGION(rec[t])];
-        const double sc = scale[t];
-        double f[4];
-        {
-            const double2* __restrict__ F2 = reinterpret_cast<const double2*>(F);
-            const double2 f01 = F2[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], T - 1, 0)], f23 = F2[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], T - 1, 1)];
-            f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
-        }
-        for (int s = 0; s < 4; s++) b[s] = R->trans[s][4] / sc;
-        if (lane == 0) {
-            reinterpret_cast<double2*>(B)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], T - 1, 0)] = make_double2(b[0], b[1]);
-            reinterpret_cast<double2*>(B)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], T - 1, 1)] = make_double2(b[2], b[3]);
-            label[t] = (int8_t) posterior_label(f, b, sc);
-        }
-    }
-    // columns T-2 .. 0 in tiles; tile covers i in [lo, lo+n)
-    for (int64_t hi = T - 1; hi > 0; hi -= 64) {
-        const int64_t lo = hi >= 64 ? hi - 64 : 0;
-        const int n = (int) (hi - lo);
-        if (lane < n) {
-            const int64_t t = t0 + lo + lane; // window i
-            rs[lane] = rec[t + 1];
-            load_E_window(E, t + 1, &Es[lane][0]);
-            {
-                const double2* __restrict__ F2 = reinterpret_cast<const double2*>(F);
-                const double2 f01 = F2[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], lo + lane, 0)], f23 = F2[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], lo + lane, 1)];
-                Fs[lane][0] = f01.x; Fs[lane][1] = f01.y; Fs[lane][2] = f23.x; Fs[lane][3] = f23.y;
-            }
-            Fs[lane][4] = scale[t];
-        }
-        __syncthreads();
-        for (int j = n - 1; j >= 0; j--) { // hmm.c:470-529
-            double Tm[16];
-            load_T(P, rs[j], Tm);
-            double nb[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int p = 0; p < 4; p++) nb[p] += Tm[p * 4 + s] * Es[j][p * 4 + s] * b[s];
-            const double sc = Fs[j][4];
-            if (sc < 1e-50) bad |= HF_FLAG_SCALE;
-            double f[4];
-#pragma unroll
-            for (int s = 0; s < 4; s++) { b[s] = nb[s] / sc; f[s] = Fs[j][s]; }
-            const int lab = posterior_label(f, b, sc);
-            if (lane == 0) { Bs[j][0] = b[0]; Bs[j][1] = b[1]; Bs[j][2] = b[2]; Bs[j][3] = b[3]; Ls[j] = (int8_t) lab; }
-        }
-        __syncthreads();
-        if (lane < n) {
-            const int64_t t = t0 + lo + lane;
-            reinterpret_cast<double2*>(B)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], lo + lane, 0)] = make_double2(Bs[lane][0], Bs[lane][1]);
-            reinterpret_cast<double2*>(B)[fb_slot_w<HF_SCAN_L>(chunk_tile0[c], lo + lane, 1)] = make_double2(Bs[lane][2], Bs[lane][3]);
-            label[t] = Ls[lane];
-        }
-        __syncthreads();
-    }
-    if (lane == 0 && bad) atomicOr(flags, bad);
-}
-
-// ------------------------------------------------------------------------------------------
-// xi sufficient statistics (A6, A12).  For every pair (i, i+1), i = 1..T-2:
-//   xi = f_i[pre] * T * e * b_{i+1}[s] / terminationProb              (hmm.c:563-650)
-// Distinct accumulators only (mean.den == var.den == weight.num; weight.den[i] all equal); they are
-// expanded into the reference's estimator layout when the chunk vector is written (k_chunk_stats).
-// ------------------------------------------------------------------------------------------
-template <int KT>
-struct StatAcc {
-    double trans[16];
-    double g_mnum[3], g_vnum[3], g_den[3];      // single-component Gaussian states 0 (Err, gaussian model), 1, 2
-    double te_num, te_den;                      // trunc-exp Err
-    double c_mnum[KT], c_vnum[KT], c_den[KT], c_wden; // Col components
-};
-
-// ------------------------------------------------------------------------------------------
-// k_stats_tile: statistics of the pairs of one tile per wavefront; lane l owns the pairs that END at its L windows.
-// f, b come from the pass arrays, T from the LDS tables, the emission row and the collapsed state's component
-// probabilities from this iteration's rows (k_tables: the table row of (region, x, x_prev), or the window's private
-// row at contig ends); the total of the component probabilities is the emission value itself (Ev[pre][Col] is
-// the same sum of the same terms).  The 3K per-component accumulators of a lane live in LDS (lane-minor,
-// conflict-free) so the component loop stays rolled and the kernel keeps its occupancy; the 27 scalar
-// accumulators stay in registers.
-// ------------------------------------------------------------------------------------------
-struct StatAccSmall {
-    double trans[16];
-    double g_mnum[3], g_vnum[3], g_den[3];
-    double te_num, te_den;
-};
-
-template <int KT>
-__global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDesc* __restrict__ td,
-                                                    const uint32_t* __restrict__ rec, const RowSrc S,
-                                                    const DevParams* __restrict__ P,
-                                                    const double* __restrict__ F, const double* __restrict__ B,
-                                                    const uint64_t* __restrict__ regmask,
-                                                    double* __restrict__ tile_stats) {
-    constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
-    constexpr int NS = 16 + 9 + 2;                  // scalar accumulators kept in registers
-    constexpr int L = HF_SCAN_L;
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    fill_tab(P, s_tab);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * (blockDim.x >> 6) + wave;   // 4 wavefronts per block unless LDS forces fewer
-    if (tile >= ntiles) return;
-    // per-wave accumulator rows [row][lane], row stride 65 doubles: lane-minor accesses and the column sums at the
-    // end of a region are both bank-conflict free.  Rows 0..3*ncol-1: component accumulators (q*ncol + cc).
-    constexpr int RS = 65;
-    const int nrows = 3 * P->ncomp[3] > NS + 1 ? 3 * P->ncomp[3] : NS + 1;
-    double* __restrict__ s_row = s_tab + P->n_regions * HF_TAB_STRIDE + wave * (nrows * RS);
-    double* __restrict__ s_acc = s_row + lane;
-    const TileDesc d = td[tile];
-    const int64_t t0 = d.t0, T = d.T, base = d.base;
-    const bool te = hf_err_is_truncexp(P);
-    const int ncol = P->ncomp[3], nreg = P->n_regions;
-    const int64_t a0 = base + (int64_t) lane * L;   // this lane owns windows a0..a0+L-1 and the pairs ending there
-    uint32_t rr[L + 1];                             // rr[j+1] = window a0+j, rr[0] = the window before
-    rr[0] = load_recs<L>(rec, t0, T, a0, lane, rr + 1);
-    int sidx[L];
-    tile_slow_index<L>(rr + 1, lane, d.slow0, sidx);
-    bool ok[L];
-    unsigned long long present = 0;
-#pragma unroll
-    for (int j = 0; j < L; j++) {
-        const int64_t w = a0 + j;                             // pair (w-1, w), w = 2..T-1  (hmm.c:638-642)
-        ok[j] = w >= 2 && w <= T - 1;
-        if (ok[j]) present |= 1ull << (REC_REGION(rr[j + 1]) & 63u);
-    }
-    for (int o = 32; o > 0; o >>= 1) present |= __shfl_xor(present, o);
-    const unsigned long long in_chunk = regmask[d.chunk];
-    double xa[4], om[4];
-    const PreDiv term_div = prediv(HF_TERMINATION_PROB);
-    for (int r = 0; r < nreg; r++) {
-        if (!((in_chunk >> r) & 1ull)) continue;   // k_chunk_stats never reads this slot
-        double* __restrict__ dst = tile_stats + ((int64_t) tile * nreg + r) * NA;
-        if (!((present >> r) & 1ull)) {            // region occurs in the chunk but not in this tile
-            for (int i = lane; i < NA; i += 64) dst[i] = 0.0;
-            continue;
-        }
-        const DevRegion* __restrict__ R = &P->reg[r];
-        StatAccSmall a;
-#pragma unroll
-        for (int i = 0; i < NS; i++) reinterpret_cast<double*>(&a)[i] = 0.0;
-        double c_wden = 0.0;
-        for (int i = 0; i < 3 * ncol; i++) s_acc[i * RS] = 0.0;
-#pragma unroll 1
-        for (int j = 0; j < L; j++) {
-            if (!(ok[j] && (int) REC_REGION(rr[j + 1]) == r)) continue;
-            double Ev[16], Tm[16], f[4], b1[4];
-#ifdef HF_PROBE_SAMEROW   // timing probe (wrong results): every lane reads lane 0's rows — one cache line per load instruction
-            const int32_t probe_idx = __shfl(row_index(S, rr[j + 1], rr[j], sidx[j]), 0);
-            load_row(reinterpret_cast<const double2*>(S.lutE) + (int64_t) probe_idx * 8, Ev);
-#else
-            load_row(row_ptr(S, rr[j + 1], rr[j], sidx[j]), Ev);
-#endif
-            // f of the window before (the previous lane's last one for j == 0), b of the window itself (hf_scan.h fb_slot)
-            const int64_t fs = j > 0 ? fb_slot<L>(tile, lane, j - 1, 0)
-                                     : (lane > 0 ? fb_slot<L>(tile, lane - 1, L - 1, 0) : fb_slot<L>(tile - 1, 63, L - 1, 0));
-            const int64_t bs = fb_slot<L>(tile, lane, j, 0);
-            const double2 f01 = reinterpret_cast<const double2*>(F)[fs], f23 = reinterpret_cast<const double2*>(F)[fs + 64];
-            const double2 b01 = reinterpret_cast<const double2*>(B)[bs], b23 = reinterpret_cast<const double2*>(B)[bs + 64];
-            const unsigned xw = REC_X(rr[j + 1]), xp = REC_X(rr[j]);
-#ifdef HF_PROBE_SAMEROW
-            const double2* __restrict__ crow = reinterpret_cast<const double2*>(S.lutC + ((int64_t) probe_idx * 4) * S.K);
-#else
-            const double2* __restrict__ crow = crow_ptr(S, rr[j + 1], rr[j], sidx[j]);
-#endif
-            lds_Tm(s_tab, rr[j + 1], Tm);
-            f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
-            b1[0] = b01.x; b1[1] = b01.y; b1[2] = b23.x; b1[3] = b23.y;
-            const double x = (double) xw, px = (double) xp;
-            // one state (column) at a time, with a scheduling barrier after each: keeps the live set small;
-            // state outer / pre inner is also the order of the reference (hmm.c:588-589)
-            double adj3[4];
-            bool col_fast = false;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                double adj[4];
-                bool okc = true;
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const int k = HF_PS(p, s);                // rows and tables are state-major
-                    adj[p] = f[p] * Tm[k] * Ev[k] * b1[s];    // count, hmm.c:612
-                    okc &= div_operand_safe(adj[p]);
-                }
-                if (s == 3) {
-#pragma unroll
-                    for (int p = 0; p < 4; p++) okc &= Ev[HF_PS(p, 3)] != 0.0 && div_operand_safe(Ev[HF_PS(p, 3)]);
-                }
-                // count / terminationProb (hmm.c:613-614): the shared-denominator form when every operand is in range
-                if (__all(okc)) {
-#pragma unroll
-                    for (int p = 0; p < 4; p++) adj[p] = divp(adj[p], term_div);
-                    if (s == 3) col_fast = true;
-                } else {
-#pragma unroll
-                    for (int p = 0; p < 4; p++) adj[p] = adj[p] / HF_TERMINATION_PROB;
-                }
-#pragma unroll
-                for (int p = 0; p < 4; p++) a.trans[p * 4 + s] += adj[p];   // hmm_utils.c:2010-2015
-                if (s == 3) {
-#pragma unroll
-                    for (int p = 0; p < 4; p++) adj3[p] = adj[p];
-                } else if (s == 0 && te) {                    // hmm_utils.c:1027-1034
-#pragma unroll
-                    for (int p = 0; p < 4; p++) { a.te_num += adj[p] * x; a.te_den += adj[p]; }
-                } else {                                      // hmm_utils.c:812-839, one component
-#pragma unroll
-                    for (int p = 0; p < 4; p++) {
-                        const int k = HF_PS(p, s);
-                        const double alpha = P->alpha[p * 4 + s];
-                        // alpha == 0 (wave-uniform): (x - 0*px) / (1 - 0) is x itself
-                        const double x_adj = alpha == 0.0 ? x : (x - alpha * px) / (1.0 - alpha);
-                        const double w = adj[p] * Ev[k] / Ev[k];
-                        a.g_mnum[s] += w * x_adj;
-                        const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
-                        a.g_vnum[s] += w * z * z;
-                        a.g_den[s] += w;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // collapsed state, component-major: one 32-byte row per component serves all four pre states
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const double alpha = P->alpha[p * 4 + 3];
-                xa[p] = alpha == 0.0 ? x : (x - alpha * px) / (1.0 - alpha);
-                om[p] = 1.0 - alpha;
-            }
-            if (col_fast) {   // w = adj3 * pc / E3 with the four reciprocals of E3 prepared once for all components
-                PreDiv e3[4];
-#pragma unroll
-                for (int p = 0; p < 4; p++) e3[p] = prediv(Ev[HF_PS(p, 3)]);
-#pragma unroll 1
-                for (int cc = 0; cc < ncol; cc++) {
-                    const double2 u01 = crow[cc * 2], u23 = crow[cc * 2 + 1];
-                    const double mu = R->mean[3][cc];
-                    double mnum = s_acc[cc * RS], vnum = s_acc[(ncol + cc) * RS], den = s_acc[(2 * ncol + cc) * RS];
-#pragma unroll
-                    for (int p = 0; p < 4; p++) {
-                        const double pc = p == 0 ? u01.x : p == 1 ? u01.y : p == 2 ? u23.x : u23.y;   // [component][previous state]
-                        const double w = divp(adj3[p] * pc, e3[p]);
-                        mnum += w * xa[p];
-                        const double z = (xa[p] - mu) * om[p];
-                        vnum += w * z * z;
-                        den += w;
-                        c_wden += w;
-                    }
-                    s_acc[cc * RS] = mnum; s_acc[(ncol + cc) * RS] = vnum; s_acc[(2 * ncol + cc) * RS] = den;
-                }
-            } else {
-#pragma unroll 1
-                for (int cc = 0; cc < ncol; cc++) {
-                    const double2 u01 = crow[cc * 2], u23 = crow[cc * 2 + 1];
-                    const double mu = R->mean[3][cc];
-                    double mnum = s_acc[cc * RS], vnum = s_acc[(ncol + cc) * RS], den = s_acc[(2 * ncol + cc) * RS];
-#pragma unroll
-                    for (int p = 0; p < 4; p++) {
-                        const double pc = p == 0 ? u01.x : p == 1 ? u01.y : p == 2 ? u23.x : u23.y;
-                        const double w = adj3[p] * pc / Ev[HF_PS(p, 3)];
-                        mnum += w * xa[p];
-                        const double z = (xa[p] - mu) * om[p];
-                        vnum += w * z * z;
-                        den += w;
-                        c_wden += w;
-                    }
-                    s_acc[cc * RS] = mnum; s_acc[(ncol + cc) * RS] = vnum; s_acc[(2 * ncol + cc) * RS] = den;
-                }
-            }
-        }
-        // sum over the 64 lanes in lane order: accumulator i is summed by lane i out of its LDS row (fixed order),
-        // results stored in StatAcc<KT> order
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        {
-            double v = 0.0;
-            if (lane < 3 * ncol) {
-                const double* __restrict__ row = s_row + lane * RS;
-#pragma unroll 8
-                for (int l = 0; l < 64; l++) v += row[l];
-            }
-            for (int i = lane; i < 3 * KT; i += 64) dst[NS + i] = 0.0;       // slots of components >= ncol
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 3 * ncol) dst[NS + (lane / ncol) * KT + (lane % ncol)] = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int i = 0; i < NS; i++) s_acc[i * RS] = reinterpret_cast<double*>(&a)[i];
-        s_acc[NS * RS] = c_wden;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane <= NS) {
-            const double* __restrict__ row = s_row + lane * RS;
-            double v = 0.0;
-#pragma unroll 8
-            for (int l = 0; l < 64; l++) v += row[l];
-            dst[lane < NS ? lane : NS + 3 * KT] = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
-// per chunk: log-likelihood = sum of the tiles' partial sums; statistics = sum of the tile partials in tile order,
-// expanded into the estimator layout of include/hmm_flagger_hip.h (mean.den == var.den == weight.num;
-// weight.den[i] all equal).  Writes the WHOLE chunk vector (zeros where nothing accumulates:
-// HMM_resetEstimators, hmm.c:129-134), so no memset is needed between passes.  full == 0: log-likelihood only.
-template <int KT>
-__global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__ chunk_tile0, const uint64_t* __restrict__ regmask,
-                                                     const double* __restrict__ tile_stats, const double* __restrict__ tile_ll,
-                                                     const DevParams* __restrict__ P, double* __restrict__ chunk_stats,
-                                                     int64_t V, int Kctx, int full) {
-    constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
-    const int c = blockIdx.x, tid = threadIdx.x;
-    const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
-    const int nreg = P->n_regions, ncol = P->ncomp[3];
-    const bool te = hf_err_is_truncexp(P);
-    const int64_t rstride = 24 * (int64_t) Kctx + 16;
-    const uint64_t present = regmask[c];
-    double* __restrict__ vec = chunk_stats + (int64_t) c * V;
-    if (tid < 64) {
-        double s = 0.0;
-        for (int k = tid; k < nt; k += 64) s += tile_ll[k0 + k];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        if (tid == 0) vec[0] = s;
-    }
-    for (int64_t v = 1 + tid; v < V; v += blockDim.x) vec[v] = 0.0;
-    if (!full) return;
-    __shared__ double red[NA];
-    __syncthreads();
-    for (int r = 0; r < nreg; r++) {
-        if (!((present >> r) & 1ull)) continue;
-        if (tid < NA) {
-            double v = 0.0;
-            int k = 0;
-            for (; k + 8 <= nt; k += 8) {   // 8 loads in flight, adds stay in tile order
-                double xk[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) xk[u] = tile_stats[((int64_t) (k0 + k + u) * nreg + r) * NA + tid];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v += xk[u];
-            }
-            for (; k < nt; k++) v += tile_stats[((int64_t) (k0 + k) * nreg + r) * NA + tid];
-            red[tid] = v;
-        }
-        __syncthreads();
-        double* __restrict__ dst = vec + 1 + r * rstride;
-        const StatAcc<KT>* __restrict__ Sa = reinterpret_cast<const StatAcc<KT>*>(red);
-        if (tid < 16) dst[24 * Kctx + tid] = Sa->trans[tid];
-        if (tid == 32 && te) { dst[(0 * 2 + 0) * Kctx] = Sa->te_num; dst[(0 * 2 + 1) * Kctx] = Sa->te_den; }
-        if (tid >= 64 && tid < 67) {
-            const int s = tid - 64;
-            if (!(s == 0 && te)) {
-                double* dd = dst + (int64_t) (s * 3) * 2 * Kctx;
-                dd[(0 * 2 + 0) * Kctx] = Sa->g_mnum[s]; dd[(0 * 2 + 1) * Kctx] = Sa->g_den[s];
-                dd[(1 * 2 + 0) * Kctx] = Sa->g_vnum[s]; dd[(1 * 2 + 1) * Kctx] = Sa->g_den[s];
-                dd[(2 * 2 + 0) * Kctx] = Sa->g_den[s];  dd[(2 * 2 + 1) * Kctx] = Sa->g_den[s];
-            }
-        }
-        if (tid >= 96 && tid < 96 + KT && (tid - 96) < ncol) {
-            const int cc = tid - 96;
-            double* dd = dst + (int64_t) (3 * 3) * 2 * Kctx;
-            dd[(0 * 2 + 0) * Kctx + cc] = Sa->c_mnum[cc]; dd[(0 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
-            dd[(1 * 2 + 0) * Kctx + cc] = Sa->c_vnum[cc]; dd[(1 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
-            dd[(2 * 2 + 0) * Kctx + cc] = Sa->c_den[cc];  dd[(2 * 2 + 1) * Kctx + cc] = Sa->c_wden;
-        }
-        __syncthreads();
-    }
-}
-
-// sum over chunks (hmm.c:759-763) in a fixed order that depends only on the chunk list: one wavefront per vector
-// element, lane l adds chunks l, l+64, ... in list order, then a fixed shuffle tree over the lanes.  The same
-// kernel reduces the local chunk list on one GPU and the all-gathered list on N GPUs => identical bits.
-// seq != 0: `out` is the pinned host block and the host polls out[V+1]: the block that finishes last stamps it.
-__global__ void __launch_bounds__(64) k_reduce(const double* __restrict__ chunk_stats, const int32_t* __restrict__ row_index,
-                                               int64_t n_chunks, int64_t V, double* __restrict__ out,
-                                               const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done) {
-    const int64_t v = blockIdx.x;
-    const int lane = threadIdx.x;
-    if (v == V) { if (flags && lane == 0) out[V] = (double) *flags; }   // error flags ride along with the vector
-    else {
-        double acc = 0.0;
-        // row_index (multi-GPU): row of global chunk c inside the all-gathered, per-rank padded buffer
-        for (int64_t c = lane; c < n_chunks; c += 64) acc += chunk_stats[(row_index ? (int64_t) row_index[c] : c) * V + v];
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-        if (lane == 0) out[v] = acc;
-    }
-    if (seq != 0.0 && lane == 0) {
-        __threadfence_system();
-        if (atomicAdd(done, 1u) == gridDim.x - 1) { *done = 0u; out[V + 1] = seq; __threadfence_system(); }
-    }
-}
-
+#include "hf_chunks.h"
 #include "hf_rows.h"
+
 
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
