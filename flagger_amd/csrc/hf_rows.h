@@ -8,7 +8,7 @@
 // summed per row first (k_pair_sums: 48 multiplications per window, no division, no component loop) and the component
 // arithmetic runs once per ROW (k_row_stats: ~8 k rows on BASELINE configs[2] against 1.5 M windows).  Each count is the
 // reference's own product in the reference's operand order; only the order of the additions differs from the per-chunk
-// path (hf_estep.hip k_stats_tile), i.e. the results agree to rounding (tests: 1e-12 relative against each other, 1e-9
+// path (hf_chunks.h k_stats_tile), i.e. the results agree to rounding (tests: 1e-12 relative against each other, 1e-9
 // against the oracle).  The order is fixed by the plan built in hf_create, so a run is reproducible bit for bit.
 //
 // Plan (static, hf_create): the pairs (t-1, t), t = 2..T-1 of every chunk, sorted by (region, row, t); a GROUP is up to 64
