@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
     sig("hf_version", C.c_char_p)
     sig("hf_last_error", C.c_char_p)
     sig("hf_device_count", C.c_int)
+    sig("hf_warmup", C.c_int, C.c_int)
     sig("hf_create", C.c_int, C.POINTER(hf_windows), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp))
     sig("hf_destroy", None, vp)
     sig("hf_estep", C.c_int, vp, C.POINTER(hf_params), C.c_int, vp)

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <ctime>
 #include <string>
+#include <thread>
 #include <vector>
 
 static const char* ts() {                                   // common.c:116 get_timestamp
@@ -245,10 +246,12 @@ int main(int argc, char* argv[]) {
     if (windowLen <= 0) { fprintf(stderr, "[%s] Error: windowLen cannot be <= 0.\n", ts()); return EXIT_FAILURE; }
     if (0.5 < initialRandomDeviation) { fprintf(stderr, "[%s] Error: Initial random deviation for the model parameters cannot be greater than 0.5. \n", ts()); return EXIT_FAILURE; }
 
-    // 1. windows
+    // 1. windows; the HIP runtime and the device context come up on a second thread while the input is read
     fprintf(stderr, "[%s] Parsing/Creating coverage chunks. \n", ts());
     Run run;
+    std::thread warm([device] { (void) hf_warmup(device); });
     run.tab = hfio_load(inputPath, chunkLen, windowLen);
+    warm.join();
     if (!run.tab) { fprintf(stderr, "[%s] %s\n", ts(), hfio_last_error()); return EXIT_FAILURE; }
     hfio_table* tab = run.tab;
     if (contigListPath) {                                        // hmm_flagger.c:915-921, 93-99

@@ -297,6 +297,13 @@ int hf_device_count(void) {
 }
 
 
+int hf_warmup(int device) {
+    if (hf_device_count() <= 0) return set_err(HF_E_NOGPU, "hf_warmup: no HIP device");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(nullptr));      // forces the context
+    return HF_OK;
+}
+
 int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int algo, hf_ctx** out) {
     if (!w || !out || w->n_windows < 0 || w->n_chunks < 0 || n_regions < 1 || n_regions > HF_MAXREGIONS ||
         max_comps < 1 || max_comps > HF_MAXCOMP || (algo != HF_ALGO_SCAN && algo != HF_ALGO_SEQ))

@@ -108,6 +108,9 @@ static inline int64_t hf_stats_len(int n_regions, int max_comps) {
 const char *hf_version(void);
 const char *hf_last_error(void);
 int hf_device_count(void);
+/* Optional: bring up the HIP runtime and the context of `device` ahead of hf_create (≈ 0.1 s), e.g. on another thread
+ * while the input is being read.  Returns HF_E_NOGPU without a device. */
+int hf_warmup(int device);
 
 /* Upload the windows to `device` and build the device-resident window store. */
 int hf_create(const hf_windows *w, int n_regions, int max_comps, int device, int algo, hf_ctx **out);
