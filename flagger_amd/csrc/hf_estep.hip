@@ -482,7 +482,12 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     cnt[(size_t) row]++;
                 }
             }
-            if (!pidx.empty() && ctx->n_lut + (int64_t) slow.size() < INT32_MAX && N < (size_t) INT32_MAX) {
+            // a plan is padded to 64 slots per group: when most pairs sit in rows of their own (reads longer than the contigs:
+            // every window is a contig-end window) it would cost 64 slots per window — then the per-chunk statistics stay
+            int64_t n_groups_all = 0;
+            for (size_t r = 0; r < n_rows_all; r++) n_groups_all += (cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS;
+            const bool dense = n_groups_all * HF_GRP_PAIRS <= 4 * (int64_t) pidx.size() + (4 << 20);   // 32 MiB of slack
+            if (!pidx.empty() && dense && ctx->n_lut + (int64_t) slow.size() < INT32_MAX && N < (size_t) INT32_MAX) {
                 // counting sort by row (pairs of a row stay in window order)
                 std::vector<int64_t> start(n_rows_all + 1, 0);
                 for (size_t r = 0; r < n_rows_all; r++) start[r + 1] = start[r] + cnt[r];

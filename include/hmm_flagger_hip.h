@@ -159,7 +159,9 @@ int hf_check(hf_ctx *ctx, void *stream);
  *                    (flagger_amd/csrc/hf_rows.h); hf_finish returns the same vector up to the rounding of a different
  *                    summation order (fixed by the plan of hf_create: reproducible), ~2.5x less statistics time.  The
  *                    per-chunk vectors are NOT produced (only element 0, the chunk's log-likelihood).
- * Default: HF_STATS_ROWS where it applies (else HF_STATS_CHUNKS is used silently); environment HF_STATS=chunks|rows
+ * Default: HF_STATS_ROWS where it applies — HF_ALGO_SCAN, not the negative-binomial model, and a plan that is not
+ * dominated by padding (it is when nearly every window has a private emission row: reads longer than the contigs) —
+ * else HF_STATS_CHUNKS is used silently (hf_get_stats_mode tells); environment HF_STATS=chunks|rows
  * overrides the default at hf_create. */
 enum { HF_STATS_CHUNKS = 0, HF_STATS_ROWS = 1 };
 int hf_set_stats_mode(hf_ctx *ctx, int mode);

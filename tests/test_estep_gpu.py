@@ -391,3 +391,18 @@ def test_partial_range_getters_and_rank_total_in_both_statistics_modes():
     finally:
         em.close()
         other.close()
+
+
+def test_sparse_statistics_plan_falls_back_to_per_chunk_statistics():
+    """Reads longer than the contigs: every window is a contig-end window with a private emission row, a plan padded to 64
+    slots per row would cost 64 slots per window — hf_create keeps the per-chunk statistics then; results as ever."""
+    store = synth.synthesize([350_000] * 240, 1000, 200_000, [20], seed=5, avg_alignment_len=400_000)   # 84 k windows, none interior
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, store, synth.HIFI_ALPHA)
+    em = hmm.EMList(store, model)
+    try:
+        assert em.stats_mode == N.HF_STATS_CHUNKS
+        em.set_stats_mode(N.HF_STATS_ROWS)            # asking for it does not help: there is no plan
+        assert em.stats_mode == N.HF_STATS_CHUNKS
+    finally:
+        em.close()
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, synth.HIFI_ALPHA, N.HF_ALGO_SCAN, n_iter=1)
