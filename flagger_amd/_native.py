@@ -43,6 +43,7 @@ class hf_params(C.Structure):
         ("mean", C.POINTER(C.c_double)), ("var", C.POINTER(C.c_double)), ("weight", C.POINTER(C.c_double)),
         ("nb_E", C.POINTER(C.c_double)), ("nb_P", C.POINTER(C.c_double)), ("nb_dig", C.POINTER(C.c_double)),
         ("nb_r", C.POINTER(C.c_double)), ("nb_beta", C.POINTER(C.c_double)),
+        ("nb_max_x", C.c_int32),
     ]
 
 
@@ -132,6 +133,7 @@ def lib() -> C.CDLL:
     sig("hfs_last_error", C.c_char_p)
     # SQUAREM + misc model helpers
     sig("hfm_scale_initial_means", None, vp, dbl)
+    sig("hfm_set_max_coverage", None, vp, C.c_int)
     sig("hfm_squarem_create", vp, vp, vp, vp)
     sig("hfm_squarem_destroy", None, vp)
     sig("hfm_squarem_alpha", dbl, vp)

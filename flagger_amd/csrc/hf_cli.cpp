@@ -291,6 +291,13 @@ int main(int argc, char* argv[]) {
                                   hfio_start_only(tab), hfio_avg_alignment_len(tab), hfio_window_len(tab), alpha,
                                   maxHighMapqRatio, minHighMapqRatio);
     if (!model) { fprintf(stderr, "[%s] Error: cannot create the model (collapsedComps must be 1..%d, regions 1..%d).\n", ts(), HF_MAXCOMP, HF_MAXREGIONS); return EXIT_FAILURE; }
+    if (modelType == HF_MODEL_NEGATIVE_BINOMIAL) {         // the model's per-x tables: only up to the largest coverage present
+        hf_windows wv;
+        hfio_windows(tab, &wv);
+        int maxx = 0;
+        for (int64_t i = 0; i < wv.n_windows; i++) { const int x = wv.cov[i] & 0xff; if (x > maxx) maxx = x; }
+        hfm_set_max_coverage(model, maxx);
+    }
     if (initialRandomDeviation > 0.0) {                    // hmm_flagger.c:213-220: same factor within one second
         std::vector<double> pv((size_t) hfm_param_len(model));
         hfm_get_param_vector(model, pv.data());

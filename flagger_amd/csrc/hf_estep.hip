@@ -656,6 +656,8 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         if (nbm) {   // the caller's per-x tables go up with the parameters
             if (!p->nb_E || !p->nb_P || !p->nb_dig || !p->nb_r || !p->nb_beta)
                 return set_err(HF_E_ARG, "hf_estep: negative_binomial needs hf_params.nb_E/nb_P/nb_dig/nb_r/nb_beta");
+            if (p->nb_max_x > 0 && ctx->M - 1 > p->nb_max_x)
+                return set_err(HF_E_ARG, "hf_estep: the windows hold coverage values above hf_params.nb_max_x (hfm_set_max_coverage)");
             const size_t nE = (size_t) ctx->R * 4 * HF_NB_NX * 8, nP = (size_t) ctx->R * 4 * ctx->K * HF_NB_NX * 8,
                          nR = (size_t) ctx->R * 4 * ctx->K * 8;
             if (!ctx->d_nbE) {

@@ -74,6 +74,7 @@ struct hfm_model {
     std::vector<double> mean, var, weight; // [R][4][KM]; negative_binomial model: mean = theta, var = lambda (hmm_utils.h NegativeBinomial)
     // negative_binomial: per-iteration tables handed to the E-step (rebuilt by hfm_params)
     mutable std::vector<double> nb_E, nb_P, nb_dig, nb_r, nb_beta;
+    int nb_max_x = kMaxCov;          // tables filled for x = 0..nb_max_x (hfm_set_max_coverage)
     bool nb() const { return model_type == HF_MODEL_NEGATIVE_BINOMIAL; }
     double& M(int r, int s, int c) { return mean[((size_t) r * S + s) * KM + c]; }
     double& Vr(int r, int s, int c) { return var[((size_t) r * S + s) * KM + c]; }
@@ -152,11 +153,13 @@ void hfm_params(const hfm_model* m, hf_params* out) {
     out->trans = m->trans.data(); out->lambda = m->lambda.data(); out->trunc_point = m->trunc.data();
     out->mean = m->mean.data(); out->var = m->var.data(); out->weight = m->weight.data();
     out->nb_E = out->nb_P = out->nb_dig = out->nb_r = out->nb_beta = nullptr;
+    out->nb_max_x = 0;
     if (!m->nb()) return;
     // negative_binomial: everything that depends on x only is tabulated here with the host libm, exactly as the
     // reference evaluates it (lgamma/exp/log of glibc, digamma in long double): emission value E[r][s][x]
     // (hmm_utils.c:480-520), component probabilities P[r][s][c][x], digamma table (:394-408), r and beta (:545-547)
     const int NX = kMaxCov + 1, K = m->K;
+    const int NXF = m->nb_max_x + 1;                       // entries actually filled (the rest stay 0 and are never read)
     hfm_model* mm = const_cast<hfm_model*>(m);
     static double lgx1[kMaxCov + 1];                       // lgamma(x + 1), x = 0..250
     static bool lgx1_ready = false;
@@ -178,23 +181,28 @@ void hfm_params(const hfm_model* m, hf_params* out) {
                 double* D = &m->nb_dig[pc * NX];
                 // the x-independent terms once per component (pure functions of the same arguments: same doubles)
                 const double lg_r = lgamma(rr), r_log_theta = rr * std::log(theta), log_1m_theta = std::log(1 - theta);
-                for (int x = 0; x < NX; x++) {
+                for (int x = 0; x < NXF; x++) {
                     double p = w * std::exp(lgamma(rr + x) - lg_r - lgx1[x] + r_log_theta + (double) x * log_1m_theta);
                     if (!(p != p) && p < 1e-40) p = 1e-40;       // NaN is kept: the E-step reports it if the value is used
                     P[x] = p;
                 }
                 D[0] = (double) digammal_(rr);
-                for (int x = 1; x < NX; x++) D[x] = D[x - 1] + 1.0 / (rr + x - 1);
+                for (int x = 1; x < NXF; x++) D[x] = D[x - 1] + 1.0 / (rr + x - 1);
             }
     for (int r = 0; r < m->R; r++)
         for (int s = 0; s < S; s++)
-            for (int x = 0; x < NX; x++) {
+            for (int x = 0; x < NXF; x++) {
                 double tot = 0.0;                                 // Double_sum1DArray, component order
                 for (int c = 0; c < m->ncomp[s]; c++) tot += m->nb_P[((((size_t) r * S + s) * K + c)) * NX + x];
                 m->nb_E[((size_t) r * S + s) * NX + x] = tot;
             }
     out->nb_E = m->nb_E.data(); out->nb_P = m->nb_P.data(); out->nb_dig = m->nb_dig.data();
     out->nb_r = m->nb_r.data(); out->nb_beta = m->nb_beta.data();
+    out->nb_max_x = m->nb_max_x;
+}
+
+void hfm_set_max_coverage(hfm_model* m, int max_x) {
+    if (m) m->nb_max_x = max_x < 1 ? 1 : (max_x > kMaxCov ? kMaxCov : max_x);   // hf_params.nb_max_x <= 0 means "all of them"
 }
 
 // hmm_utils.c:949-956

@@ -134,6 +134,9 @@ def createModel(modelType: int, numberOfCollapsedComps: int, store: WindowStore,
                            maxHighMapqRatio, minHighMapqRatio)
     if not h:
         raise ValueError("createModel: bad arguments")
+    if modelType == MODEL_NEGATIVE_BINOMIAL and store.n_windows:
+        # the per-x tables of the model are rebuilt on the host every iteration: only up to the largest coverage present
+        N.lib().hfm_set_max_coverage(h, int(min(int((np.asarray(store.cov) & 0xff).max()), 250)))
     return HMM(h)
 
 

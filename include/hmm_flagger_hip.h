@@ -90,6 +90,9 @@ typedef struct hf_params {
      *   nb_dig[r][s][c][x]   NegativeBinomial.digammaTable                                 hmm_utils.c:394-408
      *   nb_r, nb_beta[r][s][c]   r = -lambda/log(theta), beta = -theta/(1-theta) - 1/log(theta)   :458-461, 547 */
     const double *nb_E, *nb_P, *nb_dig, *nb_r, *nb_beta;
+    /* <= 0: the nb_* tables are filled for every x; else the largest x for which they are (hfm_set_max_coverage): hf_estep
+     * refuses a context whose windows exceed it.  The tables cost ~70 ns per (component, x) on the host every iteration. */
+    int32_t nb_max_x;
 } hf_params;
 
 /* Layout of one statistics vector (doubles):

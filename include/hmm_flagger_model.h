@@ -60,6 +60,9 @@ void hfm_set_param_vector(hfm_model *m, const double *in);
 /* --initialRandomDev (hmm_flagger.c:213-220): every initial mean is multiplied by the same random factor
  * (the reference reseeds with time(NULL) at every draw), the collapsed means twice. */
 void hfm_scale_initial_means(hfm_model *m, double factor);
+/* negative_binomial only: the largest coverage value of the windows the model will meet (<= HF_NB_MAX_COVERAGE); the
+ * per-x tables of hfm_params are then filled up to it only.  Default: HF_NB_MAX_COVERAGE. */
+void hfm_set_max_coverage(hfm_model *m, int max_x);
 
 /* SQUAREM acceleration (--accelerate): SquareAccelerator_*, submodules/hmm/hmm.c:820-1098.
  * m0 = parameters the last E-step ran with (with its log-likelihood), m1/m2 = after one/two EM updates. */
