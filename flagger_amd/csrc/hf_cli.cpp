@@ -215,6 +215,15 @@ int main(int argc, char* argv[]) {
         }
     }
     const double realtimeStart = real_time();
+    // HF_CLI_TIMING=1: wall time of every phase on stderr (where does a run go now that the E-step is milliseconds?)
+    const bool phaseTiming = getenv("HF_CLI_TIMING") != nullptr;
+    double phaseStart = realtimeStart;
+    auto phase = [&](const char* name) {
+        if (!phaseTiming) return;
+        const double now = real_time();
+        fprintf(stderr, "[phase] %-28s %8.1f ms\n", name, (now - phaseStart) * 1e3);
+        phaseStart = now;
+    };
     if (!inputPath) { fprintf(stderr, "[%s] Error: Input path cannot be NULL.\n", ts()); return EXIT_FAILURE; }
     if (convergenceTol <= 0.0 || convergenceTol > 1.0) {
         fprintf(stderr, "[%s] Error: convergence tol = %2.f should be between 0 and 1.\n", ts(), convergenceTol);
@@ -273,6 +282,7 @@ int main(int argc, char* argv[]) {
     fprintf(stderr, "[%s] %d chunks are parsed (%ld windows of %d bases). \n", ts(), hfio_n_chunks(tab), (long) N, hfio_window_len(tab));
     if (N == 0 || hfio_n_chunks(tab) == 0) { fprintf(stderr, "[%s] Error: no windows in the input.\n", ts()); return EXIT_FAILURE; }
 
+    phase("load input (+ HIP start-up)");
     // 2. number of collapsed components (hmm_flagger.c:1008-1022)
     hf_windows w;
     memset(&w, 0, sizeof w);
@@ -304,6 +314,7 @@ int main(int argc, char* argv[]) {
         hfm_scale_initial_means(model, random_factor(initialRandomDeviation));
     }
 
+    phase("model");
     // 4. device context: windows resident in HBM for the whole run
     w.adjust_contig_ends = adjustContigEnds ? 1 : 0; w.min_read_frac = adjustContigEnds ? minReadFractionAtEnds : 0.0;
     w.max_high_mapq_ratio = maxHighMapqRatio; w.min_high_mapq_ratio = minHighMapqRatio;
@@ -312,6 +323,7 @@ int main(int argc, char* argv[]) {
     if (rc != HF_OK) { fprintf(stderr, "[%s] Error: %s\n", ts(), hf_last_error()); return EXIT_FAILURE; }
     run.stats.assign((size_t) hf_chunk_stats_len(run.ctx), 0.0);
 
+    phase("hf_create");
     // 5. EM (runHMMFlagger, hmm_flagger.c:285-488)
     fprintf(stderr, "[%s] Running EM for estimating parameters. \n", ts());
     const std::string dir(outputDir);
@@ -378,6 +390,7 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "[%s] Writing posterior bed : %s\n", ts(), pp.c_str());
         hfio_write_posterior_bed(tab, post.data(), labels.data(), pp.c_str());
     }
+    phase("EM + final inference");
     // 6. final BED
     fprintf(stderr, "[%s] Writing final BED file. \n", ts());
     if (hfio_write_final_bed(tab, labels.data(), (dir + "/final_flagger_prediction.bed").c_str(), trackName, minLenPerState) != 0) {
@@ -390,6 +403,7 @@ int main(int argc, char* argv[]) {
     hfm_destroy(model);
     hfio_destroy(tab);
     fprintf(stderr, "[%s] Done! \n", ts());
+    phase("outputs");
     const double realtime = real_time() - realtimeStart, cputime = cpu_time();
     fprintf(stderr, "Real time:  %.3f sec; CPU: %.3f sec; Peak RSS: %.3f GB; CPU usage: %.1f%%\n", realtime, cputime,
             peak_rss_gb(), (cputime + 1e-9) / (realtime + 1e-9) * 100.0);

@@ -66,6 +66,23 @@ struct Windows {
     const uint64_t* annot = nullptr;
     const int8_t* truth = nullptr;
     const int8_t* pred = nullptr;
+    std::vector<uint64_t> annot_v;            // the runs own their annotation word and labels
+    std::vector<int8_t> truth_v, pred_v;
+
+    // Consecutive windows of one contig that touch and carry the same annotation word and labels behave as ONE longer
+    // window in every table (fill_one_category only acts on changes and adds lengths): they are merged while the list is
+    // built, every pass of every category then walks the runs (tens of thousands) instead of the windows (millions).
+    void push(int32_t st, int32_t en, int32_t c, uint64_t a, int8_t t, int8_t p) {
+        if (n > 0) {
+            const size_t k = (size_t) n - 1;
+            if (ctg[k] == c && st == end[k] + 1 && a == annot_v[k] && t == truth_v[k] && p == pred_v[k]) { end[k] = en; return; }
+        }
+        start.push_back(st); end.push_back(en); ctg.push_back(c); annot_v.push_back(a); truth_v.push_back(t); pred_v.push_back(p);
+        n++;
+    }
+    void seal(bool has_truth, bool has_pred) {
+        annot = annot_v.data(); truth = has_truth ? truth_v.data() : nullptr; pred = has_pred ? pred_v.data() : nullptr;
+    }
 };
 
 inline bool in_category(const Windows& w, int64_t i, int cat_type, int c1) {
@@ -315,10 +332,9 @@ int hfs_write_all_tables(const hfs_input* in, const char* output_path, const cha
     const int n_rows = in->n_labels + 1;
     // ---- windows in iterator order (chunk.c:915-950) ----
     Windows w;
-    w.n = in->n_windows; w.annot = in->annot; w.truth = in->truth; w.pred = in->prediction;
-    w.start.resize((size_t) w.n); w.end.resize((size_t) w.n); w.ctg.resize((size_t) w.n);
     {
         std::map<std::string, int32_t> ids;
+        const int8_t* tr = in->truth; const int8_t* pr = in->prediction;
         for (int c = 0; c < in->n_chunks; c++) {
             const std::string name = in->chunk_ctg[c];
             auto it = ids.find(name);
@@ -328,11 +344,10 @@ int hfs_write_all_tables(const hfs_input* in, const char* output_path, const cha
             for (int64_t i = 0; i < T; i++) {
                 const int st = s + (int) i * W;
                 const int en0 = s + ((int) i + 1) * W - 1;
-                w.start[(size_t) (t0 + i)] = st;
-                w.end[(size_t) (t0 + i)] = en0 < e ? en0 : e;
-                w.ctg[(size_t) (t0 + i)] = it->second;
+                w.push(st, en0 < e ? en0 : e, it->second, in->annot[t0 + i], tr ? tr[t0 + i] : (int8_t) -1, pr ? pr[t0 + i] : (int8_t) -1);
             }
         }
+        w.seal(tr != nullptr, pr != nullptr);
     }
     const bool truth = in->truth_available != 0, pred = in->prediction_available != 0;
     // ---- the catalog: [category type][metric][comparison] (summary_table.c:1696-1737) ----

@@ -12,7 +12,7 @@ PY
 mkdir -p $T/o
 for rep in 1 2 3; do
   S=$(date +%s%N)
-  flagger_amd/csrc/hmm_flagger -i $T/cfg2.cov.gz -n 100 -W 4000 -A tests/golden/alpha_hifi.tsv -o $T/o > $T/err 2>&1
-  echo "rc=$? wall $(( ($(date +%s%N) - S) / 1000000 )) ms   $(grep -o 'EM+decode: [0-9]* passes.*' $T/err | cut -c1-90)"
+  HF_CLI_TIMING=1 flagger_amd/csrc/hmm_flagger -i $T/cfg2.cov.gz -n 100 -W 4000 -A tests/golden/alpha_hifi.tsv -o $T/o > $T/err 2>&1
+  grep "^\[phase\]" $T/err; echo "rc=$? wall $(( ($(date +%s%N) - S) / 1000000 )) ms   $(grep -o 'EM+decode: [0-9]* passes.*' $T/err | cut -c1-90)"
 done
 grep -c . $T/o/final_flagger_prediction.bed
