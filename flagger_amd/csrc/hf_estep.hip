@@ -297,10 +297,16 @@ int hf_device_count(void) {
 }
 
 
+__global__ void k_selftest_div(int64_t n, const double* __restrict__ a, const double* __restrict__ d, double* __restrict__ fast,
+                               double* __restrict__ exact, int32_t* __restrict__ safe);
+
 int hf_warmup(int device) {
     if (hf_device_count() <= 0) return set_err(HF_E_NOGPU, "hf_warmup: no HIP device");
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));      // forces the context
+    hipLaunchKernelGGL(k_selftest_div, dim3(1), dim3(64), 0, 0, (int64_t) 0, (const double*) nullptr, (const double*) nullptr,
+                       (double*) nullptr, (double*) nullptr, (int32_t*) nullptr);   // loads this library's code object
+    HIPCHK(hipDeviceSynchronize());
     return HF_OK;
 }
 
@@ -312,6 +318,14 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     HIPCHK(hipSetDevice(device));
     hf_ctx* ctx = new hf_ctx();
     ctx->device = device; ctx->algo = algo;
+    const bool ctrace = std::getenv("HF_HOST_TRACE") != nullptr;
+    auto ct0 = std::chrono::steady_clock::now();
+    auto cphase = [&](const char* name) {
+        if (!ctrace) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[hf_create] %-34s %7.2f ms\n", name, std::chrono::duration<double, std::milli>(now - ct0).count());
+        ct0 = now;
+    };
     {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) ctx->lds_max = (size_t) v;
@@ -376,6 +390,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                            ctx->beta_star, ctx->d_rec, ctx->d_beta, ctx->d_flags);
         hipLaunchKernelGGL(k_regmask, dim3((unsigned) C), dim3(256), 0, 0, ctx->d_off, ctx->d_rec, ctx->d_regmask);
     }
+    cphase("uploads + window records");
     hipError_t e = hipDeviceSynchronize();
     hipFree(d_cov); hipFree(d_mapq); hipFree(d_clip); hipFree(d_annot); hipFree(d_cs); hipFree(d_ce); hipFree(d_cl);
     if (e != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("setup: ") + hipGetErrorString(e)); }
@@ -418,6 +433,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         DMALLOC(ctx->d_lutC, ((size_t) ctx->n_lut + slow.size() + 1) * 4 * (size_t) max_comps * 8);
         ctx->d_Es = ctx->d_lutE + (size_t) ctx->n_lut * 16;
         ctx->d_Cs = ctx->d_lutC + (size_t) ctx->n_lut * 4 * (size_t) max_comps;
+        cphase("contig-end list, keys, row tables");
         // tiles of 64*HF_SCAN_L windows, enumerated chunk by chunk
         std::vector<int32_t> ctile0(C + 1, 0);
         std::vector<TileDesc> desc;
@@ -454,6 +470,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         ctx->h_off.assign(w->chunk_off, w->chunk_off + C + 1);
         ctx->h_tile0 = ctile0;
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
+        cphase("tiles + work arrays");
         // ---- plan of the statistics by emission row (hf_rows.h) ----
         if (N > 0 && C > 0) {
             std::vector<uint32_t> hrec(N);
@@ -462,9 +479,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             }
             const size_t n_rows_all = (size_t) ctx->n_lut + slow.size();
             std::vector<int32_t> cnt(n_rows_all + 1, 0);
-            std::vector<int32_t> prow; std::vector<PairIdx> pidx;
-            prow.reserve(N); pidx.reserve(N);
-            size_t sp = 0;
+            std::vector<int32_t> prow(N); std::vector<PairIdx> pidx(N);
+            size_t np = 0, sp = 0;
             for (size_t c = 0; c < C; c++) {
                 const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
                 for (int64_t x = 2; x < T; x++) {          // pairs (x-1, x), x = 2..T-1 (hmm.c:638-642)
@@ -477,16 +493,18 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
                         row = (int64_t) ((reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu));
                     }
-                    PairIdx q; q.t = (int32_t) t; q.rec = hrec[t];
-                    prow.push_back((int32_t) row); pidx.push_back(q);
+                    pidx[np].t = (int32_t) t; pidx[np].rec = hrec[t];
+                    prow[np++] = (int32_t) row;
                     cnt[(size_t) row]++;
                 }
             }
+            prow.resize(np); pidx.resize(np);
             // a plan is padded to 64 slots per group: when most pairs sit in rows of their own (reads longer than the contigs:
             // every window is a contig-end window) it would cost 64 slots per window — then the per-chunk statistics stay
             int64_t n_groups_all = 0;
             for (size_t r = 0; r < n_rows_all; r++) n_groups_all += (cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS;
             const bool dense = n_groups_all * HF_GRP_PAIRS <= 4 * (int64_t) pidx.size() + (4 << 20);   // 32 MiB of slack
+            cphase("plan: pairs");
             if (!pidx.empty() && dense && ctx->n_lut + (int64_t) slow.size() < INT32_MAX && N < (size_t) INT32_MAX) {
                 // counting sort by row (pairs of a row stay in window order)
                 std::vector<int64_t> start(n_rows_all + 1, 0);
@@ -496,6 +514,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     std::vector<int64_t> fill(start.begin(), start.end() - 1);
                     for (size_t i = 0; i < pidx.size(); i++) sorted[(size_t) fill[(size_t) prow[i]]++] = pidx[i];
                 }
+                cphase("plan: sort");
                 // occurring rows ordered by (region, row)
                 struct OccRow { int32_t region, row; };
                 std::vector<OccRow> occ;
@@ -508,6 +527,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 }
                 std::stable_sort(occ.begin(), occ.end(), [](const OccRow& a, const OccRow& b) { return a.region < b.region; });
                 std::vector<PairIdx> gp; std::vector<int32_t> grow;
+                gp.reserve((size_t) n_groups_all * HF_GRP_PAIRS); grow.reserve((size_t) n_groups_all);
                 std::vector<RowSlot> rslots; std::vector<int32_t> rwreg, rwoff((size_t) n_regions + 1, 0);
                 const PairIdx empty = {-1, 0u};
                 size_t oi = 0;
@@ -518,7 +538,9 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         const int64_t n = cnt[r], s0 = start[r];
                         const int32_t g_first = (int32_t) grow.size();
                         for (int64_t b = 0; b < n; b += HF_GRP_PAIRS) {
-                            for (int64_t i = 0; i < HF_GRP_PAIRS; i++) gp.push_back(b + i < n ? sorted[(size_t) (s0 + b + i)] : empty);
+                            const int64_t m = n - b < HF_GRP_PAIRS ? n - b : HF_GRP_PAIRS;
+                            gp.insert(gp.end(), sorted.begin() + (s0 + b), sorted.begin() + (s0 + b + m));
+                            if (m < HF_GRP_PAIRS) gp.insert(gp.end(), (size_t) (HF_GRP_PAIRS - m), empty);
                             grow.push_back((int32_t) r);
                         }
                         const int32_t ng_all = (int32_t) grow.size() - g_first;
@@ -535,6 +557,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / 16; k++) rwreg.push_back(reg);
                 }
                 rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / 16);
+                cphase("plan: groups, row slots");
                 ctx->n_groups = (int) grow.size(); ctx->n_rowwaves = (int) (rslots.size() / 16);   // 16 slots per wavefront, 64 per region pad
                 TRY(dev_upload(&ctx->d_pairs, gp.data(), gp.size()));
                 TRY(dev_upload(&ctx->d_grp_row, grow.data(), grow.size()));
@@ -546,6 +569,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 DMALLOC(ctx->d_chunk_ll, C * 8);
                 DMALLOC(ctx->d_rw_stats, (size_t) ctx->n_rowwaves * (16 + 9 + 2 + 3 * 16 + 1) * 8);
                 ctx->rows_ready = true;
+                cphase("plan: uploads, allocations");
             }
         }
     }
