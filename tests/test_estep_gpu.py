@@ -406,3 +406,40 @@ def test_sparse_statistics_plan_falls_back_to_per_chunk_statistics():
     finally:
         em.close()
     _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, synth.HIFI_ALPHA, N.HF_ALGO_SCAN, n_iter=1)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_inputs_both_statistics_modes_against_each_other_and_the_oracle(seed):
+    """Seeded random shapes — contig lengths from a few windows to many tiles, window / chunk lengths, 1-5 regions with
+    short region runs, clipped windows (End column), read lengths from shorter than a window to longer than a contig,
+    K 2..9, the three alpha tables — one full pass: statistics by row == per-chunk statistics to rounding, and the
+    per-chunk vector, log-likelihood and labels against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    window_len = int(rng.choice([500, 1000, 4000]))
+    chunk_len = int(rng.choice([20, 77, 300])) * window_len
+    n_ctg = int(rng.integers(1, 7))
+    lengths = [int(rng.integers(2, 4000)) * window_len + int(rng.integers(0, window_len)) for _ in range(n_ctg)]
+    R = int(rng.integers(1, 6))
+    region_cov = [int(rng.integers(8, 40)) for _ in range(R)]
+    avg_len = int(rng.choice([0, 300, 15_000, 3_000_000]))
+    store = synth.synthesize(lengths, window_len, chunk_len, region_cov, seed=seed, avg_alignment_len=avg_len,
+                             region_run_bases=(3 * window_len, 200 * window_len))
+    clip = np.asarray(store.clip).copy()
+    hit = rng.random(clip.size) < 0.03
+    clip[hit] = (np.asarray(store.cov)[hit] * 2 + 1).astype(clip.dtype)      # clip ratio >= 1: the End column takes part
+    store.clip = clip
+    K = int(rng.integers(2, 10))
+    alpha = [synth.HIFI_ALPHA, synth.ONT_R10_ALPHA, np.zeros((4, 4))][int(rng.integers(0, 3))]
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
+    em = hmm.EMList(store, model, bool(rng.integers(0, 2)), 0.9)
+    try:
+        em.launch(model); a = em.finish(); lab_a = em.labels()
+        mode_a = em.stats_mode
+        em.set_stats_mode(N.HF_STATS_CHUNKS)
+        em.launch(model); b = em.finish(); lab_b = em.labels()
+        assert a[0] == b[0] and np.array_equal(lab_a, lab_b)
+        scale = np.maximum(np.abs(b), 1e-9 * np.abs(b).max())
+        assert np.all(np.abs(a - b) <= 1e-11 * scale), (mode_a, np.max(np.abs(a - b) / scale))
+    finally:
+        em.close()
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, alpha, N.HF_ALGO_SCAN, n_iter=1)
