@@ -277,8 +277,8 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
 static int launch_rows_total(hf_ctx* ctx, hipStream_t st, double* out, bool with_flags = true, double seq = 0.0) {
     KTimer t(ctx, st, HF_K_ROWS_TOTAL);
     const int kc = ctx->pass_kc;
-#define ROWS_TOTAL(KT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_total<KT>), dim3(1), dim3(1024), 0, st, ctx->d_rw_off, ctx->pass_wpb, ctx->d_rw_stats, \
-        ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out, with_flags ? ctx->d_flags : (const unsigned*) nullptr, seq)
+#define ROWS_TOTAL(KT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_total<KT>), dim3((unsigned) ctx->R), dim3(1024), 0, st, ctx->d_rw_off, ctx->pass_wpb, ctx->d_rw_stats, \
+        ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out, with_flags ? ctx->d_flags : (const unsigned*) nullptr, seq, ctx->d_done)
     if (kc <= 4) ROWS_TOTAL(4); else if (kc <= 8) ROWS_TOTAL(8); else ROWS_TOTAL(16);
 #undef ROWS_TOTAL
     HIPCHK(hipGetLastError());

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
 }
 
 // ------------------------------------------------------------------------------------------
-// k_rows_total: one block.  Element 0 = sum of the chunks' log-likelihoods (k_row_stats) in k_reduce's order (the same
+// k_rows_total: one block per region (block 0 also sums the log-likelihoods).  Element 0 = sum of the chunks' log-likelihoods (k_row_stats) in k_reduce's order (the same
 // bits as the per-chunk path); per region, the block partials of k_row_stats summed in plan order by 960/NA interleaved
 // accumulators per element (fixed), expanded into the estimator layout of include/hmm_flagger_hip.h exactly as
 // k_chunk_stats does; a region's block of the vector is assembled in LDS and written to `out` (the pinned host block) once.
@@ -255,7 +255,8 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
 template <int KT>
 __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_stats,
                                                      const DevParams* __restrict__ P, const double* __restrict__ chunk_ll, int64_t C,
-                                                     int64_t V, int Kctx, double* __restrict__ out, const unsigned* __restrict__ flags, double seq) {
+                                                     int64_t V, int Kctx, double* __restrict__ out, const unsigned* __restrict__ flags, double seq,
+                                                     unsigned* __restrict__ done) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NQ = 960 / NA;                  // interleaved accumulators per element (the last wavefront sums the log-likelihoods)
     const int tid = threadIdx.x;
@@ -263,7 +264,7 @@ __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__
     __shared__ double red[NA];
     __shared__ double blockv[24 * HF_MAXCOMP + 16];   // one region's block of the vector, assembled in LDS
     const unsigned fl = (tid == 0 && flags) ? *flags : 0u;
-    if (tid >= 960) {   // k_reduce's order over the chunk list
+    if (tid >= 960 && blockIdx.x == 0) {   // k_reduce's order over the chunk list
         const int lane = tid - 960;
         double acc = 0.0;
         int64_t c = lane;
@@ -278,7 +279,7 @@ __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__
     const int nreg = P->n_regions, ncol = P->ncomp[3];
     const bool te = hf_err_is_truncexp(P);
     const int rstride = 24 * Kctx + 16;
-    for (int r = 0; r < nreg; r++) {
+    for (int r = blockIdx.x; r < nreg; r += gridDim.x) {
         const int w0 = rw_off[r] / wpb, w1 = rw_off[r + 1] / wpb;   // rw_off counts wavefronts, a multiple of 4 per region
         for (int v = tid; v < rstride; v += 1024) blockv[v] = 0.0;
         const int q = tid / NA, i = tid % NA;
@@ -329,10 +330,10 @@ __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__
         for (int v = tid; v < rstride; v += 1024) out[1 + (int64_t) r * rstride + v] = blockv[v];
         __syncthreads();
     }
-    if (tid == 0 && flags) out[V] = (double) fl;
-    if (seq != 0.0) {   // completion stamp for a host that polls the pinned block: after every write above is visible
+    if (tid == 0 && flags && blockIdx.x == 0) out[V] = (double) fl;
+    if (seq != 0.0) {   // completion stamp for a host that polls the pinned block: after every write of every block is visible
         __threadfence_system();
         __syncthreads();
-        if (tid == 0) { out[V + 1] = seq; __threadfence_system(); }
+        if (tid == 0 && atomicAdd(done, 1u) == gridDim.x - 1) { *done = 0u; out[V + 1] = seq; __threadfence_system(); }
     }
 }
