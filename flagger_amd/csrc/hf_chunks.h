@@ -325,20 +325,30 @@ __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__
 // seq != 0: `out` is the pinned host block and the host polls out[V+1]: the block that finishes last stamps it.
 __global__ void __launch_bounds__(64) k_reduce(const double* __restrict__ chunk_stats, const int32_t* __restrict__ row_index,
                                                int64_t n_chunks, int64_t V, double* __restrict__ out,
-                                               const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done) {
+                                               const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done,
+                                               unsigned long long* __restrict__ cks) {
     const int64_t v = blockIdx.x;
     const int lane = threadIdx.x;
-    if (v == V) { if (flags && lane == 0) out[V] = (double) *flags; }   // error flags ride along with the vector
+    double written = 0.0;
+    if (v == V) { if (flags && lane == 0) { written = (double) *flags; out[V] = written; } }   // error flags ride along with the vector
     else {
         double acc = 0.0;
         // row_index (multi-GPU): row of global chunk c inside the all-gathered, per-rank padded buffer
         for (int64_t c = lane; c < n_chunks; c += 64) acc += chunk_stats[(row_index ? (int64_t) row_index[c] : c) * V + v];
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
         if (lane == 0) out[v] = acc;
+        written = acc;
     }
-    if (seq != 0.0 && lane == 0) {
+    if (seq != 0.0 && lane == 0) {   // checksum of every word written (hf_cks_term), bound to the pass, then the stamp: see wait_total
+        atomicAdd(cks, hf_cks_term((unsigned long long) __double_as_longlong(written), v));
         __threadfence_system();
-        if (atomicAdd(done, 1u) == gridDim.x - 1) { *done = 0u; out[V + 1] = seq; __threadfence_system(); }
+        if (atomicAdd(done, 1u) == gridDim.x - 1) {
+            const unsigned long long c = atomicAdd(cks, 0ull) + (unsigned long long) __double_as_longlong(seq);
+            *cks = 0ull; *done = 0u;
+            out[V + 2] = __longlong_as_double((long long) c);
+            out[V + 1] = seq;
+            __threadfence_system();
+        }
     }
 }
 

@@ -218,3 +218,10 @@ __device__ __forceinline__ int posterior_label(const double f[4], const double b
     for (int s = 0; s < 4; s++) if (mx < p[s]) { mx = p[s]; idx = s; }
     return idx;
 }
+
+// Checksum of a polled result block (hf_estep.hip wait_total): wrapping sum of bit pattern x position weight.  Position-
+// dependent on purpose: the estimator layout repeats values (mean.den == var.den == weight.num), and a plain XOR is blind
+// to two equal stale words.
+__host__ __device__ inline unsigned long long hf_cks_term(unsigned long long bits, long long index) {
+    return bits * ((0x9E3779B97F4A7C15ull * (unsigned long long) (index + 1)) | 1ull);
+}

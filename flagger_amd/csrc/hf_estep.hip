@@ -28,6 +28,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cmath>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 
@@ -88,7 +89,9 @@ struct hf_ctx {
     // statistics by emission row (hf_rows.h): the static plan and its work arrays
     int stats_mode = HF_STATS_CHUNKS; bool rows_ready = false, pass_rows = false; int pass_kc = 0, pass_wpb = 4;
     double poll_seq = 0.0;         // completion stamp of the last polled pass (hf_finish)
-    unsigned* d_done = nullptr;    // k_reduce: blocks finished (the last one stamps the host block)
+    unsigned* d_done = nullptr;    // k_reduce / k_rows_total: blocks finished (the last one stamps the host block)
+    unsigned long long* d_cks = nullptr;   // k_reduce: XOR of the words written (checksum of a polled pass)
+    int poll_kind = 0;             // what the last polled kernel was: 1 k_rows_total (a checksum per region), 2 k_reduce (one)
     int n_groups = 0, n_rowwaves = 0;
     double* d_chunk_ll = nullptr;  // [C] log-likelihood per chunk (rows mode)
     double* d_recs = nullptr;      // [N+1] pair records { f_{t-1}, b_t } (k_fb_tile RECS); fb_recs: the last full pass wrote them
@@ -367,11 +370,13 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     DMALLOC(ctx->d_flags, 4);
     DMALLOC(ctx->d_done, 4);
     hipMemset(ctx->d_done, 0, 4);
+    DMALLOC(ctx->d_cks, 8);
+    hipMemset(ctx->d_cks, 0, 8);
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
     DMALLOC(ctx->d_params, ctx->params_bytes);
     if (hipHostMalloc((void**) &ctx->h_params, ctx->params_bytes) != hipSuccess ||
         hipHostMalloc((void**) &ctx->h_flags, 4) != hipSuccess ||
-        hipHostMalloc((void**) &ctx->h_total, ((size_t) ctx->V + 2) * 8) != hipSuccess) {
+        hipHostMalloc((void**) &ctx->h_total, ((size_t) ctx->V + 2 + HF_MAXREGIONS) * 8) != hipSuccess) {
         hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed");
     }
     {
@@ -594,7 +599,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_carry_desc);
-    hipFree(ctx->d_done); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
+    hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
@@ -844,7 +849,7 @@ static int reduce_chunks_seq(hf_ctx* ctx, const double* chunk_stats_dev, const i
         hipLaunchKernelGGL(k_reduce, dim3((unsigned) (ctx->V + 1)), dim3(64), 0, (hipStream_t) stream, chunk_stats_dev, row_index_dev,
                            n_chunks, ctx->V, out_dev,
                            (out_dev == ctx->d_total || out_dev == ctx->d_total_host) ? ctx->d_flags : (const unsigned*) nullptr,
-                           seq, ctx->d_done);
+                           seq, ctx->d_done, ctx->d_cks);
     }
     ctx->prof_mask = keep;
     HIPCHK(hipGetLastError());
@@ -897,18 +902,56 @@ static bool poll_ok(const hf_ctx* ctx, int last_kernel) {
 #endif
 }
 static double next_stamp(hf_ctx* ctx) { ctx->poll_seq += 1.0; ctx->h_total[ctx->V + 1] = 0.0; return ctx->poll_seq; }
+// The stamp alone is not enough: the device's writes to host memory may become visible out of order (a soak test saw a
+// stale element once in ~2 000 passes).  So the kernel also writes a checksum of everything it wrote (hf_cks_term: bit
+// pattern x position weight, summed mod 2^64) plus the pass's stamp value; the host accepts the block only when what it
+// READ has that checksum — stale data, a stale checksum or both fail the comparison and the host keeps polling.  (A plain
+// XOR was not enough either: the estimator layout repeats values, and two equal stale words cancel — seen once in 300 000.)
+static bool polled_block_consistent(const hf_ctx* ctx) {
+    const double* h = ctx->h_total;
+    const int64_t V = ctx->V;
+    auto bits = [](double d) { unsigned long long u; std::memcpy(&u, &d, 8); return u; };
+    const unsigned long long s = bits(ctx->poll_seq);
+    if (ctx->poll_kind == 2) {
+        unsigned long long x = s;
+        for (int64_t v = 0; v <= V; v++) x += hf_cks_term(bits(h[v]), v);
+        return x == bits(h[V + 2]);
+    }
+    const int64_t rstride = 24 * (int64_t) ctx->K + 16;
+    for (int r = 0; r < ctx->R; r++) {
+        unsigned long long x = s;
+        for (int64_t v = 0; v < rstride; v++) { const int64_t at = 1 + r * rstride + v; x += hf_cks_term(bits(h[at]), at); }
+        if (r == 0) x += hf_cks_term(bits(h[0]), 0) + hf_cks_term(bits(h[V]), V);
+        if (x != bits(h[V + 2 + r])) return false;
+    }
+    return true;
+}
 static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_host) {
     bool seen = false;
     if (polled) {
         volatile double* stamp = ctx->h_total + ctx->V + 1;
         const auto t0 = std::chrono::steady_clock::now();
         long spins = 0;
-        while (!(seen = (*stamp == ctx->poll_seq))) {
+        for (;;) {
+            if (*stamp == ctx->poll_seq) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                if (polled_block_consistent(ctx)) { seen = true; break; }
+            }
             __builtin_ia32_pause();
             if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;   // let the stream report
         }
     }
     if (!seen) HIPCHK(hipStreamSynchronize(st));
+#ifdef HF_POLL_DEBUG
+    if (seen) {   // did anything still arrive after the block was accepted?
+        std::vector<double> snap(ctx->h_total, ctx->h_total + ctx->V + 1);
+        HIPCHK(hipStreamSynchronize(st));
+        for (int64_t v = 0; v <= ctx->V; v++)
+            if (std::memcmp(&snap[(size_t) v], &ctx->h_total[v], 8) != 0)
+                std::fprintf(stderr, "[poll debug] seq %.0f kind %d element %ld changed after acceptance: %.17g -> %.17g\n", ctx->poll_seq,
+                             ctx->poll_kind, (long) v, snap[(size_t) v], ctx->h_total[v]);
+    }
+#endif
     accumulate_kernel_times(ctx);   // events of the kernels before the last one have completed
     std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
     return flags_to_code((unsigned) ctx->h_total[ctx->V]);
@@ -922,6 +965,7 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
     double* out = ctx->d_total_host ? ctx->d_total_host : ctx->d_total;
     const bool polled = poll_ok(ctx, ctx->pass_rows ? HF_K_ROWS_TOTAL : HF_K_REDUCE);
     const double seq = polled ? next_stamp(ctx) : 0.0;
+    ctx->poll_kind = ctx->pass_rows ? 1 : 2;
     int rc = ctx->pass_rows ? launch_rows_total(ctx, st, out, true, seq)
                             : reduce_chunks_seq(ctx, ctx->d_chunk_stats, nullptr, ctx->C, out, stream, seq);
     if (rc) return rc;
@@ -941,6 +985,7 @@ int hf_finish_gathered(hf_ctx* ctx, const double* rows_dev, const int32_t* row_i
     double* out = ctx->d_total_host ? ctx->d_total_host : ctx->d_total;
     const bool polled = poll_ok(ctx, HF_K_REDUCE);
     const double seq = polled ? next_stamp(ctx) : 0.0;
+    ctx->poll_kind = 2;
     int rc = reduce_chunks_seq(ctx, rows_dev, row_index_dev, n_chunks, out, stream, seq);
     if (rc) return rc;
     if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev1, st));

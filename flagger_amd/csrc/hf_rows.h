@@ -249,7 +249,8 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
 // k_rows_total: one block per region (block 0 also sums the log-likelihoods).  Element 0 = sum of the chunks' log-likelihoods (k_row_stats) in k_reduce's order (the same
 // bits as the per-chunk path); per region, the block partials of k_row_stats summed in plan order by 960/NA interleaved
 // accumulators per element (fixed), expanded into the estimator layout of include/hmm_flagger_hip.h exactly as
-// k_chunk_stats does; a region's block of the vector is assembled in LDS and written to `out` (the pinned host block) once.
+// k_chunk_stats does; a region's block of the vector is assembled in LDS and written to `out` (the pinned host block) once, followed by a
+// per-region checksum word bound to the pass (out[V+2+r]) and the completion stamp (out[V+1]): see wait_total.
 // blk_off[r]..blk_off[r+1]: the partials of region r.
 // ------------------------------------------------------------------------------------------
 template <int KT>
@@ -263,6 +264,8 @@ __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__
     __shared__ double part[NQ][NA];
     __shared__ double red[NA];
     __shared__ double blockv[24 * HF_MAXCOMP + 16];   // one region's block of the vector, assembled in LDS
+    __shared__ double s_ll;
+    __shared__ unsigned long long s_x[16];
     const unsigned fl = (tid == 0 && flags) ? *flags : 0u;
     if (tid >= 960 && blockIdx.x == 0) {   // k_reduce's order over the chunk list
         const int lane = tid - 960;
@@ -274,7 +277,7 @@ __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__
         }
         for (; c < C; c += 64) acc += chunk_ll[c];
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-        if (lane == 0) out[0] = acc;
+        if (lane == 0) { out[0] = acc; s_ll = acc; }
     }
     const int nreg = P->n_regions, ncol = P->ncomp[3];
     const bool te = hf_err_is_truncexp(P);
@@ -327,7 +330,25 @@ __global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__
             }
         }
         __syncthreads();
-        for (int v = tid; v < rstride; v += 1024) out[1 + (int64_t) r * rstride + v] = blockv[v];
+        unsigned long long x = 0ull;           // checksum of what this block writes (hf_cks_term): the host verifies what it read
+        for (int v = tid; v < rstride; v += 1024) {
+            const double d = blockv[v];
+            const int64_t at = 1 + (int64_t) r * rstride + v;
+            out[at] = d;
+            x += hf_cks_term((unsigned long long) __double_as_longlong(d), at);
+        }
+        if (seq != 0.0) {
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if ((tid & 63) == 0) s_x[tid >> 6] = x;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long c = (unsigned long long) __double_as_longlong(seq);
+                for (int w = 0; w < 16; w++) c += s_x[w];
+                if (r == 0) c += hf_cks_term((unsigned long long) __double_as_longlong(s_ll), 0) +
+                                 hf_cks_term((unsigned long long) __double_as_longlong((double) fl), V);
+                out[V + 2 + r] = __longlong_as_double((long long) c);
+            }
+        }
         __syncthreads();
     }
     if (tid == 0 && flags && blockIdx.x == 0) out[V] = (double) fl;

@@ -443,3 +443,28 @@ def test_random_inputs_both_statistics_modes_against_each_other_and_the_oracle(s
     finally:
         em.close()
     _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, alpha, N.HF_ALGO_SCAN, n_iter=1)
+
+
+def test_polled_completion_never_returns_a_stale_vector():
+    """hf_finish polls a stamp that the last kernel writes after its results (no stream synchronisation): alternate two
+    parameter sets for a few hundred passes — every returned vector must be exactly the one of its own parameters, in both
+    statistics modes."""
+    store = synth.config(2, scale=0.01)
+    K = 4
+    model_a = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+    model_b = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+    em = hmm.EMList(store, model_a)
+    try:
+        hmm.EM_runOneIterationForList(em, model_b)
+        hmm.HMM_estimateParameters(model_b, 1e-3)            # b: one EM step away from a
+        for mode in (N.HF_STATS_ROWS, N.HF_STATS_CHUNKS):
+            em.set_stats_mode(mode)
+            em.launch(model_a); ref_a = em.finish().copy()
+            em.launch(model_b); ref_b = em.finish().copy()
+            assert not np.array_equal(ref_a, ref_b)
+            for i in range(300):
+                m, ref = (model_a, ref_a) if i % 2 == 0 else (model_b, ref_b)
+                em.launch(m)
+                assert np.array_equal(em.finish(), ref), (mode, i)
+    finally:
+        em.close()
