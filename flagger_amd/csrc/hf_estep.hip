@@ -898,7 +898,8 @@ static bool poll_ok(const hf_ctx* ctx, int last_kernel) {
 #ifdef HF_NO_POLL
     return false;
 #else
-    return ctx->d_total_host && !((ctx->prof_mask >> last_kernel) & 1u) && !(ctx->prof_mask & HF_PROF_PASS) && !ctx->host_trace;
+    static const bool off = [] { const char* e = std::getenv("HF_POLL"); return e && e[0] == '0'; }();   // HF_POLL=0: always synchronise the stream
+    return !off && ctx->d_total_host && !((ctx->prof_mask >> last_kernel) & 1u) && !(ctx->prof_mask & HF_PROF_PASS) && !ctx->host_trace;
 #endif
 }
 static double next_stamp(hf_ctx* ctx) { ctx->poll_seq += 1.0; ctx->h_total[ctx->V + 1] = 0.0; return ctx->poll_seq; }

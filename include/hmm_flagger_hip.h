@@ -149,6 +149,8 @@ int hf_finish_gathered(hf_ctx *ctx, const double *rows_dev, const int32_t *row_i
 
 /* Single-GPU convenience: reduce this context's chunks, copy the vector to `stats_host`,
  * wait for the stream and translate the device error flags (HF_E_SCALE / HF_E_NAN / ...). */
+/* (hf_finish waits by polling a checksummed completion stamp in the pinned result block instead of synchronising the
+ * stream; environment HF_POLL=0 makes it synchronise.) */
 int hf_finish(hf_ctx *ctx, double *stats_host, void *stream);
 /* Only wait + error flags (multi-GPU callers reduce the gathered vectors themselves). */
 int hf_check(hf_ctx *ctx, void *stream);
