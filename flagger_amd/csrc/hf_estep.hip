@@ -13,7 +13,7 @@
 //                                                                        (hmm.c:563-650, hmm_utils.c:812-839, 1027-1034)
 //   hf_chunks.h  k_stats_tile, k_chunk_stats, k_reduce: the same statistics as one vector per chunk, summed in chunk-list
 //                order (hmm.c:759-763) — HF_STATS_CHUNKS, the per-chunk multi-GPU exchange, HF_ALGO_SEQ
-//   hf_nb.h      the negative_binomial model's tables and count data
+//   hf_nb.h, hf_nb_rows.h   the negative_binomial model's tables and count data (per chunk / by emission row)
 //   hf_seq.h     HF_ALGO_SEQ, an independent on-device check: k_emit_rows (direct evaluation of every window's row),
 //                k_fwd_seq / k_bwd_seq (one wavefront per chunk, sequential recurrences)
 // There is no CPU fallback: without a HIP device hf_create fails with HF_E_NOGPU.
@@ -93,6 +93,8 @@ struct hf_ctx {
     unsigned long long* d_cks = nullptr;   // k_reduce: XOR of the words written (checksum of a polled pass)
     int poll_kind = 0;             // what the last polled kernel was: 1 k_rows_total (a checksum per region), 2 k_reduce (one)
     int n_groups = 0, n_rowwaves = 0;
+    bool pass_nb = false;          // the last rows-mode pass ran the negative_binomial kernels (hf_nb_rows.h)
+    int32_t* d_bin_off = nullptr; int32_t* d_bin_list = nullptr; double* d_slot_h = nullptr; double* d_H = nullptr;   // count-data plan
     double* d_chunk_ll = nullptr;  // [C] log-likelihood per chunk (rows mode)
     double* d_recs = nullptr;      // [N+1] pair records { f_{t-1}, b_t } (k_fb_tile RECS); fb_recs: the last full pass wrote them
     bool fb_recs = false;
@@ -175,6 +177,7 @@ __global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __res
 #include "hf_nb.h"
 #include "hf_chunks.h"
 #include "hf_rows.h"
+#include "hf_nb_rows.h"
 
 
 // ------------------------------------------------------------------------------------------
@@ -279,6 +282,15 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
 // the last kernel of a pass in HF_STATS_ROWS mode: total vector (+ flag word) into `out`
 static int launch_rows_total(hf_ctx* ctx, hipStream_t st, double* out, bool with_flags = true, double seq = 0.0) {
     KTimer t(ctx, st, HF_K_ROWS_TOTAL);
+    if (ctx->pass_nb) {
+        NbTables nt;
+        nt.E = ctx->d_nbE; nt.P = ctx->d_nbP; nt.dig = ctx->d_nbDig; nt.r = ctx->d_nbR; nt.beta = ctx->d_nbBeta;
+        hipLaunchKernelGGL(k_nb_total, dim3((unsigned) ctx->R), dim3(1024), 0, st, ctx->d_rw_off, ctx->pass_wpb, ctx->d_rw_stats, ctx->d_H,
+                           ctx->d_params, nt, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out,
+                           with_flags ? ctx->d_flags : (const unsigned*) nullptr, seq, ctx->d_done);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     const int kc = ctx->pass_kc;
 #define ROWS_TOTAL(KT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_total<KT>), dim3((unsigned) ctx->R), dim3(1024), 0, st, ctx->d_rw_off, ctx->pass_wpb, ctx->d_rw_stats, \
         ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out, with_flags ? ctx->d_flags : (const unsigned*) nullptr, seq, ctx->d_done)
@@ -562,6 +574,27 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / 16; k++) rwreg.push_back(reg);
                 }
                 rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / 16);
+                // negative_binomial count data: the row slots of every (region, min(x, 249)) bin, in plan order
+                {
+                    std::vector<int32_t> boff((size_t) n_regions * 256 + 1, 0), blist;
+                    for (size_t k = 0; k < rslots.size(); k++)
+                        if (rslots[k].row >= 0) {
+                            const int x = rslots[k].xpx & 0xff;
+                            boff[(size_t) rwreg[k / 16] * 256 + (size_t) (x < HF_NB_MAX_COVERAGE ? x : HF_NB_MAX_COVERAGE - 1) + 1]++;
+                        }
+                    for (size_t b = 0; b + 1 < boff.size(); b++) boff[b + 1] += boff[b];
+                    blist.resize((size_t) boff.back());
+                    std::vector<int32_t> fill(boff.begin(), boff.end() - 1);
+                    for (size_t k = 0; k < rslots.size(); k++)
+                        if (rslots[k].row >= 0) {
+                            const int x = rslots[k].xpx & 0xff;
+                            blist[(size_t) fill[(size_t) rwreg[k / 16] * 256 + (size_t) (x < HF_NB_MAX_COVERAGE ? x : HF_NB_MAX_COVERAGE - 1)]++] = (int32_t) k;
+                        }
+                    TRY(dev_upload(&ctx->d_bin_off, boff.data(), boff.size()));
+                    TRY(dev_upload(&ctx->d_bin_list, blist.data(), blist.size()));
+                    DMALLOC(ctx->d_slot_h, rslots.size() * 4 * 8);
+                    DMALLOC(ctx->d_H, (size_t) n_regions * 4 * 256 * 8);
+                }
                 cphase("plan: groups, row slots");
                 ctx->n_groups = (int) grow.size(); ctx->n_rowwaves = (int) (rslots.size() / 16);   // 16 slots per wavefront, 64 per region pad
                 TRY(dev_upload(&ctx->d_pairs, gp.data(), gp.size()));
@@ -599,7 +632,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_carry_desc);
-    hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
+    hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
@@ -750,7 +783,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
 #endif
                 const TileGeom g = full ? tile_geom(ctx, k_fb_tile<HF_SCAN_L, true>, fb_wave) : tile_geom(ctx, k_fb_tile<HF_SCAN_L, false>, fb_wave);
                 if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
-                const bool recs = full && !nbm && rows_pass(ctx);
+                const bool recs = full && rows_pass(ctx);
                 if (full) ctx->fb_recs = recs;
                 if (recs)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true, true>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
@@ -768,7 +801,28 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         }
         const int kc = p->ncomp[3];
         const int fl = full && ctx->ntiles > 0;
-        if (nbm) {
+        ctx->pass_nb = false;
+        if (nbm && fl && rows_pass(ctx)) {   // statistics by emission row, negative_binomial (hf_nb_rows.h)
+            {
+                KTimer t(ctx, st, HF_K_PAIR_SUMS);
+                const TileGeom g = tile_geom(ctx, k_pair_sums, 0);
+                if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
+                hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) (((int64_t) ctx->n_groups * 16 + 255) / 256)), dim3(256), g.lds, st, ctx->n_groups,
+                                   ctx->d_pairs, ctx->d_grp_row, ctx->d_lutE, ctx->d_params, ctx->d_recs, ctx->d_grp_sums);
+            }
+            {
+                KTimer t(ctx, st, HF_K_ROW_STATS);
+                const int n_rw_blocks = (ctx->n_rowwaves + 3) / 4, n_ll_blocks = (ctx->C + 3) / 4;
+                hipLaunchKernelGGL(k_row_stats_nb, dim3((unsigned) (n_rw_blocks + n_ll_blocks)), dim3(256), 0, st, ctx->n_rowwaves, n_rw_blocks,
+                                   ctx->d_rowslots, ctx->d_grp_sums, ctx->d_slot_h, ctx->d_rw_stats, ctx->C, ctx->d_chunk_tile0, ctx->d_tile_ll,
+                                   ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll);
+                const int n_bins = ctx->R * 256;
+                hipLaunchKernelGGL(k_nb_hist, dim3((unsigned) ((n_bins + 3) / 4)), dim3(256), 0, st, n_bins, ctx->d_bin_off, ctx->d_bin_list,
+                                   ctx->d_slot_h, ctx->d_H);
+            }
+            ctx->pass_rows = true; ctx->pass_nb = true; ctx->pass_wpb = 4;
+        }
+        else if (nbm) {
             if (fl) {
                 KTimer t(ctx, st, HF_K_STATS_TILE);
                 const TileGeom g = tile_geom(ctx, k_stats_tile_nb<HF_SCAN_L>, (size_t) HF_NB_WAVE_LDS * 8);

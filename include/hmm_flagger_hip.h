@@ -155,7 +155,7 @@ int hf_finish(hf_ctx *ctx, double *stats_host, void *stream);
 /* Only wait + error flags (multi-GPU callers reduce the gathered vectors themselves). */
 int hf_check(hf_ctx *ctx, void *stream);
 
-/* How a HF_MODE_FULL pass of HF_ALGO_SCAN produces the statistics (Gaussian / trunc-exp models):
+/* How a HF_MODE_FULL pass of HF_ALGO_SCAN produces the statistics:
  *   HF_STATS_CHUNKS  one estimator vector per chunk (EM_runOneIterationForList's per-chunk EM objects, hmm.c:739-763),
  *                    reduced over the chunk list in list order: hf_chunk_stats_dev / hf_copy_chunk_stats /
  *                    hf_reduce_chunks* / hf_finish_gathered work on these vectors, and the result does not depend on how
@@ -164,7 +164,7 @@ int hf_check(hf_ctx *ctx, void *stream);
  *                    (flagger_amd/csrc/hf_rows.h); hf_finish returns the same vector up to the rounding of a different
  *                    summation order (fixed by the plan of hf_create: reproducible), ~2.5x less statistics time.  The
  *                    per-chunk vectors are NOT produced (only element 0, the chunk's log-likelihood).
- * Default: HF_STATS_ROWS where it applies — HF_ALGO_SCAN, not the negative-binomial model, and a plan that is not
+ * Default: HF_STATS_ROWS where it applies — HF_ALGO_SCAN and a plan that is not
  * dominated by padding (it is when nearly every window has a private emission row: reads longer than the contigs) —
  * else HF_STATS_CHUNKS is used silently (hf_get_stats_mode tells); environment HF_STATS=chunks|rows
  * overrides the default at hf_create. */
