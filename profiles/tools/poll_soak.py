@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Soak test of the polled completion (hf_finish without stream synchronisation): alternate two parameter sets for N passes
 per statistics mode and compare every returned vector with the one of its own parameters; prints what differs.
-  python profiles/tools/poll_soak.py 400000      (history: stamp only: 1 stale pass in ~2 000; + XOR checksum: 1 in ~300 000,
+  python profiles/tools/poll_soak.py 400000 [nb]      (history: stamp only: 1 stale pass in ~2 000; + XOR checksum: 1 in ~300 000,
   two equal stale words cancel; + position-weighted checksum: 0 in 800 000)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path.insert(0, "tests")
@@ -9,8 +9,10 @@ import numpy as np
 from flagger_amd import hmm, synth, _native as N
 store = synth.config(2, scale=0.01)
 K = 4
-model_a = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
-model_b = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+MT = hmm.MODEL_NEGATIVE_BINOMIAL if len(sys.argv) > 2 and sys.argv[2] == "nb" else hmm.MODEL_TRUNC_EXP_GAUSSIAN
+ALPHA = np.zeros((4, 4)) if MT == hmm.MODEL_NEGATIVE_BINOMIAL else synth.HIFI_ALPHA
+model_a = hmm.createModel(MT, K, store, ALPHA)
+model_b = hmm.createModel(MT, K, store, ALPHA)
 em = hmm.EMList(store, model_a)
 hmm.EM_runOneIterationForList(em, model_b); hmm.HMM_estimateParameters(model_b, 1e-3)
 for mode in (N.HF_STATS_ROWS, N.HF_STATS_CHUNKS):
