@@ -173,3 +173,28 @@ def test_cli_summary_tables_and_contig_list(tmp_path):
         for f in ("prediction_summary_final.tsv", "prediction_summary_final.benchmarking.tsv",
                   "prediction_summary_final.benchmarking.auN_ratio.tsv"):
             assert (out / f).read_text() == (ref / f).read_text(), f
+
+
+def test_environment_switches_of_the_library():
+    """HF_STATS=chunks makes the per-chunk statistics the default of a context; HF_POLL=0 makes hf_finish synchronise the
+    stream instead of polling — the same vector bit for bit."""
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from flagger_amd import hmm, synth, _native as N\n"
+        "store = synth.config(2, scale=0.004)\n"
+        "model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, store, synth.HIFI_ALPHA)\n"
+        "em = hmm.EMList(store, model)\n"
+        "em.launch(model); v = em.finish()\n"
+        "print(em.stats_mode, v.tobytes().hex())\n" % ROOT)
+    outs = {}
+    for name, env in (("default", {}), ("nopoll", {"HF_POLL": "0"}), ("chunks", {"HF_STATS": "chunks"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-1500:]
+        mode, hexv = r.stdout.split()[-2:]
+        outs[name] = (int(mode), hexv)
+    assert outs["default"][0] == 1 and outs["nopoll"][0] == 1 and outs["chunks"][0] == 0
+    assert outs["default"][1] == outs["nopoll"][1]
+    a = np.frombuffer(bytes.fromhex(outs["default"][1])); b = np.frombuffer(bytes.fromhex(outs["chunks"][1]))
+    assert a[0] == b[0] and np.allclose(a, b, rtol=1e-11, atol=0)
