@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""One-off fuzz of the drop-in claim: random small inputs through the product command line and the oracle command line
+(-n 15, outputs compared byte for byte).  python profiles/tools/fuzz_cli.py <first seed> <n seeds>"""
+import filecmp
+import os
+import subprocess
+import sys
+import tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+from flagger_amd import synth  # noqa: E402
+
+first, count = int(sys.argv[1]), int(sys.argv[2])
+CLI = os.path.join(ROOT, "flagger_amd", "csrc", "hmm_flagger"); ORC = os.path.join(ROOT, "oracle", "hf_oracle")
+ALPHA = os.path.join(ROOT, "tests", "golden", "alpha_hifi.tsv")
+FILES = ["final_flagger_prediction.bed", "loglikelihood.tsv", "emission_final.tsv", "transition_final.tsv"]
+bad = 0
+for seed in range(first, first + count):
+    rng = np.random.default_rng(9000 + seed)
+    window_len = int(rng.choice([1000, 4000]))
+    lengths = [int(rng.integers(50, 3000)) * window_len + int(rng.integers(0, window_len)) for _ in range(int(rng.integers(1, 5)))]
+    R = int(rng.integers(1, 4))
+    store = synth.synthesize(lengths, window_len, int(rng.choice([50, 300])) * window_len, [int(rng.integers(10, 40)) for _ in range(R)],
+                             seed=seed, avg_alignment_len=int(rng.choice([0, 15_000])), region_run_bases=(5 * window_len, 300 * window_len))
+    d = tempfile.mkdtemp()
+    store.write_bin(os.path.join(d, "in.bin"))
+    model = ["trunc_exp_gaussian", "gaussian", "negative_binomial"][seed % 3]
+    extra = ["--accelerate"] if seed % 5 == 0 else []
+    args = ["-i", os.path.join(d, "in.bin"), "-n", "15", "-W", str(window_len), "-m", model] + ([] if model == "negative_binomial" else ["-A", ALPHA]) + extra
+    outs = []
+    for exe, name in ((CLI, "p"), (ORC, "o")):
+        o = os.path.join(d, name); os.mkdir(o)
+        r = subprocess.run([exe] + args + ["-o", o] + (["--threads", "8"] if exe == ORC else []), capture_output=True, text=True)
+        outs.append((r.returncode, o))
+    if outs[0][0] != outs[1][0]:
+        bad += 1; print("seed", seed, model, extra, "return codes differ", outs[0][0], outs[1][0]); continue
+    if outs[0][0] != 0:
+        continue
+    diff = [f for f in FILES if not filecmp.cmp(os.path.join(outs[0][1], f), os.path.join(outs[1][1], f), shallow=False)]
+    if diff:
+        bad += 1; print("seed", seed, model, extra, "windows", store.n_windows, "DIFFERENT:", diff)
+print("seeds", first, "..", first + count - 1, "runs with a difference:", bad)
