@@ -20,12 +20,30 @@ constexpr int kMaxCoverage = 250;   // chunk.c:8
 struct ChunkMeta { std::string ctg; int32_t ctg_len, s, e; };
 
 // window accumulator of one chunk being filled (Chunk.windowSum*, chunk.h:24-33)
+// value histogram for the mode rules (common.c:407-427) that remembers which entries it touched: a window usually sees
+// one value, and clearing / scanning 125 counters per window was a third of the loader's time
+template <int NV>
+struct SmallHist {
+    int h[NV] = {0};
+    int touched[NV];
+    int nt = 0;
+    void add(int v, int n) { if (h[v] == 0) touched[nt++] = v; h[v] += n; }
+    void reset() { for (int i = 0; i < nt; i++) h[touched[i]] = 0; nt = 0; }
+    int mode(int minv) const {                // the largest count, the lowest value on ties; minv when nothing was added
+        int best = -1, maxc = 0;
+        for (int i = 0; i < nt; i++) {
+            const int v = touched[i], c = h[v];
+            if (c > maxc || (c == maxc && c > 0 && v < best)) { best = v; maxc = c; }
+        }
+        return best < 0 ? minv : minv + best;
+    }
+};
 struct WindowAcc {
     int n = 0;                      // bases in the open window (windowItr + 1)
     double cov = 0, mapq = 0, clip = 0;
     uint64_t flag = 0;
-    int reg[101] = {0}, tru[12] = {0}, pre[12] = {0};   // value histograms for the mode rules
-    void reset() { n = 0; cov = mapq = clip = 0; flag = 0; std::memset(reg, 0, sizeof reg); std::memset(tru, 0, sizeof tru); std::memset(pre, 0, sizeof pre); }
+    SmallHist<101> reg; SmallHist<12> tru, pre;
+    void reset() { n = 0; cov = mapq = clip = 0; flag = 0; reg.reset(); tru.reset(); pre.reset(); }
 };
 
 // n repeated additions of v onto sum, as the reference does per base (chunk.c:459-461); when both are
@@ -36,11 +54,6 @@ inline void add_run(double& sum, double v, int n) {
     for (int i = 0; i < n; i++) sum += v;
 }
 
-inline int hist_mode(const int* h, int n_values, int minv) {   // common.c:407-427, lowest value wins ties
-    int mode = minv, maxc = h[0];
-    for (int i = 1; i < n_values; i++) if (maxc < h[i]) { mode = minv + i; maxc = h[i]; }
-    return mode;
-}
 inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 }  // namespace
 
@@ -67,10 +80,10 @@ struct hfio_table {
         cov.push_back((uint16_t) (kMaxCoverage < std::round(c) ? kMaxCoverage : std::round(c)));
         mapq.push_back((uint16_t) (kMaxCoverage < std::round(m) ? kMaxCoverage : std::round(m)));
         clip.push_back((uint16_t) (kMaxCoverage < std::round(k) ? kMaxCoverage : std::round(k)));
-        const int region = hist_mode(a.reg, 101, 0);
+        const int region = a.reg.mode(0);
         annot.push_back((a.flag & 0x03FFFFFFFFFFFFFFULL) | ((uint64_t) region << 58));   // ptBlock.c:300-304
-        truth.push_back((int8_t) hist_mode(a.tru, 12, -1));
-        prediction.push_back((int8_t) hist_mode(a.pre, 12, -1));
+        truth.push_back((int8_t) a.tru.mode(-1));
+        prediction.push_back((int8_t) a.pre.mode(-1));
         a.reset();
     }
     void close_chunk(const ChunkMeta& cm) {
@@ -339,7 +352,7 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
             const int seg_end = e < wend ? e : wend;
             const int n = seg_end - pos + 1;
             add_run(acc.cov, v_cov, n); add_run(acc.mapq, v_mapq, n); add_run(acc.clip, v_clip, n);
-            acc.flag |= flag; acc.reg[region] += n; acc.tru[truth] += n; acc.pre[pred] += n; acc.n += n;
+            acc.flag |= flag; acc.reg.add(region, n); acc.tru.add(truth, n); acc.pre.add(pred, n); acc.n += n;
             if (seg_end == wend) t->push_window(acc);              // full window, or the chunk's trailing partial window
             if (seg_end == cur.e) { t->close_chunk(cur); if (cur.e < ctg_len - 1) next_chunk(); }
             pos = seg_end + 1;
