@@ -6,8 +6,12 @@ One "step" = one EM pass over the whole synthetic diploid track: E-step on the G
 forward, backward, posterior decode, sufficient statistics, ordered reduction), the statistics
 vector to the host, the M-step, and the next parameter block back up — i.e. exactly what
 runHMMFlagger repeats (hmm_flagger.c:337-445).  The windows are resident in HBM before the timed
-region.  With --gpus N (one process per GPU under torch.distributed.run) the chunk list is sharded
-across ranks and the per-chunk statistics are all-gathered every step (flagger_amd/dist.py).
+region.  With --gpus N the chunk list is sharded across N ranks (one process per GPU over RCCL: the driver's
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, or — when WORLD_SIZE is not set —
+bench.py re-executes itself under that launcher) and the statistics are all-gathered every step
+(flagger_amd/dist.py).  It refuses to run when fewer than N GPUs are visible: it never reports a run of fewer
+ranks as N.  --scaling strong (default) shards the fixed BASELINE workload (configs[3]); --scaling weak gives every
+rank a whole configs[2] genome (N genomes in one EM: the statistics exchange is the same, the per-GPU work fixed).
 """
 import argparse
 import json
@@ -74,12 +78,36 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events inside the timed region; the dominant kernel's duration then comes from the untimed "
                          "passes that follow — for comparing launch paths, not the default")
-    ap.add_argument("--exchange", choices=["ranks", "chunks"], default="ranks",
-                    help="multi-GPU exchange: one statistics vector per rank, summed in rank order (default), or the per-chunk "
-                         "vectors summed in chunk-list order (bit-identical to a one-GPU run of the per-chunk statistics)")
+    ap.add_argument("--exchange", choices=["ranks", "chunks"], default="chunks",
+                    help="multi-GPU exchange: the per-chunk vectors summed in chunk-list order (default: statistics, EM trajectory "
+                         "and BED labels identical for every number of GPUs, bit for bit), or one statistics vector per rank "
+                         "summed in rank order (statistics by emission row on every rank: faster, equal up to rounding)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: the BASELINE workload sharded over the GPUs (configs[3]); weak: one whole configs[2] genome per GPU")
+    ap.add_argument("--no-weak-leg", action="store_true",
+                    help="with --gpus N > 1 and strong scaling the line also carries a `weak_scaling` object (one whole genome per "
+                         "GPU, timed after the main region); this switch skips it")
     ap.add_argument("--dist-path", action="store_true",
                     help="take the multi-GPU code path (process group, all-gather, indexed reduction) even with one GPU")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if world_env is None and args.gpus > 1:
+        # not under a launcher: become `torch.distributed.run --nproc-per-node N` ourselves (one process per GPU)
+        import socket
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) visible: refusing to run fewer ranks "
+                     f"(one RCCL rank per GPU)")
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
 
     import numpy as np
     import torch
@@ -87,9 +115,13 @@ def main():
     from flagger_amd import dist as fdist
     from flagger_amd import hmm, synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local_rank}, {torch.cuda.device_count()} visible): one RCCL rank per GPU")
     dist_path = world > 1 or args.dist_path
     if dist_path:
         import torch.distributed as tdist
@@ -97,10 +129,13 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(local_rank)
         tdist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node <gpus>"
+        assert tdist.get_world_size() == args.gpus
 
     # ---- workload: BASELINE.json configs[2] (= configs[3] when sharded over 8 GPUs) ----
     store = synth.config(args.config, scale=args.scale)
+    base_store = store
+    if args.scaling == "weak" and world > 1:      # one whole genome per rank: the chunk list of `world` genomes
+        store = store.subset_chunks(list(range(store.n_chunks)) * world)
     K = hmm.getBestNumberOfCollapsedComps(store)
     alpha = synth.HIFI_ALPHA if args.config == 2 else synth.ONT_R10_ALPHA
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
@@ -159,6 +194,34 @@ def main():
         dt = float(t.item())
     ll = model.loglikelihood
 
+    # second leg at N > 1: the same exchange with one WHOLE genome per GPU (weak scaling), outside the timed region above
+    weak = None
+    if world > 1 and args.scaling == "strong" and not args.no_weak_leg:
+        try:
+            wstore = base_store.subset_chunks(list(range(base_store.n_chunks)) * world)
+            wmodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, wstore, alpha)
+            wsh = fdist.make_sharded_hip(wstore, wmodel, rank, world, local_rank, True, 0.95, algo, exchange=args.exchange)
+
+            def wstep():
+                hmm.EM_runOneIterationForList(wsh, wmodel)
+                hmm.HMM_estimateParameters(wmodel, 1e-3)
+                hmm.HMM_resetEstimators(wmodel)
+            for _ in range(max(args.warmup, 1)):
+                wstep()
+            barrier()
+            w0 = time.perf_counter()
+            for _ in range(args.steps):
+                wstep()
+            barrier()
+            wt = torch.tensor([time.perf_counter() - w0], dtype=torch.float64, device="cuda")
+            tdist.all_reduce(wt, op=tdist.ReduceOp.MAX)
+            wdt = float(wt.item())
+            weak = {"value": wstore.n_windows * args.steps / wdt, "unit": "windows/s", "ms_per_step": wdt / args.steps * 1e3,
+                    "n_windows": wstore.n_windows, "windows_per_gpu": wsh.local_store.n_windows, "scaling": "weak",
+                    "loglikelihood_after_last_step": wmodel.loglikelihood}
+        except Exception as e:              # the headline number above stays valid
+            weak = {"error": repr(e)}
+
     if rank == 0:
         kavg = {k: v / extra for k, v in ksum.items() if v > 0}
         if args.no_kernel_events:
@@ -167,27 +230,34 @@ def main():
         achieved = ALGO_BYTES_PER_WINDOW * local_windows / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json,
         # made by profiles/pmc_summary.py on this same command; FETCH_SIZE x2 on gfx950): full workload, 1 GPU only
-        traffic = None
+        # NOT measured by this run: the PMC passes need rocprofv3 around the process, so the figure is read from the
+        # committed summary of the same command (profiles/collect.sh -> profiles/pmc_traffic.json, FETCH_SIZE x2 on
+        # gfx950) and labelled with where it came from; null for any other workload
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and world == 1 and args.scale == 1.0 and args.config == 2:
             try:
                 for k, v in json.load(open(pmc)).items():
                     if k.split("<")[0] == dom:
                         traffic = v["hbm_bytes_per_launch"]
+                import hashlib
+                traffic_src = "profiles/pmc_traffic.json sha256:" + hashlib.sha256(open(pmc, "rb").read()).hexdigest()[:12] + \
+                              " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
             except Exception:
                 traffic = None
         out = {
             "metric": "coverage windows/sec through EM+decode; achieved HBM GB/s vs roofline",
             "value": n_windows * args.steps / dt, "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: synthetic 2x3.03 Gb diploid HiFi-like coverage, "
                                     "4 kb windows, 20 Mb chunks, trunc_exp_gaussian, HiFi v1.1.0 alpha, full EM step "
                                     "(E-step+decode on GPU, M-step on host)" if args.config == 2 else
                                     "BASELINE.json configs[4]: synthetic 2x3.03 Gb diploid, ONT-R10 preset (8 kb windows), 7 bias "
                                     "regions with their own emission parameters, ONT-R10 v1.1.0 alpha, full EM step")
-                                   + ("" if args.scale == 1.0 else f" [scale {args.scale}]"),
+                                   + ("" if args.scale == 1.0 else f" [scale {args.scale}]")
+                                   + (f" [weak scaling: {world} such genomes, one per GPU]" if args.scaling == "weak" and world > 1 else ""),
                        "n_windows": n_windows, "n_chunks": store.n_chunks, "collapsed_comps": K,
                        "algo": args.algo,
                        "statistics": "per chunk, ordered reduction" if em.stats_mode == N.HF_STATS_CHUNKS else "by emission row",
@@ -195,12 +265,14 @@ def main():
                                        "all-gather of one statistics vector per rank" if args.exchange == "ranks" else
                                        "all-gather of per-chunk statistics"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": dom,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
                          "kernel_ms_timed": dom_ms, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_WINDOW * local_windows,
                          "kernel_ms_all": kavg, "algorithmic_bytes_per_window": ALGO_BYTES_PER_WINDOW,
                          "windows_per_launch": local_windows},
             "loglikelihood_after_last_step": ll,
         }
+        if weak is not None:
+            out["weak_scaling"] = weak
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(store, K, alpha, effective_cores())
         print(json.dumps(out))

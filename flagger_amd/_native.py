@@ -16,6 +16,8 @@ HF_MODEL_TRUNC_EXP_GAUSSIAN, HF_MODEL_GAUSSIAN, HF_MODEL_NEGATIVE_BINOMIAL = 0, 
 HF_MODE_FULL, HF_MODE_FORWARD_ONLY = 0, 1
 HF_ALGO_SCAN, HF_ALGO_SEQ = 0, 1
 HF_STATS_CHUNKS, HF_STATS_ROWS = 0, 1
+HF_EXCHANGE_CHUNKS, HF_EXCHANGE_RANKS = 0, 1
+HF_TRANSPORT_RCCL, HF_TRANSPORT_LOOPBACK = 0, 1
 HF_PROF_PASS = 0x80000000
 HF_OK, HF_E_ARG, HF_E_HIP, HF_E_SCALE, HF_E_NAN, HF_E_REGION, HF_E_NOGPU = 0, -1, -2, -3, -4, -5, -6
 
@@ -106,6 +108,32 @@ def lib() -> C.CDLL:
     sig("hf_set_stats_mode", C.c_int, vp, C.c_int)
     sig("hf_rank_total", C.c_int, vp, vp, vp)
     sig("hf_get_stats_mode", C.c_int, vp)
+    sig("hf_finish_exchange", C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, pd, vp)
+    sig("hf_bind_chunk_stats", C.c_int, vp, vp)
+    sig("hf_write_flag_row", C.c_int, vp, vp, vp)
+    # multi-GPU (include/hmm_flagger_multi.h)
+    sig("hf_comm_unique_id", C.c_int, vp)
+    sig("hf_comm_init_rank", C.c_int, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp))
+    sig("hf_comm_init_all", C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(vp))
+    sig("hf_comm_init_loopback", C.c_int, C.c_int, C.c_int, C.POINTER(vp))
+    sig("hf_comm_destroy", None, vp)
+    sig("hf_comm_rank", C.c_int, vp)
+    sig("hf_comm_size", C.c_int, vp)
+    sig("hf_comm_allgather", C.c_int, vp, vp, vp, i64, vp)
+    sig("hf_comm_last_error", C.c_char_p)
+    sig("hf_shard_bounds", C.c_int, C.POINTER(i64), i32, C.c_int, C.POINTER(i32))
+    sig("hf_multi_create", C.c_int, C.POINTER(hf_windows), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
+        C.POINTER(vp))
+    sig("hf_multi_destroy", None, vp)
+    sig("hf_multi_estep", C.c_int, vp, C.POINTER(hf_params), C.c_int, pd)
+    sig("hf_multi_get_labels", C.c_int, vp, C.POINTER(C.c_int8))
+    sig("hf_multi_get_posterior", C.c_int, vp, i64, i64, pd)
+    sig("hf_multi_world", C.c_int, vp)
+    sig("hf_multi_stats_len", i64, vp)
+    sig("hf_multi_shard_windows", i64, vp, C.c_int)
+    sig("hf_multi_shard_chunks", i32, vp, C.c_int)
+    sig("hf_multi_rank_stats", C.c_int, vp, C.c_int, pd)
+    sig("hf_multi_last_error", C.c_char_p)
     sig("hf_selftest_division", C.c_int, C.c_int, i64, pd, pd, pd, pd, C.POINTER(C.c_int32))
     # host model
     sig("hfm_create", vp, C.c_int, C.c_int, C.POINTER(i32), C.c_int, C.c_int, C.c_int, C.c_int, pd, dbl, dbl)

@@ -92,12 +92,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
         for (int j = 0; j < L; j++) {
             if (!(ok[j] && (int) REC_REGION(rr[j + 1]) == r)) continue;
             double Ev[16], Tm[16], f[4], b1[4];
-#ifdef HF_PROBE_SAMEROW   // timing probe (wrong results): every lane reads lane 0's rows — one cache line per load instruction
-            const int32_t probe_idx = __shfl(row_index(S, rr[j + 1], rr[j], sidx[j]), 0);
-            load_row(reinterpret_cast<const double2*>(S.lutE) + (int64_t) probe_idx * 8, Ev);
-#else
             load_row(row_ptr(S, rr[j + 1], rr[j], sidx[j]), Ev);
-#endif
             // f of the window before (the previous lane's last one for j == 0), b of the window itself (hf_scan.h fb_slot)
             const int64_t fs = j > 0 ? fb_slot<L>(tile, lane, j - 1, 0)
                                      : (lane > 0 ? fb_slot<L>(tile, lane - 1, L - 1, 0) : fb_slot<L>(tile - 1, 63, L - 1, 0));
@@ -105,11 +100,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
             const double2 f01 = reinterpret_cast<const double2*>(F)[fs], f23 = reinterpret_cast<const double2*>(F)[fs + 64];
             const double2 b01 = reinterpret_cast<const double2*>(B)[bs], b23 = reinterpret_cast<const double2*>(B)[bs + 64];
             const unsigned xw = REC_X(rr[j + 1]), xp = REC_X(rr[j]);
-#ifdef HF_PROBE_SAMEROW
-            const double2* __restrict__ crow = reinterpret_cast<const double2*>(S.lutC + ((int64_t) probe_idx * 4) * S.K);
-#else
             const double2* __restrict__ crow = crow_ptr(S, rr[j + 1], rr[j], sidx[j]);
-#endif
             lds_Tm(s_tab, rr[j + 1], Tm);
             f[0] = f01.x; f[1] = f01.y; f[2] = f23.x; f[3] = f23.y;
             b1[0] = b01.x; b1[1] = b01.y; b1[2] = b23.x; b1[3] = b23.y;
@@ -322,16 +313,26 @@ __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__
 // sum over chunks (hmm.c:759-763) in a fixed order that depends only on the chunk list: one wavefront per vector
 // element, lane l adds chunks l, l+64, ... in list order, then a fixed shuffle tree over the lanes.  The same
 // kernel reduces the local chunk list on one GPU and the all-gathered list on N GPUs => identical bits.
+// Error flags ride along as element V: this context's flag word, OR-ed with the flag rows of an exchange buffer
+// (n_ranks > 0: rank k's word is element 0 of row k*rows_per_rank + flag_row, written by k_flag_row) so that every rank
+// of a multi-GPU pass reports the same error.
 // seq != 0: `out` is the pinned host block and the host polls out[V+1]: the block that finishes last stamps it.
 __global__ void __launch_bounds__(64) k_reduce(const double* __restrict__ chunk_stats, const int32_t* __restrict__ row_index,
                                                int64_t n_chunks, int64_t V, double* __restrict__ out,
-                                               const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done,
-                                               unsigned long long* __restrict__ cks) {
+                                               const unsigned* __restrict__ flags, int n_ranks, int rows_per_rank, int flag_row,
+                                               double seq, unsigned* __restrict__ done, unsigned long long* __restrict__ cks) {
     const int64_t v = blockIdx.x;
     const int lane = threadIdx.x;
     double written = 0.0;
-    if (v == V) { if (flags && lane == 0) { written = (double) *flags; out[V] = written; } }   // error flags ride along with the vector
-    else {
+    if (v == V) {
+        if (flags) {
+            unsigned fl = lane == 0 ? *flags : 0u;
+            for (int k = lane; k < n_ranks; k += 64) fl |= (unsigned) chunk_stats[((int64_t) k * rows_per_rank + flag_row) * V];
+            for (int o = 32; o > 0; o >>= 1) fl |= __shfl_xor(fl, o);
+            written = (double) fl;
+            if (lane == 0) out[V] = written;
+        }
+    } else {
         double acc = 0.0;
         // row_index (multi-GPU): row of global chunk c inside the all-gathered, per-rank padded buffer
         for (int64_t c = lane; c < n_chunks; c += 64) acc += chunk_stats[(row_index ? (int64_t) row_index[c] : c) * V + v];
@@ -352,3 +353,7 @@ __global__ void __launch_bounds__(64) k_reduce(const double* __restrict__ chunk_
     }
 }
 
+// this rank's error-flag word as element 0 of a row of the exchange buffer (the rest of the row is not read)
+__global__ void k_flag_row(const unsigned* __restrict__ flags, double* __restrict__ row) {
+    if (threadIdx.x == 0) row[0] = (double) *flags;
+}

@@ -4,6 +4,7 @@
 #include "../../include/hmm_flagger_hip.h"
 #include "../../include/hmm_flagger_io.h"
 #include "../../include/hmm_flagger_model.h"
+#include "../../include/hmm_flagger_multi.h"
 #include "hf_squarem.h"
 #include <getopt.h>
 #include <sys/resource.h>
@@ -51,6 +52,9 @@ static struct option long_options[] = {                    // hmm_flagger.c:578-
     {"minimumLengths", required_argument, nullptr, 'M'},
     {"device", required_argument, nullptr, 1001},          // additions of this build (not in the reference)
     {"algo", required_argument, nullptr, 1002},
+    {"gpus", required_argument, nullptr, 1003},            // chunks sharded over GPUs device..device+N-1, one RCCL all-gather per pass
+    {"exchange", required_argument, nullptr, 1004},        // chunks (bit-identical for every N, default) | ranks
+    {"loopbackRanks", required_argument, nullptr, 1005},   // TEST: N ranks sharing one GPU (no RCCL): the multi-GPU path on a 1-GPU box
     {nullptr, 0, nullptr, 0}};
 
 static void usage(const char* program) {
@@ -77,7 +81,11 @@ static void usage(const char* program) {
             "         --minimumLengths, -M         Err,Dup,Col minimum lengths [0,0,0]\n"
             "         --threads, -@                accepted for compatibility (the E-step runs on the GPU)\n"
             "         --labelNames -l, --binArrayFile -a, --overlapRatioThreshold -v, -k: summary tables (prediction_summary_*.tsv)\n"
-            "         --device                     GPU index [0]        --algo scan|seq [scan]\n");
+            "         --device                     (first) GPU index [0]        --algo scan|seq [scan]\n"
+            "         --gpus N                     shard the chunks over GPUs device..device+N-1 (one process, one thread + one RCCL\n"
+            "                                      rank per GPU, one all-gather of statistics per EM pass)\n"
+            "         --exchange chunks|ranks      what the GPUs exchange: per-chunk vectors summed in chunk-list order (default with\n"
+            "                                      --gpus: results identical for every N) | one vector per GPU summed in rank order\n");
 }
 
 static bool dir_exists(const char* p) { struct stat sb; return stat(p, &sb) == 0 && S_ISDIR(sb.st_mode); }
@@ -89,32 +97,45 @@ static double random_factor(double dev) {                  // hmm_flagger.c:113-
     return (double) rand() / (double) (RAND_MAX / (end - start)) + start;
 }
 
+struct Run;
+static const char* run_error();
 static int die_estep(int rc) {
     if (rc == HF_E_SCALE) fprintf(stderr, "scale is very low!\n");                 // hmm.c:413
     else if (rc == HF_E_NAN) fprintf(stderr, "[Error] prob is NAN\n");             // hmm_utils.c:784
-    else fprintf(stderr, "[%s] Error: %s\n", ts(), hf_last_error());
+    else fprintf(stderr, "[%s] Error: %s\n", ts(), run_error());
     return EXIT_FAILURE;
 }
 
+// the E-step behind runHMMFlagger: one context on one GPU, or the sharded multi-GPU list (hmm_flagger_multi.h)
 struct Run {
     hf_ctx* ctx = nullptr;
+    hf_multi* multi = nullptr;
     hfio_table* tab = nullptr;
     std::vector<double> stats;
-    int estep(hfm_model* m, int mode) {
+    int estep(hfm_model* m, int mode, double* out) {
         hf_params p;
         hfm_params(m, &p);
+        if (multi) return hf_multi_estep(multi, &p, mode, out);
         int rc = hf_estep(ctx, &p, mode, nullptr);
-        if (rc == HF_OK) rc = hf_finish(ctx, stats.data(), nullptr);
+        if (rc == HF_OK) rc = hf_finish(ctx, out, nullptr);
         return rc;
     }
+    int estep(hfm_model* m, int mode) { return estep(m, mode, stats.data()); }
+    int labels(int8_t* out) { return multi ? hf_multi_get_labels(multi, out) : hf_get_labels(ctx, out); }
+    int posterior(int64_t first, int64_t n, double* out) {
+        return multi ? hf_multi_get_posterior(multi, first, n, out) : hf_get_posterior(ctx, first, n, out);
+    }
+    const char* error() const { return multi ? hf_multi_last_error() : hf_last_error(); }
 };
+static Run* g_run = nullptr;
+static const char* run_error() { return g_run ? g_run->error() : hf_last_error(); }
 
 // writeBenchmarkingStats, hmm_flagger.c:134-162
 static int write_summary(Run& run, const std::string& dir, const std::string& suffix, const std::vector<std::string>& labelNames,
                          const char* binArrayFilePath, double overlapRatioThreshold, int threads) {
     const int64_t N = hfio_n_windows(run.tab);
     std::vector<int8_t> labels((size_t) N);
-    int rc = hf_get_labels(run.ctx, labels.data());
+    int rc = run.labels(labels.data());
     if (rc != HF_OK) return rc;
     std::vector<const char*> names;
     for (const auto& s : labelNames) names.push_back(s.c_str());
@@ -143,7 +164,7 @@ int main(int argc, char* argv[]) {
     double convergenceTol = 0.001, maxHighMapqRatio = 0.25, minHighMapqRatio = 0.75, minReadFractionAtEnds = -1.0;
     double initialRandomDeviation = 0.0;
     bool adjustContigEnds = true, writeParamsPerIter = false, writePosterior = false, dumpBin = false, acceleration = false;
-    int modelType = -1, device = 0, algo = HF_ALGO_SCAN;
+    int modelType = -1, device = 0, algo = HF_ALGO_SCAN, nGpus = 0, exchange = -1, loopbackRanks = 0;
     const char* binArrayFilePath = nullptr;
     bool writeBenchmarkingStatsPerIteration = false;
     double overlapRatioThreshold = 0.4;
@@ -209,6 +230,13 @@ int main(int argc, char* argv[]) {
             }
             case 1001: device = atoi(optarg); break;
             case 1002: algo = !strcmp(optarg, "seq") ? HF_ALGO_SEQ : HF_ALGO_SCAN; break;
+            case 1003: nGpus = atoi(optarg); break;
+            case 1004:
+                if (!strcmp(optarg, "chunks")) exchange = HF_EXCHANGE_CHUNKS;
+                else if (!strcmp(optarg, "ranks")) exchange = HF_EXCHANGE_RANKS;
+                else { fprintf(stderr, "[%s] Error: --exchange can be chunks or ranks.\n", ts()); return EXIT_FAILURE; }
+                break;
+            case 1005: loopbackRanks = atoi(optarg); break;
             default:
                 if (c != 'h') fprintf(stderr, "[E::%s] undefined option %c\n", __func__, c);
                 usage(program);
@@ -225,6 +253,8 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "[phase] %-28s %8.1f ms\n", name, (now - phaseStart) * 1e3);
         phaseStart = now;
     };
+    if (nGpus < 0 || nGpus > 64 || loopbackRanks < 0 || loopbackRanks > 64) { fprintf(stderr, "[%s] Error: --gpus should be between 1 and 64.\n", ts()); return EXIT_FAILURE; }
+    if (nGpus > 0 && loopbackRanks > 0) { fprintf(stderr, "[%s] Error: --gpus and --loopbackRanks exclude each other.\n", ts()); return EXIT_FAILURE; }
     if (!inputPath) { fprintf(stderr, "[%s] Error: Input path cannot be NULL.\n", ts()); return EXIT_FAILURE; }
     if (convergenceTol <= 0.0 || convergenceTol > 1.0) {
         fprintf(stderr, "[%s] Error: convergence tol = %2.f should be between 0 and 1.\n", ts(), convergenceTol);
@@ -259,6 +289,7 @@ int main(int argc, char* argv[]) {
     // 1. windows; the HIP runtime and the device context come up on a second thread while the input is read
     fprintf(stderr, "[%s] Parsing/Creating coverage chunks. \n", ts());
     Run run;
+    g_run = &run;
     std::thread warm([device] { (void) hf_warmup(device); });
     run.tab = hfio_load(inputPath, chunkLen, windowLen);
     warm.join();
@@ -320,9 +351,27 @@ int main(int argc, char* argv[]) {
     w.adjust_contig_ends = adjustContigEnds ? 1 : 0; w.min_read_frac = adjustContigEnds ? minReadFractionAtEnds : 0.0;
     w.max_high_mapq_ratio = maxHighMapqRatio; w.min_high_mapq_ratio = minHighMapqRatio;
     w.min_highly_clipped_ratio = hfm_min_highly_clipped_ratio(model);
-    int rc = hf_create(&w, hfio_n_regions(tab), numberOfCollapsedComps, device, algo, &run.ctx);
-    if (rc != HF_OK) { fprintf(stderr, "[%s] Error: %s\n", ts(), hf_last_error()); return EXIT_FAILURE; }
-    run.stats.assign((size_t) hf_chunk_stats_len(run.ctx), 0.0);
+    // one GPU: one context (statistics by emission row).  --gpus N (or an explicit --exchange): the sharded list — by
+    // default with the chunk-order exchange, whose result does not depend on N (bit for bit)
+    const bool sharded = nGpus > 1 || loopbackRanks > 0 || (nGpus == 1 && exchange >= 0);
+    int rc;
+    if (sharded) {
+        const int world = loopbackRanks > 0 ? loopbackRanks : nGpus;
+        std::vector<int> devs((size_t) world);
+        for (int i = 0; i < world; i++) devs[(size_t) i] = loopbackRanks > 0 ? device : device + i;
+        rc = hf_multi_create(&w, hfio_n_regions(tab), numberOfCollapsedComps, world, devs.data(), algo,
+                             exchange < 0 ? HF_EXCHANGE_CHUNKS : exchange, loopbackRanks > 0 ? HF_TRANSPORT_LOOPBACK : HF_TRANSPORT_RCCL,
+                             &run.multi);
+        if (rc != HF_OK) { fprintf(stderr, "[%s] Error: %s\n", ts(), hf_multi_last_error()); return EXIT_FAILURE; }
+        for (int r = 0; r < world; r++)
+            fprintf(stderr, "[%s] GPU %d: %d chunks, %ld windows\n", ts(), devs[(size_t) r], hf_multi_shard_chunks(run.multi, r),
+                    (long) hf_multi_shard_windows(run.multi, r));
+        run.stats.assign((size_t) hf_multi_stats_len(run.multi), 0.0);
+    } else {
+        rc = hf_create(&w, hfio_n_regions(tab), numberOfCollapsedComps, device, algo, &run.ctx);
+        if (rc != HF_OK) { fprintf(stderr, "[%s] Error: %s\n", ts(), hf_last_error()); return EXIT_FAILURE; }
+        run.stats.assign((size_t) hf_chunk_stats_len(run.ctx), 0.0);
+    }
 
     phase("hf_create");
     // 5. EM (runHMMFlagger, hmm_flagger.c:285-488)
@@ -352,10 +401,7 @@ int main(int argc, char* argv[]) {
         if (acceleration) {                                  // hmm_flagger.c:382-416
             fprintf(stderr, "[%s] [Iteration accelerated = %d] Running SQUAREM acceleration.\n", ts(), iter);
             auto estep_cb = [&](hfm_model* m, int mode, double* st) -> int {
-                hf_params p; hfm_params(m, &p);
-                int r = hf_estep(run.ctx, &p, mode, nullptr);
-                if (r == HF_OK) r = hf_finish(run.ctx, st, nullptr);
-                return r;
+                return run.estep(m, mode, st);
             };
             rc = squarem_iteration(&model, run.stats, convergenceTol, estep_cb, &passes);
             if (rc != HF_OK) return die_estep(rc);
@@ -382,11 +428,11 @@ int main(int argc, char* argv[]) {
     write_params(model, dir, "final");
     if ((rc = write_summary(run, dir, "final", labelNames, binArrayFilePath, overlapRatioThreshold, threads)) != HF_OK) return die_estep(rc);
     std::vector<int8_t> labels((size_t) N);
-    if ((rc = hf_get_labels(run.ctx, labels.data())) != HF_OK) return die_estep(rc);
+    if ((rc = run.labels(labels.data())) != HF_OK) return die_estep(rc);
     memcpy(hfio_prediction(tab), labels.data(), (size_t) N);
     if (writePosterior) {
         std::vector<double> post((size_t) N * 4);
-        if ((rc = hf_get_posterior(run.ctx, 0, N, post.data())) != HF_OK) return die_estep(rc);
+        if ((rc = run.posterior(0, N, post.data())) != HF_OK) return die_estep(rc);
         const std::string pp = dir + "/posterior_prediction_final.bed";
         fprintf(stderr, "[%s] Writing posterior bed : %s\n", ts(), pp.c_str());
         hfio_write_posterior_bed(tab, post.data(), labels.data(), pp.c_str());
@@ -400,6 +446,7 @@ int main(int argc, char* argv[]) {
     }
     fprintf(stderr, "[%s] EM+decode: %d passes over %ld windows in %.4f s = %.3e windows/s on GPU %d\n", ts(), passes, (long) N, emTime,
             (double) N * passes / emTime, device);
+    if (run.multi) hf_multi_destroy(run.multi);
     hf_destroy(run.ctx);
     hfm_destroy(model);
     hfio_destroy(tab);

@@ -55,7 +55,8 @@ struct hf_ctx {
     std::vector<int64_t> h_off; std::vector<int32_t> h_tile0;   // host copies for hf_get_forward_backward
     double* d_scale = nullptr;     // [N]
     int8_t* d_label = nullptr;     // [N]
-    double* d_chunk_stats = nullptr; // [C][V]
+    double* d_chunk_stats = nullptr; // [C][V]; own_chunk_stats: allocated here (else bound to an exchange buffer, hf_bind_chunk_stats)
+    bool own_chunk_stats = true;
     double* d_total = nullptr;     // [V]
     double* d_total_host = nullptr; // device address of the pinned h_total: k_reduce writes the result straight to the host
     // scan algorithm: tile tables and per-tile work arrays
@@ -76,9 +77,6 @@ struct hf_ctx {
     bool have_full = false;
     size_t lds_max = 64 * 1024;    // LDS one workgroup may use (hipDeviceAttributeMaxSharedMemoryPerBlock)
     bool launch_failed = false;
-    struct GraphSlot { int key = 0; hipGraphExec_t exec = nullptr; };   // key 0: not captured yet, -1: capture unavailable
-    GraphSlot graphs[2];           // HF_MODE_FULL, HF_MODE_FORWARD_ONLY
-    hipStream_t gstream = nullptr; // capture stream
     double beta_star = 1.0;
     // per-iteration emission rows (k_tables): keys = occurring (region, x, x_prev) of interior windows,
     // slow = chunk-first and contig-end windows (beta != beta_star), ascending; slow_off[c] = chunk c's first entry
@@ -185,11 +183,7 @@ __global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __res
 // ------------------------------------------------------------------------------------------
 // the event pair around a whole pass (hf_last_kernel_ms) costs two extra packets per step: only while profiling is on
 static bool pass_events(const hf_ctx* ctx) {
-#ifdef HF_ALWAYS_EVENTS
-    return true;
-#else
     return (ctx->prof_mask & HF_PROF_PASS) != 0 || ctx->host_trace;
-#endif
 }
 
 template <typename T>
@@ -627,7 +621,7 @@ void hf_destroy(hf_ctx* ctx) {
         std::fprintf(stderr, "[hf host trace] %ld EM steps: enqueue %.1f us, wait %.1f us, m-step %.1f us, gpu span (first launch .. reduction) %.1f us\n",
                      ctx->ht_n, ctx->ht[0] / ctx->ht_n, ctx->ht[1] / ctx->ht_n, ctx->ht[2] / ctx->ht_n, ctx->ht[3] / ctx->ht_n);
     hipFree(ctx->d_off); hipFree(ctx->d_rec); hipFree(ctx->d_beta); hipFree(ctx->d_regmask); hipFree(ctx->d_E);
-    hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); hipFree(ctx->d_chunk_stats);
+    hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); if (ctx->own_chunk_stats) hipFree(ctx->d_chunk_stats);
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
@@ -638,8 +632,6 @@ void hf_destroy(hf_ctx* ctx) {
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
     if (ctx->h_total) hipHostFree(ctx->h_total);
-    for (auto& g : ctx->graphs) if (g.exec) hipGraphExecDestroy(g.exec);
-    if (ctx->gstream) hipStreamDestroy(ctx->gstream);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 2 * HF_NKERNELS; i++) if (ctx->kev[i]) hipEventDestroy(ctx->kev[i]);
@@ -776,11 +768,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                                        ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb);
                 }
                 KTimer t(ctx, st, HF_K_FB_TILE);
-#ifdef HF_FB_LDS
-                const size_t fb_wave = (size_t) HF_SCAN_L * 5 * HF_FW_STRIDE * 8;
-#else
-                const size_t fb_wave = 0;
-#endif
+                const size_t fb_wave = (size_t) HF_SCAN_L * 5 * HF_FW_STRIDE * 8;   // wave-private f / scale block
                 const TileGeom g = full ? tile_geom(ctx, k_fb_tile<HF_SCAN_L, true>, fb_wave) : tile_geom(ctx, k_fb_tile<HF_SCAN_L, false>, fb_wave);
                 if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
                 const bool recs = full && rows_pass(ctx);
@@ -879,6 +867,7 @@ int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
     if (!ctx || !dst_dev) return set_err(HF_E_ARG, "hf_copy_chunk_stats: bad argument");
     if (ctx->pass_rows) return set_err(HF_E_ARG, "hf_copy_chunk_stats: the last pass ran in HF_STATS_ROWS mode (no per-chunk vectors)");
     HIPCHK(hipSetDevice(ctx->device));
+    if (dst_dev == ctx->d_chunk_stats) return HF_OK;   // bound to the exchange buffer: the kernels already wrote in place
     HIPCHK(hipMemcpyAsync(dst_dev, ctx->d_chunk_stats, (size_t) ctx->C * ctx->V * 8, hipMemcpyDeviceToDevice,
                           (hipStream_t) stream));
     return HF_OK;
@@ -891,8 +880,9 @@ int hf_rank_total(hf_ctx* ctx, double* out_dev, void* stream) {
     return hf_reduce_chunks_indexed(ctx, ctx->d_chunk_stats, nullptr, ctx->C, out_dev, stream);
 }
 
+struct ExchangeGeom { int n_ranks = 0, rows_per_rank = 0, flag_row = 0; };   // n_ranks == 0: no flag rows to merge
 static int reduce_chunks_seq(hf_ctx* ctx, const double* chunk_stats_dev, const int32_t* row_index_dev, int64_t n_chunks,
-                             double* out_dev, void* stream, double seq) {
+                             double* out_dev, void* stream, double seq, ExchangeGeom xg = ExchangeGeom()) {
     if (!ctx || !chunk_stats_dev || !out_dev || n_chunks < 0) return set_err(HF_E_ARG, "hf_reduce_chunks: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
     const bool own = chunk_stats_dev == ctx->d_chunk_stats;
@@ -903,7 +893,7 @@ static int reduce_chunks_seq(hf_ctx* ctx, const double* chunk_stats_dev, const i
         hipLaunchKernelGGL(k_reduce, dim3((unsigned) (ctx->V + 1)), dim3(64), 0, (hipStream_t) stream, chunk_stats_dev, row_index_dev,
                            n_chunks, ctx->V, out_dev,
                            (out_dev == ctx->d_total || out_dev == ctx->d_total_host) ? ctx->d_flags : (const unsigned*) nullptr,
-                           seq, ctx->d_done, ctx->d_cks);
+                           xg.n_ranks, xg.rows_per_rank, xg.flag_row, seq, ctx->d_done, ctx->d_cks);
     }
     ctx->prof_mask = keep;
     HIPCHK(hipGetLastError());
@@ -945,16 +935,28 @@ int hf_check(hf_ctx* ctx, void* stream) {
     return flags_to_code(*ctx->h_flags);
 }
 
-// Polled completion: the last kernel of a pass writes the statistics into the pinned host block and then a stamp; the host
-// spins on the stamp instead of waiting for the stream's completion signal (≈ 12 us less per EM step).  Not used while
-// the last kernel itself is being timed with events, nor with the host trace (both need the stream drained).
+// Completion of a pass.  Default: hipStreamSynchronize on the launch stream — the HIP-defined way to see the statistics
+// block that the last kernel wrote into pinned host memory.
+// Opt-in (environment HF_POLL=1): the last kernel also writes a completion stamp behind a system-scope fence and the host
+// spins on it instead of waiting for the stream's completion signal (3-12 us less per EM step, depending on the box).  The
+// order in which device writes to host memory become visible is NOT defined by the HIP memory model: round 1 measured a
+// stale element in one of ~2 000 passes with the stamp alone, so a polled block is only accepted when a position-weighted
+// checksum of what the host READ matches the one the kernel wrote (polled_block_consistent; none in 800 000 passes,
+// profiles/tools/poll_soak.py), and the memory must be coherent host memory (HIP_HOST_COHERENT=0 falls back to the
+// stream after the 2 s bail-out).  HF_POLL=debug additionally synchronises after acceptance and reports any word
+// that still changed.  It stays off by default: no EM step should depend on a probabilistic check.
+static int poll_mode() {
+    static const int mode = [] {
+        const char* e = std::getenv("HF_POLL");
+        if (!e) return 0;
+        if (!std::strcmp(e, "debug")) return 2;
+        return e[0] == '1' ? 1 : 0;
+    }();
+    return mode;
+}
 static bool poll_ok(const hf_ctx* ctx, int last_kernel) {
-#ifdef HF_NO_POLL
-    return false;
-#else
-    static const bool off = [] { const char* e = std::getenv("HF_POLL"); return e && e[0] == '0'; }();   // HF_POLL=0: always synchronise the stream
-    return !off && ctx->d_total_host && !((ctx->prof_mask >> last_kernel) & 1u) && !(ctx->prof_mask & HF_PROF_PASS) && !ctx->host_trace;
-#endif
+    return poll_mode() != 0 && ctx->d_total_host && !((ctx->prof_mask >> last_kernel) & 1u) && !(ctx->prof_mask & HF_PROF_PASS) &&
+           !ctx->host_trace;
 }
 static double next_stamp(hf_ctx* ctx) { ctx->poll_seq += 1.0; ctx->h_total[ctx->V + 1] = 0.0; return ctx->poll_seq; }
 // The stamp alone is not enough: the device's writes to host memory may become visible out of order (a soak test saw a
@@ -997,8 +999,7 @@ static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_ho
         }
     }
     if (!seen) HIPCHK(hipStreamSynchronize(st));
-#ifdef HF_POLL_DEBUG
-    if (seen) {   // did anything still arrive after the block was accepted?
+    if (seen && poll_mode() == 2) {   // HF_POLL=debug: did anything still arrive after the block was accepted?
         std::vector<double> snap(ctx->h_total, ctx->h_total + ctx->V + 1);
         HIPCHK(hipStreamSynchronize(st));
         for (int64_t v = 0; v <= ctx->V; v++)
@@ -1006,7 +1007,6 @@ static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_ho
                 std::fprintf(stderr, "[poll debug] seq %.0f kind %d element %ld changed after acceptance: %.17g -> %.17g\n", ctx->poll_seq,
                              ctx->poll_kind, (long) v, snap[(size_t) v], ctx->h_total[v]);
     }
-#endif
     accumulate_kernel_times(ctx);   // events of the kernels before the last one have completed
     std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
     return flags_to_code((unsigned) ctx->h_total[ctx->V]);
@@ -1031,17 +1031,19 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
 }
 
 // Multi-GPU counterpart of hf_finish: the rows of ALL chunks are in `rows_dev` (all-gathered, row_index_dev maps list
-// position -> row); reduce them in the fixed order straight into pinned host memory, wait, translate the flags of
-// THIS rank's pass.  One synchronisation per EM step.
-int hf_finish_gathered(hf_ctx* ctx, const double* rows_dev, const int32_t* row_index_dev, int64_t n_chunks, double* stats_host,
-                       void* stream) {
-    if (!ctx || !rows_dev || !stats_host || n_chunks < 0) return set_err(HF_E_ARG, "hf_finish_gathered: bad argument");
+// position -> row); reduce them in the fixed order straight into pinned host memory, wait, translate the flags.
+// With an exchange geometry the flag rows of all ranks are OR-ed in, so every rank reports the same error and nobody is
+// left waiting in the next collective.  One synchronisation per EM step.
+static int finish_rows(hf_ctx* ctx, const double* rows_dev, const int32_t* row_index_dev, int64_t n_rows, ExchangeGeom xg,
+                       double* stats_host, void* stream, const char* who) {
+    if (!ctx || !rows_dev || !stats_host || n_rows < 0) return set_err(HF_E_ARG, std::string(who) + ": bad argument");
     hipStream_t st = (hipStream_t) stream;
+    HIPCHK(hipSetDevice(ctx->device));
     double* out = ctx->d_total_host ? ctx->d_total_host : ctx->d_total;
     const bool polled = poll_ok(ctx, HF_K_REDUCE);
     const double seq = polled ? next_stamp(ctx) : 0.0;
     ctx->poll_kind = 2;
-    int rc = reduce_chunks_seq(ctx, rows_dev, row_index_dev, n_chunks, out, stream, seq);
+    int rc = reduce_chunks_seq(ctx, rows_dev, row_index_dev, n_rows, out, stream, seq, xg);
     if (rc) return rc;
     if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev1, st));
     if (!ctx->d_total_host)
@@ -1049,43 +1051,40 @@ int hf_finish_gathered(hf_ctx* ctx, const double* rows_dev, const int32_t* row_i
     return wait_total(ctx, st, polled, stats_host);
 }
 
-// One EM step in one call: E-step with the model's current parameters, reduced statistics back on the host,
-// then (do_mstep) HMM_estimateParameters.  What runHMMFlagger repeats (hmm_flagger.c:337-445) without going back
-// to the caller between the two halves.
-// The pass of hf_em_iterate as a HIP graph: parameter block up, every kernel of the pass, the reduction and the
-// statistics (+ flag word) down — captured once per (mode, model type, number of collapsed components) and replayed:
-// one graph launch instead of ten stream operations.  Kernel arguments never change between
-// iterations (the parameters live in the pinned block the first node copies).  Falls back to plain launches when
-// per-kernel timing is on, for the negative_binomial model (its tables come from caller memory), or if capture fails.
-using GraphSlot = hf_ctx::GraphSlot;
-// Opt-in (HF_USE_GRAPH=1): measured on MI355X / ROCm 7.2 the graph replay is SLOWER than the ten plain stream
-// operations (0.39 vs 0.34 ms per EM step at cfg-2), so plain launches stay the default.
-static bool graph_eligible(const hf_ctx* ctx, const hf_params* p) {
-    static const bool enabled = std::getenv("HF_USE_GRAPH") != nullptr;
-    return enabled && ctx->prof_mask == 0 && ctx->C > 0 && ctx->ntiles > 0 && p->model_type != HF_MODEL_NEGATIVE_BINOMIAL &&
-           ctx->graphs[0].key != -1 && !(ctx->stats_mode == HF_STATS_ROWS && ctx->rows_ready);
+int hf_finish_gathered(hf_ctx* ctx, const double* rows_dev, const int32_t* row_index_dev, int64_t n_chunks, double* stats_host,
+                       void* stream) {
+    return finish_rows(ctx, rows_dev, row_index_dev, n_chunks, ExchangeGeom(), stats_host, stream, "hf_finish_gathered");
 }
 
-static int graph_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t st) {
-    const int key = ((mode * 4 + p->model_type) * 64 + p->ncomp[3]) * 2 + 1;
-    GraphSlot& g = ctx->graphs[mode == HF_MODE_FULL ? 0 : 1];
-    if (g.key != key) {
-        if (g.exec) { hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-        g.key = 0;
-        if (!ctx->gstream && hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) != hipSuccess) return -1;
-        if (hipStreamBeginCapture(ctx->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void) hipGetLastError(); return -1; }
-        int rc = enqueue_pass(ctx, p, mode, ctx->gstream);
-        if (rc == HF_OK) rc = hf_reduce_chunks(ctx, ctx->d_chunk_stats, ctx->C, ctx->d_total, ctx->gstream);
-        if (rc == HF_OK && hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, ctx->gstream) != hipSuccess) rc = -1;
-        hipGraph_t graph = nullptr;
-        const hipError_t e = hipStreamEndCapture(ctx->gstream, &graph);
-        if (rc != HF_OK || e != hipSuccess || !graph) { if (graph) hipGraphDestroy(graph); (void) hipGetLastError(); return -1; }
-        const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
-        hipGraphDestroy(graph);
-        if (ei != hipSuccess) { g.exec = nullptr; (void) hipGetLastError(); return -1; }
-        g.key = key;
+int hf_finish_exchange(hf_ctx* ctx, const double* rows_dev, const int32_t* row_index_dev, int64_t n_rows, int n_ranks,
+                       int rows_per_rank, int flag_row, double* stats_host, void* stream) {
+    if (n_ranks < 1 || rows_per_rank < 2 || flag_row < 0 || flag_row >= rows_per_rank)
+        return set_err(HF_E_ARG, "hf_finish_exchange: bad exchange geometry");
+    ExchangeGeom xg;
+    xg.n_ranks = n_ranks; xg.rows_per_rank = rows_per_rank; xg.flag_row = flag_row;
+    return finish_rows(ctx, rows_dev, row_index_dev, n_rows, xg, stats_host, stream, "hf_finish_exchange");
+}
+
+int hf_bind_chunk_stats(hf_ctx* ctx, double* rows_dev) {
+    if (!ctx) return set_err(HF_E_ARG, "hf_bind_chunk_stats: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (rows_dev) {
+        if (ctx->own_chunk_stats) hipFree(ctx->d_chunk_stats);
+        ctx->d_chunk_stats = rows_dev; ctx->own_chunk_stats = false;
+    } else if (!ctx->own_chunk_stats) {
+        ctx->d_chunk_stats = nullptr;
+        HIPCHK(hipMalloc((void**) &ctx->d_chunk_stats, ((size_t) ctx->C * (size_t) ctx->V + 1) * 8));
+        ctx->own_chunk_stats = true;
     }
-    return hipGraphLaunch(g.exec, st) == hipSuccess ? 0 : -1;
+    return HF_OK;
+}
+
+int hf_write_flag_row(hf_ctx* ctx, double* row_dev, void* stream) {
+    if (!ctx || !row_dev) return set_err(HF_E_ARG, "hf_write_flag_row: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_flag_row, dim3(1), dim3(64), 0, (hipStream_t) stream, ctx->d_flags, row_dev);
+    HIPCHK(hipGetLastError());
+    return HF_OK;
 }
 
 // One EM step in one call: E-step with the model's current parameters, reduced statistics back on the host,
@@ -1097,42 +1096,21 @@ int hf_em_iterate(hf_ctx* ctx, hfm_model* model, int mode, int do_mstep, double 
         return set_err(HF_E_ARG, "hf_em_iterate: bad argument");
     hf_params p;
     hfm_params(model, &p);
-    hipStream_t st = (hipStream_t) stream;
     int rc = HF_OK;
-    bool done = false;
-    if (graph_eligible(ctx, &p)) {
-        HIPCHK(hipSetDevice(ctx->device));
-        rc = pack_params(ctx, &p);
-        if (rc) return rc;
-        HIPCHK(hipEventRecord(ctx->ev0, st));
-        if (graph_pass(ctx, &p, mode, st) == 0) {
-            HIPCHK(hipEventRecord(ctx->ev1, st));
-            HIPCHK(hipStreamSynchronize(st));
-            ctx->ev_valid = true;
-            ctx->have_full = (mode == HF_MODE_FULL);
-            std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
-            rc = flags_to_code((unsigned) ctx->h_total[ctx->V]);
-            done = true;
-        } else {
-            ctx->graphs[0].key = ctx->graphs[1].key = -1;   // capture is not available here: plain launches from now on
-        }
-    }
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     auto t1 = t0, t2 = t0;
-    if (!done) {
-        rc = hf_estep(ctx, &p, mode, stream);
-        t1 = clk::now();
-        if (rc == HF_OK) rc = hf_finish(ctx, stats_host, stream);
-        t2 = clk::now();
-    }
+    rc = hf_estep(ctx, &p, mode, stream);
+    t1 = clk::now();
+    if (rc == HF_OK) rc = hf_finish(ctx, stats_host, stream);
+    t2 = clk::now();
     if (rc != HF_OK) return rc;
     hfm_set_loglikelihood(model, stats_host[0]);
     if (do_mstep && mode == HF_MODE_FULL) {
         const int cv = hfm_estimate(model, stats_host, tol);
         if (converged) *converged = cv;
     }
-    if (ctx->host_trace && !done) {
+    if (ctx->host_trace) {
         const auto t3 = clk::now();
         float gpu_ms = 0.f;
         (void) hipEventElapsedTime(&gpu_ms, ctx->ev0, ctx->ev1);
@@ -1151,6 +1129,8 @@ int hf_get_labels(hf_ctx* ctx, int8_t* labels_host) {
 
 int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_host, double* b_host, double* scales_host) {
     if (!ctx || first < 0 || n < 0 || first + n > ctx->N) return set_err(HF_E_ARG, "hf_get_forward_backward: bad range");
+    if (!ctx->have_full && (f_host || b_host))
+        return set_err(HF_E_ARG, "hf_get_forward_backward: the last pass was not HF_MODE_FULL (backward values would be stale)");
     HIPCHK(hipSetDevice(ctx->device));
     if (scales_host && n) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
     if ((!f_host && !b_host) || n == 0) return HF_OK;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -174,6 +175,9 @@ class LineReader {
         }
     }
 
+    // true when the stream ended on a zlib error (truncated or corrupt .cov.gz) instead of its end
+    bool failed() const { return failed_; }
+
   private:
     static constexpr size_t kCap = 4u << 20;
     static constexpr int kN = 3;
@@ -187,9 +191,16 @@ class LineReader {
             size_t got = 0;
             while (got < kCap) {                        // gzread returns short counts only at the end of the stream
                 const int r = gzread(f_, buf_[i].data() + got, (unsigned) (kCap - got));
-                if (r <= 0) break;
+                if (r < 0) { failed_ = true; break; }   // corrupt deflate data, I/O error
+                if (r == 0) {                           // end of data: a stream cut before its trailer is an error, not EOF
+                    int errnum = Z_OK;
+                    (void) gzerror(f_, &errnum);
+                    if (errnum != Z_OK && errnum != Z_STREAM_END) failed_ = true;
+                    break;
+                }
                 got += (size_t) r;
             }
+            if (failed_) got = 0;                       // hand the parser the end marker; load_cov asks failed()
             {
                 std::lock_guard<std::mutex> g(m_);
                 len_[i] = got; filled_++;
@@ -220,6 +231,7 @@ class LineReader {
     int filled_ = 0, cur_ = 0, next_ = 0;
     size_t pos_ = 0;
     bool have_ = false, stop_ = false;
+    std::atomic<bool> failed_{false};
 };
 
 // atoi / atof of a field for the shapes that occur in coverage files, with the library calls as the fallback.
@@ -359,6 +371,7 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
         }
         next_pos = e + 1;
     }
+    if (reader->failed()) return fail(std::string("Error: ") + path + " is truncated or corrupt (zlib reported an error before the end of the stream)");
     delete reader;
     gzclose(f);
     if (in_contig) { t->push_window(acc); t->close_chunk(cur); }

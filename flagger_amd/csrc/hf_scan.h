@@ -315,7 +315,6 @@ __global__ void __launch_bounds__(256, HF_PROD_BLOCKS) k_prod_tile(int ntiles, c
     const uint32_t rp = load_recs<L>(rec, t0, T, a, lane, rr);
     int sidx[L];
     tile_slow_index<L>(rr, lane, d.slow0, sidx);
-#ifndef HF_NO_COOP_ROWS
     // rows through the cooperative fetch: window i+1's loads are in flight while window i is multiplied in
     double2* __restrict__ xp = reinterpret_cast<double2*>(s_tab + P->n_regions * HF_TAB_STRIDE) + (threadIdx.x >> 6) * 512;
     int32_t ridx[L];
@@ -345,44 +344,10 @@ __global__ void __launch_bounds__(256, HF_PROD_BLOCKS) k_prod_tile(int ntiles, c
             }
         }
     }
-#else
-    double Ecur[16];
-    if (a < T) load_row(row_ptr(S, rr[0], rp, sidx[0]), Ecur);
-    unsigned nan = 0;
-    M4 Q;
-    m4_identity(Q);
-#pragma unroll
-    for (int i = 0; i < L; i++) {
-        double Enext[16];
-        if (i + 1 < L && a + i + 1 < T) load_row(row_ptr(S, rr[i + 1], rr[i], sidx[i + 1]), Enext);
-        if (a + i < T) {
-            if (row_has_nan(Ecur)) nan |= HF_FLAG_NAN;
-            if (!REC_FIRST(rr[i])) {
-                double Tm[16];
-                lds_Tm(s_tab, rr[i], Tm);
-                M4 A, R;
-#pragma unroll
-                for (int k = 0; k < 16; k++) A.m[k] = Tm[HF_PS(k >> 2, k & 3)] * Ecur[HF_PS(k >> 2, k & 3)];
-                m4_mul(R, Q, A);
-                Q = R;
-                m4_renorm(Q);
-            }
-        }
-        if (i + 1 < L) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) Ecur[k] = Enext[k];
-        }
-    }
-#endif
     {   // lane-minor: the 64 lanes of a wavefront write / read 1 KiB contiguous per instruction
-#ifdef HF_QS_ROWMAJOR
-        double2* dst = reinterpret_cast<double2*>(Qs + ((int64_t) tile * 64 + lane) * 16);
-        for (int k = 0; k < 8; k++) dst[k] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
-#else
         double2* dst = reinterpret_cast<double2*>(Qs) + (int64_t) tile * 8 * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 8; k++) dst[k * 64] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
-#endif
     }
     // ordered tree product over lanes: after step d, lane l (l % 2d == 0) holds the product of lanes l..l+2d-1
 #pragma unroll
@@ -400,14 +365,9 @@ __global__ void __launch_bounds__(256, HF_PROD_BLOCKS) k_prod_tile(int ntiles, c
 }
 
 __device__ __forceinline__ void load_lane_product(M4& Q, const double* __restrict__ Qs, int tile, int lane) {
-#ifdef HF_QS_ROWMAJOR
-    const double2* __restrict__ src = reinterpret_cast<const double2*>(Qs + ((int64_t) tile * 64 + lane) * 16);
-    for (int k = 0; k < 8; k++) { const double2 v = src[k]; Q.m[2 * k] = v.x; Q.m[2 * k + 1] = v.y; }
-#else
     const double2* __restrict__ src = reinterpret_cast<const double2*>(Qs) + (int64_t) tile * 8 * 64 + lane;
 #pragma unroll
     for (int k = 0; k < 8; k++) { const double2 v = src[k * 64]; Q.m[2 * k] = v.x; Q.m[2 * k + 1] = v.y; }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -528,9 +488,6 @@ __global__ void __launch_bounds__(128) k_carry(const CarryDesc* __restrict__ cde
 #ifndef HF_FB_BLOCKS
 #define HF_FB_BLOCKS 3
 #endif
-#ifndef HF_FB_REGS
-#define HF_FB_LDS 1
-#endif
 // RECS (with BWD): instead of the lane-minor arrays F, B the pass writes one 64-byte PAIR RECORD per window into F —
 // record t = { f_{t-1}[4], b_t[4] } (window-major, N+1 records) — what the statistics by emission row read (hf_rows.h);
 // the halves are written out of LDS by neighbouring lanes (16 cache lines per store instruction instead of 64).
@@ -557,16 +514,6 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
     const double2* rowp[L];
 #pragma unroll
     for (int i = 0; i < L; i++) rowp[i] = row_ptr(S, rr[i], i == 0 ? rp : rr[i - 1], sidx[i]);
-#ifdef HF_PROBE_SAMEROW   // timing probe (wrong results): every lane reads lane 0's row — one cache line per load instruction
-#pragma unroll
-    for (int i = 0; i < L; i++)
-        rowp[i] = reinterpret_cast<const double2*>(S.lutE) + (int64_t) __shfl(row_index(S, rr[i], i == 0 ? rp : rr[i - 1], sidx[i]), 0) * 8;
-#endif
-#ifdef HF_PROBE_NODIV     // timing probe (wrong results): the replay's divisions become multiplications
-#define HF_PDIV(x, y) ((x) * (y))
-#else
-#define HF_PDIV(x, y) ((x) / (y))
-#endif
     double Ecur[16];
     if (a < T) load_row(rowp[0], Ecur);           // in flight during the scan
     double carry[4];
@@ -610,16 +557,10 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
         for (int j = 0; j < 4; j++) f[j] = (lane == 0) ? carry[j] : u[j] / su;
     }
     // replay this lane's windows in the reference's operation order (hmm.c:333-420); f and scale stay in registers
-#ifdef HF_FB_LDS
     // f and scale of the lane's windows wait for the backward half in wave-private LDS, lane-minor (conflict-free)
     double* __restrict__ s_fw = s_tab + P->n_regions * HF_TAB_STRIDE + (threadIdx.x >> 6) * (L * 5 * HF_FW_STRIDE) + lane;
 #define FW(i, s) s_fw[((i) * 5 + (s)) * HF_FW_STRIDE]
 #define SCW(i) s_fw[((i) * 5 + 4) * HF_FW_STRIDE]
-#else
-    double fw[L][4], scw[L];
-#define FW(i, s) fw[i][s]
-#define SCW(i) scw[i]
-#endif
     double ll = 0.0;
 #pragma unroll
     for (int i = 0; i < L; i++) {
@@ -641,7 +582,7 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
             }
             if (!REC_FIRST(r) && sc < 1e-50) bad |= HF_FLAG_SCALE;   // hmm.c:412-415
 #pragma unroll
-            for (int s = 0; s < 4; s++) f[s] = HF_PDIV(nf[s], sc);
+            for (int s = 0; s < 4; s++) f[s] = nf[s] / sc;
             ll += log(sc);                                            // hmm.c:428
             if (!RECS) {
                 reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 0)] = make_double2(f[0], f[1]);
@@ -663,7 +604,6 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
     }
     for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
     if (lane == 0) tile_ll[tile] = ll;
-#ifdef HF_FB_LDS
     // pair records: window k of the tile is written by lanes 2k', 2k'+1 (16 bytes each) out of the wave's LDS block
     // (wave-uniform record base in scalar registers, one 32-bit lane offset: no 64-bit address arithmetic per store)
 #define HF_COOP_HALF(DST_OFF, REC_SHIFT)                                                                               \
@@ -688,7 +628,6 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
         }                                                                                                               \
     }
     if (RECS) HF_COOP_HALF(0, 1)      // f_t goes into record t+1
-#endif
     if (BWD) {
         // ---- backward: exclusive SUFFIX product over lanes ----
         const int64_t Tm1 = T - 1;
@@ -750,7 +689,6 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
                     }
                 }
                 label[t] = (int8_t) posterior_label(fl, b, scl);
-#ifdef HF_FB_LDS
                 if (RECS) {   // f of this window is not needed any more: its LDS slots take b for the record write
 #pragma unroll
                     for (int i = 0; i < L; i++)
@@ -759,7 +697,6 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
                             for (int s = 0; s < 4; s++) FW(i, s) = b[s];
                         }
                 }
-#endif
             }
         }
         // replay the other windows (decreasing) in the reference's operation order: window i uses the row of i+1
@@ -779,7 +716,7 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
                 const double sc = SCW(i);
                 if (sc < 1e-50) bad |= HF_FLAG_SCALE;                 // hmm.c:521-524
 #pragma unroll
-                for (int s = 0; s < 4; s++) b[s] = HF_PDIV(nb[s], sc);
+                for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
                 if (!RECS) {
                     reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 0)] = make_double2(b[0], b[1]);
                     reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 1)] = make_double2(b[2], b[3]);
@@ -788,12 +725,10 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
                     const double fi[4] = {FW(i, 0), FW(i, 1), FW(i, 2), FW(i, 3)};
                     label[t] = (int8_t) posterior_label(fi, b, sc);
                 }
-#ifdef HF_FB_LDS
                 if (RECS) {
 #pragma unroll
                     for (int s = 0; s < 4; s++) FW(i, s) = b[s];
                 }
-#endif
             }
             if (i >= 1) {
 #pragma unroll
@@ -801,9 +736,9 @@ __global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const
             }
         }
     }
-#ifdef HF_FB_LDS
     if (BWD && RECS) HF_COOP_HALF(2, 0)   // b_t goes into record t
 #undef HF_COOP_HALF
-#endif
+#undef FW
+#undef SCW
     if (bad) atomicOr(flags, bad);
 }

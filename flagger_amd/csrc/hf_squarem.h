@@ -24,6 +24,10 @@ int squarem_iteration(hfm_model** model, std::vector<double>& stats, double tol,
     hfm_model* prime = hfm_squarem_model_prime(acc);
     rc = estep(prime, HF_MODE_FORWARD_ONLY, stats.data());
     while (rc == HF_OK && stats[0] < ll0) {
+        // alpha == -1: prime IS model 0 (hmm.c:871-884), whose likelihood is ll0 by definition.  The reference compares the
+        // same code path's sums on both sides; here ll0 comes from a FULL pass and stats[0] from a FORWARD_ONLY pass, whose
+        // summation orders are matched by construction but not by contract — never shrink past the fixed point.
+        if (hfm_squarem_alpha(acc) == -1.0) break;
         prime = hfm_squarem_shrink(acc);
         rc = estep(prime, HF_MODE_FORWARD_ONLY, stats.data());
     }

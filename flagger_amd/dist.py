@@ -55,51 +55,51 @@ class ShardedEMList:
         self.local = make_local(self.local_store)
         self.V = stats_len
         self.device = device if device is not None else torch.device("cpu")
-        self.send = torch.zeros((self.maxc, self.V), dtype=torch.float64, device=self.device)
-        self.recv = torch.zeros((world, self.maxc, self.V), dtype=torch.float64, device=self.device)
-        # row of global chunk c inside recv viewed as [world*maxc, V]: rank-major, padded to maxc rows per rank
-        rows = [r * self.maxc + k for r in range(world) for k in range(self.counts[r])]
-        self.row_index = torch.tensor(rows if rows else [0], dtype=torch.int32, device=self.device)
+        # Exchange buffers: rows of V doubles, `rpr` rows per rank, the LAST row of a rank carries its device error-flag
+        # word (hf_write_flag_row) so that every rank sees every rank's flags after the one collective of the pass.
         # exchange "chunks": all-gather the per-chunk vectors, sum in global list order (bit-identical to one GPU);
         # "ranks": every rank sums its own chunks (hf_rank_total, statistics by emission row on the HIP backend), one
         # vector per rank is all-gathered and summed in rank order (the same numbers up to the rounding of the order)
         if exchange not in ("chunks", "ranks"):
             raise ValueError("exchange must be 'chunks' or 'ranks'")
         self.exchange = exchange
-        if exchange == "ranks":
+        self.rpr = (self.maxc if exchange == "chunks" else 1) + 1
+        self.flag_row = self.rpr - 1
+        self.send = torch.zeros((self.rpr, self.V), dtype=torch.float64, device=self.device)
+        self.recv = torch.zeros((world, self.rpr, self.V), dtype=torch.float64, device=self.device)
+        if exchange == "chunks":
+            # row of global chunk c inside recv viewed as [world*rpr, V]: rank-major, padded to rpr rows per rank
+            rows = [r * self.rpr + k for r in range(world) for k in range(self.counts[r])]
+            self.n_rows = self.n_chunks_total
+            if hasattr(self.local, "bind_chunk_stats"):    # HIP backend: the pass writes its vectors straight into `send`
+                self.local.bind_chunk_stats(self.send)
+        else:
+            rows = [r * self.rpr for r in range(world)]
+            self.n_rows = world
             self.local.use_rank_totals()
-            self.rsend = torch.zeros((self.V,), dtype=torch.float64, device=self.device)
-            self.rrecv = torch.zeros((world, self.V), dtype=torch.float64, device=self.device)
-            self.rank_rows = torch.arange(world, dtype=torch.int32, device=self.device)
+        self.row_index = torch.tensor(rows if rows else [0], dtype=torch.int32, device=self.device)
         self.force_collective = False      # run the collective even with world == 1 (exercises the RCCL path on one GPU)
         self.total = torch.zeros((self.V,), dtype=torch.float64, device=self.device)
 
     def run_sharded(self, model, mode: int) -> np.ndarray:
-        torch = self.torch
         import torch.distributed as dist
         self.local.launch(model, mode)
         if self.exchange == "ranks":
-            self.local.rank_total_into(self.rsend)
-            if self.world > 1 or self.force_collective:
-                dist.all_gather_into_tensor(self.rrecv.view(-1), self.rsend, group=self.group)
-            else:
-                self.rrecv[0].copy_(self.rsend)
-            if hasattr(self.local, "finish_gathered"):    # HIP backend: rank-order sum into pinned host memory, one sync
-                return self.local.finish_gathered(self.rrecv, None, self.world).copy()
-            self.local.reduce_into(self.rrecv, self.rank_rows, self.world, self.total)
-            stats = self.total.cpu().numpy().copy()
-            self.local.check()
-            return stats
+            self.local.rank_total_into(self.send[0])
+        else:
+            self.local.chunk_stats_into(self.send)        # no-op when the pass already wrote into `send`
+        hip = hasattr(self.local, "finish_exchange")
+        if hip:
+            self.local.write_flag_row(self.send[self.flag_row])
         if self.world > 1 or self.force_collective:
-            self.local.chunk_stats_into(self.send)        # [maxc, V] rows of this rank, device-to-device
             dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group)
         else:
-            self.local.chunk_stats_into(self.recv[0])
-        # every rank sums ALL chunks in global list order straight out of the gathered buffer
-        rows = self.recv.view(self.world * self.maxc, self.V)
-        if hasattr(self.local, "finish_gathered"):        # HIP backend: sum into pinned host memory, one sync, flags checked
-            return self.local.finish_gathered(rows, self.row_index, self.n_chunks_total).copy()
-        self.local.reduce_into(rows, self.row_index, self.n_chunks_total, self.total)
+            self.recv[0].copy_(self.send)
+        # every rank sums ALL rows in the fixed order straight out of the gathered buffer
+        rows = self.recv.view(self.world * self.rpr, self.V)
+        if hip:      # sum into pinned host memory, one sync; the flags of ALL ranks are checked: every rank raises together
+            return self.local.finish_exchange(rows, self.row_index, self.n_rows, self.world, self.rpr, self.flag_row).copy()
+        self.local.reduce_into(rows, self.row_index, self.n_rows, self.total)
         stats = self.total.cpu().numpy().copy()           # device->host copy synchronises the stream
         self.local.check()
         return stats
@@ -135,6 +135,9 @@ class HipLocal:
     def launch(self, model, mode):
         self.em.launch(model, mode)
 
+    def bind_chunk_stats(self, send):
+        self.em.bind_chunk_stats(send.data_ptr())
+
     def chunk_stats_into(self, send):
         self.em.copy_chunk_stats(send.data_ptr())
 
@@ -144,11 +147,14 @@ class HipLocal:
     def rank_total_into(self, send):
         self.em.rank_total(send.data_ptr())
 
+    def write_flag_row(self, row):
+        self.em.write_flag_row(row.data_ptr())
+
     def reduce_into(self, rows, row_index, n_chunks, total):
         self.em.reduce_chunks_indexed(rows.data_ptr(), row_index.data_ptr(), n_chunks, total.data_ptr())
 
-    def finish_gathered(self, rows, row_index, n_chunks):
-        return self.em.finish_gathered(rows.data_ptr(), row_index.data_ptr() if row_index is not None else 0, n_chunks)
+    def finish_exchange(self, rows, row_index, n_rows, world, rows_per_rank, flag_row):
+        return self.em.finish_exchange(rows.data_ptr(), row_index.data_ptr(), n_rows, world, rows_per_rank, flag_row)
 
     def check(self):
         self.em.check()

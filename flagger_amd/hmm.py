@@ -140,6 +140,98 @@ def createModel(modelType: int, numberOfCollapsedComps: int, store: WindowStore,
     return HMM(h)
 
 
+def _windows_struct(store: WindowStore, model: "HMM", adjustContigEnds: bool, minReadFractionAtEnds: float):
+    """hf_windows over the store's arrays (+ the dict that keeps the contiguous copies alive)."""
+    L = N.lib()
+    k = dict(
+        off=np.ascontiguousarray(store.chunk_off, np.int64), cov=np.ascontiguousarray(store.cov, np.uint16),
+        mapq=np.ascontiguousarray(store.mapq, np.uint16), clip=np.ascontiguousarray(store.clip, np.uint16),
+        annot=np.ascontiguousarray(store.annot, np.uint64), s=np.ascontiguousarray(store.chunk_s, np.int32),
+        e=np.ascontiguousarray(store.chunk_e, np.int32), cl=np.ascontiguousarray(store.chunk_ctg_len, np.int32))
+    w = N.hf_windows()
+    w.n_windows, w.n_chunks = store.n_windows, store.n_chunks
+    w.chunk_off = k["off"].ctypes.data_as(C.POINTER(C.c_int64))
+    w.cov = k["cov"].ctypes.data_as(C.POINTER(C.c_uint16))
+    w.mapq = k["mapq"].ctypes.data_as(C.POINTER(C.c_uint16))
+    w.clip = k["clip"].ctypes.data_as(C.POINTER(C.c_uint16))
+    w.annot = k["annot"].ctypes.data_as(C.POINTER(C.c_uint64))
+    w.chunk_s = k["s"].ctypes.data_as(C.POINTER(C.c_int32))
+    w.chunk_e = k["e"].ctypes.data_as(C.POINTER(C.c_int32))
+    w.chunk_ctg_len = k["cl"].ctypes.data_as(C.POINTER(C.c_int32))
+    w.window_len, w.mean_read_len = store.window_len, store.avg_alignment_len
+    w.adjust_contig_ends, w.min_read_frac = int(adjustContigEnds), float(minReadFractionAtEnds)
+    w.max_high_mapq_ratio = L.hfm_max_high_mapq_ratio(model._h)
+    w.min_high_mapq_ratio = L.hfm_min_high_mapq_ratio(model._h)
+    w.min_highly_clipped_ratio = L.hfm_min_highly_clipped_ratio(model._h)
+    return w, k
+
+
+class MultiHFError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        self.code = code
+        super().__init__(f"{where} failed with code {code}: {N.lib().hf_multi_last_error().decode(errors='replace')}")
+
+
+class MultiEMList:
+    """The chunk list sharded over the GPUs of this node inside ONE process (include/hmm_flagger_multi.h hf_multi: one
+    host thread, stream and RCCL rank per device; one all-gather of statistics per pass).  What `hmm_flagger --gpus N`
+    drives; `transport=N.HF_TRANSPORT_LOOPBACK` puts all ranks on one device (tests on a 1-GPU box)."""
+
+    def __init__(self, store: WindowStore, model: "HMM", n_devices: int, adjustContigEnds: bool = True,
+                 minReadFractionAtEnds: float = 0.95, devices: Optional[Sequence[int]] = None, algo: int = N.HF_ALGO_SCAN,
+                 exchange: int = N.HF_EXCHANGE_CHUNKS, transport: int = N.HF_TRANSPORT_RCCL):
+        L = N.lib()
+        self._L, self.store = L, store
+        w, self._keep = _windows_struct(store, model, adjustContigEnds, minReadFractionAtEnds)
+        self.n_regions, self.max_comps = model.numberOfRegions, model.maxNumberOfComps
+        self.stats_len = N.stats_len(self.n_regions, self.max_comps)
+        dev = (C.c_int * n_devices)(*devices) if devices is not None else None
+        h = C.c_void_p()
+        rc = L.hf_multi_create(C.byref(w), self.n_regions, self.max_comps, n_devices, dev, algo, exchange, transport, C.byref(h))
+        if rc != N.HF_OK:
+            raise MultiHFError(rc, "hf_multi_create")
+        self._h, self.world = h, n_devices
+        self._stats = np.empty(self.stats_len, dtype=np.float64)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.hf_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def run_sharded(self, model: "HMM", mode: int) -> np.ndarray:
+        p = model.params()
+        rc = self._L.hf_multi_estep(self._h, C.byref(p), mode, _dptr(self._stats))
+        if rc != N.HF_OK:
+            raise MultiHFError(rc, "hf_multi_estep")
+        return self._stats.copy()
+
+    def rank_stats(self, r: int) -> np.ndarray:
+        out = np.empty(self.stats_len, dtype=np.float64)
+        N.check(self._L.hf_multi_rank_stats(self._h, r, _dptr(out)), "hf_multi_rank_stats")
+        return out
+
+    def shard_sizes(self):
+        return [(int(self._L.hf_multi_shard_chunks(self._h, r)), int(self._L.hf_multi_shard_windows(self._h, r))) for r in range(self.world)]
+
+    def labels(self) -> np.ndarray:
+        out = np.empty(self.store.n_windows, dtype=np.int8)
+        rc = self._L.hf_multi_get_labels(self._h, out.ctypes.data_as(C.POINTER(C.c_int8)))
+        if rc != N.HF_OK:
+            raise MultiHFError(rc, "hf_multi_get_labels")
+        return out
+
+    def posterior(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
+        n = self.store.n_windows - first if n is None else n
+        out = np.empty((n, 4), dtype=np.float64)
+        rc = self._L.hf_multi_get_posterior(self._h, first, n, _dptr(out))
+        if rc != N.HF_OK:
+            raise MultiHFError(rc, "hf_multi_get_posterior")
+        return out
+
+
 class EMList:
     """All per-chunk EM objects of this process (stList<EM*> in the reference) as ONE device context:
     the windows are uploaded once and stay resident in HBM (hf_create)."""
@@ -151,27 +243,7 @@ class EMList:
         self._L = L
         self.store = store
         self.stream = C.c_void_p(stream)
-        self._keep = dict(
-            off=np.ascontiguousarray(store.chunk_off, np.int64), cov=np.ascontiguousarray(store.cov, np.uint16),
-            mapq=np.ascontiguousarray(store.mapq, np.uint16), clip=np.ascontiguousarray(store.clip, np.uint16),
-            annot=np.ascontiguousarray(store.annot, np.uint64), s=np.ascontiguousarray(store.chunk_s, np.int32),
-            e=np.ascontiguousarray(store.chunk_e, np.int32), cl=np.ascontiguousarray(store.chunk_ctg_len, np.int32))
-        k = self._keep
-        w = N.hf_windows()
-        w.n_windows, w.n_chunks = store.n_windows, store.n_chunks
-        w.chunk_off = k["off"].ctypes.data_as(C.POINTER(C.c_int64))
-        w.cov = k["cov"].ctypes.data_as(C.POINTER(C.c_uint16))
-        w.mapq = k["mapq"].ctypes.data_as(C.POINTER(C.c_uint16))
-        w.clip = k["clip"].ctypes.data_as(C.POINTER(C.c_uint16))
-        w.annot = k["annot"].ctypes.data_as(C.POINTER(C.c_uint64))
-        w.chunk_s = k["s"].ctypes.data_as(C.POINTER(C.c_int32))
-        w.chunk_e = k["e"].ctypes.data_as(C.POINTER(C.c_int32))
-        w.chunk_ctg_len = k["cl"].ctypes.data_as(C.POINTER(C.c_int32))
-        w.window_len, w.mean_read_len = store.window_len, store.avg_alignment_len
-        w.adjust_contig_ends, w.min_read_frac = int(adjustContigEnds), float(minReadFractionAtEnds)
-        w.max_high_mapq_ratio = L.hfm_max_high_mapq_ratio(model._h)
-        w.min_high_mapq_ratio = L.hfm_min_high_mapq_ratio(model._h)
-        w.min_highly_clipped_ratio = L.hfm_min_highly_clipped_ratio(model._h)
+        w, self._keep = _windows_struct(store, model, adjustContigEnds, minReadFractionAtEnds)
         self.n_regions, self.max_comps = model.numberOfRegions, model.maxNumberOfComps
         self.stats_len = N.stats_len(self.n_regions, self.max_comps)
         h = C.c_void_p()
@@ -222,6 +294,21 @@ class EMList:
         N.check(self._L.hf_finish_gathered(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr) if row_index_dev_ptr else None, n_chunks,
                                            _dptr(self._stats_buf), self.stream), "hf_finish_gathered")
         return self._stats_buf
+
+    def finish_exchange(self, rows_dev_ptr: int, row_index_dev_ptr: int, n_rows: int, world: int, rows_per_rank: int,
+                        flag_row: int) -> np.ndarray:
+        """hf_finish_exchange: hf_finish_gathered + the error flags of every rank (row `flag_row` of each rank's rows)."""
+        if not hasattr(self, "_stats_buf"):
+            self._stats_buf = np.empty(self.stats_len, dtype=np.float64)
+        N.check(self._L.hf_finish_exchange(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr), n_rows, world,
+                                           rows_per_rank, flag_row, _dptr(self._stats_buf), self.stream), "hf_finish_exchange")
+        return self._stats_buf
+
+    def bind_chunk_stats(self, rows_dev_ptr: int) -> None:
+        N.check(self._L.hf_bind_chunk_stats(self._h, C.c_void_p(rows_dev_ptr)), "hf_bind_chunk_stats")
+
+    def write_flag_row(self, row_dev_ptr: int) -> None:
+        N.check(self._L.hf_write_flag_row(self._h, C.c_void_p(row_dev_ptr), self.stream), "hf_write_flag_row")
 
     def reduce_chunks_indexed(self, rows_dev_ptr: int, row_index_dev_ptr: int, n_chunks: int, dst_dev_ptr: int) -> None:
         N.check(self._L.hf_reduce_chunks_indexed(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr) if row_index_dev_ptr else None, n_chunks,

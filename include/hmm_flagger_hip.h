@@ -147,10 +147,23 @@ int hf_reduce_chunks_indexed(hf_ctx *ctx, const double *rows_dev, const int32_t 
 int hf_finish_gathered(hf_ctx *ctx, const double *rows_dev, const int32_t *row_index_dev, int64_t n_chunks,
                        double *stats_host, void *stream);
 
+/* The same with the error flags of EVERY rank: the gathered buffer holds `rows_per_rank` rows per rank and row
+ * `flag_row` of each rank carries that rank's device flag word (hf_write_flag_row); the words are OR-ed into the result,
+ * so all ranks return the same HF_E_* code and none is left waiting in the next collective (hmm.c:412-415 exits the whole
+ * process; here the whole job stops).  rows_per_rank >= 2, 0 <= flag_row < rows_per_rank. */
+int hf_finish_exchange(hf_ctx *ctx, const double *rows_dev, const int32_t *row_index_dev, int64_t n_rows, int n_ranks,
+                       int rows_per_rank, int flag_row, double *stats_host, void *stream);
+/* Let the pass write its per-chunk vectors straight into caller-owned device memory (>= n_chunks rows), e.g. this rank's
+ * slot of an in-place all-gather buffer: no device-to-device copy per pass.  NULL: back to a buffer of the context. */
+int hf_bind_chunk_stats(hf_ctx *ctx, double *rows_dev);
+/* This context's device error-flag word as element 0 of `row_dev` (device memory, one row of the exchange buffer);
+ * asynchronous on `stream`, after the pass. */
+int hf_write_flag_row(hf_ctx *ctx, double *row_dev, void *stream);
+
 /* Single-GPU convenience: reduce this context's chunks, copy the vector to `stats_host`,
  * wait for the stream and translate the device error flags (HF_E_SCALE / HF_E_NAN / ...). */
-/* (hf_finish waits by polling a checksummed completion stamp in the pinned result block instead of synchronising the
- * stream; environment HF_POLL=0 makes it synchronise.) */
+/* (hf_finish synchronises the stream.  Environment HF_POLL=1 opts into polling a checksummed completion stamp in the
+ * pinned result block instead — a few microseconds less per pass, see hf_estep.hip — HF_POLL=debug verifies it.) */
 int hf_finish(hf_ctx *ctx, double *stats_host, void *stream);
 /* Only wait + error flags (multi-GPU callers reduce the gathered vectors themselves). */
 int hf_check(hf_ctx *ctx, void *stream);
@@ -176,7 +189,8 @@ int hf_set_stats_mode(hf_ctx *ctx, int mode);
 int hf_rank_total(hf_ctx *ctx, double *out_dev, void *stream);
 int hf_get_stats_mode(const hf_ctx *ctx);          /* the mode the NEXT full pass will use */
 
-/* Results of the last HF_MODE_FULL pass. */
+/* Results of the last HF_MODE_FULL pass (HF_E_ARG when the last pass was HF_MODE_FORWARD_ONLY: f and scales would be new,
+ * b and the labels stale). */
 int hf_get_labels(hf_ctx *ctx, int8_t *labels_host);                                   /* hmm.c:730-736 */
 int hf_get_posterior(hf_ctx *ctx, int64_t first, int64_t n, double *post_host);        /* [n][4] hmm.c:671-685 */
 int hf_get_forward_backward(hf_ctx *ctx, int64_t first, int64_t n, double *f_host, double *b_host,

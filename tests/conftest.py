@@ -15,10 +15,9 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built():
-    """Oracle (checker) and the HIP library are built in-tree; on the GPU box the prebuilt .so files
-    travel with the snapshot, so this is a no-op there."""
-    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle_hf.so")):
-        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
-    if not os.path.exists(os.path.join(ROOT, "flagger_amd", "csrc", "libhmmflagger_hip.so")):
-        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "flagger_amd", "csrc")], check=True)
+    """Oracle (checker) and the HIP library are built in-tree.  `make` runs every session (it is incremental: a no-op
+    when the shared objects are newer than their sources, which is the case on the GPU box where the prebuilt files
+    travel with the snapshot), so an edited source can never be tested against a stale .so."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=True)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "flagger_amd", "csrc")], check=True)
     yield

@@ -176,8 +176,8 @@ def test_cli_summary_tables_and_contig_list(tmp_path):
 
 
 def test_environment_switches_of_the_library():
-    """HF_STATS=chunks makes the per-chunk statistics the default of a context; HF_POLL=0 makes hf_finish synchronise the
-    stream instead of polling — the same vector bit for bit."""
+    """HF_STATS=chunks makes the per-chunk statistics the default of a context; HF_POLL=1 / debug makes hf_finish poll a
+    checksummed completion stamp instead of synchronising the stream (opt-in) — the same vector bit for bit."""
     import sys
     code = (
         "import sys, numpy as np\n"
@@ -189,11 +189,13 @@ def test_environment_switches_of_the_library():
         "em.launch(model); v = em.finish()\n"
         "print(em.stats_mode, v.tobytes().hex())\n" % ROOT)
     outs = {}
-    for name, env in (("default", {}), ("nopoll", {"HF_POLL": "0"}), ("chunks", {"HF_STATS": "chunks"})):
+    for name, env in (("default", {}), ("nopoll", {"HF_POLL": "1"}), ("polldebug", {"HF_POLL": "debug"}), ("chunks", {"HF_STATS": "chunks"})):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-1500:]
         mode, hexv = r.stdout.split()[-2:]
         outs[name] = (int(mode), hexv)
+        assert "[poll debug]" not in r.stderr
+    assert outs["polldebug"] == outs["default"]
     assert outs["default"][0] == 1 and outs["nopoll"][0] == 1 and outs["chunks"][0] == 0
     assert outs["default"][1] == outs["nopoll"][1]
     a = np.frombuffer(bytes.fromhex(outs["default"][1])); b = np.frombuffer(bytes.fromhex(outs["chunks"][1]))

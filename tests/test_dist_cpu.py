@@ -180,3 +180,19 @@ def test_rank_total_exchange_matches_to_rounding():
         assert np.all(np.abs(got - ref) <= 1e-12 * scale)
         assert np.array_equal(trace[0], res[0][1][0]) and np.array_equal(pv, res[0][2])     # replicas agree bit for bit
     orc.close()
+
+
+def test_native_shard_bounds_equal_the_python_rule():
+    """hf_shard_bounds (what `hmm_flagger --gpus N` shards with) and dist.shard_bounds (what the torch.distributed path
+    shards with) cut every chunk list at the same places."""
+    import ctypes as C
+    L = N.lib()
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        n = int(rng.integers(0, 40))
+        sizes = rng.integers(1, 10000, size=n)
+        off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        for world in (1, 2, 3, 5, 8, 13):
+            b = (C.c_int32 * (world + 1))()
+            assert L.hf_shard_bounds(off.ctypes.data_as(C.POINTER(C.c_int64)), n, world, b) == 0
+            assert list(b) == fdist.shard_bounds(sizes, world)

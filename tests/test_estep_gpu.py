@@ -445,26 +445,41 @@ def test_random_inputs_both_statistics_modes_against_each_other_and_the_oracle(s
     _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, alpha, N.HF_ALGO_SCAN, n_iter=1)
 
 
-def test_polled_completion_never_returns_a_stale_vector():
-    """hf_finish polls a stamp that the last kernel writes after its results (no stream synchronisation): alternate two
-    parameter sets for a few hundred passes — every returned vector must be exactly the one of its own parameters, in both
-    statistics modes."""
-    store = synth.config(2, scale=0.01)
-    K = 4
-    model_a = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
-    model_b = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
-    em = hmm.EMList(store, model_a)
-    try:
-        hmm.EM_runOneIterationForList(em, model_b)
-        hmm.HMM_estimateParameters(model_b, 1e-3)            # b: one EM step away from a
-        for mode in (N.HF_STATS_ROWS, N.HF_STATS_CHUNKS):
-            em.set_stats_mode(mode)
-            em.launch(model_a); ref_a = em.finish().copy()
-            em.launch(model_b); ref_b = em.finish().copy()
-            assert not np.array_equal(ref_a, ref_b)
-            for i in range(300):
-                m, ref = (model_a, ref_a) if i % 2 == 0 else (model_b, ref_b)
-                em.launch(m)
-                assert np.array_equal(em.finish(), ref), (mode, i)
-    finally:
-        em.close()
+_ALTERNATE = """
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from flagger_amd import hmm, synth, _native as N
+store = synth.config(2, scale=0.01)
+K = 4
+model_a = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+model_b = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+em = hmm.EMList(store, model_a)
+hmm.EM_runOneIterationForList(em, model_b)
+hmm.HMM_estimateParameters(model_b, 1e-3)            # b: one EM step away from a
+for mode in (N.HF_STATS_ROWS, N.HF_STATS_CHUNKS):
+    em.set_stats_mode(mode)
+    em.launch(model_a); ref_a = em.finish().copy()
+    em.launch(model_b); ref_b = em.finish().copy()
+    assert not np.array_equal(ref_a, ref_b)
+    for i in range(300):
+        m, ref = (model_a, ref_a) if i %% 2 == 0 else (model_b, ref_b)
+        em.launch(m)
+        assert np.array_equal(em.finish(), ref), (mode, i)
+em.close()
+print("alternation ok")
+"""
+
+
+@pytest.mark.parametrize("poll", ["0", "1", "debug"])
+def test_completion_never_returns_a_stale_vector(poll):
+    """hf_finish synchronises the stream (default) or, with HF_POLL=1, polls a checksummed stamp that the last kernel writes
+    after its results: alternate two parameter sets for a few hundred passes — every returned vector must be exactly the one
+    of its own parameters, in both statistics modes.  (The switch is read once per process: one subprocess per setting.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _ALTERNATE % root], capture_output=True, text=True, env=dict(os.environ, HF_POLL=poll))
+    assert r.returncode == 0 and "alternation ok" in r.stdout, r.stderr[-2000:]
+    assert "[poll debug]" not in r.stderr, r.stderr[-2000:]

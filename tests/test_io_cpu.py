@@ -176,3 +176,24 @@ def test_loader_number_shapes_line_endings_and_block_boundaries(tmp_path):
     (tmp_path / "empty.cov").write_text("")
     with pytest.raises(Exception):
         fio.Table(str(tmp_path / "empty.cov"), 50_000, 100)
+
+
+def test_truncated_gz_is_an_error(tmp_path):
+    """A .cov.gz cut anywhere before its trailer must be refused, not loaded as a shorter genome (zlib reports
+    Z_BUF_ERROR / Z_DATA_ERROR at the cut; the cut may fall after a complete row)."""
+    src = open(os.path.join(GOLD, "sim_gaussian_30k.cov.gz"), "rb").read()
+    ok = fio.Table(os.path.join(GOLD, "sim_gaussian_30k.cov.gz"), 1000, 1).store()
+    assert ok.n_windows == 30000
+    for cut in (len(src) // 3, len(src) // 2, len(src) - 9, len(src) - 1):
+        p = tmp_path / f"cut_{cut}.cov.gz"
+        p.write_bytes(src[:cut])
+        with pytest.raises(Exception):
+            fio.Table(str(p), 1000, 1)
+    # garbage in the middle of the deflate stream
+    bad = bytearray(src)
+    for k in range(len(bad) // 2, len(bad) // 2 + 64):
+        bad[k] ^= 0xA5
+    p = tmp_path / "corrupt.cov.gz"
+    p.write_bytes(bytes(bad))
+    with pytest.raises(Exception):
+        fio.Table(str(p), 1000, 1)

@@ -1,0 +1,194 @@
+"""The multi-GPU E-step inside one process (include/hmm_flagger_multi.h: hf_multi — one thread, stream and RCCL rank per
+device; what `hmm_flagger --gpus N` drives) on a 1-GPU box:
+
+* HF_TRANSPORT_LOOPBACK puts N ranks on the one device (RCCL refuses that): sharding, the in-place exchange buffer, the
+  flag rows and the ordered reduction run for N = 1, 2, 3, 5 and more ranks than chunks — with the chunk-order exchange the
+  statistics, the labels and whole EM runs must not depend on N, bit for bit;
+* HF_TRANSPORT_RCCL with one rank takes the product's RCCL path (ncclCommInitAll, ncclAllGather in place);
+* asking for more GPUs than are visible fails loudly (HF_E_NOGPU) instead of running fewer ranks.
+No N > 1 RCCL run is possible on this box: the 8-GPU curve is the driver's to measure.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from flagger_amd import _native as N
+from flagger_amd import hmm, synth
+from oracle_py import Oracle
+from test_oracle_cpu import GOLD, ROOT
+
+pytestmark = pytest.mark.gpu
+
+CLI = os.path.join(ROOT, "flagger_amd", "csrc", "hmm_flagger")
+ALPHA = os.path.join(GOLD, "alpha_hifi.tsv")
+
+
+def _single(store, model, mode):
+    em = hmm.EMList(store, model)
+    em.set_stats_mode(mode)
+    return em
+
+
+@pytest.mark.parametrize("model_type", [hmm.MODEL_TRUNC_EXP_GAUSSIAN, hmm.MODEL_NEGATIVE_BINOMIAL])
+def test_chunk_order_exchange_does_not_depend_on_the_number_of_ranks(model_type):
+    store = synth.config(2, scale=0.02)            # 50+ ragged chunks
+    assert store.n_chunks > 20
+    K = 4
+    model = hmm.createModel(model_type, K, store, synth.HIFI_ALPHA)
+    one = _single(store, model, N.HF_STATS_CHUNKS)
+    orc = Oracle(store, model_type, K, synth.HIFI_ALPHA, threads=8)
+    try:
+        one.launch(model); ref = one.finish().copy(); ref_lab = one.labels()
+        one.launch(model, N.HF_MODE_FORWARD_ONLY); ref_fwd = one.finish().copy()
+        assert orc.run_iteration() == 0
+        o = orc.stats_vector(K)
+        assert np.allclose(ref, o, rtol=1e-9, atol=1e-12) and np.array_equal(ref_lab, orc.labels())
+        for world in (1, 2, 3, 5, store.n_chunks + 3):
+            m = hmm.MultiEMList(store, model, world, exchange=N.HF_EXCHANGE_CHUNKS, transport=N.HF_TRANSPORT_LOOPBACK)
+            try:
+                sizes = m.shard_sizes()
+                assert sum(c for c, _ in sizes) == store.n_chunks and sum(w for _, w in sizes) == store.n_windows
+                got = m.run_sharded(model, N.HF_MODE_FULL)
+                assert np.array_equal(got, ref), (world, np.max(np.abs(got - ref)))
+                for r in range(world):                       # every rank computed the same bits
+                    assert np.array_equal(m.rank_stats(r), ref), (world, r)
+                assert np.array_equal(m.labels(), ref_lab)
+                post = m.posterior(7, store.n_windows - 20)
+                assert post.shape == (store.n_windows - 20, 4) and np.allclose(post.sum(axis=1), 1.0, rtol=1e-12)
+                assert np.array_equal(post.argmax(axis=1).astype(np.int8), ref_lab[7:7 + store.n_windows - 20])
+                got_fwd = m.run_sharded(model, N.HF_MODE_FORWARD_ONLY)
+                assert np.array_equal(got_fwd, ref_fwd)
+            finally:
+                m.close()
+    finally:
+        one.close(); orc.close()
+
+
+def test_rank_order_exchange_matches_to_rounding():
+    store = synth.config(4, scale=0.02)            # 7 regions
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.ONT_R10_ALPHA)
+    one = _single(store, model, N.HF_STATS_ROWS)
+    try:
+        one.launch(model); ref = one.finish().copy(); ref_lab = one.labels()
+        for world in (1, 2, 4):
+            m = hmm.MultiEMList(store, model, world, exchange=N.HF_EXCHANGE_RANKS, transport=N.HF_TRANSPORT_LOOPBACK)
+            try:
+                got = m.run_sharded(model, N.HF_MODE_FULL)
+                if world == 1:
+                    assert np.array_equal(got, ref)
+                scale = np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+                assert np.all(np.abs(got - ref) <= 1e-11 * scale)
+                assert np.array_equal(m.labels(), ref_lab)
+            finally:
+                m.close()
+    finally:
+        one.close()
+
+
+def test_whole_em_run_is_identical_for_every_number_of_ranks():
+    store = synth.config(2, scale=0.01)
+    K = 4
+    runs = []
+    for world in (0, 1, 3):
+        model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+        em = _single(store, model, N.HF_STATS_CHUNKS) if world == 0 else hmm.MultiEMList(
+            store, model, world, exchange=N.HF_EXCHANGE_CHUNKS, transport=N.HF_TRANSPORT_LOOPBACK)
+        try:
+            lls = hmm.runHMMFlagger(em, model, 12, 1e-3)
+            runs.append((lls, model.param_vector().copy(), em.labels().copy()))
+        finally:
+            em.close()
+    for lls, pv, lab in runs[1:]:
+        assert lls == runs[0][0] and np.array_equal(pv, runs[0][1]) and np.array_equal(lab, runs[0][2])
+
+
+def test_rccl_transport_with_one_rank():
+    store = synth.config(2, scale=0.01)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, store, synth.HIFI_ALPHA)
+    one = _single(store, model, N.HF_STATS_CHUNKS)
+    try:
+        one.launch(model); ref = one.finish().copy()
+        for exchange in (N.HF_EXCHANGE_CHUNKS, N.HF_EXCHANGE_RANKS):
+            m = hmm.MultiEMList(store, model, 1, exchange=exchange, transport=N.HF_TRANSPORT_RCCL)
+            try:
+                got = m.run_sharded(model, N.HF_MODE_FULL)
+                if exchange == N.HF_EXCHANGE_CHUNKS:
+                    assert np.array_equal(got, ref)
+                else:
+                    assert np.allclose(got, ref, rtol=1e-11, atol=0)
+                assert m.labels().shape == (store.n_windows,)
+            finally:
+                m.close()
+    finally:
+        one.close()
+
+
+def test_more_gpus_than_visible_is_refused_loudly():
+    visible = N.lib().hf_device_count()
+    store = synth.config(2, scale=0.004)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, store, synth.HIFI_ALPHA)
+    with pytest.raises(hmm.MultiHFError) as ei:
+        hmm.MultiEMList(store, model, visible + 1, transport=N.HF_TRANSPORT_RCCL)
+    assert ei.value.code == N.HF_E_NOGPU and "visible" in str(ei.value)
+    with pytest.raises(hmm.MultiHFError):                       # one RCCL rank per device
+        hmm.MultiEMList(store, model, 2, devices=[0, 0], transport=N.HF_TRANSPORT_RCCL)
+
+
+def test_an_error_on_one_shard_is_reported_by_the_whole_job():
+    """The scale underflow of test_scale_underflow_is_reported sits in the first chunks only: with three ranks one shard
+    raises HF_FLAG_SCALE, the flag row carries it through the exchange and every rank returns HF_E_SCALE (no rank is left
+    waiting in the next collective)."""
+    store = synth.synthesize([400_000, 300_000, 500_000], 1000, 100_000, [20], seed=2)
+    store.cov[100:104] = 250
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 2, store, np.zeros((4, 4)))
+    v = model.param_vector().reshape(1, -1)
+    t = v[0, :25].reshape(5, 5)
+    t[:4, :4] = 1e-30
+    t[:4, 0] = 1.0 - 1e-4
+    model.set_param_vector(v.ravel())
+    for exchange in (N.HF_EXCHANGE_CHUNKS, N.HF_EXCHANGE_RANKS):
+        m = hmm.MultiEMList(store, model, 3, exchange=exchange, transport=N.HF_TRANSPORT_LOOPBACK)
+        try:
+            for _ in range(2):                                  # and the job is still usable afterwards
+                with pytest.raises(hmm.MultiHFError) as ei:
+                    m.run_sharded(model, N.HF_MODE_FULL)
+                assert ei.value.code == N.HF_E_SCALE
+                assert "rank 0" in str(ei.value)                 # reported in rank order: rank 0 saw the OR of all flag rows
+        finally:
+            m.close()
+
+
+def _cli(args, out, env=None):
+    out.mkdir(exist_ok=True)
+    return subprocess.run([CLI] + args + ["-o", str(out)], capture_output=True, text=True, env=dict(os.environ, **(env or {})))
+
+
+OUTPUTS = ["final_flagger_prediction.bed", "loglikelihood.tsv", "emission_final.tsv", "transition_final.tsv",
+           "prediction_summary_final.tsv"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--accelerate"]], ids=["em", "squarem"])
+def test_command_line_gpus_option(extra, tmp_path):
+    """`hmm_flagger --gpus 1 --exchange chunks` (RCCL, one rank), `--loopbackRanks 3` and a one-context run of the per-chunk
+    statistics write identical files; `--gpus N` beyond the visible devices exits non-zero with a clear message."""
+    store = synth.config(2, scale=0.01)
+    binp = tmp_path / "d.bin"
+    store.write_bin(str(binp))
+    args = ["-i", str(binp), "-n", "8", "-A", ALPHA, "-P"] + extra
+    r0 = _cli(args, tmp_path / "one", env={"HF_STATS": "chunks"})
+    assert r0.returncode == 0, r0.stderr[-2000:]
+    r1 = _cli(args + ["--gpus", "1", "--exchange", "chunks"], tmp_path / "rccl1")
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert "GPU 0: %d chunks" % store.n_chunks in r1.stderr
+    r3 = _cli(args + ["--loopbackRanks", "3"], tmp_path / "loop3")
+    assert r3.returncode == 0, r3.stderr[-2000:]
+    for name in OUTPUTS + ["posterior_prediction_final.bed"]:
+        a = (tmp_path / "one" / name).read_text()
+        assert a == (tmp_path / "rccl1" / name).read_text(), name
+        assert a == (tmp_path / "loop3" / name).read_text(), name
+    visible = N.lib().hf_device_count()
+    r = _cli(args + ["--gpus", str(visible + 1)], tmp_path / "toomany")
+    assert r.returncode != 0 and "visible" in r.stderr and not (tmp_path / "toomany" / "final_flagger_prediction.bed").exists()
