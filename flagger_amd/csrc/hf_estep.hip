@@ -98,6 +98,12 @@ struct hf_ctx {
     bool fb_recs = false;
     PairIdx* d_pairs = nullptr; int32_t* d_grp_row = nullptr; double* d_grp_sums = nullptr;
     RowSlot* d_rowslots = nullptr; int32_t* d_rw_region = nullptr; int32_t* d_rw_off = nullptr; double* d_rw_stats = nullptr;
+    // segment kernels (hf_seg.h): the forward-backward of the statistics-by-row path
+    SegDesc* d_seg = nullptr; int nseg = 0; int32_t* d_chunk_seg0 = nullptr; double* d_seg_ll = nullptr; double* d_Pseg = nullptr;
+    double* d_segQ = nullptr;          // [nseg][8][NL] double2: lane products, lane-minor
+    double* d_scale_s = nullptr; int64_t n_slots = 0;
+    std::vector<int32_t> h_slot_of, h_slot_f;   // window -> record slot of its b half / of its f half (host getters)
+    bool pass_seg = false;             // the last pass ran the segment kernels (log-likelihood partials per segment)
     int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_Es = nullptr; double* d_Cs = nullptr;
 };
 
@@ -176,6 +182,7 @@ __global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __res
 #include "hf_chunks.h"
 #include "hf_rows.h"
 #include "hf_nb_rows.h"
+#include "hf_seg.h"
 
 
 // ------------------------------------------------------------------------------------------
@@ -229,6 +236,10 @@ static RowSrc row_src(const hf_ctx* ctx) {
     return S;
 }
 
+// where the log-likelihood partials of the last forward pass are: per segment (hf_seg.h) or per tile (hf_scan.h)
+static const int32_t* ll_off(const hf_ctx* ctx) { return ctx->pass_seg ? ctx->d_chunk_seg0 : ctx->d_chunk_tile0; }
+static const double* ll_part(const hf_ctx* ctx) { return ctx->pass_seg ? ctx->d_seg_ll : ctx->d_tile_ll; }
+
 // does a full pass of the Gaussian models take the statistics-by-row path?
 static bool rows_pass(const hf_ctx* ctx) { return ctx->stats_mode == HF_STATS_ROWS && ctx->rows_ready && ctx->algo == HF_ALGO_SCAN; }
 
@@ -253,7 +264,7 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         const int n_rw_blocks = (ctx->n_rowwaves + wpb - 1) / wpb, n_ll_blocks = (ctx->C + wpb - 1) / wpb;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_stats<KT>), dim3((unsigned) (n_rw_blocks + n_ll_blocks)), dim3(g.threads), g.lds, st,
                            ctx->n_rowwaves, n_rw_blocks, ctx->d_rw_region, ctx->d_rowslots, ctx->d_grp_sums, row_src(ctx), ctx->d_params,
-                           ctx->d_rw_stats, ctx->C, ctx->d_chunk_tile0, ctx->d_tile_ll, ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll);
+                           ctx->d_rw_stats, ctx->C, ll_off(ctx), ll_part(ctx), ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll);
         ctx->pass_wpb = wpb;
         ctx->pass_rows = true;
         ctx->pass_kc = ncol;
@@ -268,8 +279,8 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
                            ctx->d_tile_stats);
     }
     KTimer t(ctx, st, HF_K_CHUNK_STATS);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_chunk_tile0,
-                       ctx->d_regmask, ctx->d_tile_stats, ctx->d_tile_ll, ctx->d_params, ctx->d_chunk_stats, ctx->V, ctx->K,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ll_off(ctx),
+                       ctx->d_regmask, ctx->d_tile_stats, ll_part(ctx), ctx->d_params, ctx->d_chunk_stats, ctx->V, ctx->K,
                        full);
 }
 
@@ -482,8 +493,56 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         ctx->h_tile0 = ctile0;
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
         cphase("tiles + work arrays");
+        // ---- segments of the workgroup-per-segment forward-backward (hf_seg.h) and the record slot of every window ----
+        std::vector<int32_t>& slot_of = ctx->h_slot_of;
+        std::vector<int32_t>& slot_f = ctx->h_slot_f;
+        if (N > 0 && C > 0 && N < (size_t) INT32_MAX / 2) {
+            constexpr int64_t NL = 64 * HF_SEG_WAVES, SMAX = NL * HF_SEG_LMAX;
+            std::vector<SegDesc> segs;
+            std::vector<int32_t> cseg0(C + 1, 0);
+            slot_of.assign(N, 0); slot_f.assign(N, 0);
+            int64_t nslots = 0;
+            for (size_t c = 0; c < C; c++) {
+                const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                cseg0[c] = (int32_t) segs.size();
+                if (T <= 0) continue;
+                const int64_t nsg = (T + SMAX - 1) / SMAX, sz = (T + nsg - 1) / nsg;
+                const int first = (int) segs.size();
+                for (int64_t k = 0; k * sz < T; k++) {
+                    SegDesc d;
+                    std::memset(&d, 0, sizeof d);
+                    const int64_t w0 = k * sz, n = T - w0 < sz ? T - w0 : sz;
+                    d.t0 = t0 + w0; d.n = (int) n; d.L = (int) ((n + NL - 1) / NL);
+                    d.slot0 = (int32_t) nslots; nslots += (int64_t) d.L * NL;
+                    d.slow0 = (int32_t) (std::lower_bound(slow.begin(), slow.end(), (int64_t) d.t0) - slow.begin());
+                    d.chunk_slow0 = soff[c];
+                    d.seg0 = first; d.k = (int) k; d.chunk = (int) c;
+                    d.reg_first = (int32_t) ((w->annot[t0] & 0xFC00000000000000ULL) >> 58);
+                    d.reg_last = (int32_t) ((w->annot[t0 + T - 1] & 0xFC00000000000000ULL) >> 58);
+                    for (int64_t x = 0; x < n; x++) slot_of[(size_t) (d.t0 + x)] = d.slot0 + (int32_t) ((x % d.L) * NL + x / d.L);
+                    segs.push_back(d);
+                }
+                const int nsc = (int) segs.size() - first;
+                const int32_t spare = (int32_t) nslots++;          // takes f of the chunk's last window
+                for (int k = 0; k < nsc; k++) {
+                    segs[(size_t) (first + k)].nseg = nsc;
+                    segs[(size_t) (first + k)].next_slot = k + 1 < nsc ? segs[(size_t) (first + k + 1)].slot0 : spare;
+                }
+                for (int64_t x = 0; x < T; x++) slot_f[(size_t) (t0 + x)] = x + 1 < T ? slot_of[(size_t) (t0 + x + 1)] : spare;
+            }
+            cseg0[C] = (int32_t) segs.size();
+            if (nslots < INT32_MAX) {
+                ctx->nseg = (int) segs.size(); ctx->n_slots = nslots;
+                TRY(dev_upload(&ctx->d_seg, segs.data(), segs.size()));
+                TRY(dev_upload(&ctx->d_chunk_seg0, cseg0.data(), cseg0.size()));
+                DMALLOC(ctx->d_segQ, segs.size() * (size_t) NL * 16 * 8);
+                DMALLOC(ctx->d_seg_ll, segs.size() * 8);
+                DMALLOC(ctx->d_Pseg, segs.size() * 16 * 8);
+            } else { slot_of.clear(); slot_f.clear(); }
+            cphase("segments");
+        }
         // ---- plan of the statistics by emission row (hf_rows.h) ----
-        if (N > 0 && C > 0) {
+        if (N > 0 && C > 0 && ctx->nseg > 0) {
             std::vector<uint32_t> hrec(N);
             if (hipMemcpy(hrec.data(), ctx->d_rec, N * 4, hipMemcpyDeviceToHost) != hipSuccess) {
                 hf_destroy(ctx); return set_err(HF_E_HIP, "record download failed");
@@ -504,7 +563,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
                         row = (int64_t) ((reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu));
                     }
-                    pidx[np].t = (int32_t) t; pidx[np].rec = hrec[t];
+                    pidx[np].t = slot_of[t]; pidx[np].rec = hrec[t];      // the pair's record, by slot (hf_seg.h)
                     prow[np++] = (int32_t) row;
                     cnt[(size_t) row]++;
                 }
@@ -597,7 +656,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 TRY(dev_upload(&ctx->d_rw_region, rwreg.data(), rwreg.size()));
                 TRY(dev_upload(&ctx->d_rw_off, rwoff.data(), rwoff.size()));
                 DMALLOC(ctx->d_grp_sums, (size_t) ctx->n_groups * 16 * 8);
-                DMALLOC(ctx->d_recs, (N + 1) * 64);
+                DMALLOC(ctx->d_recs, (size_t) ctx->n_slots * 64);
+                DMALLOC(ctx->d_scale_s, (size_t) ctx->n_slots * 8);
                 DMALLOC(ctx->d_chunk_ll, C * 8);
                 DMALLOC(ctx->d_rw_stats, (size_t) ctx->n_rowwaves * (16 + 9 + 2 + 3 * 16 + 1) * 8);
                 ctx->rows_ready = true;
@@ -627,6 +687,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_carry_desc);
     hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
+    hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_scale_s);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
@@ -702,6 +763,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
     HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
     for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
     ctx->pass_rows = false;
+    ctx->pass_seg = false;
     if (ctx->C == 0) HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
     if (ctx->C > 0) {
         const RowSrc S = row_src(ctx);
@@ -754,6 +816,49 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                     hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
                                        ctx->d_E, ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
                 }
+            } else if (rows_pass(ctx)) {
+                // statistics by emission row: one workgroup per chunk segment does the whole forward-backward (hf_seg.h)
+                constexpr int NW = HF_SEG_WAVES;
+                const size_t lds = seg_lds_bytes<NW>(ctx->R);
+                if (lds > ctx->lds_max) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
+                if (lds > 64 * 1024) {
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_prod<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+                }
+                {
+                    KTimer t(ctx, st, HF_K_SEG_PROD);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_prod<NW>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_rec, S,
+                                       ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_flags);
+                }
+                KTimer t(ctx, st, HF_K_SEG_FB);
+#ifdef HF_SEG_TRACE
+                static unsigned long long* d_trace = nullptr;
+                if (!d_trace) hipMalloc((void**) &d_trace, (size_t) ctx->nseg * 16 * 8);
+#define SEG_TRACE_PTR(p) p,
+#else
+#define SEG_TRACE_PTR(p)
+#endif
+                if (full)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, true>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, SEG_TRACE_PTR(d_trace) ctx->d_seg, ctx->d_rec,
+                                       S, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, false>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, SEG_TRACE_PTR((unsigned long long*) nullptr) ctx->d_seg, ctx->d_rec,
+                                       S, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
+#ifdef HF_SEG_TRACE
+                {
+                    static int dumps = 0;
+                    if (full && ++dumps == 20 && std::getenv("HF_SEG_TRACE_FILE")) {
+                        hipStreamSynchronize(st);
+                        std::vector<unsigned long long> h((size_t) ctx->nseg * 16);
+                        hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost);
+                        FILE* tf = std::fopen(std::getenv("HF_SEG_TRACE_FILE"), "wb");
+                        if (tf) { std::fwrite(h.data(), 8, h.size(), tf); std::fclose(tf); }
+                    }
+                }
+#endif
+                ctx->pass_seg = true;
+                if (full) ctx->fb_recs = true;
             } else {
                 {
                     KTimer t(ctx, st, HF_K_PROD_TILE);
@@ -771,13 +876,8 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 const size_t fb_wave = (size_t) HF_SCAN_L * 5 * HF_FW_STRIDE * 8;   // wave-private f / scale block
                 const TileGeom g = full ? tile_geom(ctx, k_fb_tile<HF_SCAN_L, true>, fb_wave) : tile_geom(ctx, k_fb_tile<HF_SCAN_L, false>, fb_wave);
                 if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
-                const bool recs = full && rows_pass(ctx);
-                if (full) ctx->fb_recs = recs;
-                if (recs)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true, true>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
-                                       ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_recs,
-                                       ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
-                else if (full)
+                if (full) ctx->fb_recs = false;
+                if (full)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
                                        ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_f,
                                        ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
@@ -802,7 +902,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 KTimer t(ctx, st, HF_K_ROW_STATS);
                 const int n_rw_blocks = (ctx->n_rowwaves + 3) / 4, n_ll_blocks = (ctx->C + 3) / 4;
                 hipLaunchKernelGGL(k_row_stats_nb, dim3((unsigned) (n_rw_blocks + n_ll_blocks)), dim3(256), 0, st, ctx->n_rowwaves, n_rw_blocks,
-                                   ctx->d_rowslots, ctx->d_grp_sums, ctx->d_slot_h, ctx->d_rw_stats, ctx->C, ctx->d_chunk_tile0, ctx->d_tile_ll,
+                                   ctx->d_rowslots, ctx->d_grp_sums, ctx->d_slot_h, ctx->d_rw_stats, ctx->C, ll_off(ctx), ll_part(ctx),
                                    ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll);
                 const int n_bins = ctx->R * 256;
                 hipLaunchKernelGGL(k_nb_hist, dim3((unsigned) ((n_bins + 3) / 4)), dim3(256), 0, st, n_bins, ctx->d_bin_off, ctx->d_bin_list,
@@ -821,8 +921,8 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
             NbTables nt;
             nt.E = ctx->d_nbE; nt.P = ctx->d_nbP; nt.dig = ctx->d_nbDig; nt.r = ctx->d_nbR; nt.beta = ctx->d_nbBeta;
             KTimer t(ctx, st, HF_K_CHUNK_STATS);
-            hipLaunchKernelGGL(k_chunk_stats_nb, dim3((unsigned) ctx->C), dim3(256), 0, st, ctx->d_chunk_tile0, ctx->d_regmask,
-                               ctx->d_tile_hist, ctx->d_tile_ll, ctx->d_params, nt, ctx->d_chunk_stats, ctx->V, ctx->K, fl);
+            hipLaunchKernelGGL(k_chunk_stats_nb, dim3((unsigned) ctx->C), dim3(256), 0, st, ll_off(ctx), ctx->d_regmask,
+                               ctx->d_tile_hist, ll_part(ctx), ctx->d_params, nt, ctx->d_chunk_stats, ctx->V, ctx->K, fl);
         }
         else if (kc <= 4) launch_stats<4>(ctx, st, fl, kc);
         else if (kc <= 8) launch_stats<8>(ctx, st, fl, kc);
@@ -1132,16 +1232,26 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
     if (!ctx->have_full && (f_host || b_host))
         return set_err(HF_E_ARG, "hf_get_forward_backward: the last pass was not HF_MODE_FULL (backward values would be stale)");
     HIPCHK(hipSetDevice(ctx->device));
-    if (scales_host && n) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
-    if ((!f_host && !b_host) || n == 0) return HF_OK;
-    if (ctx->fb_recs) {   // pair records (k_fb_tile RECS): f_t is the first half of record t+1, b_t the second half of record t
-        std::vector<double> buf((size_t) (n + 1) * 8);
-        HIPCHK(hipMemcpy(buf.data(), ctx->d_recs + (size_t) first * 8, buf.size() * 8, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < n; i++)
+    if (n == 0) return HF_OK;
+    if (scales_host && !ctx->fb_recs) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
+    if (!f_host && !b_host && !ctx->fb_recs) return HF_OK;
+    if (ctx->fb_recs) {   // pair records in slot order (hf_seg.h): b_t is the second half of record slot_of[t], f_t the first half of slot_f[t]
+        int64_t lo = INT64_MAX, hi = -1;
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t a = ctx->h_slot_of[(size_t) (first + i)], b = ctx->h_slot_f[(size_t) (first + i)];
+            lo = std::min(lo, std::min(a, b)); hi = std::max(hi, std::max(a, b));
+        }
+        std::vector<double> buf((size_t) (hi - lo + 1) * 8), sbuf((size_t) (hi - lo + 1));
+        HIPCHK(hipMemcpy(buf.data(), ctx->d_recs + (size_t) lo * 8, buf.size() * 8, hipMemcpyDeviceToHost));
+        if (scales_host) HIPCHK(hipMemcpy(sbuf.data(), ctx->d_scale_s + lo, sbuf.size() * 8, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) {
+            const size_t sb = (size_t) (ctx->h_slot_of[(size_t) (first + i)] - lo), sf = (size_t) (ctx->h_slot_f[(size_t) (first + i)] - lo);
             for (int s = 0; s < 4; s++) {
-                if (f_host) f_host[i * 4 + s] = buf[(size_t) (i + 1) * 8 + s];
-                if (b_host) b_host[i * 4 + s] = buf[(size_t) i * 8 + 4 + s];
+                if (f_host) f_host[i * 4 + s] = buf[sf * 8 + s];
+                if (b_host) b_host[i * 4 + s] = buf[sb * 8 + 4 + s];
             }
+            if (scales_host) scales_host[i] = sbuf[sb];
+        }
         return HF_OK;
     }
     // f and b live tile-major / lane-minor on the device (hf_scan.h fb_slot): fetch the tiles that cover the range and
@@ -1216,7 +1326,7 @@ int hf_kernel_times(hf_ctx* ctx, float ms[HF_NKERNELS]) {
 const char* hf_kernel_name(int k) {
     static const char* names[HF_NKERNELS] = {"k_tables", "k_prod_tile", "k_carry", "k_fb_tile", "k_stats_tile", "k_chunk_stats",
                                              "k_reduce", "k_emit_rows", "k_fwd_seq", "k_bwd_seq", "k_pair_sums", "k_row_stats",
-                                             "k_rows_total"};
+                                             "k_rows_total", "k_seg_prod", "k_seg_fb"};
     return k >= 0 && k < HF_NKERNELS ? names[k] : "?";
 }
 

@@ -5,15 +5,23 @@
 // A chunk of T windows (hmm.c:333-545 runs it strictly sequentially) is cut into n = ceil(T / (NL*LMAX)) equal SEGMENTS
 // (NL = 64*NW lanes per workgroup); chunks of up to NL*LMAX windows are ONE segment.  Inside a segment lane j owns the
 // L = ceil(n_windows / NL) consecutive windows j*L .. j*L+L-1, in both directions:
-//   A  lane product Q_j = A_{jL} ... A_{jL+L-1}, A_t = T_t∘E_t (rows gathered from this iteration's tables, k_tables);
-//   B  Kogge-Stone prefix and suffix scans of Q over the 64 lanes of a wavefront, the NW wave totals through LDS, and —
-//      chunks of several segments only — the products of the chunk's other segments (k_seg_prod, a separate, cheap launch):
-//      every lane gets the normalised forward vector entering its first window and the direction of b at its last one;
+//   A  lane product Q_j = A_{jL} ... A_{jL+L-1}, A_t = T_t∘E_t (rows from this iteration's tables, k_tables);
+//   B  prefix and suffix scans of Q over the 64 lanes of a wavefront (DPP row shifts / broadcasts, no LDS traffic inside a
+//      row of 16 lanes), the NW wave totals through LDS, and — chunks of several segments only — the products of the
+//      chunk's other segments (k_seg_prod, a separate, cheap launch): every lane gets the normalised forward vector
+//      entering its first window and the direction of b at its last one;
 //   C  forward REPLAY of the lane's windows in the reference's exact operation order ((f·T)·e, pre-inner sums, division by
 //      the scale, log): only the carried-in vector differs from a sequential run, in the last ulp;
 //   D  backward replay + posterior argmax (hmm.c:470-529, 671-692); the magnitude of the carried-in b from the invariant
 //      sum_s f_t[s]·b_t[s]·scale_t = terminationProb of the scaled forward-backward.
 // No lane product, tile product or carry vector ever goes through HBM, and nothing is computed twice for one-segment chunks.
+//
+// Emission rows: every lane needs ITS OWN 128-byte row per window.  A lane reading its row with eight 16-byte loads touches
+// 64 different cache lines per instruction and depends on the 32 KiB L1 keeping each line for the seven loads that follow —
+// it does not (measured: ~1 000 cycles per wavefront and row).  Here the 64 rows of a step are fetched COOPERATIVELY with
+// LDS-DMA (global_load_lds_dwordx4: instruction q moves rows 8q..8q+7 complete, 8 lanes x 16 bytes each, straight into the
+// wavefront's 8 KiB LDS block — no staging registers) and every lane then reads its row with eight conflict-free
+// ds_read_b128; the piece rotation that makes the reads conflict-free is applied on the SOURCE side of the DMA.
 //
 // Output = the PAIR RECORDS the statistics by emission row read (hf_rows.h): record(t) = { f_{t-1}[4], b_t[4] }, 64 bytes,
 // and the scales — both in SLOT order: window w of a segment (w = j*L + i) lives in slot slot0 + i*NL + j, so that at every
@@ -23,24 +31,16 @@
 #include "hf_scan.h"
 
 #ifndef HF_SEG_WAVES
-#define HF_SEG_WAVES 8      // wavefronts per workgroup
+#define HF_SEG_WAVES 4      // wavefronts per workgroup
 #endif
 #ifndef HF_SEG_LMAX
 #define HF_SEG_LMAX 8       // windows per lane at most: a chunk longer than 64*HF_SEG_WAVES*HF_SEG_LMAX windows is split
 #endif
+#ifndef HF_SEG_OCC
+#define HF_SEG_OCC 4        // wavefronts per SIMD the register allocation aims at
+#endif
 
-struct SegDesc {
-    long long t0;            // global index of the segment's first window
-    int n, L;                // windows of the segment, windows per lane
-    int slot0, next_slot;    // first record slot; the slot whose f half takes f of the segment's LAST window
-    int slow0;               // slow-list position of the first slow window at or after t0 (hf_scan.h)
-    int chunk_slow0;         // slow-list position of the chunk's first window (its private row: start∘e)
-    int seg0, k, nseg;       // first segment of the chunk, this segment's position in it, segments of the chunk
-    int reg_first, reg_last; // region of the chunk's first / last window
-    int chunk;               // chunk index
-    int pad0, pad1;
-};
-static_assert(sizeof(SegDesc) == 64, "SegDesc is one 64-byte load");
+// SegDesc: hf_device.h
 
 __device__ __forceinline__ void v4_renorm(double v[4]) {
     int e;
@@ -73,6 +73,133 @@ __device__ __forceinline__ void v4_mul_left(double v[4], const double* __restric
     for (int i = 0; i < 4; i++) v[i] = u[i];
 }
 
+// power-of-two renormalisation with a tree maximum (the chain of m4_renorm is 15 dependent operations)
+__device__ __forceinline__ void m4_renorm_tree(M4& a) {
+    double t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = fmax(a.m[i], a.m[i + 8]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = fmax(t[i], t[i + 4]);
+    const double mx = fmax(fmax(t[0], t[1]), fmax(t[2], t[3]));
+    int e;
+    (void) frexp(mx, &e);
+    if (mx > 0.0) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) a.m[i] = ldexp(a.m[i], -e);
+    }
+}
+
+// ---- DPP moves of a 4x4 matrix (gfx9 row_shr / row_shl / row_bcast): lanes without a source keep their own value ----
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ void m4_dpp(M4& dst, const M4& src) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) dst.m[i] = dpp_f64<CTRL, ROW_MASK>(src.m[i]);
+}
+#define HF_DPP_ROW_SHR(n) (0x110 + (n))
+#define HF_DPP_ROW_SHL(n) (0x100 + (n))
+#define HF_DPP_ROW_BCAST15 0x142
+#define HF_DPP_ROW_BCAST31 0x143
+
+// inclusive prefix product over the 64 lanes: lane l ends with Q_0 ... Q_l (power-of-two renormalised: exact)
+__device__ __forceinline__ void m4_scan_prefix(M4& Pq, int lane) {
+    M4 Lft, R;
+#define HF_STEP_SHR(n)                                                                                  \
+    m4_dpp<HF_DPP_ROW_SHR(n)>(Lft, Pq);                                                                  \
+    if ((lane & 15) >= (n)) { m4_mul(R, Lft, Pq); Pq = R; m4_renorm_tree(Pq); }
+    HF_STEP_SHR(1) HF_STEP_SHR(2) HF_STEP_SHR(4) HF_STEP_SHR(8)
+#undef HF_STEP_SHR
+    m4_dpp<HF_DPP_ROW_BCAST15, 0xa>(Lft, Pq);                 // rows 1, 3 <- lane 15 of rows 0, 2
+    if (lane & 16) { m4_mul(R, Lft, Pq); Pq = R; m4_renorm_tree(Pq); }
+    m4_dpp<HF_DPP_ROW_BCAST31, 0xc>(Lft, Pq);                 // rows 2, 3 <- lane 31
+    if (lane >= 32) { m4_mul(R, Lft, Pq); Pq = R; m4_renorm_tree(Pq); }
+}
+// inclusive suffix product: lane l ends with Q_l ... Q_63
+__device__ __forceinline__ void m4_scan_suffix(M4& Sq, int lane) {
+    M4 Rgt, R;
+#define HF_STEP_SHL(n)                                                                                  \
+    m4_dpp<HF_DPP_ROW_SHL(n)>(Rgt, Sq);                                                                  \
+    if ((lane & 15) + (n) < 16) { m4_mul(R, Sq, Rgt); Sq = R; m4_renorm_tree(Sq); }
+    HF_STEP_SHL(1) HF_STEP_SHL(2) HF_STEP_SHL(4) HF_STEP_SHL(8)
+#undef HF_STEP_SHL
+#pragma unroll
+    for (int i = 0; i < 16; i++) Rgt.m[i] = __shfl(Sq.m[i], (lane | 15) + 1);   // first lane of the next row
+    if (!(lane & 16)) { m4_mul(R, Sq, Rgt); Sq = R; m4_renorm_tree(Sq); }       // rows 0, 2
+#pragma unroll
+    for (int i = 0; i < 16; i++) Rgt.m[i] = __shfl(Sq.m[i], 32);
+    if (lane < 32) { m4_mul(R, Sq, Rgt); Sq = R; m4_renorm_tree(Sq); }
+}
+
+// ---- cooperative row fetch through the wavefront's 8 KiB LDS block (see the header) ----
+// Row r of the step (the row lane r needs) occupies bytes r*128 .. r*128+127 of the block; piece p of the row sits in slot
+// (p + (r >> 1)) & 7: the eight ds_read_b128 of a lane group then cover all 64 banks exactly once.
+__device__ __forceinline__ void rows_issue(const double* __restrict__ rows, int32_t ridx, int lane, double* __restrict__ blk) {
+    // lane (sub, part) of instruction q moves 16 bytes of row r = 8q + sub: piece (part - (r >> 1)) & 7 = (c0 - 4q) & 7, i.e.
+    // one of two values; 32-bit byte offsets from the (wave-uniform) table base
+    const int part = lane & 7, sub = lane >> 3;
+    const uint32_t c0 = (uint32_t) (part - (sub >> 1));
+    const uint32_t off_even = (c0 & 7u) << 4, off_odd = ((c0 + 4u) & 7u) << 4;
+    const char* __restrict__ base = reinterpret_cast<const char*>(rows);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const uint32_t idx = (uint32_t) __shfl(ridx, q * 8 + sub);
+        const uint32_t off = (idx << 7) + ((q & 1) ? off_odd : off_even);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (base + off),
+                                         (__attribute__((address_space(3))) void*) (blk + q * 128), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void rows_read(const double* __restrict__ blk, int lane, double E[16]) {
+    __builtin_amdgcn_s_waitcnt(0);          // the wavefront's own LDS-DMA has landed (vmcnt) — nothing else orders it
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const double2* __restrict__ row = reinterpret_cast<const double2*>(blk) + lane * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const double2 d = row[(k + (lane >> 1)) & 7]; E[2 * k] = d.x; E[2 * k + 1] = d.y; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0);          // the reads have returned before the block is refilled
+    __builtin_amdgcn_wave_barrier();
+}
+// park / fetch a lane's matrix in the same block, same rotation (the block is idle during the scans)
+__device__ __forceinline__ void m4_park(const M4& Q, int lane, double* __restrict__ blk) {
+    double2* __restrict__ row = reinterpret_cast<double2*>(blk) + lane * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) row[(k + (lane >> 1)) & 7] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
+}
+__device__ __forceinline__ void m4_unpark(M4& Q, int lane, const double* __restrict__ blk) {
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const double2* __restrict__ row = reinterpret_cast<const double2*>(blk) + lane * 8;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const double2 d = row[(k + (lane >> 1)) & 7]; Q.m[2 * k] = d.x; Q.m[2 * k + 1] = d.y; }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// posterior argmax (hmm.c:671-692, common.c:292-304: strict >, first maximum wins) without the four divisions in the
+// common case: q[s] = fl(p[s] / total) is monotone in p[s], and when the largest p exceeds every other one by more than
+// 2^-49 relative, its quotient (>= 1/4 of a normal number) stays strictly the largest after rounding — the reference's
+// answer.  Near-ties, an all-zero or a NaN posterior take the reference's own arithmetic (posterior_label).
+__device__ __forceinline__ int posterior_label_fast(const double f[4], const double b[4], double sc) {
+    double p[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) p[s] = f[s] * b[s] * sc;
+    const double total = ((p[0] + p[1]) + p[2]) + p[3];
+    double mx = p[0]; int idx = 0;
+#pragma unroll
+    for (int s = 1; s < 4; s++) if (mx < p[s]) { mx = p[s]; idx = s; }
+    const double thr = mx * (1.0 - 0x1p-49);
+    bool close = !(total == total) || !(mx > 0.0);
+#pragma unroll
+    for (int s = 0; s < 4; s++) close |= (s != idx) && (p[s] >= thr);
+    if (close) return posterior_label(f, b, sc);
+    return idx;
+}
+
 // slow-list position of the lane's first slow window: seg.slow0 + the slow windows of the segment before window a.
 // Wave scan of the per-lane counts, wave totals through LDS (one block barrier).
 template <int NW>
@@ -90,58 +217,68 @@ __device__ __forceinline__ int seg_slow_base(const uint32_t* __restrict__ rec_se
     return before + inc - cnt;
 }
 
-// the lane's product of A_t over its m windows (chunk-first windows excluded, as in k_carry's start vector); every row the
-// pass uses goes through here: a NaN row raises HF_FLAG_NAN (hmm_utils.c:783-786)
-__device__ __forceinline__ void seg_lane_product(const uint32_t* __restrict__ rec_seg, uint32_t rp, int a, int m, int sidx,
-                                                 const RowSrc& S, const double* __restrict__ s_tab, M4& Q, unsigned& nan) {
+// the lane's product of A_t over its m windows (chunk-first windows excluded, as in the start vector); every row the pass
+// uses goes through here: a NaN row raises HF_FLAG_NAN (hmm_utils.c:783-786).  All 64 lanes run all L steps (the row
+// fetch is cooperative); lanes past their last window fetch row 0 and skip the arithmetic.
+__device__ __forceinline__ void seg_lane_product(const uint32_t* __restrict__ rec_seg, uint32_t rp, int a, int m, int L, int sidx,
+                                                 const RowSrc& S, const double* __restrict__ s_tab, double* __restrict__ blk, int lane,
+                                                 M4& Q, unsigned& nan) {
     m4_identity(Q);
-    if (m <= 0) return;
-    uint32_t r = rec_seg[a];
-    double E[16];
-    load_row(row_ptr(S, r, rp, sidx), E);
+    uint32_t r = m > 0 ? rec_seg[a] : 0u;
+    rows_issue(S.lutE, m > 0 ? row_index(S, r, rp, sidx) : 0, lane, blk);
 #pragma unroll 1
-    for (int i = 0; i < m; i++) {
+    for (int i = 0; i < L; i++) {
+        double E[16];
+        rows_read(blk, lane, E);
         const int sn = sidx + (int) REC_SLOW(r);
         uint32_t rn = 0;
-        double En[16];
-        if (i + 1 < m) { rn = rec_seg[a + i + 1]; load_row(row_ptr(S, rn, r, sn), En); }   // in flight during this window
-        if (row_has_nan(E)) nan |= HF_FLAG_NAN;
-        if (!REC_FIRST(r)) {
-            double Tm[16];
-            lds_Tm(s_tab, r, Tm);
-            M4 A, R;
-#pragma unroll
-            for (int k = 0; k < 16; k++) A.m[k] = Tm[HF_PS(k >> 2, k & 3)] * E[HF_PS(k >> 2, k & 3)];
-            m4_mul(R, Q, A);
-            Q = R;
-            m4_renorm(Q);
+        if (i + 1 < L) {                                   // the next step's rows are in flight during this one
+            const bool has = i + 1 < m;
+            if (has) rn = rec_seg[a + i + 1];
+            rows_issue(S.lutE, has ? row_index(S, rn, r, sn) : 0, lane, blk);
         }
-        if (i + 1 < m) {
+        if (i < m) {
+            if (row_has_nan(E)) nan |= HF_FLAG_NAN;
+            if (!REC_FIRST(r)) {
+                double Tm[16];
+                lds_Tm(s_tab, r, Tm);
+                M4 A, R;
 #pragma unroll
-            for (int k = 0; k < 16; k++) E[k] = En[k];
+                for (int k = 0; k < 16; k++) A.m[k] = Tm[HF_PS(k >> 2, k & 3)] * E[HF_PS(k >> 2, k & 3)];
+                m4_mul(R, Q, A);
+                Q = R;
+                m4_renorm_tree(Q);
+            }
         }
         r = rn; sidx = sn;
     }
 }
 
-// LDS of the segment kernels after the transition tables: wave totals, partial sums, counts, label bytes
+// bytes of dynamic LDS of the segment kernels: transition tables | wave totals | ll partials | slow counts | labels | row blocks
 template <int NW>
-__host__ __device__ constexpr size_t seg_lds_doubles() { return (size_t) NW * 16 + NW + NW; }
+__host__ __device__ constexpr size_t seg_lds_bytes(int n_regions) {
+    return (size_t) n_regions * HF_TAB_STRIDE * 8 + (NW * 16 + 2 * NW) * 8 + (size_t) 64 * NW * HF_SEG_LMAX + (size_t) NW * 8192;
+}
 
 // ------------------------------------------------------------------------------------------
-// k_seg_prod: product of one segment (chunks of several segments only) -> Pseg[segment][16]
+// k_seg_prod: phase A for every segment: the lane products (lane-minor: 1 KiB per store instruction; k_seg_fb's scans start
+// from them) and the product of the whole segment (used by the chunk's OTHER segments only).  Every row a pass uses goes
+// through here once: this is where a NaN row raises HF_E_NAN.
 // ------------------------------------------------------------------------------------------
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) k_seg_prod(int n_list, const int32_t* __restrict__ seg_list, const SegDesc* __restrict__ sd,
-                                                       const uint32_t* __restrict__ rec, const RowSrc S, const DevParams* __restrict__ P,
-                                                       double* __restrict__ Pseg) {
+__global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_prod(const SegDesc* __restrict__ sd, const uint32_t* __restrict__ rec,
+                                                                   const RowSrc S, const DevParams* __restrict__ P,
+                                                                   double* __restrict__ Qs, double* __restrict__ Pseg,
+                                                                   unsigned* __restrict__ flags) {
+    constexpr int NL = NW * 64;
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     fill_tab(P, s_tab);
     double* __restrict__ s_W = s_tab + P->n_regions * HF_TAB_STRIDE;
     int* __restrict__ s_cnt = reinterpret_cast<int*>(s_W + NW * 16 + NW);
-    const int g = seg_list[blockIdx.x];
+    const int g = blockIdx.x;
     const SegDesc d = sd[g];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = wave * 64 + lane;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = wave * 64 + lane;
+    double* __restrict__ blk = s_W + NW * 16 + 2 * NW + (64 * NW * HF_SEG_LMAX) / 8 + wave * 1024;
     const int a = j * d.L;
     const int m = d.n - a < d.L ? (d.n - a > 0 ? d.n - a : 0) : d.L;
     const uint32_t* __restrict__ rec_seg = rec + d.t0;
@@ -149,27 +286,30 @@ __global__ void __launch_bounds__(NW * 64) k_seg_prod(int n_list, const int32_t*
     const uint32_t rp = (m > 0 && !(a == 0 && d.k == 0)) ? rec_seg[a - 1] : 0u;
     M4 Q;
     unsigned nan = 0;
-    seg_lane_product(rec_seg, rp, a, m, sidx, S, s_tab, Q, nan);
-    // ordered tree product over lanes: after step dd, lane l (l % 2dd == 0) holds the product of lanes l..l+2dd-1
+    seg_lane_product(rec_seg, rp, a, m, d.L, sidx, S, s_tab, blk, lane, Q, nan);
+    {
+        double2* __restrict__ dst = reinterpret_cast<double2*>(Qs) + (int64_t) g * 8 * NL + j;
 #pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        M4 Rgt, R;
-        m4_shfl_down(Rgt, Q, dd);
-        if ((lane & (2 * dd - 1)) == 0) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
+        for (int k = 0; k < 8; k++) dst[k * NL] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
     }
-    if (lane == 0) {
+    if (nan) atomicOr(flags, nan);
+    if (d.nseg == 1) return;                                  // nobody reads the product of a one-segment chunk
+    m4_scan_prefix(Q, lane);                                  // lane 63: the product of the wavefront
+    if (lane == 63) {
 #pragma unroll
         for (int k = 0; k < 16; k++) s_W[wave * 16 + k] = Q.m[k];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) Q.m[k] = s_W[k];
         for (int w = 1; w < NW; w++) {
             M4 B, R;
 #pragma unroll
             for (int k = 0; k < 16; k++) B.m[k] = s_W[w * 16 + k];
             m4_mul(R, Q, B);
             Q = R;
-            m4_renorm(Q);
+            m4_renorm_tree(Q);
         }
         double2* dst = reinterpret_cast<double2*>(Pseg + (int64_t) g * 16);
 #pragma unroll
@@ -178,25 +318,36 @@ __global__ void __launch_bounds__(NW * 64) k_seg_prod(int n_list, const int32_t*
 }
 
 // ------------------------------------------------------------------------------------------
-// k_seg_fb: one workgroup per segment: phases A-D of the header.  BWD = false: forward only (EM_runForwardForList,
+// k_seg_fb: one workgroup per segment: phases B-D of the header.  BWD = false: forward only (EM_runForwardForList,
 // hmm.c:790-816): log-likelihood and error flags, nothing else is written.
 // ------------------------------------------------------------------------------------------
+#ifdef HF_SEG_TRACE
+#define SEG_STAMP(k) do { if (threadIdx.x == 0 && trace) trace[(int64_t) blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
+#define SEG_TRACE_ARG unsigned long long* __restrict__ trace,
+#else
+#define SEG_STAMP(k) do { } while (0)
+#define SEG_TRACE_ARG
+#endif
 template <int NW, bool BWD>
-__global__ void __launch_bounds__(NW * 64) k_seg_fb(const SegDesc* __restrict__ sd, const uint32_t* __restrict__ rec, const RowSrc S,
-                                                     const DevParams* __restrict__ P, const double* __restrict__ Pseg,
-                                                     double* __restrict__ recs, double* __restrict__ scale_s,
-                                                     int8_t* __restrict__ label, double* __restrict__ seg_ll,
-                                                     unsigned* __restrict__ flags) {
+__global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG const SegDesc* __restrict__ sd, const uint32_t* __restrict__ rec,
+                                                                 const RowSrc S, const DevParams* __restrict__ P,
+                                                                 const double* __restrict__ Qs, const double* __restrict__ Pseg,
+                                                                 double* __restrict__ recs,
+                                                                 double* __restrict__ scale_s, int8_t* __restrict__ label,
+                                                                 double* __restrict__ seg_ll, unsigned* __restrict__ flags) {
     constexpr int NL = NW * 64;
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
+    SEG_STAMP(0);
     fill_tab(P, s_tab);
+    SEG_STAMP(1);
     double* __restrict__ s_W = s_tab + P->n_regions * HF_TAB_STRIDE;      // [NW][16] wave totals
     double* __restrict__ s_red = s_W + NW * 16;                           // [NW] log-likelihood partials
     int* __restrict__ s_cnt = reinterpret_cast<int*>(s_red + NW);         // [NW] (+ padding to NW doubles)
-    int8_t* __restrict__ s_lab = reinterpret_cast<int8_t*>(s_red + 2 * NW);   // [n] labels of the segment
+    int8_t* __restrict__ s_lab = reinterpret_cast<int8_t*>(s_red + 2 * NW);   // [NL * LMAX] labels of the segment
     const int g = blockIdx.x;
     const SegDesc d = sd[g];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = wave * 64 + lane;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = wave * 64 + lane;
+    double* __restrict__ blk = s_red + 2 * NW + (64 * NW * HF_SEG_LMAX) / 8 + wave * 1024;   // this wavefront's 8 KiB row block
     const int L = d.L, n = d.n;
     const int a = j * L;
     const int m = n - a < L ? (n - a > 0 ? n - a : 0) : L;
@@ -205,41 +356,32 @@ __global__ void __launch_bounds__(NW * 64) k_seg_fb(const SegDesc* __restrict__ 
     const bool chunk_first = a == 0 && d.k == 0;                           // this lane's first window starts the chunk
     const uint32_t rp0 = (m > 0 && !chunk_first) ? rec_seg[a - 1] : 0u;
     unsigned bad = 0;
-    // ---- A: lane product ----
-    M4 Q;
-    seg_lane_product(rec_seg, rp0, a, m, sidx0, S, s_tab, Q, bad);
-    // ---- B: scans over the lanes of the wavefront ----
     double fin[4], bdir[4];
+    SEG_STAMP(2);
     {
-        M4 X;      // exclusive prefix of this lane (product of lanes 0..lane-1 of the wavefront)
+        // ---- A: the lane product, from k_seg_prod ----
+        M4 Q;
         {
-            M4 Pq = Q;
+            const double2* __restrict__ src = reinterpret_cast<const double2*>(Qs) + (int64_t) g * 8 * NL + j;
 #pragma unroll
-            for (int d2 = 1; d2 < 64; d2 <<= 1) {
-                M4 Lft, R;
-                m4_shfl_up(Lft, Pq, d2);
-                if (lane >= d2) { m4_mul(R, Lft, Pq); Pq = R; m4_renorm(Pq); }
-            }
-            if (lane == 63) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) s_W[wave * 16 + k] = Pq.m[k];
-            }
-            m4_shfl_up(X, Pq, 1);
+            for (int k = 0; k < 8; k++) { const double2 v = src[k * NL]; Q.m[2 * k] = v.x; Q.m[2 * k + 1] = v.y; }
         }
-        M4 Y;      // exclusive suffix (product of lanes lane+1..63)
-        if (BWD) {
-            M4 Sq = Q;
+        SEG_STAMP(3);
+        // ---- B: scans over the lanes of the wavefront; Q waits for the second scan in the (idle) row block ----
+        if (BWD) m4_park(Q, lane, blk);
+        m4_scan_prefix(Q, lane);
+        if (lane == 63) {
 #pragma unroll
-            for (int d2 = 1; d2 < 64; d2 <<= 1) {
-                M4 Rgt, R;
-                m4_shfl_down(Rgt, Sq, d2);
-                if (lane + d2 < 64) { m4_mul(R, Sq, Rgt); Sq = R; m4_renorm(Sq); }
-            }
-            m4_shfl_down(Y, Sq, 1);
+            for (int k = 0; k < 16; k++) s_W[wave * 16 + k] = Q.m[k];
         }
+        double xv[16];                                          // exclusive prefix: the product of lanes 0..lane-1
+#pragma unroll
+        for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);
+        SEG_STAMP(4);
         __syncthreads();
+        SEG_STAMP(5);
         // forward vector entering the segment: start∘e of the chunk's first window (its row is the chunk's first entry of
-        // the slow list), through the products of the chunk's earlier segments
+        // the slow list), through the products of the chunk's earlier segments and of the earlier wavefronts
         double v[4];
         {
             const DevRegion* __restrict__ R = &P->reg[d.reg_first];
@@ -252,7 +394,7 @@ __global__ void __launch_bounds__(NW * 64) k_seg_fb(const SegDesc* __restrict__ 
         }
         for (int q = 0; q < d.k; q++) { v4_mul_right(v, Pseg + (int64_t) (d.seg0 + q) * 16); v4_renorm(v); }
         for (int w = 0; w < wave; w++) { v4_mul_right(v, s_W + w * 16); v4_renorm(v); }
-        if (lane > 0) v4_mul_right(v, X.m);
+        if (lane > 0) v4_mul_right(v, xv);
         {
             const double su = ((v[0] + v[1]) + v[2]) + v[3];
 #pragma unroll
@@ -260,6 +402,10 @@ __global__ void __launch_bounds__(NW * 64) k_seg_fb(const SegDesc* __restrict__ 
         }
         if (chunk_first) { fin[0] = 1.0; fin[1] = 0.0; fin[2] = 0.0; fin[3] = 0.0; }   // (1,0,0,0)·A_first = start∘e
         if (BWD) {
+            m4_unpark(Q, lane, blk);
+            m4_scan_suffix(Q, lane);
+#pragma unroll
+            for (int k = 0; k < 16; k++) xv[k] = __shfl_down(Q.m[k], 1);   // exclusive suffix: lanes lane+1..63
             // direction of b at the lane's last window: everything after it applied to the end vector (hmm.c:452-467)
             double u[4];
             const DevRegion* __restrict__ Rl = &P->reg[d.reg_last];
@@ -270,121 +416,143 @@ __global__ void __launch_bounds__(NW * 64) k_seg_fb(const SegDesc* __restrict__ 
             for (int w = NW - 1; w > wave; w--) { v4_mul_left(u, s_W + w * 16); v4_renorm(u); }
 #pragma unroll
             for (int s = 0; s < 4; s++) bdir[s] = u[s];
-            if (lane < 63) v4_mul_left(bdir, Y.m);
+            if (lane < 63) v4_mul_left(bdir, xv);
         }
     }
+    SEG_STAMP(6);
     // ---- C: forward replay (hmm.c:333-434) ----
     double f[4] = {fin[0], fin[1], fin[2], fin[3]};
-    double ll = 0.0, scl = 1.0;
+    // log-likelihood of the lane's windows: sum of log(scale) (hmm.c:428) as log(product of the mantissas) + (sum of the
+    // exponents)·ln 2 — one log per lane instead of one (~95 instructions) per window; <= HF_SEG_LMAX mantissas in [0.5, 1)
+    double lm = 1.0, scl = 1.0;
+    int le = 0;
     uint32_t r_last = 0, r_before_last = rp0;
     int sidx_last = sidx0;
-    if (m > 0) {
-        uint32_t rp = rp0, r = rec_seg[a];
+    const int64_t slot_ij = (int64_t) d.slot0 + j;                         // + i*NL
+    {
+        uint32_t r = m > 0 ? rec_seg[a] : 0u, rp = rp0;
         int sidx = sidx0;
-        double E[16];
-        load_row(row_ptr(S, r, rp, sidx), E);
-        const int64_t slot_ij = (int64_t) d.slot0 + j;                     // + i*NL
+        rows_issue(S.lutE, m > 0 ? row_index(S, r, rp, sidx) : 0, lane, blk);
 #pragma unroll 1
-        for (int i = 0; i < m; i++) {
+        for (int i = 0; i < L; i++) {
+            double E[16];
+            rows_read(blk, lane, E);
             const int sn = sidx + (int) REC_SLOW(r);
             uint32_t rn = 0;
-            double En[16];
-            if (i + 1 < m) { rn = rec_seg[a + i + 1]; load_row(row_ptr(S, rn, r, sn), En); }
-            double Tm[16];
-            lds_Tm(s_tab, r, Tm);
-            double nf[4], sc = 0.0;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                double acc = 0.0;
-#pragma unroll
-                for (int p = 0; p < 4; p++) acc += (f[p] * Tm[HF_PS(p, s)] * E[HF_PS(p, s)]);
-                nf[s] = acc;
-                sc += acc;
+            if (i + 1 < L) {
+                const bool has = i + 1 < m;
+                if (has) rn = rec_seg[a + i + 1];
+                rows_issue(S.lutE, has ? row_index(S, rn, r, sn) : 0, lane, blk);
             }
-            if (!REC_FIRST(r) && sc < 1e-50) bad |= HF_FLAG_SCALE;        // hmm.c:412-415
+            if (i < m) {
+                double Tm[16];
+                lds_Tm(s_tab, r, Tm);
+                double nf[4], sc = 0.0;
 #pragma unroll
-            for (int s = 0; s < 4; s++) f[s] = nf[s] / sc;
-            ll += log(sc);                                                 // hmm.c:428
-            scl = sc;
-            if (BWD) {
-                scale_s[slot_ij + (int64_t) i * NL] = sc;
-                // f_t is the first half of record t+1: the lane's next slot, the next lane's first slot, or the next segment's
-                int64_t sf = i + 1 < L ? slot_ij + (int64_t) (i + 1) * NL : slot_ij + 1;
-                if (a + i + 1 == n) sf = d.next_slot;
-                double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + sf * 4;
-                dst[0] = make_double2(f[0], f[1]); dst[1] = make_double2(f[2], f[3]);
-            }
-            if (i + 1 < m) {
+                for (int s = 0; s < 4; s++) {                              // 0.0 + x == x: the sums start from their first term
+                    double acc = f[0] * Tm[HF_PS(0, s)] * E[HF_PS(0, s)];
 #pragma unroll
-                for (int k = 0; k < 16; k++) E[k] = En[k];
-                r_before_last = r; r = rn; sidx = sn;
+                    for (int p = 1; p < 4; p++) acc += (f[p] * Tm[HF_PS(p, s)] * E[HF_PS(p, s)]);
+                    nf[s] = acc;
+                    sc = s == 0 ? acc : sc + acc;
+                }
+                if (!REC_FIRST(r) && sc < 1e-50) bad |= HF_FLAG_SCALE;    // hmm.c:412-415
+#pragma unroll
+                for (int s = 0; s < 4; s++) f[s] = nf[s] / sc;
+                { int e2; lm *= frexp(sc, &e2); le += e2; }                // hmm.c:428, see above
+                scl = sc;
+                if (BWD) {
+                    scale_s[slot_ij + (int64_t) i * NL] = sc;
+                    // f_t is the first half of record t+1: the lane's next slot, the next lane's first slot, or the next segment's
+                    int64_t sf = i + 1 < L ? slot_ij + (int64_t) (i + 1) * NL : slot_ij + 1;
+                    if (a + i + 1 == n) sf = d.next_slot;
+                    double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + sf * 4;
+                    dst[0] = make_double2(f[0], f[1]); dst[1] = make_double2(f[2], f[3]);
+                }
+                r_last = r; sidx_last = sidx; r_before_last = rp;
             }
+            rp = r; r = rn; sidx = sn;
         }
-        r_last = r; sidx_last = sidx;
     }
+    double ll = log(lm) + (double) le * 0.693147180559945309417232121458;
     for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
     if (lane == 0) s_red[wave] = ll;
+    SEG_STAMP(7);
     // ---- D: backward replay + labels (hmm.c:452-545, 671-692) ----
-    if (BWD && m > 0) {
-        const int jl = m - 1;
+    if (BWD) {
+        const int jl = m - 1;                                   // the lane's last window (< 0: none)
         const DevRegion* __restrict__ Rl = &P->reg[d.reg_last];
-        double b[4];
-        if (d.k == d.nseg - 1 && a + jl == n - 1) {     // the chunk's last window, hmm.c:452-467
+        double b[4] = {0.0, 0.0, 0.0, 0.0};
+        if (jl >= 0) {
+            if (d.k == d.nseg - 1 && a + jl == n - 1) {         // the chunk's last window, hmm.c:452-467
 #pragma unroll
-            for (int s = 0; s < 4; s++) b[s] = Rl->trans[s][4] / scl;
-        } else {                                        // direction from the scans, magnitude from the invariant at this window
-            const double term = Rl->trans[0][4];
-            double dot = 0.0;
+                for (int s = 0; s < 4; s++) b[s] = Rl->trans[s][4] / scl;
+            } else {                                            // direction from the scans, magnitude from the invariant at this window
+                const double term = Rl->trans[0][4];
+                double dot = 0.0;
 #pragma unroll
-            for (int s = 0; s < 4; s++) dot += f[s] * bdir[s];
-            const double kk = term / (scl * dot);
+                for (int s = 0; s < 4; s++) dot += f[s] * bdir[s];
+                const double kk = term / (scl * dot);
 #pragma unroll
-            for (int s = 0; s < 4; s++) b[s] = bdir[s] * kk;
-        }
-        s_lab[a + jl] = (int8_t) posterior_label(f, b, scl);
-        const int64_t slot_ij = (int64_t) d.slot0 + j;
-        {
+                for (int s = 0; s < 4; s++) b[s] = bdir[s] * kk;
+            }
+            s_lab[a + jl] = (int8_t) posterior_label_fast(f, b, scl);
             double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + (slot_ij + (int64_t) jl * NL) * 4 + 2;
             dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
         }
-        // window k's row and transition table turn b_k into b_{k-1}
+        // window k's row and transition table turn b_k into b_{k-1}; all lanes run k = L-1 .. 1 (cooperative fetch)
         uint32_t rk = r_last, rkm1 = r_before_last;
         int sk = sidx_last;
-        double E[16];
-        if (jl >= 1) load_row(row_ptr(S, rk, rkm1, sk), E);
+        rows_issue(S.lutE, (jl >= 1 && jl == L - 1) ? row_index(S, rk, rkm1, sk) : 0, lane, blk);
 #pragma unroll 1
-        for (int k = jl; k >= 1; k--) {
-            // prefetch: row of window k-1 (needs the record before it)
-            const int skm1 = sk - (int) REC_SLOW(rkm1);
+        for (int k = L - 1; k >= 1; k--) {
+            double E[16];
+            rows_read(blk, lane, E);
+            const bool act = k <= jl;                           // this lane has a window k
+            // the next step's row: window k-1 of the lane (needs the record before it) — or, for a lane whose last window
+            // IS k-1, its own first row of the backward pass
             uint32_t rkm2 = 0;
-            double En[16];
-            if (k >= 2) { rkm2 = (a + k - 2 >= 0 && !(a + k - 2 == -1)) ? rec_seg[a + k - 2] : 0u; load_row(row_ptr(S, rkm1, rkm2, skm1), En); }
-            const int64_t slot_prev = slot_ij + (int64_t) (k - 1) * NL;
-            const double sc = scale_s[slot_prev];
-            const double2* __restrict__ fsrc = reinterpret_cast<const double2*>(recs) + (slot_ij + (int64_t) k * NL) * 4;
-            const double2 f01 = fsrc[0], f23 = fsrc[1];
-            double Tm[16];
-            lds_Tm(s_tab, rk, Tm);
-            double nb[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s = 0; s < 4; s++)
-#pragma unroll
-                for (int p = 0; p < 4; p++) nb[p] += Tm[HF_PS(p, s)] * E[HF_PS(p, s)] * b[s];
-            if (sc < 1e-50) bad |= HF_FLAG_SCALE;                         // hmm.c:521-524
-#pragma unroll
-            for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
-            const double fi[4] = {f01.x, f01.y, f23.x, f23.y};
-            s_lab[a + k - 1] = (int8_t) posterior_label(fi, b, sc);
-            double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + slot_prev * 4 + 2;
-            dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
+            int skm1 = sk;
             if (k >= 2) {
-#pragma unroll
-                for (int q = 0; q < 16; q++) E[q] = En[q];
+                int32_t nidx = 0;
+                if (act) {
+                    skm1 = sk - (int) REC_SLOW(rkm1);
+                    rkm2 = rec_seg[a + k - 2];
+                    nidx = row_index(S, rkm1, rkm2, skm1);
+                } else if (k - 1 == jl && jl >= 1) {
+                    nidx = row_index(S, rk, rkm1, sk);
+                }
+                rows_issue(S.lutE, nidx, lane, blk);
             }
-            rk = rkm1; rkm1 = rkm2; sk = skm1;
+            if (act) {
+                const int64_t slot_prev = slot_ij + (int64_t) (k - 1) * NL;
+                const double sc = scale_s[slot_prev];
+                const double2* __restrict__ fsrc = reinterpret_cast<const double2*>(recs) + (slot_ij + (int64_t) k * NL) * 4;
+                const double2 f01 = fsrc[0], f23 = fsrc[1];
+                double Tm[16];
+                lds_Tm(s_tab, rk, Tm);
+                double nb[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const double term = Tm[HF_PS(p, s)] * E[HF_PS(p, s)] * b[s];
+                        nb[p] = s == 0 ? term : nb[p] + term;
+                    }
+                if (sc < 1e-50) bad |= HF_FLAG_SCALE;                     // hmm.c:521-524
+#pragma unroll
+                for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
+                const double fi[4] = {f01.x, f01.y, f23.x, f23.y};
+                s_lab[a + k - 1] = (int8_t) posterior_label_fast(fi, b, sc);
+                double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + slot_prev * 4 + 2;
+                dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
+                rk = rkm1; rkm1 = rkm2; sk = skm1;
+            }
         }
     }
+    SEG_STAMP(8);
     __syncthreads();
+    SEG_STAMP(9);
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int w = 0; w < NW; w++) s += s_red[w];
@@ -395,4 +563,8 @@ __global__ void __launch_bounds__(NW * 64) k_seg_fb(const SegDesc* __restrict__ 
         for (int w = threadIdx.x; w < n; w += NL) dst[w] = s_lab[w];
     }
     if (bad) atomicOr(flags, bad);
+    SEG_STAMP(10);
+#ifdef HF_SEG_TRACE
+    if (threadIdx.x == 0 && trace) { trace[(int64_t) blockIdx.x * 16 + 11] = (unsigned long long) n; trace[(int64_t) blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 }

@@ -199,4 +199,5 @@ def test_environment_switches_of_the_library():
     assert outs["default"][0] == 1 and outs["nopoll"][0] == 1 and outs["chunks"][0] == 0
     assert outs["default"][1] == outs["nopoll"][1]
     a = np.frombuffer(bytes.fromhex(outs["default"][1])); b = np.frombuffer(bytes.fromhex(outs["chunks"][1]))
-    assert a[0] == b[0] and np.allclose(a, b, rtol=1e-11, atol=0)
+    # (the two statistics paths also sum the log-likelihood in different orders: per segment / per tile of the chunk)
+    assert np.allclose(a, b, rtol=1e-11, atol=0)

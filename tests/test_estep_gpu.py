@@ -344,12 +344,13 @@ def test_statistics_by_row_agree_with_per_chunk_statistics():
         em.set_stats_mode(N.HF_STATS_CHUNKS)
         em.launch(model); chunks = em.finish()
         lab_c = em.labels(); f_c, b_c, sc_c = em.forward_backward()
-        assert rows[0] == chunks[0]
+        assert abs(rows[0] - chunks[0]) <= 1e-12 * abs(chunks[0])
         scale = np.maximum(np.abs(chunks), 1e-9 * np.abs(chunks).max())
         assert np.all(np.abs(rows - chunks) <= 1e-12 * scale), np.max(np.abs(rows - chunks) / scale)
         assert np.array_equal(rows == 0.0, chunks == 0.0)
-        assert np.array_equal(lab_r, lab_c) and np.array_equal(sc_r, sc_c)
-        assert np.array_equal(f_r, f_c) and np.array_equal(b_r, b_c)      # pair records vs lane-minor arrays: the same values
+        # the two paths cut a chunk differently (segments / tiles): carried-in vectors differ in the last ulp
+        assert np.array_equal(lab_r, lab_c) and np.allclose(sc_r, sc_c, rtol=1e-12, atol=0)
+        assert np.allclose(f_r, f_c, rtol=1e-11, atol=1e-300) and np.allclose(b_r, b_c, rtol=1e-11, atol=1e-300)
         em.set_stats_mode(N.HF_STATS_ROWS)
         em.launch(model); again = em.finish()
         assert np.array_equal(again, rows)                                 # fixed plan: reproducible bit for bit
@@ -437,7 +438,7 @@ def test_random_inputs_both_statistics_modes_against_each_other_and_the_oracle(s
         mode_a = em.stats_mode
         em.set_stats_mode(N.HF_STATS_CHUNKS)
         em.launch(model); b = em.finish(); lab_b = em.labels()
-        assert a[0] == b[0] and np.array_equal(lab_a, lab_b)
+        assert abs(a[0] - b[0]) <= 1e-12 * abs(b[0]) and np.array_equal(lab_a, lab_b)   # per-segment / per-tile sums of the log-likelihood
         scale = np.maximum(np.abs(b), 1e-9 * np.abs(b).max())
         assert np.all(np.abs(a - b) <= 1e-11 * scale), (mode_a, np.max(np.abs(a - b) / scale))
     finally:
