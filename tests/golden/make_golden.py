@@ -7,6 +7,11 @@ exists on the GPU box and nothing here is read from it at test time).
                                    reference's own programs/src/simulate_coverage_data.py, truth parameter tables
                                    re-typed from docs/hmm_test/README.md:43-57,68-80 (they are absent from the snapshot)
   sim_truth_emission.tsv / sim_truth_transition.tsv   those tables
+  sim100k_{gaussian,exp_gaussian,negative_binomial}.cov.gz   the doc's full recipe (100 000 observations, contigs of 80 000 and
+                                   20 000 bases, regionChangeRate 0.001) for the three emission families it names; the
+                                   gaussian truth table is the doc's, the other two (programs/tests/test_files/simulate_coverage/
+                                   is absent from the snapshot) are written here in the simulator's format with the same
+                                   means / variances; sim100k_truth_*.tsv hold them
   cfg1_*.                          configs[1] outputs of the ORACLE (self-regression, not a reference pin)
   small_em_*                       a 3-contig, 2-region EM run of the ORACLE (self-regression)
   chunks_creator_test_1*.cov       the reference loader test's own data files (programs/tests/test_files/chunks_creator)
@@ -99,6 +104,33 @@ def simulate():
     print("simulated", store.n_windows, "windows in", store.n_chunks, "chunks")
 
 
+FAMILIES = {
+    "gaussian": EMISSION_TSV,
+    "exp_gaussian": EMISSION_TSV.replace("Err\tGaussian\t1\tMean\t2.0\t3.0\nErr\tGaussian\t1\tVar\t2.4\t4.0\nErr\tGaussian\t1\tWeight\t1.0\t1.0\n",
+                                         "Err\tTruncated Exponential\t1\tMean\t2.0\t3.0\nErr\tTruncated Exponential\t1\tTrunc_Point\t5.0\t7.5\n"),
+    "negative_binomial": EMISSION_TSV.replace("Gaussian", "Negative Binomial"),
+}
+
+
+def simulate_families():
+    """docs/hmm_test/README.md:99-136 at full size for every emission family the simulator knows."""
+    sys.path.insert(0, os.path.join(REF, "src"))
+    import simulate_coverage_data as sim
+    for k, (name, table) in enumerate(FAMILIES.items()):
+        ep = os.path.join(HERE, f"sim100k_truth_emission_{name}.tsv")
+        open(ep, "w").write(table)
+        np.random.seed(4321 + k)
+        emis = sim.parseEmissionParametersPerRegion(ep)
+        trans = sim.parseTransitionMatrixPerRegion(os.path.join(HERE, "sim_truth_transition.tsv"))
+        regions, states, obs = sim.generateObservations(trans, emis, numberOfObservations=100000, regionChangeRate=0.001, alphaMatrix=None)
+        cov = os.path.join(HERE, f"sim100k_{name}.cov")
+        sim.writeObservationsIntoCov(regions, states, obs, [p[2]["Mean"][0] for p in emis], [80000, 20000], pathToWrite=cov)
+        with open(cov, "rb") as f, gzip.GzipFile(cov + ".gz", "wb", mtime=0) as g:
+            shutil.copyfileobj(f, g)
+        os.unlink(cov)
+        print(name, os.path.getsize(cov + ".gz"), "bytes")
+
+
 def oracle_runs():
     from flagger_amd import synth
     orc = os.path.join(ROOT, "oracle", "hf_oracle")
@@ -127,6 +159,10 @@ def loader_files():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "families":
+        simulate_families()
+        sys.exit(0)
     simulate()
+    simulate_families()
     oracle_runs()
     loader_files()

@@ -1,0 +1,81 @@
+"""Label study on near-ties ('labels are bit-exact only empirically').
+
+The HIP path computes every window's f and b in the reference's operation order from a carried-in vector that differs from
+a sequential run in the last ulp (hf_seg.h), and evaluates exp() on the device.  Labels are argmax of the posterior with
+strict '>' (first maximum wins, common.c:292-304), so a mismatch needs two posteriors closer than those last ulps.  Here such
+inputs are CONSTRUCTED: Dup and Hap get identical emission parameters and the transition matrix is symmetric under their
+exchange, so p[Dup] == p[Hap] in exact arithmetic on every window and the two differ only by the rounding of differently
+ordered sums.  Measured and asserted:
+  * every label mismatch HIP <-> oracle sits on a window whose two largest ORACLE posteriors differ by < 1e-12 relative;
+  * windows whose top-2 gap is larger never mismatch (0 of the rest);
+  * the mismatch rate on the constructed ties is written to gpurun_out/neartie.json (DESIGN.md §2 quotes it).
+On generic inputs (all other tests) no mismatch has been observed."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from flagger_amd import _native as N
+from flagger_amd import hmm, synth
+from oracle_py import Oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MAXC = 16
+
+
+def _symmetric_model(store, K, exact_tie):
+    model = hmm.createModel(hmm.MODEL_GAUSSIAN, K, store, np.zeros((4, 4)))
+    v = model.param_vector().reshape(1, -1)
+    mean = v[0, 27:27 + 4 * MAXC].reshape(4, MAXC)
+    var = v[0, 27 + 4 * MAXC:27 + 8 * MAXC].reshape(4, MAXC)
+    mean[1, 0] = mean[2, 0] * (1.0 if exact_tie else 1.0 + 1e-13)     # Dup == Hap (or a hair apart)
+    var[1, 0] = var[2, 0]
+    t = v[0, :25].reshape(5, 5)
+    stay, move = 0.97 * (1 - 1e-4), 0.01 * (1 - 1e-4)
+    t[:4, :4] = move
+    t[np.arange(4), np.arange(4)] = stay
+    model.set_param_vector(v.ravel())
+    return model
+
+
+@pytest.mark.parametrize("exact_tie", [True, False], ids=["exact", "1e-13"])
+def test_label_mismatches_only_on_ulp_level_ties(exact_tie):
+    store = synth.synthesize([9_000_000, 4_000_000, 6_500_000], 2000, 1_000_000, [24], seed=77)
+    store.mapq = store.cov.copy()                       # every state valid everywhere
+    K = 3
+    model = _symmetric_model(store, K, exact_tie)
+    em = hmm.EMList(store, model, False, 0.95)
+    orc = Oracle(store, hmm.MODEL_GAUSSIAN, K, np.zeros((4, 4)), adjust=False, threads=8)
+    try:
+        orc.set_param_vector(model.param_vector())
+        hmm.EM_runOneIterationForList(em, model)
+        assert orc.run_iteration() == 0
+        lab, olab = em.labels(), orc.labels()
+        f, b, sc = orc.forward_backward()
+        post = f * b * sc[:, None]
+        post /= post.sum(axis=1, keepdims=True)
+        srt = np.sort(post, axis=1)
+        gap = (srt[:, 3] - srt[:, 2]) / srt[:, 3]
+        tie = gap < 1e-12
+        mism = lab != olab
+        assert not (mism & ~tie).any(), int((mism & ~tie).sum())            # clear windows never disagree
+        assert tie.sum() > 1000                                               # the construction does produce ties
+        rate = float(mism.sum()) / float(tie.sum())
+        # mismatching windows: both sides chose one of the two tied states
+        assert set(np.unique(lab[mism])) <= {1, 2} and set(np.unique(olab[mism])) <= {1, 2}
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        path = os.path.join(out, "neartie.json")
+        rec = json.load(open(path)) if os.path.exists(path) else {}
+        rec["exact" if exact_tie else "1e-13"] = dict(windows=int(lab.size), ulp_ties=int(tie.sum()), mismatches=int(mism.sum()),
+                                                      mismatch_rate_on_ties=rate, smallest_gap_without_mismatch=float(gap[~tie].min()))
+        json.dump(rec, open(path, "w"), indent=1)
+        # statistics and log-likelihood are unaffected by which side of a tie a label falls on
+        ref = orc.stats_vector(K)
+        got = model.estimators
+        assert abs(got[0] - ref[0]) <= 1e-9 * abs(ref[0])
+    finally:
+        em.close()
+        orc.close()
