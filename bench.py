@@ -72,8 +72,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink contig lengths (testing only; 1.0 = BASELINE workload)")
     ap.add_argument("--algo", choices=["scan", "seq"], default="scan")
-    ap.add_argument("--config", type=int, choices=[2, 4], default=2,
-                    help="BASELINE.json configs[n]: 2 = the headline workload (default); 4 = ONT-R10 preset, 7 bias regions, 8 kb windows")
+    ap.add_argument("--config", type=int, choices=[2, 4, 5], default=2,
+                    help="BASELINE.json configs[n]: 2 = the headline workload (default); 4 = ONT-R10 preset, 7 bias regions, 8 kb windows; "
+                         "5 = not a BASELINE config: configs[4] with coverage spread over 0..250 (worst case for the emission tables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events inside the timed region; the dominant kernel's duration then comes from the untimed "
@@ -255,7 +256,9 @@ def main():
                                     "4 kb windows, 20 Mb chunks, trunc_exp_gaussian, HiFi v1.1.0 alpha, full EM step "
                                     "(E-step+decode on GPU, M-step on host)" if args.config == 2 else
                                     "BASELINE.json configs[4]: synthetic 2x3.03 Gb diploid, ONT-R10 preset (8 kb windows), 7 bias "
-                                    "regions with their own emission parameters, ONT-R10 v1.1.0 alpha, full EM step")
+                                    "regions with their own emission parameters, ONT-R10 v1.1.0 alpha, full EM step" if args.config == 4 else
+                                    "worst case for the emission tables (not a BASELINE config): configs[4] with coverage spread over "
+                                    "0..250, ~1 window per (region, x, x_prev) key, K = 10")
                                    + ("" if args.scale == 1.0 else f" [scale {args.scale}]")
                                    + (f" [weak scaling: {world} such genomes, one per GPU]" if args.scaling == "weak" and world > 1 else ""),
                        "n_windows": n_windows, "n_chunks": store.n_chunks, "collapsed_comps": K,

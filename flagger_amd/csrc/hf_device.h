@@ -94,6 +94,8 @@ __device__ __forceinline__ bool div_operand_safe(double v) {
     return v == 0.0 || (h - 0x28300000u) <= (0x57B00000u - 0x28300000u);
 }
 
+#define HF_TABLE_MAX_ITEMS 80   // 1 + 4 + 4 + 4*HF_MAXCOMP = 73 at most
+
 struct DevRegion {
     double trans[5][5];                 // Transition.matrix (row 4 Start, column 4 End)
     double tcond[8][16];                // Transition_getProbConditional per validity mask, [pre*4+s]
@@ -117,6 +119,11 @@ struct DevParams {
     double ualpha[HF_NSTATES][4];       // [s][u]
     double alpha[16];                   // [pre*4+s]
     double beta_star;                   // value of beta_t for every window away from contig ends (hmm.c:301-316)
+    // k_tables' work list of one emission row: item i evaluates state item_s[i] for its item_u[i]-th distinct alpha,
+    // component item_c[i] (one exp each); item_base[s*4 + u] = the item of (s, u, component 0)
+    int32_t n_items;
+    int32_t item_base[16];
+    uint8_t item_s[HF_TABLE_MAX_ITEMS], item_u[HF_TABLE_MAX_ITEMS], item_c[HF_TABLE_MAX_ITEMS];
     DevRegion reg[1];                   // n_regions entries
 };
 

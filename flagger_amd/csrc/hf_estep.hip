@@ -725,7 +725,17 @@ static int pack_params(hf_ctx* ctx, const hf_params* p) {
         for (int k = nu; k < 4; k++) h->ualpha[s][k] = 0.0;
         h->nuniq[s] = nu;
     }
-    const double maxq = ctx->meta.max_high_mapq_ratio; (void) maxq;
+    {   // k_tables' items: every (state, distinct alpha, component) of a row, Err as truncated exponential is one item
+        int n = 0;
+        for (int st = 0; st < 4; st++) {
+            const bool te = st == 0 && p->model_type == HF_MODEL_TRUNC_EXP_GAUSSIAN;
+            const int nu = te ? 1 : h->nuniq[st], nc = te ? 1 : p->ncomp[st];
+            for (int u = 0; u < 4; u++) h->item_base[st * 4 + u] = u < nu ? n + u * nc : n;
+            for (int u = 0; u < nu; u++)
+                for (int c = 0; c < nc; c++) { h->item_s[n] = (uint8_t) st; h->item_u[n] = (uint8_t) u; h->item_c[n] = (uint8_t) c; n++; }
+        }
+        h->n_items = n;
+    }
     for (int r = 0; r < ctx->R; r++) {
         DevRegion* g = &h->reg[r];
         std::memcpy(g->trans, p->trans + (size_t) r * 25, sizeof(double) * 25);
@@ -795,9 +805,13 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 hipLaunchKernelGGL(k_tables_nb, dim3((unsigned) (jobs / 256 + 1)), dim3(256), 0, st, ctx->n_keys, ctx->d_keys, ctx->n_slow,
                                    ctx->d_slow_w, ctx->d_rec, ctx->M, ctx->d_nbE, ctx->d_lutE, ctx->d_Es, ctx->d_flags);
             else
-            hipLaunchKernelGGL(k_tables, dim3((unsigned) (jobs / HF_TABLE_JOBS_PER_BLOCK + 1)), dim3(256), 0, st, ctx->n_keys, ctx->d_keys, ctx->n_slow,
-                               ctx->d_slow_w, ctx->d_rec, ctx->d_beta, ctx->M, ctx->K, ctx->d_params, ctx->d_lutE, ctx->d_lutC,
-                               ctx->d_Es, ctx->d_Cs, ctx->d_flags);
+            {
+#define HF_LAUNCH_TABLES(J) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables<J>), dim3((unsigned) ((jobs + J - 1) / J + (jobs == 0))), dim3(256), 0, st, ctx->n_keys, \
+                               ctx->d_keys, ctx->n_slow, ctx->d_slow_w, ctx->d_rec, ctx->d_beta, ctx->M, ctx->K, ctx->d_params, ctx->d_lutE, ctx->d_lutC, \
+                               ctx->d_Es, ctx->d_Cs, ctx->d_flags)
+                if (jobs < 64 * 1024) HF_LAUNCH_TABLES(HF_TABLE_JOBS_SMALL); else HF_LAUNCH_TABLES(HF_TABLE_JOBS_LARGE);
+#undef HF_LAUNCH_TABLES
+            }
         }
         if (ctx->ntiles > 0) {
             if (ctx->algo == HF_ALGO_SEQ) {

@@ -206,87 +206,100 @@ __device__ __forceinline__ uint32_t load_recs(const uint32_t* __restrict__ rec, 
 //                           state, [component][previous state] — the per-iteration constants apply
 //   job - n_keys < n_slow   the slow window slow_w[k]: the same two rows with the window's own beta (or the
 //                           chunk-first row, hmm.c:338-352), in Es[k] / Cs[k]
-// 32 threads per job: thread `slot` evaluates one unit — a single-component state (slot 0..2: Err, Dup, Hap) or
-// one component of the collapsed state (slot 3+c) — for every distinct alpha of that column (<= 4 exp); then 16
-// threads assemble E[pre][s] (the collapsed state: components summed in index order, hmm_utils.c:753-758).
-// The same device functions as a direct per-window evaluation, so the values are identical.
+// A row costs one ITEM per (state, distinct alpha of its column, mixture component) — one exp each; HiFi alpha,
+// K = 6: 1 + 3 + 4 + 3*6 = 26 (DevParams.item_*).  A block takes HF_TABLE_JOBS_PER_BLOCK rows: its 256 threads sweep
+// the rows x items grid flat (every lane busy whatever K and the alpha pattern are: with ~1 window per key — coverage spread
+// over the whole 0..250 range — this kernel evaluates as many rows as there are windows), park the values in LDS, and then
+// sweep the rows x outputs grid: E[pre][s] (the collapsed state: components summed in index order, hmm_utils.c:753-758)
+// and the component table.  The same device functions as a direct per-window evaluation, so the values are identical.
 // NaNs are stored, not reported: only a window that actually uses the row raises HF_E_NAN.
 // ------------------------------------------------------------------------------------------
-#define HF_TABLE_JOBS_PER_BLOCK 8
+// rows per block: few when there are few rows (more blocks than CUs: the kernel is then latency-bound), many otherwise
+#define HF_TABLE_JOBS_SMALL 8
+#define HF_TABLE_JOBS_LARGE 32
+struct TableJob { double x, px, bt; int64_t row; int32_t r; int32_t flags; };   // flags: 1 star (table key), 2 first, 4 active; row: index of the row in lutE / lutC units
+template <int HF_TABLE_JOBS_PER_BLOCK>
 __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __restrict__ keys, int n_slow,
                                                 const int64_t* __restrict__ slow_w, const uint32_t* __restrict__ rec,
                                                 const double* __restrict__ beta, int M, int K,
                                                 const DevParams* __restrict__ P, double* __restrict__ lutE,
                                                 double* __restrict__ lutC, double* __restrict__ Es,
                                                 double* __restrict__ Cs, unsigned* __restrict__ flags) {
-    __shared__ double vals[HF_TABLE_JOBS_PER_BLOCK][3 + HF_MAXCOMP][4];
-    const int jl = threadIdx.x >> 5, slot = threadIdx.x & 31;
-    const int job = blockIdx.x * HF_TABLE_JOBS_PER_BLOCK + jl;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *flags = 0u;   // first kernel of every pass
-    const bool active = job < n_keys + n_slow;
-    const int ncol = P->ncomp[3];
+    __shared__ TableJob s_job[HF_TABLE_JOBS_PER_BLOCK];
+    __shared__ double s_val[HF_TABLE_JOBS_PER_BLOCK][HF_TABLE_MAX_ITEMS];
+    __shared__ int s_base[16];
+    __shared__ unsigned char s_item[3][HF_TABLE_MAX_ITEMS];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) *flags = 0u;   // first kernel of every pass
+    const int ncol = P->ncomp[3], n_items = P->n_items;
     const bool te = hf_err_is_truncexp(P);
-    const bool star = job < n_keys;
-    bool first = false;
-    double x = 0.0, px = 0.0, bt = P->beta_star;
-    int r = 0;
-    double *dstE = nullptr, *dstC = nullptr;
-    if (active) {
-        if (star) {
+    const int job0 = blockIdx.x * HF_TABLE_JOBS_PER_BLOCK;
+    const int n_lut_rows = (int) ((Es - lutE) / 16);   // Es / Cs are the rows n_lut.. of the same buffers
+    if (tid < HF_TABLE_JOBS_PER_BLOCK) {
+        const int job = job0 + tid;
+        TableJob J;
+        J.x = 0.0; J.px = 0.0; J.bt = P->beta_star; J.row = 0; J.r = 0; J.flags = 0;
+        if (job < n_keys) {
             const int64_t key = keys[job];
             const int64_t MM = (int64_t) M * M;
-            r = (int) (key / MM);
             const int64_t idx = key % MM;
-            x = (double) (idx / M); px = (double) (idx % M);
-            dstE = lutE + key * 16; dstC = lutC + (key * 4) * K;
-        } else {
+            J.r = (int) (key / MM); J.x = (double) (idx / M); J.px = (double) (idx % M); J.row = key; J.flags = 1 | 4;
+        } else if (job - n_keys < n_slow) {
             const int k = job - n_keys;
             const int64_t t = slow_w[k];
             const uint32_t rw = rec[t];
-            first = REC_FIRST(rw) != 0;
-            r = (int) REC_REGION(rw);
-            x = (double) REC_X(rw); px = first ? 0.0 : (double) REC_X(rec[t - 1]);
-            bt = beta[t];
-            dstE = Es + (int64_t) k * 16; dstC = Cs + ((int64_t) k * 4) * K;
+            const bool first = REC_FIRST(rw) != 0;
+            J.r = (int) REC_REGION(rw); J.x = (double) REC_X(rw); J.px = first ? 0.0 : (double) REC_X(rec[t - 1]);
+            J.bt = beta[t]; J.row = (int64_t) n_lut_rows + k; J.flags = (first ? 2 : 0) | 4;
         }
+        s_job[tid] = J;
     }
-    const DevRegion* __restrict__ R = &P->reg[r];
+    if (tid < 16) s_base[tid] = P->item_base[tid];
+    if (tid < n_items) { s_item[0][tid] = P->item_s[tid]; s_item[1][tid] = P->item_u[tid]; s_item[2][tid] = P->item_c[tid]; }
+    __syncthreads();
+    // ---- the items ----
     unsigned nan = 0;
-    if (active && slot < 3 + ncol) {
-        const int s = slot < 3 ? slot : 3, c = slot < 3 ? 0 : slot - 3;
-        double v[4] = {0.0, 0.0, 0.0, 0.0};
-        if (s == 0 && te) {
-            v[0] = star ? hf_trunc_exp_star(R, x) : hf_trunc_exp(R->lambda, R->trunc_point, x, bt);
-        } else {
-            const int nu = first ? 1 : P->nuniq[s];
-            for (int u = 0; u < nu; u++) {
-                const double alpha = first ? 0.0 : P->ualpha[s][u];
-                v[u] = star ? hf_gauss_comp_star(R->m1[s][u][c], R->gvar[s][c], R->gnorm[s][c], x, px, alpha, bt, &nan)
-                            : hf_gauss_comp(R->mean[s][c], R->var[s][c], R->weight[s][c], x, px, alpha, bt, &nan);
-            }
+    for (int w = tid; w < HF_TABLE_JOBS_PER_BLOCK * n_items; w += 256) {
+        const int jl = w / n_items, it = w - jl * n_items;
+        const TableJob J = s_job[jl];
+        if (!(J.flags & 4)) continue;
+        const int s = s_item[0][it], u = s_item[1][it], c = s_item[2][it];
+        const bool star = (J.flags & 1) != 0, first = (J.flags & 2) != 0;
+        const DevRegion* __restrict__ R = &P->reg[J.r];
+        double v;
+        if (s == 0 && te) v = star ? hf_trunc_exp_star(R, J.x) : hf_trunc_exp(R->lambda, R->trunc_point, J.x, J.bt);
+        else {
+            const double alpha = first ? 0.0 : P->ualpha[s][u];
+            v = star ? hf_gauss_comp_star(R->m1[s][u][c], R->gvar[s][c], R->gnorm[s][c], J.x, J.px, alpha, J.bt, &nan)
+                     : hf_gauss_comp(R->mean[s][c], R->var[s][c], R->weight[s][c], J.x, J.px, alpha, J.bt, &nan);
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) vals[jl][slot][u] = v[u];
-        if (slot >= 3) {   // component probabilities per PREVIOUS STATE (the value of its alpha): no select in the consumer
-#pragma unroll
-            for (int pre = 0; pre < 4; pre++) {
-                const int u = P->umap[pre * 4 + 3];
-                dstC[c * 4 + pre] = first ? 0.0 : (u == 0 ? v[0] : u == 1 ? v[1] : u == 2 ? v[2] : v[3]);
-            }
-        }
+        s_val[jl][it] = v;
     }
     __syncthreads();
-    if (active && slot < 16) {
-        const int pre = slot >> 2, s = slot & 3;
-        const int u = (first || (s == 0 && te)) ? 0 : P->umap[pre * 4 + s];
-        double e;
-        if (s < 3) e = vals[jl][s][u];
-        else {
-            e = 0.0;
-            for (int c = 0; c < ncol; c++) e += vals[jl][3 + c][u];
+    // ---- the outputs: 16 values of E and 4*ncol of the component table per row ----
+    const int n_out = 16 + 4 * ncol;
+    for (int w = tid; w < HF_TABLE_JOBS_PER_BLOCK * n_out; w += 256) {
+        const int jl = w / n_out, o = w - jl * n_out;
+        const TableJob J = s_job[jl];
+        if (!(J.flags & 4)) continue;
+        const bool first = (J.flags & 2) != 0;
+        if (o < 16) {
+            const int pre = o >> 2, s = o & 3;
+            const int u = (first || (s == 0 && te)) ? 0 : P->umap[pre * 4 + s];
+            const int b0 = s_base[s * 4 + u];
+            double e;
+            if (s < 3) e = s_val[jl][b0];
+            else {
+                e = 0.0;
+                for (int c = 0; c < ncol; c++) e += s_val[jl][b0 + c];
+            }
+            if (first && pre != 0) e = 0.0;
+            lutE[J.row * 16 + HF_PS(pre, s)] = e;
+        } else {   // component probabilities per PREVIOUS STATE (the value of its alpha): no select in the consumer
+            const int q = o - 16, c = q >> 2, pre = q & 3;
+            const int u = first ? 0 : P->umap[pre * 4 + 3];
+            lutC[(J.row * 4) * K + c * 4 + pre] = first ? 0.0 : s_val[jl][s_base[3 * 4 + u] + c];
         }
-        if (first && pre != 0) e = 0.0;
-        dstE[HF_PS(pre, s)] = e;
     }
 }
 

@@ -298,4 +298,14 @@ def config(n: int, scale: float = 1.0) -> WindowStore:
     if n == 4:   # ONT-R10 preset, 7 bias regions
         lens = [int(x * scale) for x in _HUMAN_CHROMS] * 2
         return synthesize(lens, 8000, 20_000_000, [20, 12, 16, 24, 28, 32, 14], seed, contig_prefix="hap_ctg")
+    if n == 5:   # NOT a BASELINE config: the worst case for the emission tables — configs[4]'s geometry with
+        # coverage spread over the whole 0..250 range (half uniform, half heavy-tailed negative binomial), so that nearly every
+        # (region, x, x_prev) key occurs once or twice: ~440 k keys for 764 k windows, K = 10
+        st = config(4, scale)
+        rng = np.random.default_rng(seed)
+        nwin = st.n_windows
+        heavy = np.minimum(250, rng.negative_binomial(2, 0.02, size=nwin))
+        st.cov = np.where(rng.random(nwin) < 0.5, rng.integers(0, 251, size=nwin), heavy).astype(np.uint16)
+        st.mapq = st.cov.copy()
+        return st
     raise ValueError("configs[0] is generated by tests/golden/make_golden.py (simulated .cov)")

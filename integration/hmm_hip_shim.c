@@ -1,31 +1,3 @@
-# INTEGRATION — re-pointing `hmm_flagger` at the MI355X E-step
-
-The reference (mobinasri/flagger, HMM-Flagger v1.2.0) has no plugin/FFI layer. The seam for this hot
-path is one C function pair inside the process (`programs/submodules/hmm/hmm.h:109,113`):
-
-```c
-void EM_runOneIterationForList(stList *emList, HMM *model, int threads);   /* hmm.c:739 */
-void EM_runForwardForList   (stList *emList, HMM *model, int threads);   /* hmm.c:790 */
-```
-
-called from `runHMMFlagger` (`programs/src/hmm_flagger.c:344,394,401,464`) and from the SQUAREM line
-search (`hmm.c:900,912`). Everything else in the binary (cov/bin loader, region bookkeeping, EM outer
-loop, M-step, BED/TSV writers) is unchanged. The replacement is the C ABI of
-`flagger_amd/csrc/libhmmflagger_hip.so`, declared in `include/hmm_flagger_hip.h` (plain pointers and
-sizes, no torch types, no reference structs).
-
-## 1. What the maintainer adds: `hmm_hip_shim.c`
-
-Linked into `hmm_flagger` next to `hmm.c`; the two functions above are renamed (or guarded by a
-`-DFLAGGER_HIP`) and these take their place. The shim flattens the reference's
-array-of-pointers (`EM`, `Chunk`, `CoverageInfo`, `HMM`) once, keeps the device context alive across
-iterations, and scatters the results back into the reference's own objects, so `HMM_estimateParameters`,
-the summary tables and the BED writer keep working untouched.
-
-The file is `integration/hmm_hip_shim.c` (compiled and run by `tests/test_shim_cpu.py` / `tests/test_shim_gpu.py` against mock
-declarations of the reference structs, `tests/shim_mock/hmm.h`):
-
-```c
 /* hmm_hip_shim.c — what a maintainer of mobinasri/flagger adds to re-point hmm_flagger's E-step at the MI355X library.
  * Goes in programs/submodules/hmm/ next to hmm.c, whose EM_runOneIterationForList / EM_runForwardForList / EM_getPosterior
  * (hmm.c:739, 790, 671) are renamed or guarded by -DFLAGGER_HIP; built with
@@ -151,64 +123,3 @@ double *EM_getPosterior(EM *em, int pos) {
     }
     return post;
 }
-```
-
-For `--modelType negative_binomial` the shim also fills `hf_params.nb_*` from the `NegativeBinomial` structs
-(`p->mean` = theta, `p->var` = lambda; `nb_dig` = `nb->digammaTable`, `nb_P` / `nb_E` =
-`NegativeBinomial_getComponentProbs` / `_getProb` for x = 0..250, `nb_r`, `nb_beta` as in `hmm_utils.c:545-547`); the
-returned vector then carries the theta / lambda / weight estimators in parameter slots 0 / 1 / 2. `hf_params.nb_max_x`
-stays 0 when the tables are filled for every x = 0..250.
-
-`threads` is ignored: the reference's result never depended on it (probe in SURVEY.md §8b). By default the device
-sums the statistics by emission row (`HF_STATS_ROWS`: the same sums as `hmm.c:563-650` + `759-763` in another, fixed,
-order — equal to rounding, reproducible bit for bit). A maintainer who wants the reference's own merge order calls
-`hf_set_stats_mode(g_ctx, HF_STATS_CHUNKS)` after `hf_create`: one estimator vector per chunk, summed in chunk-list
-order, so the result does not depend on the number of GPUs either (≈ 25 % more time per step).
-
-Error behaviour: the ABI returns codes where the reference calls `exit(EXIT_FAILURE)`; the shim maps
-`HF_E_SCALE`/`HF_E_NAN` to the reference's messages and exit status. Without a GPU `hf_create` returns
-`HF_E_NOGPU`; there is deliberately no CPU path behind this boundary.
-
-## 2. The same boundary from this repo's own host
-
-* Python mirror of the interface with the reference's names — `flagger_amd/hmm.py`:
-  `createModel`, `EMList` (the `stList<EM*>`), `EM_runOneIterationForList`, `EM_runForwardForList`,
-  `HMM_estimateParameters`, `HMM_resetEstimators`, `runHMMFlagger`. It calls the C ABI through `ctypes`
-  (`flagger_amd/_native.py`); torch is used only by `flagger_amd/dist.py` for the multi-GPU all-gather.
-* Host model + M-step in C++ behind `include/hmm_flagger_model.h` (`hfm_create`, `hfm_params`,
-  `hfm_estimate`, SQUAREM helpers, TSV writers) — the parts of `hmm_utils.c` that stay on the CPU — and
-  `hf_em_iterate(ctx, model, mode, do_mstep, tol, stats, &converged, stream)`: one EM step (E-step, statistics
-  down, M-step) in a single call, what `runHMMFlagger` repeats at `hmm_flagger.c:337-445`.
-* `flagger_amd/csrc/hmm_flagger` (`hf_cli.cpp`): the reference's command line (same `getopt_long` string and
-  long options, `hmm_flagger.c:560-640`) on top of the three headers: `.cov/.cov.gz/.bin` in,
-  `final_flagger_prediction.bed`, `loglikelihood.tsv`, emission/transition TSVs, posterior BED, `.bin` dump out.
-  Also `prediction_summary_{initial,iteration_k,final}.tsv` and the two benchmarking files when the input has a truth
-  track (`include/hmm_flagger_summary.h`, replacing `writeBenchmarkingStats`, `hmm_flagger.c:134-162`), `--contigsList`.
-  Extra options: `--device N`, `--algo scan|seq`. `tests/test_cli_gpu.py` diffs its outputs with the oracle CLI's.
-  The HIP runtime comes up on a second thread while the input is read (`hf_warmup`); `HF_CLI_TIMING=1` prints the wall time
-  of every phase.
-* Environment switches of the library: `HF_STATS=chunks|rows` (default statistics path at `hf_create`), `HF_POLL=0`
-  (`hf_finish` synchronises the stream instead of polling the checksummed completion stamp), `HF_HOST_TRACE=1` (host /
-  device time per EM step and the phases of `hf_create` on stderr), `HF_USE_GRAPH=1` (HIP-graph replay, per-chunk statistics).
-
-## 3. Multi-GPU
-
-One process per GPU (`torch.distributed`, backend `nccl` = RCCL). Each rank owns a contiguous run of the
-chunk list (balanced by window count), runs `hf_estep` on its shard, and **one `all_gather_into_tensor`** per EM
-iteration exchanges the statistics; every rank then runs the identical M-step. No broadcast, no all-reduce, labels stay
-sharded until the final gather. Two exchanges (`flagger_amd/dist.py`, `exchange=`):
-
-* `"ranks"`: `hf_rank_total` puts the rank's own vector (statistics by emission row, `HF_STATS_ROWS`) into the send
-  buffer, the gathered `world` vectors are summed in rank order by `hf_finish_gathered(rows, NULL, world, …)` into
-  pinned host memory (one synchronisation). What `bench.py --gpus N` runs.
-* `"chunks"`: `hf_set_stats_mode(ctx, HF_STATS_CHUNKS)`, `hf_copy_chunk_stats` puts the per-chunk vectors into the send
-  buffer, and `hf_finish_gathered(rows, row_index, n_chunks, …)` sums ALL chunks in global list order — the reference's
-  merge order, bit-identical for any number of GPUs.
-
-Launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 bench.py --gpus 8`.
-
-## 4. Build
-
-`python -c "import __graft_entry__ as g; g.build()"` → `make -C flagger_amd/csrc`
-(`hipcc --offload-arch=gfx950 -O3 -ffp-contract=off`, plus `g++` for the host model) and
-`make -C oracle` (the checker). The `.so` is kept in-tree.

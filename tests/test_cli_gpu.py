@@ -277,3 +277,26 @@ def test_docs_hmm_test_recipe_at_full_size_through_the_hip_command_line(family, 
     a = (tmp_path / ("gpu12" if extra else "gpu") / "final_flagger_prediction.bed").read_text().splitlines()[1:]
     b = (tmp_path / "cpu" / "final_flagger_prediction.bed").read_text().splitlines()[1:]
     assert a == b
+
+
+@pytest.mark.parametrize("extra", [[], ["--accelerate"]], ids=["em", "squarem"])
+def test_full_size_em_to_convergence_equals_the_oracle_command_line(extra, tmp_path):
+    """BASELINE configs[2] at full size (1 527 428 windows, 286 chunks, .bin input), EM to convergence (-n 100 -t 1e-3) with
+    and without SQUAREM (hmm_flagger.c:335-468, 382-416): every output file of the HIP command line equals the oracle command
+    line's byte for byte — loglikelihood.tsv (%.4f of a sum of 1.5 M logs), the parameter tables of every iteration (-w),
+    the final BED.  ~3 s of GPU-side wall time, ~10-20 s of the 16-thread oracle."""
+    store = synth.config(2)
+    assert store.n_windows == 1527428 and store.n_chunks == 286
+    binp = tmp_path / "cfg2.bin"
+    store.write_bin(str(binp))
+    args = ["-i", str(binp), "-n", "100", "-t", "1e-3", "-W", "4000", "-A", ALPHA, "-w"] + extra
+    r = _run(CLI, args, tmp_path / "gpu")
+    assert "Parameters converged after" in r.stderr
+    _run(ORACLE, args + ["--threads", "16"], tmp_path / "cpu")
+    names = sorted(os.listdir(tmp_path / "cpu"))
+    assert len(names) > 12 and "final_flagger_prediction.bed" in names and "loglikelihood.tsv" in names
+    for n in names:
+        if n.endswith((".tsv", ".bed")):
+            assert (tmp_path / "gpu" / n).read_text() == (tmp_path / "cpu" / n).read_text(), n
+    n_ll = len((tmp_path / "gpu" / "loglikelihood.tsv").read_text().splitlines())
+    assert (5 < n_ll < 20) if extra else (20 < n_ll < 60), n_ll

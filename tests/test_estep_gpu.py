@@ -122,6 +122,16 @@ def test_multi_region_ont(algo):
 
 
 @pytest.mark.parametrize("algo", ALGOS)
+def test_wide_coverage_support_worst_case_for_the_tables(algo):
+    """synth.config(5): coverage spread over 0..250 in 7 regions, K = 10 — nearly every window has its own emission row, the
+    statistics plan is refused as sparse (per-chunk statistics take over) and the row tables leave the L2."""
+    store = synth.config(5, scale=0.01)
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    assert K == 10 and store.n_regions == 7 and int(store.cov.max()) == 250
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, synth.ONT_R10_ALPHA, algo, n_iter=2)
+
+
+@pytest.mark.parametrize("algo", ALGOS)
 def test_empty_chunk_list(algo):
     """No chunk at all (e.g. --contigsList that matches nothing): log-likelihood 0, all-zero statistics, no labels."""
     full = synth.synthesize([50_000], 1000, 20_000, [20], seed=2)

@@ -26,7 +26,7 @@ MAXC = 16
 
 
 def _symmetric_model(store, K, exact_tie):
-    model = hmm.createModel(hmm.MODEL_GAUSSIAN, K, store, np.zeros((4, 4)))
+    model = hmm.createModel(hmm.MODEL_GAUSSIAN, K, store, np.zeros((4, 4)), 1e9, 0.0)   # every state valid at every window
     v = model.param_vector().reshape(1, -1)
     mean = v[0, 27:27 + 4 * MAXC].reshape(4, MAXC)
     var = v[0, 27 + 4 * MAXC:27 + 8 * MAXC].reshape(4, MAXC)
@@ -43,11 +43,10 @@ def _symmetric_model(store, K, exact_tie):
 @pytest.mark.parametrize("exact_tie", [True, False], ids=["exact", "1e-13"])
 def test_label_mismatches_only_on_ulp_level_ties(exact_tie):
     store = synth.synthesize([9_000_000, 4_000_000, 6_500_000], 2000, 1_000_000, [24], seed=77)
-    store.mapq = store.cov.copy()                       # every state valid everywhere
     K = 3
     model = _symmetric_model(store, K, exact_tie)
     em = hmm.EMList(store, model, False, 0.95)
-    orc = Oracle(store, hmm.MODEL_GAUSSIAN, K, np.zeros((4, 4)), adjust=False, threads=8)
+    orc = Oracle(store, hmm.MODEL_GAUSSIAN, K, np.zeros((4, 4)), max_mapq=1e9, min_mapq=0.0, adjust=False, threads=8)
     try:
         orc.set_param_vector(model.param_vector())
         hmm.EM_runOneIterationForList(em, model)
