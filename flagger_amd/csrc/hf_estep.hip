@@ -846,31 +846,12 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                                        ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_flags);
                 }
                 KTimer t(ctx, st, HF_K_SEG_FB);
-#ifdef HF_SEG_TRACE
-                static unsigned long long* d_trace = nullptr;
-                if (!d_trace) hipMalloc((void**) &d_trace, (size_t) ctx->nseg * 16 * 8);
-#define SEG_TRACE_PTR(p) p,
-#else
-#define SEG_TRACE_PTR(p)
-#endif
                 if (full)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, true>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, SEG_TRACE_PTR(d_trace) ctx->d_seg, ctx->d_rec,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, true>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_rec,
                                        S, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
                 else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, false>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, SEG_TRACE_PTR((unsigned long long*) nullptr) ctx->d_seg, ctx->d_rec,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, false>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_rec,
                                        S, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
-#ifdef HF_SEG_TRACE
-                {
-                    static int dumps = 0;
-                    if (full && ++dumps == 20 && std::getenv("HF_SEG_TRACE_FILE")) {
-                        hipStreamSynchronize(st);
-                        std::vector<unsigned long long> h((size_t) ctx->nseg * 16);
-                        hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost);
-                        FILE* tf = std::fopen(std::getenv("HF_SEG_TRACE_FILE"), "wb");
-                        if (tf) { std::fwrite(h.data(), 8, h.size(), tf); std::fclose(tf); }
-                    }
-                }
-#endif
                 ctx->pass_seg = true;
                 if (full) ctx->fb_recs = true;
             } else {

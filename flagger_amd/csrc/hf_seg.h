@@ -225,18 +225,16 @@ __device__ __forceinline__ void seg_lane_product(const uint32_t* __restrict__ re
                                                  M4& Q, unsigned& nan) {
     m4_identity(Q);
     uint32_t r = m > 0 ? rec_seg[a] : 0u;
+    uint32_t r1 = m > 1 ? rec_seg[a + 1] : 0u;            // records are fetched two steps ahead
     rows_issue(S.lutE, m > 0 ? row_index(S, r, rp, sidx) : 0, lane, blk);
 #pragma unroll 1
     for (int i = 0; i < L; i++) {
         double E[16];
         rows_read(blk, lane, E);
         const int sn = sidx + (int) REC_SLOW(r);
-        uint32_t rn = 0;
-        if (i + 1 < L) {                                   // the next step's rows are in flight during this one
-            const bool has = i + 1 < m;
-            if (has) rn = rec_seg[a + i + 1];
-            rows_issue(S.lutE, has ? row_index(S, rn, r, sn) : 0, lane, blk);
-        }
+        const uint32_t rn = r1;
+        if (i + 1 < L) rows_issue(S.lutE, i + 1 < m ? row_index(S, rn, r, sn) : 0, lane, blk);   // in flight during this step
+        r1 = i + 2 < m ? rec_seg[a + i + 2] : 0u;
         if (i < m) {
             if (row_has_nan(E)) nan |= HF_FLAG_NAN;
             if (!REC_FIRST(r)) {
@@ -286,7 +284,7 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_prod(const SegDesc*
     const uint32_t rp = (m > 0 && !(a == 0 && d.k == 0)) ? rec_seg[a - 1] : 0u;
     M4 Q;
     unsigned nan = 0;
-    seg_lane_product(rec_seg, rp, a, m, d.L, sidx, S, s_tab, blk, lane, Q, nan);
+        seg_lane_product(rec_seg, rp, a, m, d.L, sidx, S, s_tab, blk, lane, Q, nan);
     {
         double2* __restrict__ dst = reinterpret_cast<double2*>(Qs) + (int64_t) g * 8 * NL + j;
 #pragma unroll
@@ -321,15 +319,8 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_prod(const SegDesc*
 // k_seg_fb: one workgroup per segment: phases B-D of the header.  BWD = false: forward only (EM_runForwardForList,
 // hmm.c:790-816): log-likelihood and error flags, nothing else is written.
 // ------------------------------------------------------------------------------------------
-#ifdef HF_SEG_TRACE
-#define SEG_STAMP(k) do { if (threadIdx.x == 0 && trace) trace[(int64_t) blockIdx.x * 16 + (k)] = __builtin_readcyclecounter(); } while (0)
-#define SEG_TRACE_ARG unsigned long long* __restrict__ trace,
-#else
-#define SEG_STAMP(k) do { } while (0)
-#define SEG_TRACE_ARG
-#endif
 template <int NW, bool BWD>
-__global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG const SegDesc* __restrict__ sd, const uint32_t* __restrict__ rec,
+__global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* __restrict__ sd, const uint32_t* __restrict__ rec,
                                                                  const RowSrc S, const DevParams* __restrict__ P,
                                                                  const double* __restrict__ Qs, const double* __restrict__ Pseg,
                                                                  double* __restrict__ recs,
@@ -337,9 +328,7 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
                                                                  double* __restrict__ seg_ll, unsigned* __restrict__ flags) {
     constexpr int NL = NW * 64;
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    SEG_STAMP(0);
     fill_tab(P, s_tab);
-    SEG_STAMP(1);
     double* __restrict__ s_W = s_tab + P->n_regions * HF_TAB_STRIDE;      // [NW][16] wave totals
     double* __restrict__ s_red = s_W + NW * 16;                           // [NW] log-likelihood partials
     int* __restrict__ s_cnt = reinterpret_cast<int*>(s_red + NW);         // [NW] (+ padding to NW doubles)
@@ -357,7 +346,6 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
     const uint32_t rp0 = (m > 0 && !chunk_first) ? rec_seg[a - 1] : 0u;
     unsigned bad = 0;
     double fin[4], bdir[4];
-    SEG_STAMP(2);
     {
         // ---- A: the lane product, from k_seg_prod ----
         M4 Q;
@@ -366,7 +354,6 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
 #pragma unroll
             for (int k = 0; k < 8; k++) { const double2 v = src[k * NL]; Q.m[2 * k] = v.x; Q.m[2 * k + 1] = v.y; }
         }
-        SEG_STAMP(3);
         // ---- B: scans over the lanes of the wavefront; Q waits for the second scan in the (idle) row block ----
         if (BWD) m4_park(Q, lane, blk);
         m4_scan_prefix(Q, lane);
@@ -377,9 +364,7 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
         double xv[16];                                          // exclusive prefix: the product of lanes 0..lane-1
 #pragma unroll
         for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);
-        SEG_STAMP(4);
         __syncthreads();
-        SEG_STAMP(5);
         // forward vector entering the segment: start∘e of the chunk's first window (its row is the chunk's first entry of
         // the slow list), through the products of the chunk's earlier segments and of the earlier wavefronts
         double v[4];
@@ -419,7 +404,6 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
             if (lane < 63) v4_mul_left(bdir, xv);
         }
     }
-    SEG_STAMP(6);
     // ---- C: forward replay (hmm.c:333-434) ----
     double f[4] = {fin[0], fin[1], fin[2], fin[3]};
     // log-likelihood of the lane's windows: sum of log(scale) (hmm.c:428) as log(product of the mantissas) + (sum of the
@@ -429,21 +413,30 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
     uint32_t r_last = 0, r_before_last = rp0;
     int sidx_last = sidx0;
     const int64_t slot_ij = (int64_t) d.slot0 + j;                         // + i*NL
+    // The outputs of step i (scale, f) are STORED at the top of step i+1, after the wait for that step's rows: a store issued
+    // right before the wait would make every step pay the full store latency (vmcnt counts loads and stores alike).
+    auto store_fwd = [&](int i) {
+        scale_s[slot_ij + (int64_t) i * NL] = scl;
+        // f_t is the first half of record t+1: the lane's next slot, the next lane's first slot, or the next segment's
+        int64_t sf = i + 1 < L ? slot_ij + (int64_t) (i + 1) * NL : slot_ij + 1;
+        if (a + i + 1 == n) sf = d.next_slot;
+        double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + sf * 4;
+        dst[0] = make_double2(f[0], f[1]); dst[1] = make_double2(f[2], f[3]);
+    };
     {
         uint32_t r = m > 0 ? rec_seg[a] : 0u, rp = rp0;
+        uint32_t r1 = m > 1 ? rec_seg[a + 1] : 0u;                         // records are fetched two steps ahead
         int sidx = sidx0;
         rows_issue(S.lutE, m > 0 ? row_index(S, r, rp, sidx) : 0, lane, blk);
 #pragma unroll 1
         for (int i = 0; i < L; i++) {
             double E[16];
             rows_read(blk, lane, E);
+            if (BWD && i >= 1 && i - 1 < m) store_fwd(i - 1);
             const int sn = sidx + (int) REC_SLOW(r);
-            uint32_t rn = 0;
-            if (i + 1 < L) {
-                const bool has = i + 1 < m;
-                if (has) rn = rec_seg[a + i + 1];
-                rows_issue(S.lutE, has ? row_index(S, rn, r, sn) : 0, lane, blk);
-            }
+            const uint32_t rn = r1;
+            if (i + 1 < L) rows_issue(S.lutE, i + 1 < m ? row_index(S, rn, r, sn) : 0, lane, blk);
+            r1 = i + 2 < m ? rec_seg[a + i + 2] : 0u;
             if (i < m) {
                 double Tm[16];
                 lds_Tm(s_tab, r, Tm);
@@ -461,23 +454,15 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
                 for (int s = 0; s < 4; s++) f[s] = nf[s] / sc;
                 { int e2; lm *= frexp(sc, &e2); le += e2; }                // hmm.c:428, see above
                 scl = sc;
-                if (BWD) {
-                    scale_s[slot_ij + (int64_t) i * NL] = sc;
-                    // f_t is the first half of record t+1: the lane's next slot, the next lane's first slot, or the next segment's
-                    int64_t sf = i + 1 < L ? slot_ij + (int64_t) (i + 1) * NL : slot_ij + 1;
-                    if (a + i + 1 == n) sf = d.next_slot;
-                    double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + sf * 4;
-                    dst[0] = make_double2(f[0], f[1]); dst[1] = make_double2(f[2], f[3]);
-                }
                 r_last = r; sidx_last = sidx; r_before_last = rp;
             }
             rp = r; r = rn; sidx = sn;
         }
+        if (BWD && L - 1 < m) store_fwd(L - 1);
     }
     double ll = log(lm) + (double) le * 0.693147180559945309417232121458;
     for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
     if (lane == 0) s_red[wave] = ll;
-    SEG_STAMP(7);
     // ---- D: backward replay + labels (hmm.c:452-545, 671-692) ----
     if (BWD) {
         const int jl = m - 1;                                   // the lane's last window (< 0: none)
@@ -497,18 +482,31 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
                 for (int s = 0; s < 4; s++) b[s] = bdir[s] * kk;
             }
             s_lab[a + jl] = (int8_t) posterior_label_fast(f, b, scl);
-            double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + (slot_ij + (int64_t) jl * NL) * 4 + 2;
-            dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
         }
+        // b_k is stored at the top of the step that consumes it (see store_fwd); scale and f of a step are loaded one step ahead
+        auto store_bwd = [&](int k) {
+            double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + (slot_ij + (int64_t) k * NL) * 4 + 2;
+            dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
+        };
         // window k's row and transition table turn b_k into b_{k-1}; all lanes run k = L-1 .. 1 (cooperative fetch)
         uint32_t rk = r_last, rkm1 = r_before_last;
         int sk = sidx_last;
         rows_issue(S.lutE, (jl >= 1 && jl == L - 1) ? row_index(S, rk, rkm1, sk) : 0, lane, blk);
+        double nsc = 1.0;
+        double2 nf01 = make_double2(0.0, 0.0), nf23 = nf01;
+        if (jl >= 1 && jl == L - 1) {
+            nsc = scale_s[slot_ij + (int64_t) (jl - 1) * NL];
+            const double2* __restrict__ fsrc = reinterpret_cast<const double2*>(recs) + (slot_ij + (int64_t) jl * NL) * 4;
+            nf01 = fsrc[0]; nf23 = fsrc[1];
+        }
 #pragma unroll 1
         for (int k = L - 1; k >= 1; k--) {
             double E[16];
             rows_read(blk, lane, E);
             const bool act = k <= jl;                           // this lane has a window k
+            if (act) store_bwd(k);
+            const double sc = nsc;
+            const double2 f01 = nf01, f23 = nf23;
             // the next step's row: window k-1 of the lane (needs the record before it) — or, for a lane whose last window
             // IS k-1, its own first row of the backward pass
             uint32_t rkm2 = 0;
@@ -523,12 +521,13 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
                     nidx = row_index(S, rk, rkm1, sk);
                 }
                 rows_issue(S.lutE, nidx, lane, blk);
+                if (k - 1 <= jl) {                              // scale and f of step k-1, in flight during this step
+                    nsc = scale_s[slot_ij + (int64_t) (k - 2) * NL];
+                    const double2* __restrict__ fsrc = reinterpret_cast<const double2*>(recs) + (slot_ij + (int64_t) (k - 1) * NL) * 4;
+                    nf01 = fsrc[0]; nf23 = fsrc[1];
+                }
             }
             if (act) {
-                const int64_t slot_prev = slot_ij + (int64_t) (k - 1) * NL;
-                const double sc = scale_s[slot_prev];
-                const double2* __restrict__ fsrc = reinterpret_cast<const double2*>(recs) + (slot_ij + (int64_t) k * NL) * 4;
-                const double2 f01 = fsrc[0], f23 = fsrc[1];
                 double Tm[16];
                 lds_Tm(s_tab, rk, Tm);
                 double nb[4];
@@ -544,15 +543,12 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
                 for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
                 const double fi[4] = {f01.x, f01.y, f23.x, f23.y};
                 s_lab[a + k - 1] = (int8_t) posterior_label_fast(fi, b, sc);
-                double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + slot_prev * 4 + 2;
-                dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
                 rk = rkm1; rkm1 = rkm2; sk = skm1;
             }
         }
+        if (jl >= 0) store_bwd(0);
     }
-    SEG_STAMP(8);
     __syncthreads();
-    SEG_STAMP(9);
     if (threadIdx.x == 0) {
         double s = 0.0;
         for (int w = 0; w < NW; w++) s += s_red[w];
@@ -563,8 +559,4 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(SEG_TRACE_ARG co
         for (int w = threadIdx.x; w < n; w += NL) dst[w] = s_lab[w];
     }
     if (bad) atomicOr(flags, bad);
-    SEG_STAMP(10);
-#ifdef HF_SEG_TRACE
-    if (threadIdx.x == 0 && trace) { trace[(int64_t) blockIdx.x * 16 + 11] = (unsigned long long) n; trace[(int64_t) blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memrealtime(); }
-#endif
 }
