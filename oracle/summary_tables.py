@@ -1,5 +1,7 @@
 """oracle/summary_tables.py — TEST INFRASTRUCTURE ONLY (checker for flagger_amd/csrc/hf_summary.cpp; never imported
-by the product).  PARITY UNPINNED: the reference has no test or fixture for these files and cannot be built here.
+by the product).  Pinned by the reference's own known answers: tests/test_reference_kats_cpu.py reproduces the expected
+tables / strings of programs/tests/test_summary_table.c:12-470 and test_common.c:84-127 on the reference's data files with this
+module (and with the product).  The final-statistics files (benchmarking.tsv, auN) have no reference-held vector.
 
 Literal pure-Python restatement (small inputs only) of the reference's prediction summary tables,
 mobinasri/flagger programs/submodules/summary_table/summary_table.c:
