@@ -102,6 +102,7 @@ def lib() -> C.CDLL:
     sig("hf_get_forward_backward", C.c_int, vp, i64, i64, pd, pd, pd)
     sig("hf_last_kernel_ms", C.c_int, vp, C.POINTER(C.c_float))
     sig("hf_set_profiling", C.c_int, vp, C.c_uint)
+    sig("hf_set_profiling_stride", C.c_int, vp, C.c_int)
     sig("hf_kernel_times", C.c_int, vp, C.POINTER(C.c_float))
     sig("hf_kernel_time_sums", C.c_int, vp, pd, C.POINTER(C.c_int64))
     sig("hf_kernel_name", C.c_char_p, C.c_int)

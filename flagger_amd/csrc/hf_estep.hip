@@ -32,7 +32,29 @@
 #include <chrono>
 #include <cstdlib>
 
+#include <thread>
 static thread_local std::string g_err;
+
+// hf_create's host loops over the windows are independent per chunk: run fn(first chunk, last chunk + 1, part) on up to 8
+// threads, the chunk list cut into parts of about equal window count (1.5 M windows: 6-8 ms per loop on one thread)
+template <class Fn>
+static void par_chunks(const int64_t* chunk_off, size_t C, Fn fn) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t T = C < 16 ? 1 : std::min<size_t>(8, hw ? hw : 1);
+    if (T <= 1) { fn((size_t) 0, C, (size_t) 0); return; }
+    std::vector<size_t> cut(T + 1, 0);
+    const int64_t total = chunk_off[C] - chunk_off[0];
+    size_t c = 0;
+    for (size_t k = 1; k < T; k++) {
+        const int64_t target = chunk_off[0] + total * (int64_t) k / (int64_t) T;
+        while (c < C && chunk_off[c] < target) c++;
+        cut[k] = c;
+    }
+    cut[T] = C;
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < T; k++) th.emplace_back([&, k] { fn(cut[k], cut[k + 1], k); });
+    for (auto& t : th) t.join();
+}
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     return set_err(HF_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -73,6 +95,7 @@ struct hf_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
     double ksum[HF_NKERNELS] = {}; int64_t kcount[HF_NKERNELS] = {};   // accumulated by hf_finish while profiling is on
     unsigned prof_mask = 0;        // bit k: kernel k (HF_K_*) is bracketed by kev[2k], kev[2k+1]
+    int prof_stride = 1; long prof_pass = 0; bool prof_now = true;   // events only in every prof_stride-th pass (hf_set_profiling_stride)
     hipEvent_t kev[2 * HF_NKERNELS] = {}; bool kran[HF_NKERNELS] = {};
     bool have_full = false;
     size_t lds_max = 64 * 1024;    // LDS one workgroup may use (hipDeviceAttributeMaxSharedMemoryPerBlock)
@@ -203,7 +226,7 @@ static int dev_upload(T** dst, const T* src, size_t n) {
 // event pair around one kernel launch, only for the kernels selected by hf_set_profiling
 struct KTimer {
     hf_ctx* c; hipStream_t st; int k; bool on;
-    KTimer(hf_ctx* c_, hipStream_t s_, int k_) : c(c_), st(s_), k(k_), on((c_->prof_mask >> k_) & 1u) {
+    KTimer(hf_ctx* c_, hipStream_t s_, int k_) : c(c_), st(s_), k(k_), on(((c_->prof_mask >> k_) & 1u) && c_->prof_now) {
         if (on) hipEventRecord(c->kev[2 * k], st);
     }
     ~KTimer() { if (on) { hipEventRecord(c->kev[2 * k + 1], st); c->kran[k] = true; } }
@@ -431,17 +454,28 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         std::vector<int64_t> slow;
         std::vector<int32_t> soff(C + 1, 0), keys;
         std::vector<uint8_t> seen((size_t) n_regions * MM, 0);
-        for (size_t c = 0; c < C; c++) {
-            soff[c] = (int32_t) slow.size();
-            const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-            for (int64_t x = 0; x < T; x++) {
-                const size_t t = (size_t) (t0 + x);
-                if (x == 0 || hb[t] != ctx->beta_star) { slow.push_back((int64_t) t); continue; }
-                const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
-                seen[(reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu)] = 1;
-            }
+        {
+            std::vector<std::vector<int64_t>> part_slow(8);
+            std::vector<int32_t> nslow(C, 0);
+            uint8_t* seen_p = seen.data();
+            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
+                std::vector<int64_t>& mine = part_slow[part];
+                for (size_t c = c0; c < c1; c++) {
+                    const size_t before = mine.size();
+                    const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                    for (int64_t x = 0; x < T; x++) {
+                        const size_t t = (size_t) (t0 + x);
+                        if (x == 0 || hb[t] != ctx->beta_star) { mine.push_back((int64_t) t); continue; }
+                        const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
+                        __atomic_store_n(seen_p + (reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu), (uint8_t) 1, __ATOMIC_RELAXED);
+                    }
+                    nslow[c] = (int32_t) (mine.size() - before);
+                }
+            });
+            for (size_t c = 0; c < C; c++) soff[c + 1] = soff[c] + nslow[c];
+            slow.reserve((size_t) soff[C]);
+            for (auto& v : part_slow) slow.insert(slow.end(), v.begin(), v.end());   // parts are consecutive chunk ranges: ascending
         }
-        soff[C] = (int32_t) slow.size();
         for (size_t k = 0; k < seen.size(); k++) if (seen[k]) keys.push_back((int32_t) k);
         ctx->n_slow = (int) slow.size();
         ctx->n_keys = (int) keys.size();
@@ -519,7 +553,6 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     d.seg0 = first; d.k = (int) k; d.chunk = (int) c;
                     d.reg_first = (int32_t) ((w->annot[t0] & 0xFC00000000000000ULL) >> 58);
                     d.reg_last = (int32_t) ((w->annot[t0 + T - 1] & 0xFC00000000000000ULL) >> 58);
-                    for (int64_t x = 0; x < n; x++) slot_of[(size_t) (d.t0 + x)] = d.slot0 + (int32_t) ((x % d.L) * NL + x / d.L);
                     segs.push_back(d);
                 }
                 const int nsc = (int) segs.size() - first;
@@ -528,9 +561,23 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     segs[(size_t) (first + k)].nseg = nsc;
                     segs[(size_t) (first + k)].next_slot = k + 1 < nsc ? segs[(size_t) (first + k + 1)].slot0 : spare;
                 }
-                for (int64_t x = 0; x < T; x++) slot_f[(size_t) (t0 + x)] = x + 1 < T ? slot_of[(size_t) (t0 + x + 1)] : spare;
             }
             cseg0[C] = (int32_t) segs.size();
+            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
+                for (size_t c = c0; c < c1; c++) {
+                    const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                    if (T <= 0) continue;
+                    for (int k = cseg0[c]; k < cseg0[c + 1]; k++) {
+                        const SegDesc& d = segs[(size_t) k];
+                        int32_t* so = slot_of.data() + d.t0;
+                        for (int64_t l = 0, x = 0; x < d.n; l++)                  // window x = lane l's x % L-th
+                            for (int64_t i = 0; i < d.L && x < d.n; i++, x++) so[x] = d.slot0 + (int32_t) (i * NL + l);
+                    }
+                    const int32_t spare = segs[(size_t) cseg0[c + 1] - 1].next_slot;
+                    for (int64_t x = 0; x + 1 < T; x++) slot_f[(size_t) (t0 + x)] = slot_of[(size_t) (t0 + x + 1)];
+                    slot_f[(size_t) (t0 + T - 1)] = spare;
+                }
+            });
             if (nslots < INT32_MAX) {
                 ctx->nseg = (int) segs.size(); ctx->n_slots = nslots;
                 TRY(dev_upload(&ctx->d_seg, segs.data(), segs.size()));
@@ -550,24 +597,33 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             const size_t n_rows_all = (size_t) ctx->n_lut + slow.size();
             std::vector<int32_t> cnt(n_rows_all + 1, 0);
             std::vector<int32_t> prow(N); std::vector<PairIdx> pidx(N);
-            size_t np = 0, sp = 0;
+            std::vector<size_t> pair0(C + 1, 0);                  // pairs (x-1, x), x = 2..T-1 (hmm.c:638-642)
             for (size_t c = 0; c < C; c++) {
-                const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-                for (int64_t x = 2; x < T; x++) {          // pairs (x-1, x), x = 2..T-1 (hmm.c:638-642)
-                    const size_t t = (size_t) (t0 + x);
-                    int64_t row;
-                    if (hb[t] != ctx->beta_star) {
-                        while (sp < slow.size() && (size_t) slow[sp] < t) sp++;
-                        row = ctx->n_lut + (int64_t) sp;
-                    } else {
-                        const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
-                        row = (int64_t) ((reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu));
-                    }
-                    pidx[np].t = slot_of[t]; pidx[np].rec = hrec[t];      // the pair's record, by slot (hf_seg.h)
-                    prow[np++] = (int32_t) row;
-                    cnt[(size_t) row]++;
-                }
+                const int64_t T = w->chunk_off[c + 1] - w->chunk_off[c];
+                pair0[c + 1] = pair0[c] + (size_t) (T > 2 ? T - 2 : 0);
             }
+            const size_t np = pair0[C];
+            int32_t* cnt_p = cnt.data();
+            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
+                for (size_t c = c0; c < c1; c++) {
+                    const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                    size_t q = pair0[c], sp = (size_t) soff[c];
+                    for (int64_t x = 2; x < T; x++) {
+                        const size_t t = (size_t) (t0 + x);
+                        int64_t row;
+                        if (hb[t] != ctx->beta_star) {
+                            while (sp < slow.size() && (size_t) slow[sp] < t) sp++;
+                            row = ctx->n_lut + (int64_t) sp;
+                        } else {
+                            const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
+                            row = (int64_t) ((reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu));
+                        }
+                        pidx[q].t = slot_of[t]; pidx[q].rec = hrec[t];        // the pair's record, by slot (hf_seg.h)
+                        prow[q++] = (int32_t) row;
+                        __atomic_fetch_add(cnt_p + row, 1, __ATOMIC_RELAXED);
+                    }
+                }
+            });
             prow.resize(np); pidx.resize(np);
             // a plan is padded to 64 slots per group: when most pairs sit in rows of their own (reads longer than the contigs:
             // every window is a contig-end window) it would cost 64 slots per window — then the per-chunk statistics stay
@@ -772,6 +828,7 @@ static int pack_params(hf_ctx* ctx, const hf_params* p) {
 static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t st) {
     HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
     for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
+    ctx->prof_now = ctx->prof_stride <= 1 || (ctx->prof_pass++ % ctx->prof_stride) == 0;
     ctx->pass_rows = false;
     ctx->pass_seg = false;
     if (ctx->C == 0) HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
@@ -1300,6 +1357,12 @@ int hf_set_profiling(hf_ctx* ctx, unsigned kernel_mask) {
     if (kernel_mask && !ctx->kev[0]) for (int i = 0; i < 2 * HF_NKERNELS; i++) HIPCHK(hipEventCreate(&ctx->kev[i]));
     ctx->prof_mask = kernel_mask & (((1u << HF_NKERNELS) - 1u) | HF_PROF_PASS);
     for (int i = 0; i < HF_NKERNELS; i++) { ctx->kran[i] = false; ctx->ksum[i] = 0.0; ctx->kcount[i] = 0; }
+    return HF_OK;
+}
+
+int hf_set_profiling_stride(hf_ctx* ctx, int every_nth_pass) {
+    if (!ctx || every_nth_pass < 1) return set_err(HF_E_ARG, "hf_set_profiling_stride: bad argument");
+    ctx->prof_stride = every_nth_pass; ctx->prof_pass = 0;
     return HF_OK;
 }
 

@@ -348,6 +348,10 @@ class EMList:
                 mask |= 1 << names.index(k)
         N.check(self._L.hf_set_profiling(self._h, mask), "hf_set_profiling")
 
+    def set_profiling_stride(self, every_nth_pass: int) -> None:
+        """Bracket the selected kernels in every n-th pass only (hf_set_profiling_stride)."""
+        N.check(self._L.hf_set_profiling_stride(self._h, int(every_nth_pass)), "hf_set_profiling_stride")
+
     def kernel_times(self) -> dict:
         """Duration (ms) of each selected kernel in the last pass, from HIP events on the launch stream."""
         ms = (C.c_float * N.HF_NKERNELS)()

@@ -208,6 +208,9 @@ enum { HF_K_TABLES = 0, HF_K_PROD_TILE, HF_K_CARRY, HF_K_FB_TILE, HF_K_STATS_TIL
        HF_K_EMIT_ROWS, HF_K_FWD_SEQ, HF_K_BWD_SEQ, HF_K_PAIR_SUMS, HF_K_ROW_STATS, HF_K_ROWS_TOTAL, HF_K_SEG_PROD, HF_K_SEG_FB };
 #define HF_PROF_PASS 0x80000000u   /* in kernel_mask: also bracket the whole pass (hf_last_kernel_ms) */
 int hf_set_profiling(hf_ctx *ctx, unsigned kernel_mask);
+/* Bracket the selected kernels only in every n-th pass (default 1: every pass): an event pair costs a few microseconds of
+ * a 0.2 ms pass, so a timed loop can sample the dominant kernel's duration without carrying the cost in every step. */
+int hf_set_profiling_stride(hf_ctx *ctx, int every_nth_pass);
 int hf_kernel_times(hf_ctx *ctx, float ms[HF_NKERNELS]);
 /* Sum of the durations (ms) and number of timed launches of every selected kernel over all passes finished by
  * hf_finish / hf_em_iterate since the last hf_set_profiling: one call after a timed loop instead of one per pass. */
