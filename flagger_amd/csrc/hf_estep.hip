@@ -467,7 +467,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         const size_t t = (size_t) (t0 + x);
                         if (x == 0 || hb[t] != ctx->beta_star) { mine.push_back((int64_t) t); continue; }
                         const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
-                        __atomic_store_n(seen_p + (reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu), (uint8_t) 1, __ATOMIC_RELAXED);
+                        uint8_t* cell = seen_p + (reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu);
+                        if (!__atomic_load_n(cell, __ATOMIC_RELAXED)) __atomic_store_n(cell, (uint8_t) 1, __ATOMIC_RELAXED);   // a few thousand cells, all threads: read-mostly
                     }
                     nslow[c] = (int32_t) (mine.size() - before);
                 }
@@ -603,7 +604,6 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 pair0[c + 1] = pair0[c] + (size_t) (T > 2 ? T - 2 : 0);
             }
             const size_t np = pair0[C];
-            int32_t* cnt_p = cnt.data();
             par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
                 for (size_t c = c0; c < c1; c++) {
                     const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
@@ -620,10 +620,10 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         }
                         pidx[q].t = slot_of[t]; pidx[q].rec = hrec[t];        // the pair's record, by slot (hf_seg.h)
                         prow[q++] = (int32_t) row;
-                        __atomic_fetch_add(cnt_p + row, 1, __ATOMIC_RELAXED);
                     }
                 }
             });
+            for (size_t q = 0; q < np; q++) cnt[(size_t) prow[q]]++;       // popular rows: one thread, no contended atomics
             prow.resize(np); pidx.resize(np);
             // a plan is padded to 64 slots per group: when most pairs sit in rows of their own (reads longer than the contigs:
             // every window is a contig-end window) it would cost 64 slots per window — then the per-chunk statistics stay
