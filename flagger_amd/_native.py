@@ -11,7 +11,7 @@ import os
 HF_NSTATES = 4
 HF_MAXCOMP = 16
 HF_MAXREGIONS = 64
-HF_NKERNELS = 15
+HF_NKERNELS = 16
 HF_MODEL_TRUNC_EXP_GAUSSIAN, HF_MODEL_GAUSSIAN, HF_MODEL_NEGATIVE_BINOMIAL = 0, 1, 2
 HF_MODE_FULL, HF_MODE_FORWARD_ONLY = 0, 1
 HF_ALGO_SCAN, HF_ALGO_SEQ = 0, 1

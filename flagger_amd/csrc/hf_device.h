@@ -35,13 +35,14 @@
 struct TileDesc { long long t0; int T; int base; int chunk; int slow0; };
 // per chunk, for k_carry: first tile, number of tiles, first slow row, region of the first / last window (one 32-byte load)
 struct CarryDesc { int32_t k0, nt, slow0, reg_first, reg_last, pad0, pad1, pad2; };
+#define HF_AROW_CLASSES 9   // transition classes of an interior window: the 8 validity masks, 8 = region change (first window: 9)
 // one segment of a chunk = one workgroup of the segment kernels (hf_seg.h), built once in hf_create
 struct SegDesc {
     long long t0;            // global index of the segment's first window
     int n, L;                // windows of the segment, windows per lane
     int slot0, next_slot;    // first record slot; the slot whose f half takes f of the segment's LAST window
     int slow0;               // slow-list position of the first slow window at or after t0 (hf_scan.h)
-    int chunk_slow0;         // slow-list position of the chunk's first window (its private row: start∘e)
+    int chunk_slow0;         // row of A (hf_seg.h) of the chunk's first window: start∘e
     int seg0, k, nseg;       // first segment of the chunk, this segment's position in it, segments of the chunk
     int reg_first, reg_last; // region of the chunk's first / last window
     int chunk;               // chunk index

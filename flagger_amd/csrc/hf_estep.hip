@@ -124,6 +124,10 @@ struct hf_ctx {
     // segment kernels (hf_seg.h): the forward-backward of the statistics-by-row path
     SegDesc* d_seg = nullptr; int nseg = 0; int32_t* d_chunk_seg0 = nullptr; double* d_seg_ll = nullptr; double* d_Pseg = nullptr;
     double* d_segQ = nullptr;          // [nseg][8][NL] double2: lane products, lane-minor
+    // rows of A_t = T_t∘e_t (hf_seg.h): one per (emission key, transition class) that occurs at an interior window, then one
+    // per slow window; d_arow[t] = the row of window t (bit 31: chunk-first), d_arow_src / d_arow_cls = where a row comes from
+    int32_t* d_arow = nullptr; int32_t* d_arow_src = nullptr; int32_t* d_arow_cls = nullptr; double* d_lutA = nullptr;
+    int n_arows = 0, n_combo = 0;
     double* d_scale_s = nullptr; int64_t n_slots = 0;
     std::vector<int32_t> h_slot_of, h_slot_f;   // window -> record slot of its b half / of its f half (host getters)
     bool pass_seg = false;             // the last pass ran the segment kernels (log-likelihood partials per segment)
@@ -529,10 +533,74 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
         cphase("tiles + work arrays");
         // ---- segments of the workgroup-per-segment forward-backward (hf_seg.h) and the record slot of every window ----
+        std::vector<uint32_t> hrec;
         std::vector<int32_t>& slot_of = ctx->h_slot_of;
         std::vector<int32_t>& slot_f = ctx->h_slot_f;
         if (N > 0 && C > 0 && N < (size_t) INT32_MAX / 2) {
-            constexpr int64_t NL = 64 * HF_SEG_WAVES, SMAX = NL * HF_SEG_LMAX;
+            constexpr int64_t NL = 64 * HF_SEG_WAVES;
+            static_assert(HF_SEG_SPLIT <= 64 * HF_SEG_WAVES * HF_SEG_LMAX, "a segment has at most HF_SEG_LMAX windows per lane");
+            // (cutting small inputs finer than this was tried: more, shorter workgroups are slower — the scans are a fixed cost)
+            constexpr int64_t SMAX = HF_SEG_SPLIT;
+            // ---- rows of A = T∘e: the (key, transition class) pairs that occur, then the slow windows ----
+            hrec.resize(N);
+            if (hipMemcpy(hrec.data(), ctx->d_rec, N * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                hf_destroy(ctx); return set_err(HF_E_HIP, "record download failed");
+            }
+            {
+                constexpr int NC = HF_AROW_CLASSES;
+                auto cls_of = [](uint32_t r) { return REC_REGCHG(r) ? 8 : (int) REC_VMASK(r); };
+                std::vector<int32_t> combo_id((size_t) ctx->n_lut * NC, 0);
+                int32_t* cid = combo_id.data();
+                auto key_of = [&](size_t t) {
+                    const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
+                    return (reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu);
+                };
+                par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
+                    for (size_t c = c0; c < c1; c++) {
+                        const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                        for (int64_t x = 1; x < T; x++) {
+                            const size_t t = (size_t) (t0 + x);
+                            if (hb[t] != ctx->beta_star) continue;
+                            int32_t* cell = cid + key_of(t) * NC + cls_of(hrec[t]);
+                            if (!__atomic_load_n(cell, __ATOMIC_RELAXED)) __atomic_store_n(cell, 1, __ATOMIC_RELAXED);
+                        }
+                    }
+                });
+                std::vector<int32_t> a_src, a_cls;
+                for (size_t k = 0; k < combo_id.size(); k++)
+                    if (combo_id[k]) {
+                        combo_id[k] = (int32_t) a_src.size() + 1;            // id + 1
+                        a_src.push_back((int32_t) (k / NC));
+                        a_cls.push_back((int32_t) (k % NC) | (int32_t) ((k / NC / MM) << 8));
+                    }
+                const int32_t n_combo = (int32_t) a_src.size();
+                a_src.resize((size_t) n_combo + slow.size()); a_cls.resize((size_t) n_combo + slow.size());
+                std::vector<int32_t> arow(N);
+                par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
+                    for (size_t c = c0; c < c1; c++) {
+                        const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                        int32_t sp = soff[c];
+                        for (int64_t x = 0; x < T; x++) {
+                            const size_t t = (size_t) (t0 + x);
+                            const uint32_t r = hrec[t];
+                            if (x == 0 || hb[t] != ctx->beta_star) {
+                                const size_t id = (size_t) n_combo + (size_t) sp;
+                                a_src[id] = (int32_t) (ctx->n_lut + sp);
+                                a_cls[id] = (x == 0 ? 9 : cls_of(r)) | (int32_t) (REC_REGION(r) << 8);
+                                arow[t] = (int32_t) id | (x == 0 ? (int32_t) 0x80000000 : 0);
+                                sp++;
+                            } else arow[t] = cid[key_of(t) * NC + cls_of(r)] - 1;
+                        }
+                    }
+                });
+                ctx->n_combo = n_combo; ctx->n_arows = (int) a_src.size();
+                TRY(dev_upload(&ctx->d_arow, arow.data(), arow.size()));
+                TRY(dev_upload(&ctx->d_arow_src, a_src.data(), a_src.size()));
+                TRY(dev_upload(&ctx->d_arow_cls, a_cls.data(), a_cls.size()));
+                DMALLOC(ctx->d_lutA, (a_src.size() + 1) * 16 * 8);
+                if (ctrace) std::fprintf(stderr, "[hf_create] %d emission keys, %d (key, transition class) rows, %d slow windows\n",
+                                         ctx->n_keys, n_combo, ctx->n_slow);
+            }
             std::vector<SegDesc> segs;
             std::vector<int32_t> cseg0(C + 1, 0);
             slot_of.assign(N, 0); slot_f.assign(N, 0);
@@ -550,7 +618,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     d.t0 = t0 + w0; d.n = (int) n; d.L = (int) ((n + NL - 1) / NL);
                     d.slot0 = (int32_t) nslots; nslots += (int64_t) d.L * NL;
                     d.slow0 = (int32_t) (std::lower_bound(slow.begin(), slow.end(), (int64_t) d.t0) - slow.begin());
-                    d.chunk_slow0 = soff[c];
+                    d.chunk_slow0 = ctx->n_combo + soff[c];               // the A row of the chunk's first window
                     d.seg0 = first; d.k = (int) k; d.chunk = (int) c;
                     d.reg_first = (int32_t) ((w->annot[t0] & 0xFC00000000000000ULL) >> 58);
                     d.reg_last = (int32_t) ((w->annot[t0 + T - 1] & 0xFC00000000000000ULL) >> 58);
@@ -591,10 +659,6 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         }
         // ---- plan of the statistics by emission row (hf_rows.h) ----
         if (N > 0 && C > 0 && ctx->nseg > 0) {
-            std::vector<uint32_t> hrec(N);
-            if (hipMemcpy(hrec.data(), ctx->d_rec, N * 4, hipMemcpyDeviceToHost) != hipSuccess) {
-                hf_destroy(ctx); return set_err(HF_E_HIP, "record download failed");
-            }
             const size_t n_rows_all = (size_t) ctx->n_lut + slow.size();
             std::vector<int32_t> cnt(n_rows_all + 1, 0);
             std::vector<int32_t> prow(N); std::vector<PairIdx> pidx(N);
@@ -744,6 +808,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_carry_desc);
     hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
     hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_scale_s);
+    hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats); hipFree(ctx->d_Pt);
     hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
     if (ctx->h_params) hipHostFree(ctx->h_params);
@@ -857,15 +922,19 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         }
         {   // also clears the flag word: first kernel of every pass
             KTimer t(ctx, st, HF_K_TABLES);
-            const int jobs = ctx->n_keys + ctx->n_slow;
+            // statistics by emission row: the job list of the Gaussian tables is the (key, class) list of the rows of A (hf_seg.h)
+            const bool arows = !nbm && ctx->algo != HF_ALGO_SEQ && ctx->ntiles > 0 && rows_pass(ctx);
+            const int nk = arows ? ctx->n_combo : ctx->n_keys;
+            const int32_t* kl = arows ? ctx->d_arow_src : ctx->d_keys;
+            const int jobs = nk + ctx->n_slow;
             if (nbm)
                 hipLaunchKernelGGL(k_tables_nb, dim3((unsigned) (jobs / 256 + 1)), dim3(256), 0, st, ctx->n_keys, ctx->d_keys, ctx->n_slow,
                                    ctx->d_slow_w, ctx->d_rec, ctx->M, ctx->d_nbE, ctx->d_lutE, ctx->d_Es, ctx->d_flags);
             else
             {
-#define HF_LAUNCH_TABLES(J) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables<J>), dim3((unsigned) ((jobs + J - 1) / J + (jobs == 0))), dim3(256), 0, st, ctx->n_keys, \
-                               ctx->d_keys, ctx->n_slow, ctx->d_slow_w, ctx->d_rec, ctx->d_beta, ctx->M, ctx->K, ctx->d_params, ctx->d_lutE, ctx->d_lutC, \
-                               ctx->d_Es, ctx->d_Cs, ctx->d_flags)
+#define HF_LAUNCH_TABLES(J) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables<J>), dim3((unsigned) ((jobs + J - 1) / J + (jobs == 0))), dim3(256), 0, st, nk, \
+                               kl, ctx->n_slow, ctx->d_slow_w, ctx->d_rec, ctx->d_beta, ctx->M, ctx->K, ctx->d_params, ctx->d_lutE, ctx->d_lutC, \
+                               ctx->d_Es, ctx->d_Cs, ctx->d_flags, arows ? ctx->d_arow_cls : (const int32_t*) nullptr, arows ? ctx->d_lutA : (double*) nullptr)
                 if (jobs < 64 * 1024) HF_LAUNCH_TABLES(HF_TABLE_JOBS_SMALL); else HF_LAUNCH_TABLES(HF_TABLE_JOBS_LARGE);
 #undef HF_LAUNCH_TABLES
             }
@@ -890,25 +959,24 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
             } else if (rows_pass(ctx)) {
                 // statistics by emission row: one workgroup per chunk segment does the whole forward-backward (hf_seg.h)
                 constexpr int NW = HF_SEG_WAVES;
-                const size_t lds = seg_lds_bytes<NW>(ctx->R);
-                if (lds > ctx->lds_max) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
-                if (lds > 64 * 1024) {
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_prod<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<NW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-                    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<NW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+                const size_t lds = seg_lds_bytes<NW>();
+                if (nbm) {   // k_tables_nb leaves the emission rows; the Gaussian k_tables writes the rows of A itself
+                    KTimer t(ctx, st, HF_K_AROWS);
+                    hipLaunchKernelGGL(k_arows, dim3((unsigned) (((int64_t) ctx->n_arows * 16 + 255) / 256)), dim3(256), 0, st, ctx->n_arows,
+                                       ctx->d_arow_src, ctx->d_arow_cls, ctx->d_lutE, ctx->d_params, ctx->d_lutA);
                 }
                 {
                     KTimer t(ctx, st, HF_K_SEG_PROD);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_prod<NW>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_rec, S,
-                                       ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_flags);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_prod<NW>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_arow,
+                                       ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
                 }
                 KTimer t(ctx, st, HF_K_SEG_FB);
                 if (full)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, true>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_rec,
-                                       S, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, true>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_arow,
+                                       ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
                 else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, false>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_rec,
-                                       S, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, false>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_arow,
+                                       ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
                 ctx->pass_seg = true;
                 if (full) ctx->fb_recs = true;
             } else {
@@ -1384,7 +1452,7 @@ int hf_kernel_times(hf_ctx* ctx, float ms[HF_NKERNELS]) {
 const char* hf_kernel_name(int k) {
     static const char* names[HF_NKERNELS] = {"k_tables", "k_prod_tile", "k_carry", "k_fb_tile", "k_stats_tile", "k_chunk_stats",
                                              "k_reduce", "k_emit_rows", "k_fwd_seq", "k_bwd_seq", "k_pair_sums", "k_row_stats",
-                                             "k_rows_total", "k_seg_prod", "k_seg_fb"};
+                                             "k_rows_total", "k_seg_prod", "k_seg_fb", "k_arows"};
     return k >= 0 && k < HF_NKERNELS ? names[k] : "?";
 }
 

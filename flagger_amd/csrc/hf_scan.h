@@ -217,14 +217,18 @@ __device__ __forceinline__ uint32_t load_recs(const uint32_t* __restrict__ rec, 
 // rows per block: few when there are few rows (more blocks than CUs: the kernel is then latency-bound), many otherwise
 #define HF_TABLE_JOBS_SMALL 8
 #define HF_TABLE_JOBS_LARGE 32
-struct TableJob { double x, px, bt; int64_t row; int32_t r; int32_t flags; };   // flags: 1 star (table key), 2 first, 4 active; row: index of the row in lutE / lutC units
+// flags: 1 star (table key), 2 first, 4 active; bits 8..: transition class of the job's row of A (hf_seg.h); row: index of the row in lutE / lutC units
+struct TableJob { double x, px, bt; int64_t row; int32_t r; int32_t flags; };
 template <int HF_TABLE_JOBS_PER_BLOCK>
 __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __restrict__ keys, int n_slow,
                                                 const int64_t* __restrict__ slow_w, const uint32_t* __restrict__ rec,
                                                 const double* __restrict__ beta, int M, int K,
                                                 const DevParams* __restrict__ P, double* __restrict__ lutE,
                                                 double* __restrict__ lutC, double* __restrict__ Es,
-                                                double* __restrict__ Cs, unsigned* __restrict__ flags) {
+                                                double* __restrict__ Cs, unsigned* __restrict__ flags,
+                                                const int32_t* __restrict__ cls, double* __restrict__ lutA) {
+    // cls / lutA (statistics by emission row, hf_seg.h): job j also writes row j of A = (transition table of class cls[j]) ∘ E;
+    // `keys` is then the list of the (key, class) pairs that occur — a key with two classes is evaluated twice (same values)
     __shared__ TableJob s_job[HF_TABLE_JOBS_PER_BLOCK];
     __shared__ double s_val[HF_TABLE_JOBS_PER_BLOCK][HF_TABLE_MAX_ITEMS];
     __shared__ int s_base[16];
@@ -244,6 +248,7 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
             const int64_t MM = (int64_t) M * M;
             const int64_t idx = key % MM;
             J.r = (int) (key / MM); J.x = (double) (idx / M); J.px = (double) (idx % M); J.row = key; J.flags = 1 | 4;
+            if (cls) J.flags |= (cls[job] & 0xff) << 8;
         } else if (job - n_keys < n_slow) {
             const int k = job - n_keys;
             const int64_t t = slow_w[k];
@@ -251,6 +256,7 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
             const bool first = REC_FIRST(rw) != 0;
             J.r = (int) REC_REGION(rw); J.x = (double) REC_X(rw); J.px = first ? 0.0 : (double) REC_X(rec[t - 1]);
             J.bt = beta[t]; J.row = (int64_t) n_lut_rows + k; J.flags = (first ? 2 : 0) | 4;
+            if (cls) J.flags |= (cls[job] & 0xff) << 8;
         }
         s_job[tid] = J;
     }
@@ -295,6 +301,12 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
             }
             if (first && pre != 0) e = 0.0;
             lutE[J.row * 16 + HF_PS(pre, s)] = e;
+            if (lutA) {
+                const int k = J.flags >> 8;
+                const DevRegion* __restrict__ R = &P->reg[J.r];
+                const double t = k == 9 ? R->trans[4][s] : (k == 8 ? 1.0 / (HF_NSTATES + 1) : R->tcond[k][pre * 4 + s]);
+                lutA[(int64_t) (job0 + jl) * 16 + HF_PS(pre, s)] = t * e;
+            }
         } else {   // component probabilities per PREVIOUS STATE (the value of its alpha): no select in the consumer
             const int q = o - 16, c = q >> 2, pre = q & 3;
             const int u = first ? 0 : P->umap[pre * 4 + 3];

@@ -36,6 +36,9 @@
 #ifndef HF_SEG_LMAX
 #define HF_SEG_LMAX 8       // windows per lane at most: a chunk longer than 64*HF_SEG_WAVES*HF_SEG_LMAX windows is split
 #endif
+#ifndef HF_SEG_SPLIT
+#define HF_SEG_SPLIT (64 * HF_SEG_WAVES * HF_SEG_LMAX)   // windows per segment a chunk is cut by (equal parts of at most this)
+#endif
 #ifndef HF_SEG_OCC
 #define HF_SEG_OCC 4        // wavefronts per SIMD the register allocation aims at
 #endif
@@ -200,97 +203,88 @@ __device__ __forceinline__ int posterior_label_fast(const double f[4], const dou
     return idx;
 }
 
-// slow-list position of the lane's first slow window: seg.slow0 + the slow windows of the segment before window a.
-// Wave scan of the per-lane counts, wave totals through LDS (one block barrier).
-template <int NW>
-__device__ __forceinline__ int seg_slow_base(const uint32_t* __restrict__ rec_seg, int a, int m, int slow0, int wave, int lane,
-                                             int* __restrict__ s_cnt) {
-    int cnt = 0;
-    for (int i = 0; i < m; i++) cnt += (int) REC_SLOW(rec_seg[a + i]);
-    int inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d); if (lane >= d) inc += v; }
-    if (lane == 63) s_cnt[wave] = inc;
-    __syncthreads();
-    int before = slow0;
-    for (int w = 0; w < wave; w++) before += s_cnt[w];
-    return before + inc - cnt;
+// ------------------------------------------------------------------------------------------
+// Rows of A_t = T_t∘e_t.  The transition factor of a window depends on its region, its validity mask (3 bits), a region
+// change and chunk-first-ness only (hmm_utils.c:2278-2292, hmm.c:398-400, 333-364) — iteration-invariant CLASSES; together
+// with the emission key (region, x, x_prev) of hf_scan.h that makes a few thousand distinct 4x4 matrices per pass.
+// They are multiplied out once per pass (row = class table ∘ emission row of this iteration's tables; one row per
+// (key, class) that occurs at an interior window, one per slow window: by k_tables itself, hf_scan.h, or — after
+// k_tables_nb — by k_arows), and the segment kernels fetch ONE 128-byte row per window and step: no transition-table lookup, no second factor, no region tables in LDS, and the row of a window is a
+// precomputed index (hf_create: d_arow, bit 31 = chunk-first) instead of a function of two records and a slow-list rank.
+// The product f·(T·e) differs from the reference's (f·T)·e in the last bit of a term; the segment kernels never were
+// bit-identical to a sequential run (the carried-in vectors differ in the last bit already).
+// A NaN in a row (hmm_utils.c:783-786) reaches the scale of the window that uses it: k_seg_fb raises HF_FLAG_NAN there.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_arows(int n_rows, const int32_t* __restrict__ src, const int32_t* __restrict__ cls,
+                                               const double* __restrict__ lutE, const DevParams* __restrict__ P,
+                                               double* __restrict__ lutA) {
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int id = (int) (i >> 4), o = (int) (i & 15);          // o = s*4 + pre (state-major, HF_PS)
+    if (id >= n_rows) return;
+    const int c = cls[id], k = c & 0xff, pre = o & 3, st = o >> 2;
+    const DevRegion* __restrict__ R = &P->reg[c >> 8];
+    const double t = k == 9 ? R->trans[4][st] : (k == 8 ? 1.0 / (HF_NSTATES + 1) : R->tcond[k][pre * 4 + st]);
+    lutA[(int64_t) id * 16 + o] = t * lutE[(int64_t) src[id] * 16 + o];
 }
 
-// the lane's product of A_t over its m windows (chunk-first windows excluded, as in the start vector); every row the pass
-// uses goes through here: a NaN row raises HF_FLAG_NAN (hmm_utils.c:783-786).  All 64 lanes run all L steps (the row
-// fetch is cooperative); lanes past their last window fetch row 0 and skip the arithmetic.
-__device__ __forceinline__ void seg_lane_product(const uint32_t* __restrict__ rec_seg, uint32_t rp, int a, int m, int L, int sidx,
-                                                 const RowSrc& S, const double* __restrict__ s_tab, double* __restrict__ blk, int lane,
-                                                 M4& Q, unsigned& nan) {
+#define HF_AROW_ID(r) ((r) & 0x7fffffff)
+
+// the lane's product of A_t over its m windows (a chunk-first window is left out: it belongs to the start vector).  All 64
+// lanes run all L steps (the row fetch is cooperative); lanes past their last window fetch row 0 and skip the arithmetic.
+__device__ __forceinline__ void seg_lane_product(const int32_t* __restrict__ arow_seg, int a, int m, int L,
+                                                 const double* __restrict__ lutA, double* __restrict__ blk, int lane, M4& Q) {
     m4_identity(Q);
-    uint32_t r = m > 0 ? rec_seg[a] : 0u;
-    uint32_t r1 = m > 1 ? rec_seg[a + 1] : 0u;            // records are fetched two steps ahead
-    rows_issue(S.lutE, m > 0 ? row_index(S, r, rp, sidx) : 0, lane, blk);
+    int32_t r = m > 0 ? arow_seg[a] : 0;
+    int32_t r1 = m > 1 ? arow_seg[a + 1] : 0;              // row indices are fetched two steps ahead
+    rows_issue(lutA, HF_AROW_ID(r), lane, blk);
 #pragma unroll 1
     for (int i = 0; i < L; i++) {
         double E[16];
         rows_read(blk, lane, E);
-        const int sn = sidx + (int) REC_SLOW(r);
-        const uint32_t rn = r1;
-        if (i + 1 < L) rows_issue(S.lutE, i + 1 < m ? row_index(S, rn, r, sn) : 0, lane, blk);   // in flight during this step
-        r1 = i + 2 < m ? rec_seg[a + i + 2] : 0u;
-        if (i < m) {
-            if (row_has_nan(E)) nan |= HF_FLAG_NAN;
-            if (!REC_FIRST(r)) {
-                double Tm[16];
-                lds_Tm(s_tab, r, Tm);
-                M4 A, R;
+        const int32_t rn = r1;
+        if (i + 1 < L) rows_issue(lutA, HF_AROW_ID(rn), lane, blk);   // in flight during this step
+        r1 = i + 2 < m ? arow_seg[a + i + 2] : 0;
+        if (i < m && r >= 0) {
+            M4 A, R;
 #pragma unroll
-                for (int k = 0; k < 16; k++) A.m[k] = Tm[HF_PS(k >> 2, k & 3)] * E[HF_PS(k >> 2, k & 3)];
-                m4_mul(R, Q, A);
-                Q = R;
-                m4_renorm_tree(Q);
-            }
+            for (int k = 0; k < 16; k++) A.m[k] = E[HF_PS(k >> 2, k & 3)];
+            m4_mul(R, Q, A);
+            Q = R;
+            m4_renorm_tree(Q);
         }
-        r = rn; sidx = sn;
+        r = rn;
     }
 }
 
-// bytes of dynamic LDS of the segment kernels: transition tables | wave totals | ll partials | slow counts | labels | row blocks
+// bytes of dynamic LDS of the segment kernels: wave totals | ll partials (+ padding) | labels | row blocks
 template <int NW>
-__host__ __device__ constexpr size_t seg_lds_bytes(int n_regions) {
-    return (size_t) n_regions * HF_TAB_STRIDE * 8 + (NW * 16 + 2 * NW) * 8 + (size_t) 64 * NW * HF_SEG_LMAX + (size_t) NW * 8192;
+__host__ __device__ constexpr size_t seg_lds_bytes() {
+    return (NW * 16 + 2 * NW) * 8 + (size_t) 64 * NW * HF_SEG_LMAX + (size_t) NW * 8192;
 }
 
 // ------------------------------------------------------------------------------------------
 // k_seg_prod: phase A for every segment: the lane products (lane-minor: 1 KiB per store instruction; k_seg_fb's scans start
-// from them) and the product of the whole segment (used by the chunk's OTHER segments only).  Every row a pass uses goes
-// through here once: this is where a NaN row raises HF_E_NAN.
+// from them) and the product of the whole segment (used by the chunk's OTHER segments only).
 // ------------------------------------------------------------------------------------------
 template <int NW>
-__global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_prod(const SegDesc* __restrict__ sd, const uint32_t* __restrict__ rec,
-                                                                   const RowSrc S, const DevParams* __restrict__ P,
-                                                                   double* __restrict__ Qs, double* __restrict__ Pseg,
-                                                                   unsigned* __restrict__ flags) {
+__global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_prod(const SegDesc* __restrict__ sd, const int32_t* __restrict__ arow,
+                                                                   const double* __restrict__ lutA,
+                                                                   double* __restrict__ Qs, double* __restrict__ Pseg) {
     constexpr int NL = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    fill_tab(P, s_tab);
-    double* __restrict__ s_W = s_tab + P->n_regions * HF_TAB_STRIDE;
-    int* __restrict__ s_cnt = reinterpret_cast<int*>(s_W + NW * 16 + NW);
+    extern __shared__ __attribute__((aligned(16))) double s_W[];
     const int g = blockIdx.x;
     const SegDesc d = sd[g];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = wave * 64 + lane;
     double* __restrict__ blk = s_W + NW * 16 + 2 * NW + (64 * NW * HF_SEG_LMAX) / 8 + wave * 1024;
     const int a = j * d.L;
     const int m = d.n - a < d.L ? (d.n - a > 0 ? d.n - a : 0) : d.L;
-    const uint32_t* __restrict__ rec_seg = rec + d.t0;
-    const int sidx = seg_slow_base<NW>(rec_seg, a, m, d.slow0, wave, lane, s_cnt);
-    const uint32_t rp = (m > 0 && !(a == 0 && d.k == 0)) ? rec_seg[a - 1] : 0u;
     M4 Q;
-    unsigned nan = 0;
-        seg_lane_product(rec_seg, rp, a, m, d.L, sidx, S, s_tab, blk, lane, Q, nan);
+    seg_lane_product(arow + d.t0, a, m, d.L, lutA, blk, lane, Q);
     {
         double2* __restrict__ dst = reinterpret_cast<double2*>(Qs) + (int64_t) g * 8 * NL + j;
 #pragma unroll
         for (int k = 0; k < 8; k++) dst[k * NL] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
     }
-    if (nan) atomicOr(flags, nan);
     if (d.nseg == 1) return;                                  // nobody reads the product of a one-segment chunk
     m4_scan_prefix(Q, lane);                                  // lane 63: the product of the wavefront
     if (lane == 63) {
@@ -320,18 +314,15 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_prod(const SegDesc*
 // hmm.c:790-816): log-likelihood and error flags, nothing else is written.
 // ------------------------------------------------------------------------------------------
 template <int NW, bool BWD>
-__global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* __restrict__ sd, const uint32_t* __restrict__ rec,
-                                                                 const RowSrc S, const DevParams* __restrict__ P,
+__global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* __restrict__ sd, const int32_t* __restrict__ arow,
+                                                                 const double* __restrict__ lutA, const DevParams* __restrict__ P,
                                                                  const double* __restrict__ Qs, const double* __restrict__ Pseg,
                                                                  double* __restrict__ recs,
                                                                  double* __restrict__ scale_s, int8_t* __restrict__ label,
                                                                  double* __restrict__ seg_ll, unsigned* __restrict__ flags) {
     constexpr int NL = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    fill_tab(P, s_tab);
-    double* __restrict__ s_W = s_tab + P->n_regions * HF_TAB_STRIDE;      // [NW][16] wave totals
-    double* __restrict__ s_red = s_W + NW * 16;                           // [NW] log-likelihood partials
-    int* __restrict__ s_cnt = reinterpret_cast<int*>(s_red + NW);         // [NW] (+ padding to NW doubles)
+    extern __shared__ __attribute__((aligned(16))) double s_W[];           // [NW][16] wave totals
+    double* __restrict__ s_red = s_W + NW * 16;                           // [NW] log-likelihood partials (+ NW of padding)
     int8_t* __restrict__ s_lab = reinterpret_cast<int8_t*>(s_red + 2 * NW);   // [NL * LMAX] labels of the segment
     const int g = blockIdx.x;
     const SegDesc d = sd[g];
@@ -340,10 +331,8 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* _
     const int L = d.L, n = d.n;
     const int a = j * L;
     const int m = n - a < L ? (n - a > 0 ? n - a : 0) : L;
-    const uint32_t* __restrict__ rec_seg = rec + d.t0;
-    const int sidx0 = seg_slow_base<NW>(rec_seg, a, m, d.slow0, wave, lane, s_cnt);
+    const int32_t* __restrict__ arow_seg = arow + d.t0;
     const bool chunk_first = a == 0 && d.k == 0;                           // this lane's first window starts the chunk
-    const uint32_t rp0 = (m > 0 && !chunk_first) ? rec_seg[a - 1] : 0u;
     unsigned bad = 0;
     double fin[4], bdir[4];
     {
@@ -365,15 +354,14 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* _
 #pragma unroll
         for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);
         __syncthreads();
-        // forward vector entering the segment: start∘e of the chunk's first window (its row is the chunk's first entry of
-        // the slow list), through the products of the chunk's earlier segments and of the earlier wavefronts
+        // forward vector entering the segment: start∘e of the chunk's first window (row (0, s) of its row of A), through the
+        // products of the chunk's earlier segments and of the earlier wavefronts
         double v[4];
         {
-            const DevRegion* __restrict__ R = &P->reg[d.reg_first];
-            const double* __restrict__ E0 = S.Es + (int64_t) d.chunk_slow0 * 16;
+            const double* __restrict__ A0 = lutA + (int64_t) d.chunk_slow0 * 16;
             double sv = 0.0;
 #pragma unroll
-            for (int s = 0; s < 4; s++) { v[s] = E0[HF_PS(0, s)] * R->trans[4][s]; sv += v[s]; }
+            for (int s = 0; s < 4; s++) { v[s] = A0[HF_PS(0, s)]; sv += v[s]; }
 #pragma unroll
             for (int s = 0; s < 4; s++) v[s] /= sv;
         }
@@ -410,8 +398,6 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* _
     // exponents)·ln 2 — one log per lane instead of one (~95 instructions) per window; <= HF_SEG_LMAX mantissas in [0.5, 1)
     double lm = 1.0, scl = 1.0;
     int le = 0;
-    uint32_t r_last = 0, r_before_last = rp0;
-    int sidx_last = sidx0;
     const int64_t slot_ij = (int64_t) d.slot0 + j;                         // + i*NL
     // The outputs of step i (scale, f) are STORED at the top of step i+1, after the wait for that step's rows: a store issued
     // right before the wait would make every step pay the full store latency (vmcnt counts loads and stores alike).
@@ -424,39 +410,35 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* _
         dst[0] = make_double2(f[0], f[1]); dst[1] = make_double2(f[2], f[3]);
     };
     {
-        uint32_t r = m > 0 ? rec_seg[a] : 0u, rp = rp0;
-        uint32_t r1 = m > 1 ? rec_seg[a + 1] : 0u;                         // records are fetched two steps ahead
-        int sidx = sidx0;
-        rows_issue(S.lutE, m > 0 ? row_index(S, r, rp, sidx) : 0, lane, blk);
+        int32_t r = m > 0 ? arow_seg[a] : 0;
+        int32_t r1 = m > 1 ? arow_seg[a + 1] : 0;                          // row indices are fetched two steps ahead
+        rows_issue(lutA, HF_AROW_ID(r), lane, blk);
 #pragma unroll 1
         for (int i = 0; i < L; i++) {
-            double E[16];
-            rows_read(blk, lane, E);
+            double A[16];
+            rows_read(blk, lane, A);
             if (BWD && i >= 1 && i - 1 < m) store_fwd(i - 1);
-            const int sn = sidx + (int) REC_SLOW(r);
-            const uint32_t rn = r1;
-            if (i + 1 < L) rows_issue(S.lutE, i + 1 < m ? row_index(S, rn, r, sn) : 0, lane, blk);
-            r1 = i + 2 < m ? rec_seg[a + i + 2] : 0u;
+            const int32_t rn = r1;
+            if (i + 1 < L) rows_issue(lutA, HF_AROW_ID(rn), lane, blk);
+            r1 = i + 2 < m ? arow_seg[a + i + 2] : 0;
             if (i < m) {
-                double Tm[16];
-                lds_Tm(s_tab, r, Tm);
-                double nf[4], sc = 0.0;
+                double nf[4];
 #pragma unroll
-                for (int s = 0; s < 4; s++) {                              // 0.0 + x == x: the sums start from their first term
-                    double acc = f[0] * Tm[HF_PS(0, s)] * E[HF_PS(0, s)];
+                for (int s = 0; s < 4; s++) {
+                    double acc = f[0] * A[HF_PS(0, s)];
 #pragma unroll
-                    for (int p = 1; p < 4; p++) acc += (f[p] * Tm[HF_PS(p, s)] * E[HF_PS(p, s)]);
+                    for (int p = 1; p < 4; p++) acc = fma(f[p], A[HF_PS(p, s)], acc);
                     nf[s] = acc;
-                    sc = s == 0 ? acc : sc + acc;
                 }
-                if (!REC_FIRST(r) && sc < 1e-50) bad |= HF_FLAG_SCALE;    // hmm.c:412-415
+                const double sc = ((nf[0] + nf[1]) + nf[2]) + nf[3];
+                if (r >= 0 && sc < 1e-50) bad |= HF_FLAG_SCALE;           // hmm.c:412-415 (not at the chunk's first window)
+                if (!(sc == sc)) bad |= HF_FLAG_NAN;                      // a NaN emission value (hmm_utils.c:783-786)
 #pragma unroll
                 for (int s = 0; s < 4; s++) f[s] = nf[s] / sc;
                 { int e2; lm *= frexp(sc, &e2); le += e2; }                // hmm.c:428, see above
                 scl = sc;
-                r_last = r; sidx_last = sidx; r_before_last = rp;
             }
-            rp = r; r = rn; sidx = sn;
+            r = rn;
         }
         if (BWD && L - 1 < m) store_fwd(L - 1);
     }
@@ -488,10 +470,10 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* _
             double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + (slot_ij + (int64_t) k * NL) * 4 + 2;
             dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
         };
-        // window k's row and transition table turn b_k into b_{k-1}; all lanes run k = L-1 .. 1 (cooperative fetch)
-        uint32_t rk = r_last, rkm1 = r_before_last;
-        int sk = sidx_last;
-        rows_issue(S.lutE, (jl >= 1 && jl == L - 1) ? row_index(S, rk, rkm1, sk) : 0, lane, blk);
+        // window k's row turns b_k into b_{k-1}; all lanes run k = L-1 .. 1 (cooperative fetch), a lane joins at its last window
+        auto row_of = [&](int k) { return (k >= 1 && k <= jl) ? HF_AROW_ID(arow_seg[a + k]) : 0; };
+        int32_t rkm1 = row_of(L - 2);                           // the row of the NEXT step, fetched one step ahead
+        rows_issue(lutA, row_of(L - 1), lane, blk);
         double nsc = 1.0;
         double2 nf01 = make_double2(0.0, 0.0), nf23 = nf01;
         if (jl >= 1 && jl == L - 1) {
@@ -501,26 +483,15 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* _
         }
 #pragma unroll 1
         for (int k = L - 1; k >= 1; k--) {
-            double E[16];
-            rows_read(blk, lane, E);
+            double A[16];
+            rows_read(blk, lane, A);
             const bool act = k <= jl;                           // this lane has a window k
             if (act) store_bwd(k);
             const double sc = nsc;
             const double2 f01 = nf01, f23 = nf23;
-            // the next step's row: window k-1 of the lane (needs the record before it) — or, for a lane whose last window
-            // IS k-1, its own first row of the backward pass
-            uint32_t rkm2 = 0;
-            int skm1 = sk;
             if (k >= 2) {
-                int32_t nidx = 0;
-                if (act) {
-                    skm1 = sk - (int) REC_SLOW(rkm1);
-                    rkm2 = rec_seg[a + k - 2];
-                    nidx = row_index(S, rkm1, rkm2, skm1);
-                } else if (k - 1 == jl && jl >= 1) {
-                    nidx = row_index(S, rk, rkm1, sk);
-                }
-                rows_issue(S.lutE, nidx, lane, blk);
+                rows_issue(lutA, rkm1, lane, blk);
+                rkm1 = row_of(k - 2);
                 if (k - 1 <= jl) {                              // scale and f of step k-1, in flight during this step
                     nsc = scale_s[slot_ij + (int64_t) (k - 2) * NL];
                     const double2* __restrict__ fsrc = reinterpret_cast<const double2*>(recs) + (slot_ij + (int64_t) (k - 1) * NL) * 4;
@@ -528,22 +499,19 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* _
                 }
             }
             if (act) {
-                double Tm[16];
-                lds_Tm(s_tab, rk, Tm);
                 double nb[4];
 #pragma unroll
-                for (int s = 0; s < 4; s++)
+                for (int p = 0; p < 4; p++) {
+                    double acc = A[HF_PS(p, 0)] * b[0];
 #pragma unroll
-                    for (int p = 0; p < 4; p++) {
-                        const double term = Tm[HF_PS(p, s)] * E[HF_PS(p, s)] * b[s];
-                        nb[p] = s == 0 ? term : nb[p] + term;
-                    }
+                    for (int s = 1; s < 4; s++) acc = fma(A[HF_PS(p, s)], b[s], acc);
+                    nb[p] = acc;
+                }
                 if (sc < 1e-50) bad |= HF_FLAG_SCALE;                     // hmm.c:521-524
 #pragma unroll
                 for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
                 const double fi[4] = {f01.x, f01.y, f23.x, f23.y};
                 s_lab[a + k - 1] = (int8_t) posterior_label_fast(fi, b, sc);
-                rk = rkm1; rkm1 = rkm2; sk = skm1;
             }
         }
         if (jl >= 0) store_bwd(0);

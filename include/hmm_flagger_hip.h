@@ -203,9 +203,9 @@ int hf_last_kernel_ms(hf_ctx *ctx, float *ms);
  * by a pair of HIP events on the launch stream; hf_kernel_times returns the duration of each selected kernel in
  * the LAST pass in milliseconds (0 for kernels not selected or not run).  Call after hf_finish/hf_check.
  * Each selected kernel adds two event packets to the stream, so select only what is being measured. */
-#define HF_NKERNELS 15
+#define HF_NKERNELS 16
 enum { HF_K_TABLES = 0, HF_K_PROD_TILE, HF_K_CARRY, HF_K_FB_TILE, HF_K_STATS_TILE, HF_K_CHUNK_STATS, HF_K_REDUCE,
-       HF_K_EMIT_ROWS, HF_K_FWD_SEQ, HF_K_BWD_SEQ, HF_K_PAIR_SUMS, HF_K_ROW_STATS, HF_K_ROWS_TOTAL, HF_K_SEG_PROD, HF_K_SEG_FB };
+       HF_K_EMIT_ROWS, HF_K_FWD_SEQ, HF_K_BWD_SEQ, HF_K_PAIR_SUMS, HF_K_ROW_STATS, HF_K_ROWS_TOTAL, HF_K_SEG_PROD, HF_K_SEG_FB, HF_K_AROWS };
 #define HF_PROF_PASS 0x80000000u   /* in kernel_mask: also bracket the whole pass (hf_last_kernel_ms) */
 int hf_set_profiling(hf_ctx *ctx, unsigned kernel_mask);
 /* Bracket the selected kernels only in every n-th pass (default 1: every pass): an event pair costs a few microseconds of
