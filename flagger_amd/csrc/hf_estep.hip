@@ -960,6 +960,13 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 // statistics by emission row: one workgroup per chunk segment does the whole forward-backward (hf_seg.h)
                 constexpr int NW = HF_SEG_WAVES;
                 const size_t lds = seg_lds_bytes<NW>();
+                if (ctx->host_trace && !ctx->ht_n) {
+                    int o1 = 0, o2 = 0;
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_seg_prod<NW>, NW * 64, lds);
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_seg_fb<NW, true>, NW * 64, lds);
+                    std::fprintf(stderr, "[hf host trace] segment kernels: %d workgroups of %d threads, %zu B of LDS; resident per CU: k_seg_prod %d, k_seg_fb %d\n",
+                                 ctx->nseg, NW * 64, lds, o1, o2);
+                }
                 if (nbm) {   // k_tables_nb leaves the emission rows; the Gaussian k_tables writes the rows of A itself
                     KTimer t(ctx, st, HF_K_AROWS);
                     hipLaunchKernelGGL(k_arows, dim3((unsigned) (((int64_t) ctx->n_arows * 16 + 255) / 256)), dim3(256), 0, st, ctx->n_arows,

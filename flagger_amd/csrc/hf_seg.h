@@ -31,7 +31,7 @@
 #include "hf_scan.h"
 
 #ifndef HF_SEG_WAVES
-#define HF_SEG_WAVES 4      // wavefronts per workgroup
+#define HF_SEG_WAVES 1      // wavefronts per workgroup (1: the finest load balance over the CUs; measured best or equal from 0.2 M to 6 M windows)
 #endif
 #ifndef HF_SEG_LMAX
 #define HF_SEG_LMAX 8       // windows per lane at most: a chunk longer than 64*HF_SEG_WAVES*HF_SEG_LMAX windows is split
