@@ -81,10 +81,16 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events inside the timed region; the dominant kernel's duration then comes from the untimed "
                          "passes that follow — for comparing launch paths, not the default")
-    ap.add_argument("--exchange", choices=["ranks", "chunks"], default="chunks",
-                    help="multi-GPU exchange: the per-chunk vectors summed in chunk-list order (default: statistics, EM trajectory "
-                         "and BED labels identical for every number of GPUs, bit for bit), or one statistics vector per rank "
-                         "summed in rank order (statistics by emission row on every rank: faster, equal up to rounding)")
+    ap.add_argument("--exchange", choices=["ranks", "chunks"], default="ranks",
+                    help="multi-GPU exchange: one statistics vector per rank, all-gathered and summed in rank order (default: BASELINE "
+                         "north_star's single collective over the EM sufficient statistics; statistics by emission row on every rank, "
+                         "equal to a one-GPU run up to the rounding of the order), or the per-chunk vectors summed in chunk-list order "
+                         "(what `hmm_flagger --gpus N` defaults to: statistics, EM trajectory and BED labels identical for every N, "
+                         "bit for bit; slower per-chunk statistics kernels)")
+    ap.add_argument("--collective", choices=["native", "torch"], default="native",
+                    help="multi-GPU path: native = pass + RCCL all-gather + ordered reduction in ONE library call per EM pass on the "
+                         "pass's own stream (hf_multi_create_rank; torch.distributed only carries the RCCL id at start-up); "
+                         "torch = the exchange through torch.distributed.all_gather_into_tensor (flagger_amd/dist.py)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
                     help="strong: the BASELINE workload sharded over the GPUs (configs[3]); weak: one whole configs[2] genome per GPU")
     ap.add_argument("--no-weak-leg", action="store_true",
@@ -144,8 +150,17 @@ def main():
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
     algo = N.HF_ALGO_SCAN if args.algo == "scan" else N.HF_ALGO_SEQ
     torch.cuda.set_device(local_rank)
-    sharded = fdist.make_sharded_hip(store, model, rank, world, local_rank, True, 0.95, algo, exchange=args.exchange)
-    em = sharded.local.em
+    def make_sharded(st, mdl):
+        if dist_path and args.collective == "native":
+            uid = [hmm.comm_unique_id() if rank == 0 else None]
+            tdist.broadcast_object_list(uid, src=0, device=torch.device("cuda", local_rank))
+            sh = hmm.RankEMList(st, mdl, world, rank, local_rank, uid[0], True, 0.95, algo,
+                                exchange=N.HF_EXCHANGE_RANKS if args.exchange == "ranks" else N.HF_EXCHANGE_CHUNKS)
+            return sh, sh.em
+        sh = fdist.make_sharded_hip(st, mdl, rank, world, local_rank, True, 0.95, algo, exchange=args.exchange)
+        return sh, sh.local.em
+
+    sharded, em = make_sharded(store, model)
     if not dist_path:                      # one GPU, no exchange: statistics by emission row (the library's default)
         em.set_stats_mode(N.HF_STATS_ROWS)
     em.set_profiling(True)                 # warm-up passes time every kernel to find the dominant one
@@ -205,7 +220,7 @@ def main():
         try:
             wstore = base_store.subset_chunks(list(range(base_store.n_chunks)) * world)
             wmodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, wstore, alpha)
-            wsh = fdist.make_sharded_hip(wstore, wmodel, rank, world, local_rank, True, 0.95, algo, exchange=args.exchange)
+            wsh, _ = make_sharded(wstore, wmodel)
 
             def wstep():
                 hmm.EM_runOneIterationForList(wsh, wmodel)
@@ -222,7 +237,7 @@ def main():
             tdist.all_reduce(wt, op=tdist.ReduceOp.MAX)
             wdt = float(wt.item())
             weak = {"value": wstore.n_windows * args.steps / wdt, "unit": "windows/s", "ms_per_step": wdt / args.steps * 1e3,
-                    "n_windows": wstore.n_windows, "windows_per_gpu": wsh.local_store.n_windows, "scaling": "weak",
+                    "n_windows": wstore.n_windows, "windows_per_gpu": (wsh.n_local_windows if hasattr(wsh, "n_local_windows") else wsh.local_store.n_windows), "scaling": "weak",
                     "loglikelihood_after_last_step": wmodel.loglikelihood}
         except Exception as e:              # the headline number above stays valid
             weak = {"error": repr(e)}
@@ -231,7 +246,7 @@ def main():
         kavg = {k: v / extra for k, v in ksum.items() if v > 0}
         if args.no_kernel_events:
             dom_ms = kavg.get(dom, 0.0)
-        local_windows = sharded.local_store.n_windows
+        local_windows = sharded.n_local_windows if hasattr(sharded, "n_local_windows") else sharded.local_store.n_windows
         achieved = ALGO_BYTES_PER_WINDOW * local_windows / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json,
         # made by profiles/pmc_summary.py on this same command; FETCH_SIZE x2 on gfx950): full workload, 1 GPU only
@@ -270,7 +285,9 @@ def main():
                        "statistics": "per chunk, ordered reduction" if em.stats_mode == N.HF_STATS_CHUNKS else "by emission row",
                        "parallelism": (f"chunks sharded over {world} GPU(s), " + ("no exchange" if not dist_path else
                                        "all-gather of one statistics vector per rank" if args.exchange == "ranks" else
-                                       "all-gather of per-chunk statistics"))},
+                                       "all-gather of per-chunk statistics")
+                                       + ("" if not dist_path else ", one native call per pass (pass + RCCL all-gather + ordered reduction on one stream)"
+                                          if args.collective == "native" else ", exchange through torch.distributed"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
                          "kernel_ms_timed": dom_ms, "kernel_events": (0 if args.no_kernel_events else

@@ -125,6 +125,11 @@ def lib() -> C.CDLL:
     sig("hf_shard_bounds", C.c_int, C.POINTER(i64), i32, C.c_int, C.POINTER(i32))
     sig("hf_multi_create", C.c_int, C.POINTER(hf_windows), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int,
         C.POINTER(vp))
+    sig("hf_multi_create_rank", C.c_int, C.POINTER(hf_windows), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp,
+        C.POINTER(vp))
+    sig("hf_multi_local_ctx", vp, vp)
+    sig("hf_multi_local_first_window", i64, vp)
+    sig("hf_multi_local_windows", i64, vp)
     sig("hf_multi_destroy", None, vp)
     sig("hf_multi_estep", C.c_int, vp, C.POINTER(hf_params), C.c_int, pd)
     sig("hf_multi_get_labels", C.c_int, vp, C.POINTER(C.c_int8))

@@ -212,7 +212,9 @@ struct hf_multi {
     int n_regions = 1, max_comps = 2;
     int64_t V = 0, N = 0; int32_t C = 0;
     int rows_per_rank = 2, flag_row = 1, maxc = 1;
+    int local_rank = -1;               // >= 0: hf_multi_create_rank — this process holds rank `local_rank` only (ranks[0]), no workers
     std::vector<int32_t> bounds;
+    std::vector<int64_t> shard_nw;     // windows of every rank's shard
     std::vector<RankState> ranks;
     const hf_windows* w = nullptr;     // valid during hf_multi_create only
     // command channel: main bumps `gen`, workers run `cmd` and decrement `pending`
@@ -372,6 +374,7 @@ int hf_multi_create(const hf_windows* w, int n_regions, int max_comps, int n_dev
     if (rc != HF_OK) { delete M; return rc; }
     M->maxc = 1;
     for (int r = 0; r < n_devices; r++) { const int n = M->bounds[(size_t) r + 1] - M->bounds[(size_t) r]; if (n > M->maxc) M->maxc = n; }
+    for (int r = 0; r < n_devices; r++) M->shard_nw.push_back(w->chunk_off[M->bounds[(size_t) r + 1]] - w->chunk_off[M->bounds[(size_t) r]]);
     if (exchange == HF_EXCHANGE_CHUNKS) { M->rows_per_rank = M->maxc + 1; M->flag_row = M->maxc; }
     else { M->rows_per_rank = 2; M->flag_row = 1; }
     std::vector<hf_comm*> comms((size_t) n_devices, nullptr);
@@ -407,9 +410,57 @@ int hf_multi_create(const hf_windows* w, int n_regions, int max_comps, int n_dev
     return HF_OK;
 }
 
+// One process per GPU (the layout torch.distributed.run / mpirun start): this process is rank `rank` of `world`, owns
+// `device` and the rank's shard of `w` (every process passes the same whole window set, or at least the same chunk list and
+// its own shard's windows at their global positions); `unique_id` = hf_comm_unique_id() of rank 0, carried to the others by
+// the launcher.  Collective: every rank must call it.  hf_multi_estep then runs on the caller's thread.
+int hf_multi_create_rank(const hf_windows* w, int n_regions, int max_comps, int world, int rank, int device, int algo, int exchange,
+                         const void* unique_id, hf_multi** out) {
+    if (!w || !out || !unique_id || world < 1 || world > 4096 || rank < 0 || rank >= world ||
+        (exchange != HF_EXCHANGE_CHUNKS && exchange != HF_EXCHANGE_RANKS))
+        return merr(HF_E_ARG, "hf_multi_create_rank: bad argument");
+    const int visible = hf_device_count();
+    if (visible <= 0) return merr(HF_E_NOGPU, "hf_multi_create_rank: no HIP device (there is no CPU fallback)");
+    if (device < 0 || device >= visible) return merr(HF_E_NOGPU, "hf_multi_create_rank: device " + std::to_string(device) + " is not visible");
+    hf_multi* M = new hf_multi();
+    M->world = world; M->exchange = exchange; M->transport = HF_TRANSPORT_RCCL; M->algo = algo; M->local_rank = rank;
+    M->n_regions = n_regions; M->max_comps = max_comps;
+    M->V = hf_stats_len(n_regions, max_comps); M->N = w->n_windows; M->C = w->n_chunks;
+    M->bounds.assign((size_t) world + 1, 0);
+    int rc = hf_shard_bounds(w->chunk_off, w->n_chunks, world, M->bounds.data());
+    if (rc != HF_OK) { delete M; return rc; }
+    M->maxc = 1;
+    for (int r = 0; r < world; r++) { const int n = M->bounds[(size_t) r + 1] - M->bounds[(size_t) r]; if (n > M->maxc) M->maxc = n; }
+    for (int r = 0; r < world; r++) M->shard_nw.push_back(w->chunk_off[M->bounds[(size_t) r + 1]] - w->chunk_off[M->bounds[(size_t) r]]);
+    if (exchange == HF_EXCHANGE_CHUNKS) { M->rows_per_rank = M->maxc + 1; M->flag_row = M->maxc; }
+    else { M->rows_per_rank = 2; M->flag_row = 1; }
+    M->ranks.resize(1);
+    RankState& R = M->ranks[0];
+    R.r = rank; R.device = device;
+    R.c0 = M->bounds[(size_t) rank]; R.nc = M->bounds[(size_t) rank + 1] - R.c0;
+    R.w0 = w->chunk_off[R.c0] - w->chunk_off[0]; R.nw = w->chunk_off[R.c0 + R.nc] - w->chunk_off[R.c0];
+    rc = hf_comm_init_rank(world, rank, device, unique_id, &R.comm);
+    if (rc == HF_OK) {
+        M->w = w;
+        rc = rank_create(M, R);
+        M->w = nullptr;
+        if (rc != HF_OK) merr(rc, "rank " + std::to_string(rank) + " (GPU " + std::to_string(device) + "): " + R.err);
+    }
+    if (rc != HF_OK) {
+        const std::string keep = g_merr;
+        if (R.ctx) hf_destroy(R.ctx);
+        if (R.comm) hf_comm_destroy(R.comm);
+        delete M;
+        g_merr = keep;
+        return rc;
+    }
+    *out = M;
+    return HF_OK;
+}
+
 void hf_multi_destroy(hf_multi* M) {
     if (!M) return;
-    (void) run_all(M, CMD_EXIT);
+    if (M->local_rank < 0) (void) run_all(M, CMD_EXIT);
     for (auto& R : M->ranks) {
         if (R.th.joinable()) R.th.join();
         hipSetDevice(R.device);
@@ -425,6 +476,14 @@ void hf_multi_destroy(hf_multi* M) {
 int hf_multi_estep(hf_multi* M, const hf_params* p, int mode, double* stats_host) {
     if (!M || !p || !stats_host || (mode != HF_MODE_FULL && mode != HF_MODE_FORWARD_ONLY)) return merr(HF_E_ARG, "hf_multi_estep: bad argument");
     M->p = p; M->mode = mode;
+    if (M->local_rank >= 0) {           // one process per GPU: this thread is the rank
+        RankState& R = M->ranks[0];
+        hipSetDevice(R.device);
+        const int rc1 = rank_estep(M, R);
+        if (rc1 != HF_OK) return merr(rc1, "rank " + std::to_string(R.r) + " (GPU " + std::to_string(R.device) + "): " + R.err);
+        std::memcpy(stats_host, R.stats.data(), (size_t) M->V * 8);
+        return HF_OK;
+    }
     const int rc = run_all(M, CMD_ESTEP);
     if (rc != HF_OK) return rc;
     std::memcpy(stats_host, M->ranks[0].stats.data(), (size_t) M->V * 8);
@@ -434,23 +493,45 @@ int hf_multi_estep(hf_multi* M, const hf_params* p, int mode, double* stats_host
 int hf_multi_get_labels(hf_multi* M, int8_t* labels_host) {
     if (!M || !labels_host) return merr(HF_E_ARG, "hf_multi_get_labels: bad argument");
     M->labels_out = labels_host;
+    if (M->local_rank >= 0) {           // this rank's windows only, at their global positions
+        RankState& R = M->ranks[0];
+        if (R.nw <= 0) return HF_OK;
+        const int rc = hf_get_labels(R.ctx, labels_host + R.w0);
+        return rc == HF_OK ? HF_OK : merr(rc, hf_last_error());
+    }
     return run_all(M, CMD_LABELS);
 }
 
 int hf_multi_get_posterior(hf_multi* M, int64_t first, int64_t n, double* post_host) {
     if (!M || !post_host || first < 0 || n < 0 || first + n > M->N) return merr(HF_E_ARG, "hf_multi_get_posterior: bad range");
     M->post_first = first; M->post_n = n; M->post_out = post_host;
+    if (M->local_rank >= 0) {
+        RankState& R = M->ranks[0];
+        const int64_t a = first > R.w0 ? first : R.w0, b = first + n < R.w0 + R.nw ? first + n : R.w0 + R.nw;
+        if (a >= b) return HF_OK;
+        const int rc = hf_get_posterior(R.ctx, a - R.w0, b - a, post_host + (a - first) * 4);
+        return rc == HF_OK ? HF_OK : merr(rc, hf_last_error());
+    }
     return run_all(M, CMD_POSTERIOR);
 }
 
 int hf_multi_world(const hf_multi* M) { return M ? M->world : 0; }
 int64_t hf_multi_stats_len(const hf_multi* M) { return M ? M->V : 0; }
-int64_t hf_multi_shard_windows(const hf_multi* M, int r) { return (M && r >= 0 && r < M->world) ? M->ranks[(size_t) r].nw : 0; }
-int32_t hf_multi_shard_chunks(const hf_multi* M, int r) { return (M && r >= 0 && r < M->world) ? M->ranks[(size_t) r].nc : 0; }
+static const RankState* rank_of(const hf_multi* M, int r) {
+    if (!M || r < 0 || r >= M->world) return nullptr;
+    if (M->local_rank >= 0) return r == M->local_rank ? &M->ranks[0] : nullptr;
+    return &M->ranks[(size_t) r];
+}
+int64_t hf_multi_shard_windows(const hf_multi* M, int r) { return (M && r >= 0 && r < M->world) ? M->shard_nw[(size_t) r] : 0; }
+int32_t hf_multi_shard_chunks(const hf_multi* M, int r) { return (M && r >= 0 && r < M->world) ? M->bounds[(size_t) r + 1] - M->bounds[(size_t) r] : 0; }
+hf_ctx* hf_multi_local_ctx(hf_multi* M) { return (M && M->local_rank >= 0) ? M->ranks[0].ctx : nullptr; }
+int64_t hf_multi_local_first_window(const hf_multi* M) { return (M && M->local_rank >= 0) ? M->ranks[0].w0 : 0; }
+int64_t hf_multi_local_windows(const hf_multi* M) { return (M && M->local_rank >= 0) ? M->ranks[0].nw : (M ? M->N : 0); }
 
 int hf_multi_rank_stats(hf_multi* M, int r, double* stats_host) {
-    if (!M || r < 0 || r >= M->world || !stats_host) return merr(HF_E_ARG, "hf_multi_rank_stats: bad argument");
-    std::memcpy(stats_host, M->ranks[(size_t) r].stats.data(), (size_t) M->V * 8);
+    const RankState* R = rank_of(M, r);
+    if (!R || !stats_host) return merr(HF_E_ARG, "hf_multi_rank_stats: bad argument");
+    std::memcpy(stats_host, R->stats.data(), (size_t) M->V * 8);
     return HF_OK;
 }
 

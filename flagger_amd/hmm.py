@@ -232,6 +232,55 @@ class MultiEMList:
         return out
 
 
+HF_COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0's RCCL id for `RankEMList` (include/hmm_flagger_multi.h hf_comm_unique_id); the launcher carries it to the others."""
+    buf = C.create_string_buffer(HF_COMM_ID_BYTES)
+    N.check(N.lib().hf_comm_unique_id(buf), "hf_comm_unique_id")
+    return buf.raw
+
+
+class RankEMList(MultiEMList):
+    """One PROCESS per GPU (torch.distributed.run): this process is rank `rank` of `world` on `device` and holds its shard of
+    the chunk list; pass + exchange (RCCL all-gather on the pass's own stream) + ordered reduction are ONE native call per
+    EM pass (hf_multi_create_rank / hf_multi_estep).  Collective: every rank constructs it with the same store."""
+
+    def __init__(self, store: WindowStore, model: "HMM", world: int, rank: int, device: int, unique_id: bytes,
+                 adjustContigEnds: bool = True, minReadFractionAtEnds: float = 0.95, algo: int = N.HF_ALGO_SCAN,
+                 exchange: int = N.HF_EXCHANGE_CHUNKS):
+        L = N.lib()
+        self._L, self.store = L, store
+        w, self._keep = _windows_struct(store, model, adjustContigEnds, minReadFractionAtEnds)
+        self.n_regions, self.max_comps = model.numberOfRegions, model.maxNumberOfComps
+        self.stats_len = N.stats_len(self.n_regions, self.max_comps)
+        if len(unique_id) != HF_COMM_ID_BYTES:
+            raise ValueError("unique_id must be the %d bytes of comm_unique_id()" % HF_COMM_ID_BYTES)
+        self._id = C.create_string_buffer(unique_id, HF_COMM_ID_BYTES)
+        h = C.c_void_p()
+        rc = L.hf_multi_create_rank(C.byref(w), self.n_regions, self.max_comps, world, rank, device, algo, exchange, self._id, C.byref(h))
+        if rc != N.HF_OK:
+            raise MultiHFError(rc, "hf_multi_create_rank")
+        self._h, self.world, self.rank = h, world, rank
+        self._stats = np.empty(self.stats_len, dtype=np.float64)
+        self.first_window = int(L.hf_multi_local_first_window(h))
+        self.n_local_windows = int(L.hf_multi_local_windows(h))
+        # borrowed view of the rank's context: profiling switches and kernel times (bench.py)
+        self.em = EMList.__new__(EMList)
+        self.em._L, self.em.store, self.em._h, self.em._borrowed = L, None, C.c_void_p(L.hf_multi_local_ctx(h)), True
+        self.em.n_regions, self.em.max_comps, self.em.stats_len = self.n_regions, self.max_comps, self.stats_len
+
+    def close(self):
+        if getattr(self, "em", None) is not None:
+            self.em._h = None
+        super().close()
+
+    def local_labels(self) -> np.ndarray:
+        """Labels of this rank's windows (global positions first_window .. first_window + n_local_windows)."""
+        return self.labels()[self.first_window:self.first_window + self.n_local_windows]
+
+
 class EMList:
     """All per-chunk EM objects of this process (stList<EM*> in the reference) as ONE device context:
     the windows are uploaded once and stay resident in HBM (hf_create)."""
@@ -252,6 +301,9 @@ class EMList:
         self.device = device
 
     def close(self):
+        if getattr(self, "_borrowed", False):      # a view of a context something else owns (RankEMList.em)
+            self._h = None
+            return
         if getattr(self, "_h", None):
             self._L.hf_destroy(self._h)
             self._h = None

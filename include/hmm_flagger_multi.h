@@ -65,6 +65,17 @@ typedef struct hf_multi hf_multi;
  * exchange buffers.  Fails with HF_E_NOGPU when fewer than n_devices (distinct, HF_TRANSPORT_RCCL) devices are visible. */
 int hf_multi_create(const hf_windows *w, int n_regions, int max_comps, int n_devices, const int *devices, int algo,
                     int exchange, int transport, hf_multi **out);
+/* The same object for hosts that run one PROCESS per GPU (torch.distributed.run, mpirun: what the reference's
+ * EM_runOneIterationForList would be called from under such a launcher): this process is rank `rank` of `world` on `device`
+ * and holds that rank's shard only; unique_id = rank 0's hf_comm_unique_id(), carried to the other ranks by the launcher.
+ * Collective (every rank calls it, with the same chunk list).  hf_multi_estep runs on the calling thread and every rank
+ * gets the same reduced vector; hf_multi_get_labels / _get_posterior fill this rank's windows only (at their global
+ * positions: hf_multi_local_first_window, hf_multi_local_windows); hf_multi_rank_stats answers for the own rank. */
+int hf_multi_create_rank(const hf_windows *w, int n_regions, int max_comps, int world, int rank, int device, int algo,
+                         int exchange, const void *unique_id, hf_multi **out);
+hf_ctx *hf_multi_local_ctx(hf_multi *m);   /* borrowed: the rank's E-step context (profiling switches, getters); NULL for hf_multi_create objects */
+int64_t hf_multi_local_first_window(const hf_multi *m);
+int64_t hf_multi_local_windows(const hf_multi *m);
 void hf_multi_destroy(hf_multi *m);
 /* One pass on every shard + the exchange + the ordered reduction: EM_runOneIterationForList (HF_MODE_FULL) /
  * EM_runForwardForList (HF_MODE_FORWARD_ONLY) for the whole chunk list.  stats_host gets the reduced vector

@@ -126,6 +126,40 @@ def test_rccl_transport_with_one_rank():
         one.close()
 
 
+def test_one_process_per_gpu_rank_object_with_one_rank():
+    """hf_multi_create_rank (what bench.py's ranks run under torch.distributed.run): RCCL id -> init_rank -> pass + all-gather +
+    ordered reduction in one call; with one rank it must reproduce the one-context statistics and labels."""
+    store = synth.config(2, scale=0.01)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, store, synth.HIFI_ALPHA)
+    one = _single(store, model, N.HF_STATS_CHUNKS)
+    try:
+        one.launch(model); ref = one.finish().copy()
+        ref_labels = one.labels().copy()
+        for exchange in (N.HF_EXCHANGE_CHUNKS, N.HF_EXCHANGE_RANKS):
+            m = hmm.RankEMList(store, model, 1, 0, 0, hmm.comm_unique_id(), exchange=exchange)
+            try:
+                got = m.run_sharded(model, N.HF_MODE_FULL)
+                if exchange == N.HF_EXCHANGE_CHUNKS:
+                    assert np.array_equal(got, ref)
+                else:
+                    assert np.allclose(got, ref, rtol=1e-11, atol=0)
+                assert (m.first_window, m.n_local_windows) == (0, store.n_windows)
+                assert np.array_equal(m.local_labels(), ref_labels)
+                assert np.array_equal(m.rank_stats(0), got)
+                fwd = m.run_sharded(model, N.HF_MODE_FORWARD_ONLY)
+                assert fwd[0] == got[0] or abs(fwd[0] - got[0]) <= 1e-11 * abs(got[0])
+                m.em.set_profiling(True)                         # the borrowed context view answers
+                m.run_sharded(model, N.HF_MODE_FULL)
+                assert m.em.kernel_times()["k_tables"] > 0.0
+                m.em.set_profiling(False)
+            finally:
+                m.close()
+        with pytest.raises(ValueError):
+            hmm.RankEMList(store, model, 1, 0, 0, b"short")
+    finally:
+        one.close()
+
+
 def test_more_gpus_than_visible_is_refused_loudly():
     visible = N.lib().hf_device_count()
     store = synth.config(2, scale=0.004)
