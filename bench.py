@@ -150,13 +150,25 @@ def main():
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
     algo = N.HF_ALGO_SCAN if args.algo == "scan" else N.HF_ALGO_SEQ
     torch.cuda.set_device(local_rank)
+    collective_used = {"name": args.collective if dist_path else "none"}
+
     def make_sharded(st, mdl):
-        if dist_path and args.collective == "native":
+        if dist_path and collective_used["name"] == "native":
             uid = [hmm.comm_unique_id() if rank == 0 else None]
             tdist.broadcast_object_list(uid, src=0, device=torch.device("cuda", local_rank))
-            sh = hmm.RankEMList(st, mdl, world, rank, local_rank, uid[0], True, 0.95, algo,
-                                exchange=N.HF_EXCHANGE_RANKS if args.exchange == "ranks" else N.HF_EXCHANGE_CHUNKS)
-            return sh, sh.em
+            sh, err = None, ""
+            try:
+                sh = hmm.RankEMList(st, mdl, world, rank, local_rank, uid[0], True, 0.95, algo,
+                                    exchange=N.HF_EXCHANGE_RANKS if args.exchange == "ranks" else N.HF_EXCHANGE_CHUNKS)
+            except Exception as e:          # never seen; N > 1 cannot be tried on the 1-GPU development boxes
+                err = repr(e)
+            ok = torch.tensor([1 if sh is not None else 0], dtype=torch.int32, device="cuda")
+            tdist.all_reduce(ok, op=tdist.ReduceOp.MIN)      # all ranks take the same path
+            if int(ok.item()) == 1:
+                return sh, sh.em
+            if sh is not None:
+                sh.close()
+            collective_used["name"] = "torch (native set-up failed on some rank: %s)" % (err or "another rank")
         sh = fdist.make_sharded_hip(st, mdl, rank, world, local_rank, True, 0.95, algo, exchange=args.exchange)
         return sh, sh.local.em
 
@@ -287,7 +299,7 @@ def main():
                                        "all-gather of one statistics vector per rank" if args.exchange == "ranks" else
                                        "all-gather of per-chunk statistics")
                                        + ("" if not dist_path else ", one native call per pass (pass + RCCL all-gather + ordered reduction on one stream)"
-                                          if args.collective == "native" else ", exchange through torch.distributed"))},
+                                          if collective_used["name"] == "native" else ", exchange through torch.distributed: " + collective_used["name"]))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
                          "kernel_ms_timed": dom_ms, "kernel_events": (0 if args.no_kernel_events else
