@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
                                                     const DevParams* __restrict__ P,
                                                     const double* __restrict__ F, const double* __restrict__ B,
                                                     const uint64_t* __restrict__ regmask,
-                                                    double* __restrict__ tile_stats) {
+                                                    double* __restrict__ tile_stats, const int32_t* __restrict__ slot_of) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NS = 16 + 9 + 2;                  // scalar accumulators kept in registers
     constexpr int L = HF_SCAN_L;
@@ -94,11 +94,17 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
             double Ev[16], Tm[16], f[4], b1[4];
             load_row(row_ptr(S, rr[j + 1], rr[j], sidx[j]), Ev);
             // f of the window before (the previous lane's last one for j == 0), b of the window itself (hf_scan.h fb_slot)
-            const int64_t fs = j > 0 ? fb_slot<L>(tile, lane, j - 1, 0)
-                                     : (lane > 0 ? fb_slot<L>(tile, lane - 1, L - 1, 0) : fb_slot<L>(tile - 1, 63, L - 1, 0));
-            const int64_t bs = fb_slot<L>(tile, lane, j, 0);
-            const double2 f01 = reinterpret_cast<const double2*>(F)[fs], f23 = reinterpret_cast<const double2*>(F)[fs + 64];
-            const double2 b01 = reinterpret_cast<const double2*>(B)[bs], b23 = reinterpret_cast<const double2*>(B)[bs + 64];
+            double2 f01, f23, b01, b23;
+            if (slot_of) {      // the pair record {f_{t-1}, b_t} of the segment kernels (hf_seg.h), by slot; F = the records
+                const double2* __restrict__ pr = reinterpret_cast<const double2*>(F) + (int64_t) slot_of[t0 + a0 + j] * 4;
+                f01 = pr[0]; f23 = pr[1]; b01 = pr[2]; b23 = pr[3];
+            } else {            // HF_ALGO_SEQ: f, b tile-major / lane-minor (hf_seq.h)
+                const int64_t fs = j > 0 ? fb_slot<L>(tile, lane, j - 1, 0)
+                                         : (lane > 0 ? fb_slot<L>(tile, lane - 1, L - 1, 0) : fb_slot<L>(tile - 1, 63, L - 1, 0));
+                const int64_t bs = fb_slot<L>(tile, lane, j, 0);
+                f01 = reinterpret_cast<const double2*>(F)[fs]; f23 = reinterpret_cast<const double2*>(F)[fs + 64];
+                b01 = reinterpret_cast<const double2*>(B)[bs]; b23 = reinterpret_cast<const double2*>(B)[bs + 64];
+            }
             const unsigned xw = REC_X(rr[j + 1]), xp = REC_X(rr[j]);
             const double2* __restrict__ crow = crow_ptr(S, rr[j + 1], rr[j], sidx[j]);
             lds_Tm(s_tab, rr[j + 1], Tm);
@@ -248,7 +254,8 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
 // weight.den[i] all equal).  Writes the WHOLE chunk vector (zeros where nothing accumulates:
 // HMM_resetEstimators, hmm.c:129-134), so no memset is needed between passes.  full == 0: log-likelihood only.
 template <int KT>
-__global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__ chunk_tile0, const uint64_t* __restrict__ regmask,
+__global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__ chunk_tile0, const int32_t* __restrict__ chunk_ll0,
+                                                     const uint64_t* __restrict__ regmask,
                                                      const double* __restrict__ tile_stats, const double* __restrict__ tile_ll,
                                                      const DevParams* __restrict__ P, double* __restrict__ chunk_stats,
                                                      int64_t V, int Kctx, int full) {
@@ -260,9 +267,10 @@ __global__ void __launch_bounds__(128) k_chunk_stats(const int32_t* __restrict__
     const int64_t rstride = 24 * (int64_t) Kctx + 16;
     const uint64_t present = regmask[c];
     double* __restrict__ vec = chunk_stats + (int64_t) c * V;
-    if (tid < 64) {
+    if (tid < 64) {      // the log-likelihood partials of the chunk: per segment (hf_seg.h) or per tile (HF_ALGO_SEQ)
         double s = 0.0;
-        for (int k = tid; k < nt; k += 64) s += tile_ll[k0 + k];
+        const int l0 = chunk_ll0[c], nl = chunk_ll0[c + 1] - l0;
+        for (int k = tid; k < nl; k += 64) s += tile_ll[l0 + k];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
         if (tid == 0) vec[0] = s;
     }

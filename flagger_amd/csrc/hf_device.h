@@ -33,8 +33,6 @@
 // of dependent loads
 // slow0 = position in the slow list of the tile's first slow window
 struct TileDesc { long long t0; int T; int base; int chunk; int slow0; };
-// per chunk, for k_carry: first tile, number of tiles, first slow row, region of the first / last window (one 32-byte load)
-struct CarryDesc { int32_t k0, nt, slow0, reg_first, reg_last, pad0, pad1, pad2; };
 #define HF_AROW_CLASSES 9   // transition classes of an interior window: the 8 validity masks, 8 = region change (first window: 9)
 // one segment of a chunk = one workgroup of the segment kernels (hf_seg.h), built once in hf_create
 struct SegDesc {

@@ -4,10 +4,9 @@
 // Replaces EM_runOneIterationForList / EM_runForwardForList (programs/submodules/hmm/hmm.c:739,790).
 // One pass (per EM iteration), HF_ALGO_SCAN:
 //   hf_scan.h    k_tables      emission rows of this iteration (per occurring (region, x, x_prev) + per contig-end window)
-//                                                                        (hmm_utils.c:753-793, 941-947)
-//                k_prod_tile   lane / tile products of A_t = T_t∘E_t
-//                k_carry       per chunk: carried-in forward vector / backward direction of every tile
-//                k_fb_tile     scaled forward + log-likelihood, scaled backward + posterior argmax
+//                              and the rows of A_t = T_t∘e_t           (hmm_utils.c:753-793, 941-947, 2278-2292)
+//   hf_seg.h     k_seg_prod    one workgroup per chunk segment: lane products of A_t, product of the segment
+//                k_seg_fb      scans, scaled forward + log-likelihood, scaled backward + posterior argmax, pair records
 //                                                                        (hmm.c:333-434, 452-545, 671-692)
 //   hf_rows.h    k_pair_sums, k_row_stats, k_rows_total: xi sufficient statistics summed by emission row (default)
 //                                                                        (hmm.c:563-650, hmm_utils.c:812-839, 1027-1034)
@@ -83,11 +82,10 @@ struct hf_ctx {
     double* d_total_host = nullptr; // device address of the pinned h_total: k_reduce writes the result straight to the host
     // scan algorithm: tile tables and per-tile work arrays
     TileDesc* d_tile_desc = nullptr;
-    int ntiles = 0; int32_t* d_chunk_tile0 = nullptr; CarryDesc* d_carry_desc = nullptr;
+    int ntiles = 0; int32_t* d_chunk_tile0 = nullptr;
     bool host_trace = false; double ht[5] = {0, 0, 0, 0, 0}; long ht_n = 0;   // HF_HOST_TRACE=1: where an EM step's host time goes
-    double* d_Pt = nullptr; double* d_cf = nullptr; double* d_cb = nullptr; double* d_tile_ll = nullptr;
+    double* d_tile_ll = nullptr;
     double* d_tile_stats = nullptr; // [ntiles][R][NA(16)]
-    double* d_Qs = nullptr;         // [ntiles][64][16] lane products
     unsigned* d_flags = nullptr;
     DevParams* d_params = nullptr; DevParams* h_params = nullptr; size_t params_bytes = 0;
     unsigned* h_flags = nullptr;
@@ -117,7 +115,7 @@ struct hf_ctx {
     bool pass_nb = false;          // the last rows-mode pass ran the negative_binomial kernels (hf_nb_rows.h)
     int32_t* d_bin_off = nullptr; int32_t* d_bin_list = nullptr; double* d_slot_h = nullptr; double* d_H = nullptr;   // count-data plan
     double* d_chunk_ll = nullptr;  // [C] log-likelihood per chunk (rows mode)
-    double* d_recs = nullptr;      // [N+1] pair records { f_{t-1}, b_t } (k_fb_tile RECS); fb_recs: the last full pass wrote them
+    double* d_recs = nullptr;      // [n_slots] pair records { f_{t-1}, b_t } of k_seg_fb, slot order; fb_recs: the last full pass wrote them
     bool fb_recs = false;
     PairIdx* d_pairs = nullptr; int32_t* d_grp_row = nullptr; double* d_grp_sums = nullptr;
     RowSlot* d_rowslots = nullptr; int32_t* d_rw_region = nullptr; int32_t* d_rw_off = nullptr; double* d_rw_stats = nullptr;
@@ -126,6 +124,7 @@ struct hf_ctx {
     double* d_segQ = nullptr;          // [nseg][8][NL] double2: lane products, lane-minor
     // rows of A_t = T_t∘e_t (hf_seg.h): one per (emission key, transition class) that occurs at an interior window, then one
     // per slow window; d_arow[t] = the row of window t (bit 31: chunk-first), d_arow_src / d_arow_cls = where a row comes from
+    int32_t* d_slot_of = nullptr;      // [N] record slot of every window (the per-chunk statistics kernels read pair records by window)
     int32_t* d_arow = nullptr; int32_t* d_arow_src = nullptr; int32_t* d_arow_cls = nullptr; double* d_lutA = nullptr;
     int n_arows = 0, n_combo = 0;
     double* d_scale_s = nullptr; int64_t n_slots = 0;
@@ -267,6 +266,9 @@ static RowSrc row_src(const hf_ctx* ctx) {
 static const int32_t* ll_off(const hf_ctx* ctx) { return ctx->pass_seg ? ctx->d_chunk_seg0 : ctx->d_chunk_tile0; }
 static const double* ll_part(const hf_ctx* ctx) { return ctx->pass_seg ? ctx->d_seg_ll : ctx->d_tile_ll; }
 
+// HF_ALGO_SCAN runs the segment kernels (hf_seg.h) whatever the statistics path
+static bool seg_pass(const hf_ctx* ctx) { return ctx->algo == HF_ALGO_SCAN && ctx->nseg > 0; }
+
 // does a full pass of the Gaussian models take the statistics-by-row path?
 static bool rows_pass(const hf_ctx* ctx) { return ctx->stats_mode == HF_STATS_ROWS && ctx->rows_ready && ctx->algo == HF_ALGO_SCAN; }
 
@@ -302,11 +304,11 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         const TileGeom g = tile_geom(ctx, k_stats_tile<KT>, (size_t) (3 * ncol > 28 ? 3 * ncol : 28) * 65 * 8);
         TILE_GEOM_OR_FAIL(g);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
-                           ctx->d_tile_desc, ctx->d_rec, row_src(ctx), ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask,
-                           ctx->d_tile_stats);
+                           ctx->d_tile_desc, ctx->d_rec, row_src(ctx), ctx->d_params, ctx->pass_seg ? ctx->d_recs : ctx->d_f, ctx->d_b, ctx->d_regmask,
+                           ctx->d_tile_stats, ctx->pass_seg ? ctx->d_slot_of : (const int32_t*) nullptr);
     }
     KTimer t(ctx, st, HF_K_CHUNK_STATS);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ll_off(ctx),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_chunk_tile0, ll_off(ctx),
                        ctx->d_regmask, ctx->d_tile_stats, ll_part(ctx), ctx->d_params, ctx->d_chunk_stats, ctx->V, ctx->K,
                        full);
 }
@@ -514,20 +516,11 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         ctx->ntiles = (int) desc.size();
         TRY(dev_upload(&ctx->d_tile_desc, desc.data(), desc.size()));
         TRY(dev_upload(&ctx->d_chunk_tile0, ctile0.data(), ctile0.size()));
-        std::vector<CarryDesc> cdesc(C);
-        for (size_t c = 0; c < C; c++) {
-            const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-            CarryDesc d = {ctile0[c], ctile0[c + 1] - ctile0[c], soff[c], 0, 0, 0, 0, 0};
-            if (T > 0) { d.reg_first = (int32_t) ((w->annot[t0] & 0xFC00000000000000ULL) >> 58);
-                         d.reg_last = (int32_t) ((w->annot[t0 + T - 1] & 0xFC00000000000000ULL) >> 58); }
-            cdesc[c] = d;
-        }
-        TRY(dev_upload(&ctx->d_carry_desc, cdesc.data(), cdesc.size()));
         const size_t nt = (size_t) ctx->ntiles;
-        DMALLOC(ctx->d_Pt, nt * 16 * 8); DMALLOC(ctx->d_cf, nt * 4 * 8); DMALLOC(ctx->d_cb, nt * 4 * 8);
         DMALLOC(ctx->d_tile_ll, nt * 8);
-        DMALLOC(ctx->d_Qs, nt * 64 * 16 * 8);
-        DMALLOC(ctx->d_f, nt * 64 * HF_SCAN_L * 4 * 8); DMALLOC(ctx->d_b, nt * 64 * HF_SCAN_L * 4 * 8);   // tile-major, lane-minor (hf_scan.h fb_slot)
+        if (algo == HF_ALGO_SEQ) {   // f, b tile-major / lane-minor (hf_device.h fb_slot): only the sequential cross-check keeps them
+            DMALLOC(ctx->d_f, nt * 64 * HF_SCAN_L * 4 * 8); DMALLOC(ctx->d_b, nt * 64 * HF_SCAN_L * 4 * 8);
+        }
         ctx->h_off.assign(w->chunk_off, w->chunk_off + C + 1);
         ctx->h_tile0 = ctile0;
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
@@ -650,10 +643,13 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             if (nslots < INT32_MAX) {
                 ctx->nseg = (int) segs.size(); ctx->n_slots = nslots;
                 TRY(dev_upload(&ctx->d_seg, segs.data(), segs.size()));
+                TRY(dev_upload(&ctx->d_slot_of, slot_of.data(), slot_of.size()));
                 TRY(dev_upload(&ctx->d_chunk_seg0, cseg0.data(), cseg0.size()));
                 DMALLOC(ctx->d_segQ, segs.size() * (size_t) NL * 16 * 8);
                 DMALLOC(ctx->d_seg_ll, segs.size() * 8);
                 DMALLOC(ctx->d_Pseg, segs.size() * 16 * 8);
+                DMALLOC(ctx->d_recs, (size_t) ctx->n_slots * 64);
+                DMALLOC(ctx->d_scale_s, (size_t) ctx->n_slots * 8);
             } else { slot_of.clear(); slot_f.clear(); }
             cphase("segments");
         }
@@ -776,8 +772,6 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 TRY(dev_upload(&ctx->d_rw_region, rwreg.data(), rwreg.size()));
                 TRY(dev_upload(&ctx->d_rw_off, rwoff.data(), rwoff.size()));
                 DMALLOC(ctx->d_grp_sums, (size_t) ctx->n_groups * 16 * 8);
-                DMALLOC(ctx->d_recs, (size_t) ctx->n_slots * 64);
-                DMALLOC(ctx->d_scale_s, (size_t) ctx->n_slots * 8);
                 DMALLOC(ctx->d_chunk_ll, C * 8);
                 DMALLOC(ctx->d_rw_stats, (size_t) ctx->n_rowwaves * (16 + 9 + 2 + 3 * 16 + 1) * 8);
                 ctx->rows_ready = true;
@@ -805,12 +799,12 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
-    hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0); hipFree(ctx->d_carry_desc);
+    hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0);
     hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
     hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_scale_s);
-    hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
-    hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats); hipFree(ctx->d_Pt);
-    hipFree(ctx->d_cf); hipFree(ctx->d_cb); hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats); hipFree(ctx->d_Qs);
+    hipFree(ctx->d_slot_of); hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
+    hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats);
+    hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats);
     if (ctx->h_params) hipHostFree(ctx->h_params);
     if (ctx->h_flags) hipHostFree(ctx->h_flags);
     if (ctx->h_total) hipHostFree(ctx->h_total);
@@ -923,7 +917,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         {   // also clears the flag word: first kernel of every pass
             KTimer t(ctx, st, HF_K_TABLES);
             // statistics by emission row: the job list of the Gaussian tables is the (key, class) list of the rows of A (hf_seg.h)
-            const bool arows = !nbm && ctx->algo != HF_ALGO_SEQ && ctx->ntiles > 0 && rows_pass(ctx);
+            const bool arows = !nbm && seg_pass(ctx);
             const int nk = arows ? ctx->n_combo : ctx->n_keys;
             const int32_t* kl = arows ? ctx->d_arow_src : ctx->d_keys;
             const int jobs = nk + ctx->n_slow;
@@ -951,13 +945,14 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                     hipLaunchKernelGGL(k_fwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
                                        ctx->d_E, ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_tile_ll, ctx->d_flags);
                 }
+                if (full) ctx->fb_recs = false;
                 if (full) {
                     KTimer t(ctx, st, HF_K_BWD_SEQ);
                     hipLaunchKernelGGL(k_bwd_seq, dim3((unsigned) ctx->C), dim3(64), 0, st, ctx->d_off, ctx->d_chunk_tile0, ctx->d_rec,
                                        ctx->d_E, ctx->d_params, ctx->d_f, ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_flags);
                 }
-            } else if (rows_pass(ctx)) {
-                // statistics by emission row: one workgroup per chunk segment does the whole forward-backward (hf_seg.h)
+            } else if (seg_pass(ctx)) {
+                // one workgroup per chunk segment does the whole forward-backward (hf_seg.h)
                 constexpr int NW = HF_SEG_WAVES;
                 const size_t lds = seg_lds_bytes<NW>();
                 if (ctx->host_trace && !ctx->ht_n) {
@@ -986,33 +981,8 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                                        ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
                 ctx->pass_seg = true;
                 if (full) ctx->fb_recs = true;
-            } else {
-                {
-                    KTimer t(ctx, st, HF_K_PROD_TILE);
-                    const TileGeom g = tile_geom(ctx, k_prod_tile<HF_SCAN_L>, 8192);
-                    if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_prod_tile<HF_SCAN_L>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
-                                       ctx->d_tile_desc, ctx->d_rec, ctx->d_params, S, ctx->d_Qs, ctx->d_Pt, ctx->d_flags);
-                }
-                {
-                    KTimer t(ctx, st, HF_K_CARRY);
-                    hipLaunchKernelGGL(k_carry, dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_carry_desc, ctx->d_Es,
-                                       ctx->d_params, ctx->d_Pt, ctx->d_cf, ctx->d_cb);
-                }
-                KTimer t(ctx, st, HF_K_FB_TILE);
-                const size_t fb_wave = (size_t) HF_SCAN_L * 5 * HF_FW_STRIDE * 8;   // wave-private f / scale block
-                const TileGeom g = full ? tile_geom(ctx, k_fb_tile<HF_SCAN_L, true>, fb_wave) : tile_geom(ctx, k_fb_tile<HF_SCAN_L, false>, fb_wave);
-                if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
-                if (full) ctx->fb_recs = false;
-                if (full)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, true>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
-                                       ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_f,
-                                       ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
-                else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fb_tile<HF_SCAN_L, false>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
-                                       ctx->d_tile_desc, ctx->d_rec, S, ctx->d_Qs, ctx->d_params, ctx->d_cf, ctx->d_cb, ctx->d_f,
-                                       ctx->d_scale, ctx->d_b, ctx->d_label, ctx->d_tile_ll, ctx->d_flags);
-            }
+            } else
+                return set_err(HF_E_ARG, "hf_estep: HF_ALGO_SCAN holds at most 2^30 windows per context (shard the chunk list: hmm_flagger_multi.h)");
         }
         const int kc = p->ncomp[3];
         const int fl = full && ctx->ntiles > 0;
@@ -1043,12 +1013,13 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 const TileGeom g = tile_geom(ctx, k_stats_tile_nb<HF_SCAN_L>, (size_t) HF_NB_WAVE_LDS * 8);
                 if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile_nb<HF_SCAN_L>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles, ctx->d_tile_desc,
-                                   ctx->d_rec, S, ctx->d_params, ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_hist);
+                                   ctx->d_rec, S, ctx->d_params, ctx->pass_seg ? ctx->d_recs : ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_hist,
+                                   ctx->pass_seg ? ctx->d_slot_of : (const int32_t*) nullptr);
             }
             NbTables nt;
             nt.E = ctx->d_nbE; nt.P = ctx->d_nbP; nt.dig = ctx->d_nbDig; nt.r = ctx->d_nbR; nt.beta = ctx->d_nbBeta;
             KTimer t(ctx, st, HF_K_CHUNK_STATS);
-            hipLaunchKernelGGL(k_chunk_stats_nb, dim3((unsigned) ctx->C), dim3(256), 0, st, ll_off(ctx), ctx->d_regmask,
+            hipLaunchKernelGGL(k_chunk_stats_nb, dim3((unsigned) ctx->C), dim3(256), 0, st, ctx->d_chunk_tile0, ll_off(ctx), ctx->d_regmask,
                                ctx->d_tile_hist, ll_part(ctx), ctx->d_params, nt, ctx->d_chunk_stats, ctx->V, ctx->K, fl);
         }
         else if (kc <= 4) launch_stats<4>(ctx, st, fl, kc);

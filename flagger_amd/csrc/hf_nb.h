@@ -7,7 +7,7 @@
 // :537-566).  The caller tabulates E(x), the component probabilities and the digamma table with its own libm
 // (hf_params.nb_*), so the device only gathers, multiplies and sums:
 //   k_tables_nb       emission rows of the occurring keys / contig-end windows from E[r][s][x]
-//   (k_prod_tile, k_carry, k_fb_tile: unchanged — they only consume rows)
+//   (the segment kernels of hf_seg.h: unchanged — they only consume rows; k_arows makes their rows of A)
 //   k_stats_tile_nb   per tile: xi transition counts + count data hist[state][min(x,249)]
 //   k_chunk_stats_nb  per chunk: tile partials in tile order -> estimator increments in the standard vector layout
 //                     (parameter 0 = theta, 1 = lambda, 2 = weight)
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) k_stats_tile_nb(int ntiles, const TileDes
                                                        const uint32_t* __restrict__ rec, const RowSrc S,
                                                        const DevParams* __restrict__ P, const double* __restrict__ F,
                                                        const double* __restrict__ B, const uint64_t* __restrict__ regmask,
-                                                       double* __restrict__ tile_hist) {
+                                                       double* __restrict__ tile_hist, const int32_t* __restrict__ slot_of) {
     extern __shared__ __attribute__((aligned(16))) double s_tab[];
     fill_tab(P, s_tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -120,11 +120,17 @@ __global__ void __launch_bounds__(256) k_stats_tile_nb(int ntiles, const TileDes
                 double Ev[16], Tm[16];
                 load_row(row_ptr(S, rr[j + 1], rr[j], sidx[j]), Ev);
                 // f of the window before (the previous lane's last one for j == 0), b of the window itself
-                const int64_t fs = j > 0 ? fb_slot<L>(tile, lane, j - 1, 0)
-                                         : (lane > 0 ? fb_slot<L>(tile, lane - 1, L - 1, 0) : fb_slot<L>(tile - 1, 63, L - 1, 0));
-                const int64_t bs = fb_slot<L>(tile, lane, j, 0);
-                const double2 f01 = reinterpret_cast<const double2*>(F)[fs], f23 = reinterpret_cast<const double2*>(F)[fs + 64];
-                const double2 b01 = reinterpret_cast<const double2*>(B)[bs], b23 = reinterpret_cast<const double2*>(B)[bs + 64];
+                double2 f01, f23, b01, b23;
+                if (slot_of) {      // the pair record {f_{t-1}, b_t} of the segment kernels (hf_seg.h), by slot; F = the records
+                    const double2* __restrict__ pr = reinterpret_cast<const double2*>(F) + (int64_t) slot_of[t0 + a0 + j] * 4;
+                    f01 = pr[0]; f23 = pr[1]; b01 = pr[2]; b23 = pr[3];
+                } else {            // HF_ALGO_SEQ: f, b tile-major / lane-minor (hf_seq.h)
+                    const int64_t fs = j > 0 ? fb_slot<L>(tile, lane, j - 1, 0)
+                                             : (lane > 0 ? fb_slot<L>(tile, lane - 1, L - 1, 0) : fb_slot<L>(tile - 1, 63, L - 1, 0));
+                    const int64_t bs = fb_slot<L>(tile, lane, j, 0);
+                    f01 = reinterpret_cast<const double2*>(F)[fs]; f23 = reinterpret_cast<const double2*>(F)[fs + 64];
+                    b01 = reinterpret_cast<const double2*>(B)[bs]; b23 = reinterpret_cast<const double2*>(B)[bs + 64];
+                }
                 lds_Tm(s_tab, rr[j + 1], Tm);
                 const double f[4] = {f01.x, f01.y, f23.x, f23.y};
                 const double b1[4] = {b01.x, b01.y, b23.x, b23.y};
@@ -186,7 +192,8 @@ __global__ void __launch_bounds__(256) k_stats_tile_nb(int ntiles, const TileDes
 // per chunk: log-likelihood, transition counts, count data (tile partials in tile order), then the estimator
 // increments of NegativeBinomial_updateEstimator for every (state, x < 250) with a positive count, x ascending
 // (hmm_utils.c:1661-1673, 537-566), written in the standard chunk-vector layout.
-__global__ void __launch_bounds__(256) k_chunk_stats_nb(const int32_t* __restrict__ chunk_tile0, const uint64_t* __restrict__ regmask,
+__global__ void __launch_bounds__(256) k_chunk_stats_nb(const int32_t* __restrict__ chunk_tile0, const int32_t* __restrict__ chunk_ll0,
+                                                        const uint64_t* __restrict__ regmask,
                                                         const double* __restrict__ tile_hist, const double* __restrict__ tile_ll,
                                                         const DevParams* __restrict__ P, const NbTables nb,
                                                         double* __restrict__ chunk_stats, int64_t V, int K, int full) {
@@ -196,9 +203,10 @@ __global__ void __launch_bounds__(256) k_chunk_stats_nb(const int32_t* __restric
     const int64_t rstride = 24 * (int64_t) K + 16;
     const uint64_t present = regmask[c];
     double* __restrict__ vec = chunk_stats + (int64_t) c * V;
-    if (tid < 64) {
+    if (tid < 64) {      // the log-likelihood partials of the chunk: per segment (hf_seg.h) or per tile (HF_ALGO_SEQ)
         double s = 0.0;
-        for (int k = tid; k < nt; k += 64) s += tile_ll[k0 + k];
+        const int l0 = chunk_ll0[c], nl = chunk_ll0[c + 1] - l0;
+        for (int k = tid; k < nl; k += 64) s += tile_ll[l0 + k];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
         if (tid == 0) vec[0] = s;
     }

@@ -26,7 +26,7 @@
 // ------------------------------------------------------------------------------------------
 // k_pair_sums: sum over a group's pairs of the counts f[pre]·T[pre][s]·e[pre][s]·b[s] (before the division).
 // 16 lanes per group (4 groups per wavefront), FOUR lanes per pair: lane q of a quad loads 16-byte piece q of the pair
-// record (k_fb_tile RECS: f01 f23 b01 b23) — one load instruction covers 16 whole records — takes the f piece and the b
+// record (k_seg_fb: f01 f23 b01 b23) — one load instruction covers 16 whole records — takes the f piece and the b
 // piece of its 2x2 block of the 4x4 count matrix from its quad by DPP, and accumulates the block; the four quads of a
 // group take the pairs round-robin and are summed by a fixed butterfly at the end.
 // ------------------------------------------------------------------------------------------

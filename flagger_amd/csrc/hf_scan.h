@@ -1,20 +1,13 @@
-// hf_scan.h — HF_ALGO_SCAN: tile-parallel forward/backward for 4-state chains on gfx950.
+// hf_scan.h — what the kernels of HF_ALGO_SCAN share: the 4x4 matrix helpers, the LDS transition tables, the emission-row
+// tables and k_tables.
 //
-// The scaled forward recurrence f_t ∝ f_{t-1}·A_t (A_t[pre][s] = T_t(pre,s)·e_t(pre,s), hmm.c:366-420)
-// is a product of 4x4 non-negative matrices, hence associative.  A chunk is cut into tiles of 64·L
-// windows, one wavefront per tile, every lane owning L consecutive windows:
+// The scaled forward recurrence f_t ∝ f_{t-1}·A_t (A_t[pre][s] = T_t(pre,s)·e_t(pre,s), hmm.c:366-420) is a product of 4x4
+// non-negative matrices, hence associative: the segment kernels (hf_seg.h) cut a chunk into segments and lanes, scan the lane
+// products and replay every lane's windows.  (Round 1's tile kernels k_prod_tile / k_carry / k_fb_tile lived here; since
+// round 2 every HF_ALGO_SCAN pass runs the segment kernels and the per-chunk statistics read their pair records.)
 //   k_tables     this iteration's emission rows: one per (region, x, x_prev) that occurs at an interior window, and
-//                one per contig-end / chunk-first window (generic evaluation with the window's own beta)
-//   k_prod_tile  lane products and the product of every tile (all tiles of all chunks at once)
-//   k_carry      per chunk: sweep over its tile products -> carried-in forward vector and carried-in backward
-//                direction of every tile
-//   k_fb_tile    per tile: Kogge-Stone scan of the 64 lane products (power-of-two renormalisation after every
-//                product: exact, nothing underflows) gives each lane the product of everything before it; the lane
-//                then REPLAYS its L windows with the reference's exact operation order from the carried-in,
-//                normalised vector (hmm.c:333-420).  The same wavefront then runs the mirror image with suffix
-//                products (hmm.c:470-529) + posterior argmax (hmm.c:671-692) with f and scale still in registers; the
-//                absolute magnitude of a carried-in b vector is recovered from the invariant
-//                sum_s f_t[s]·b_t[s]·scale_t = terminationProb of the scaled forward-backward.
+//                one per contig-end / chunk-first window (generic evaluation with the window's own beta); and the rows of
+//                A = T∘e of hf_seg.h
 // No emission value is ever written to HBM per window: a row is 128 B gathered from the tables (L2-resident) where
 // it is used.
 #pragma once
@@ -313,457 +306,4 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
             lutC[(J.row * 4) * K + c * 4 + pre] = first ? 0.0 : s_val[jl][s_base[3 * 4 + u] + c];
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_prod_tile: one wavefront per tile.  Each lane multiplies the matrices A = T∘E of its L windows into its lane
-// product Q_l (written to Qs: the scans of k_fb_tile start from it), and an ordered shuffle tree over the lanes
-// gives the tile product Pt.  Chunk-first windows are excluded from Q_l and Pt.  Every row a pass uses goes
-// through here once: this is where a NaN row raises HF_E_NAN (hmm_utils.c:783-786).
-// ------------------------------------------------------------------------------------------
-#ifndef HF_PROD_BLOCKS
-#define HF_PROD_BLOCKS 3
-#endif
-template <int L>
-__global__ void __launch_bounds__(256, HF_PROD_BLOCKS) k_prod_tile(int ntiles, const TileDesc* __restrict__ td,
-                                                   const uint32_t* __restrict__ rec, const DevParams* __restrict__ P,
-                                                   const RowSrc S, double* __restrict__ Qs, double* __restrict__ Pt,
-                                                   unsigned* __restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    fill_tab(P, s_tab);
-    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (tile >= ntiles) return;
-    const TileDesc d = td[tile];
-    const int64_t t0 = d.t0, T = d.T, base = d.base;
-    const int64_t a = base + (int64_t) lane * L;
-    uint32_t rr[L];
-    const uint32_t rp = load_recs<L>(rec, t0, T, a, lane, rr);
-    int sidx[L];
-    tile_slow_index<L>(rr, lane, d.slow0, sidx);
-    // rows through the cooperative fetch: window i+1's loads are in flight while window i is multiplied in
-    double2* __restrict__ xp = reinterpret_cast<double2*>(s_tab + P->n_regions * HF_TAB_STRIDE) + (threadIdx.x >> 6) * 512;
-    int32_t ridx[L];
-#pragma unroll
-    for (int i = 0; i < L; i++) ridx[i] = (a + i < T) ? row_index(S, rr[i], i == 0 ? rp : rr[i - 1], sidx[i]) : 0;
-    double2 vq[8];
-    coop_rows_issue(S.lutE, ridx[0], lane, vq);
-    unsigned nan = 0;
-    M4 Q;
-    m4_identity(Q);
-#pragma unroll
-    for (int i = 0; i < L; i++) {
-        double Ecur[16];
-        coop_rows_finish(vq, lane, xp, Ecur);
-        if (i + 1 < L) coop_rows_issue(S.lutE, ridx[i + 1], lane, vq);
-        if (a + i < T) {
-            if (row_has_nan(Ecur)) nan |= HF_FLAG_NAN;
-            if (!REC_FIRST(rr[i])) {
-                double Tm[16];
-                lds_Tm(s_tab, rr[i], Tm);
-                M4 A, R;
-#pragma unroll
-                for (int k = 0; k < 16; k++) A.m[k] = Tm[HF_PS(k >> 2, k & 3)] * Ecur[HF_PS(k >> 2, k & 3)];
-                m4_mul(R, Q, A);
-                Q = R;
-                m4_renorm(Q);
-            }
-        }
-    }
-    {   // lane-minor: the 64 lanes of a wavefront write / read 1 KiB contiguous per instruction
-        double2* dst = reinterpret_cast<double2*>(Qs) + (int64_t) tile * 8 * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < 8; k++) dst[k * 64] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
-    }
-    // ordered tree product over lanes: after step d, lane l (l % 2d == 0) holds the product of lanes l..l+2d-1
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-        M4 Rgt, R;
-        m4_shfl_down(Rgt, Q, dd);
-        if ((lane & (2 * dd - 1)) == 0) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
-    }
-    if (lane == 0) {
-        double2* dst = reinterpret_cast<double2*>(Pt + (int64_t) tile * 16);
-#pragma unroll
-        for (int k = 0; k < 8; k++) dst[k] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
-    }
-    if (nan) atomicOr(flags, nan);
-}
-
-__device__ __forceinline__ void load_lane_product(M4& Q, const double* __restrict__ Qs, int tile, int lane) {
-    const double2* __restrict__ src = reinterpret_cast<const double2*>(Qs) + (int64_t) tile * 8 * 64 + lane;
-#pragma unroll
-    for (int k = 0; k < 8; k++) { const double2 v = src[k * 64]; Q.m[2 * k] = v.x; Q.m[2 * k + 1] = v.y; }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_carry: per chunk, sweep the tile products.  cf[tile] = normalised forward vector entering the tile
-// (tile 0 of a chunk: unused, the tile kernel starts from window 0); cb[tile] = direction of b at the LAST window
-// of the tile (= product of all later tiles applied to the end vector).
-// Wave 0 sweeps forward, wave 1 backward; each stages the tile products through its half of LDS in batches of
-// HF_CARRY_BATCH tiles (coalesced loads by all 64 lanes), then lane 0 runs the dependent chain out of LDS.
-// ------------------------------------------------------------------------------------------
-#define HF_CARRY_BATCH 128
-__global__ void __launch_bounds__(128) k_carry(const CarryDesc* __restrict__ cdesc, const double* __restrict__ Es,
-                                               const DevParams* __restrict__ P, const double* __restrict__ Pt,
-                                               double* __restrict__ cf, double* __restrict__ cb) {
-    __shared__ __attribute__((aligned(16))) double s_pt[2][HF_CARRY_BATCH * 16];
-    __shared__ __attribute__((aligned(16))) double s_out[2][HF_CARRY_BATCH * 4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const CarryDesc D = cdesc[blockIdx.x];
-    const int k0 = D.k0, nt = D.nt;
-    if (nt <= 0) return;
-    double* __restrict__ sp = s_pt[wave];
-    double* __restrict__ so = s_out[wave];
-    double v[4];
-    if (wave == 0) {   // start∘e of the chunk's first window (its row is the chunk's first entry of the slow list)
-        const DevRegion* __restrict__ R = &P->reg[D.reg_first];
-        const double* __restrict__ E0 = Es + (int64_t) D.slow0 * 16;
-        double sv = 0.0;
-#pragma unroll
-        for (int s = 0; s < 4; s++) { v[s] = E0[HF_PS(0, s)] * R->trans[4][s]; sv += v[s]; }
-#pragma unroll
-        for (int s = 0; s < 4; s++) v[s] /= sv;
-    } else {
-        const DevRegion* __restrict__ R = &P->reg[D.reg_last];
-        double sw = 0.0;
-#pragma unroll
-        for (int s = 0; s < 4; s++) { v[s] = R->trans[s][4]; sw += v[s]; }
-#pragma unroll
-        for (int s = 0; s < 4; s++) v[s] /= sw;
-    }
-    const int nb = (nt + HF_CARRY_BATCH - 1) / HF_CARRY_BATCH;
-    for (int bi = 0; bi < nb; bi++) {
-        // forward takes the batches in increasing order, backward in decreasing order
-        const int b0 = wave == 0 ? bi * HF_CARRY_BATCH : (nb - 1 - bi) * HF_CARRY_BATCH;
-        const int n = nt - b0 < HF_CARRY_BATCH ? nt - b0 : HF_CARRY_BATCH;
-        {
-            const double2* __restrict__ src = reinterpret_cast<const double2*>(Pt + (int64_t) (k0 + b0) * 16);
-            double2* dst = reinterpret_cast<double2*>(sp);
-            for (int i = lane; i < n * 8; i += 64) dst[i] = src[i];
-        }
-        __builtin_amdgcn_s_waitcnt(0);   // the wave's own LDS stores have landed (one wave per half: no block barrier)
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
-            // the chain carries the vector renormalised by a power of two (exact, and nothing else on the dependent
-            // path: one lane of one wavefront per SIMD pays the full latency of every instruction)
-            if (wave == 0) {
-                for (int k = 0; k < n; k++) {
-                    so[k * 4 + 0] = v[0]; so[k * 4 + 1] = v[1]; so[k * 4 + 2] = v[2]; so[k * 4 + 3] = v[3];
-                    const double* __restrict__ M = sp + k * 16;
-                    double u[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        double s = v[0] * M[j];
-                        s = fma(v[1], M[4 + j], s); s = fma(v[2], M[8 + j], s); s = fma(v[3], M[12 + j], s);
-                        u[j] = s;
-                    }
-                    int e;
-                    (void) frexp(fmax(fmax(u[0], u[1]), fmax(u[2], u[3])), &e);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) v[j] = ldexp(u[j], -e);
-                }
-            } else {
-                for (int k = n - 1; k >= 0; k--) {        // only the direction of b is used
-                    so[k * 4 + 0] = v[0]; so[k * 4 + 1] = v[1]; so[k * 4 + 2] = v[2]; so[k * 4 + 3] = v[3];
-                    const double* __restrict__ M = sp + k * 16;
-                    double u[4];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        double s = M[i * 4] * v[0];
-                        s = fma(M[i * 4 + 1], v[1], s); s = fma(M[i * 4 + 2], v[2], s); s = fma(M[i * 4 + 3], v[3], s);
-                        u[i] = s;
-                    }
-                    int e;
-                    (void) frexp(fmax(fmax(u[0], u[1]), fmax(u[2], u[3])), &e);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) v[i] = ldexp(u[i], -e);
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        if (wave == 0) {
-            // what a tile starts from is the carried vector divided by its sum (the reference's f sums to 1): one tile
-            // per lane, off the chain
-            double2* __restrict__ dst = reinterpret_cast<double2*>(cf + (int64_t) (k0 + b0) * 4);
-            const double2* __restrict__ so2 = reinterpret_cast<const double2*>(so);
-            for (int k = lane; k < n; k += 64) {
-                const double2 a = so2[k * 2], b = so2[k * 2 + 1];
-                const double sv = a.x + a.y + b.x + b.y;
-                dst[k * 2] = make_double2(a.x / sv, a.y / sv); dst[k * 2 + 1] = make_double2(b.x / sv, b.y / sv);
-            }
-        } else {
-            double* __restrict__ dst = cb + (int64_t) (k0 + b0) * 4;
-            for (int i = lane; i < n * 4; i += 64) dst[i] = so[i];
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_fb_tile: one wavefront per tile, forward then (BWD) backward + posterior labels.
-// Lane l owns windows a = base + l*L .. a+L-1 in both directions.  Backward: b_i = A_{i+1}·b_{i+1} / scale_i
-// (hmm.c:470-529); the vector a lane starts from is b at its own LAST window: direction = (product of the lane
-// products after it)·cb[tile], magnitude from sum_s f·b·scale = terminationProb with the lane's own f and scale;
-// the chunk's last window is b_{T-1}[s] = M[s][End] / scale_{T-1} (hmm.c:452-467).
-// ------------------------------------------------------------------------------------------
-// f and scale of a lane's windows wait for the backward half in LDS (not in 40 VGPRs): 165 VGPRs, 3 blocks per CU
-// (measured 77 -> 68 us against 190 VGPRs / 2 blocks; at 4 blocks the kernel spills)
-#ifndef HF_FB_BLOCKS
-#define HF_FB_BLOCKS 3
-#endif
-// RECS (with BWD): instead of the lane-minor arrays F, B the pass writes one 64-byte PAIR RECORD per window into F —
-// record t = { f_{t-1}[4], b_t[4] } (window-major, N+1 records) — what the statistics by emission row read (hf_rows.h);
-// the halves are written out of LDS by neighbouring lanes (16 cache lines per store instruction instead of 64).
-#define HF_FW_STRIDE 65   // doubles between the rows of the wave-private f / scale block: conflict-free both ways
-template <int L, bool BWD, bool RECS = false>
-__global__ void __launch_bounds__(256, HF_FB_BLOCKS) k_fb_tile(int ntiles, const TileDesc* __restrict__ td,
-                                                 const uint32_t* __restrict__ rec, const RowSrc S,
-                                                 const double* __restrict__ Qs, const DevParams* __restrict__ P,
-                                                 const double* __restrict__ cf, const double* __restrict__ cb,
-                                                 double* __restrict__ F, double* __restrict__ scale,
-                                                 double* __restrict__ B, int8_t* __restrict__ label,
-                                                 double* __restrict__ tile_ll, unsigned* __restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    fill_tab(P, s_tab);
-    const int tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (tile >= ntiles) return;
-    const TileDesc d = td[tile];
-    const int64_t t0 = d.t0, T = d.T, base = d.base;
-    const int64_t a = base + (int64_t) lane * L;
-    uint32_t rr[L];
-    const uint32_t rp = load_recs<L>(rec, t0, T, a, lane, rr);
-    int sidx[L];
-    tile_slow_index<L>(rr, lane, d.slow0, sidx);
-    const double2* rowp[L];
-#pragma unroll
-    for (int i = 0; i < L; i++) rowp[i] = row_ptr(S, rr[i], i == 0 ? rp : rr[i - 1], sidx[i]);
-    double Ecur[16];
-    if (a < T) load_row(rowp[0], Ecur);           // in flight during the scan
-    double carry[4];
-    if (base == 0) { carry[0] = 1.0; carry[1] = 0.0; carry[2] = 0.0; carry[3] = 0.0; }  // (1,0,0,0)·A_first = start∘e
-    else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) carry[j] = cf[(int64_t) tile * 4 + j];
-    }
-    unsigned bad = 0;
-    // ---- forward: exclusive prefix product over lanes ----
-    double f[4];
-    {
-        M4 Q;
-        load_lane_product(Q, Qs, tile, lane);
-        if (base == 0 && lane == 0) {   // the chunk's first window is not in Q_l: prepend A_first = start∘e (row 0 only)
-            double Tm[16];
-            lds_Tm(s_tab, rr[0], Tm);
-            M4 A, R;
-#pragma unroll
-            for (int k = 0; k < 16; k++) A.m[k] = Tm[HF_PS(k >> 2, k & 3)] * Ecur[HF_PS(k >> 2, k & 3)];
-            m4_mul(R, A, Q);
-            Q = R;
-            m4_renorm(Q);
-        }
-#pragma unroll
-        for (int d2 = 1; d2 < 64; d2 <<= 1) {
-            M4 Lft, R;
-            m4_shfl_up(Lft, Q, d2);
-            if (lane >= d2) { m4_mul(R, Lft, Q); Q = R; m4_renorm(Q); }
-        }
-        M4 X;
-        m4_shfl_up(X, Q, 1);
-        double u[4], su = 0.0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            double s = carry[0] * X.m[j];
-            s = fma(carry[1], X.m[4 + j], s); s = fma(carry[2], X.m[8 + j], s); s = fma(carry[3], X.m[12 + j], s);
-            u[j] = s; su += s;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) f[j] = (lane == 0) ? carry[j] : u[j] / su;
-    }
-    // replay this lane's windows in the reference's operation order (hmm.c:333-420); f and scale stay in registers
-    // f and scale of the lane's windows wait for the backward half in wave-private LDS, lane-minor (conflict-free)
-    double* __restrict__ s_fw = s_tab + P->n_regions * HF_TAB_STRIDE + (threadIdx.x >> 6) * (L * 5 * HF_FW_STRIDE) + lane;
-#define FW(i, s) s_fw[((i) * 5 + (s)) * HF_FW_STRIDE]
-#define SCW(i) s_fw[((i) * 5 + 4) * HF_FW_STRIDE]
-    double ll = 0.0;
-#pragma unroll
-    for (int i = 0; i < L; i++) {
-        double Enext[16];
-        if (i + 1 < L && a + i + 1 < T) load_row(rowp[i + 1], Enext);   // next window's row is in flight during this one
-        if (a + i < T) {
-            const int64_t t = t0 + a + i;
-            const uint32_t r = rr[i];
-            double Tm[16];
-            lds_Tm(s_tab, r, Tm);
-            double nf[4], sc = 0.0;
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                double acc = 0.0;
-#pragma unroll
-                for (int p = 0; p < 4; p++) acc += (f[p] * Tm[HF_PS(p, s)] * Ecur[HF_PS(p, s)]);
-                nf[s] = acc;
-                sc += acc;
-            }
-            if (!REC_FIRST(r) && sc < 1e-50) bad |= HF_FLAG_SCALE;   // hmm.c:412-415
-#pragma unroll
-            for (int s = 0; s < 4; s++) f[s] = nf[s] / sc;
-            ll += log(sc);                                            // hmm.c:428
-            if (!RECS) {
-                reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 0)] = make_double2(f[0], f[1]);
-                reinterpret_cast<double2*>(F)[fb_slot<L>(tile, lane, i, 1)] = make_double2(f[2], f[3]);
-            }
-            scale[t] = sc;
-#pragma unroll
-            for (int s = 0; s < 4; s++) FW(i, s) = f[s];
-            SCW(i) = sc;
-        } else {
-#pragma unroll
-            for (int s = 0; s < 4; s++) FW(i, s) = 0.0;
-            SCW(i) = 1.0;
-        }
-        if (i + 1 < L) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) Ecur[k] = Enext[k];
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
-    if (lane == 0) tile_ll[tile] = ll;
-    // pair records: window k of the tile is written by lanes 2k', 2k'+1 (16 bytes each) out of the wave's LDS block
-    // (wave-uniform record base in scalar registers, one 32-bit lane offset: no 64-bit address arithmetic per store)
-#define HF_COOP_HALF(DST_OFF, REC_SHIFT)                                                                               \
-    {                                                                                                                   \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                          \
-        __builtin_amdgcn_wave_barrier();                                                                                \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                          \
-        const double* __restrict__ s_w = s_fw - lane;                                                                   \
-        const int64_t rec0 = t0 + base;                                                                                 \
-        const int64_t rec0u = ((int64_t) __builtin_amdgcn_readfirstlane((int) (rec0 >> 32)) << 32) |                    \
-                              (uint32_t) __builtin_amdgcn_readfirstlane((int) rec0);                                    \
-        double2* __restrict__ Pw = reinterpret_cast<double2*>(F) + rec0u * 4;                                           \
-        const int nvalid = __builtin_amdgcn_readfirstlane((int) (T - base < 64 * L ? T - base : 64 * L));               \
-        const int sh = lane & 1, kl = lane >> 1;                                                                        \
-        _Pragma("unroll") for (int q = 0; q < (64 * L) / 32; q++) {                                                     \
-            const int k = 32 * q + kl, owner = k / L, i = k % L;                                                        \
-            if (k < nvalid) {                                                                                           \
-                const double2 v = make_double2(s_w[(i * 5 + 2 * sh) * HF_FW_STRIDE + owner],                            \
-                                               s_w[(i * 5 + 2 * sh + 1) * HF_FW_STRIDE + owner]);                       \
-                Pw[(k + (REC_SHIFT)) * 4 + (DST_OFF) + sh] = v;                                                         \
-            }                                                                                                           \
-        }                                                                                                               \
-    }
-    if (RECS) HF_COOP_HALF(0, 1)      // f_t goes into record t+1
-    if (BWD) {
-        // ---- backward: exclusive SUFFIX product over lanes ----
-        const int64_t Tm1 = T - 1;
-        int jl = (int) (T - a < L ? T - a : L) - 1;          // the lane's last window inside the chunk (< 0: none)
-        double b[4];
-        double Er[16];
-        if (jl == L - 1 && L >= 2) load_row(rowp[L - 1], Er);   // row of the first replayed step, in flight during the scan
-        {
-            M4 Q;
-            load_lane_product(Q, Qs, tile, lane);
-#pragma unroll
-            for (int d2 = 1; d2 < 64; d2 <<= 1) {
-                M4 Rgt, R;
-                m4_shfl_down(Rgt, Q, d2);
-                if (lane + d2 < 64) { m4_mul(R, Q, Rgt); Q = R; m4_renorm(Q); }
-            }
-            M4 X;
-            m4_shfl_down(X, Q, 1);
-            double cv[4];
-#pragma unroll
-            for (int s = 0; s < 4; s++) cv[s] = cb[(int64_t) tile * 4 + s];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                double s = X.m[i * 4] * cv[0];
-                s = fma(X.m[i * 4 + 1], cv[1], s); s = fma(X.m[i * 4 + 2], cv[2], s); s = fma(X.m[i * 4 + 3], cv[3], s);
-                b[i] = lane == 63 ? cv[i] : s;
-            }
-        }
-        if (jl >= 0) {
-            const uint32_t rlast = rec[t0 + T - 1];
-            const DevRegion* __restrict__ Rl = &P->reg[REC_REGION(rlast)];
-            double fl[4] = {0.0, 0.0, 0.0, 0.0}, scl = 1.0;      // f / scale of the lane's last window
-#pragma unroll
-            for (int i = 0; i < L; i++)
-                if (i == jl) {
-#pragma unroll
-                    for (int s = 0; s < 4; s++) fl[s] = FW(i, s);
-                    scl = SCW(i);
-                }
-            if (a + jl == Tm1) {   // hmm.c:452-467
-#pragma unroll
-                for (int s = 0; s < 4; s++) b[s] = Rl->trans[s][4] / scl;
-            } else {               // jl == L-1: direction from the scan, magnitude from the invariant at this window
-                const double term = Rl->trans[0][4];
-                double dot = 0.0;
-#pragma unroll
-                for (int s = 0; s < 4; s++) dot += fl[s] * b[s];
-                const double k = term / (scl * dot);
-#pragma unroll
-                for (int s = 0; s < 4; s++) b[s] *= k;
-            }
-            {
-                const int64_t t = t0 + a + jl;
-                {   // jl is wave-divergent only in a chunk's last tile
-                    if (!RECS) {
-                        const int64_t s0 = fb_slot<L>(tile, lane, jl, 0);
-                        reinterpret_cast<double2*>(B)[s0] = make_double2(b[0], b[1]);
-                        reinterpret_cast<double2*>(B)[s0 + 64] = make_double2(b[2], b[3]);
-                    }
-                }
-                label[t] = (int8_t) posterior_label(fl, b, scl);
-                if (RECS) {   // f of this window is not needed any more: its LDS slots take b for the record write
-#pragma unroll
-                    for (int i = 0; i < L; i++)
-                        if (i == jl) {
-#pragma unroll
-                            for (int s = 0; s < 4; s++) FW(i, s) = b[s];
-                        }
-                }
-            }
-        }
-        // replay the other windows (decreasing) in the reference's operation order: window i uses the row of i+1
-#pragma unroll
-        for (int i = L - 2; i >= 0; i--) {
-            double Enext[16];
-            if (i >= 1 && i <= jl) load_row(rowp[i], Enext);          // row of window i, used by window i-1
-            if (i < jl) {
-                const int64_t t = t0 + a + i;
-                double Tm[16];
-                lds_Tm(s_tab, rr[i + 1], Tm);
-                double nb[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int s = 0; s < 4; s++)
-#pragma unroll
-                    for (int p = 0; p < 4; p++) nb[p] += Tm[HF_PS(p, s)] * Er[HF_PS(p, s)] * b[s];
-                const double sc = SCW(i);
-                if (sc < 1e-50) bad |= HF_FLAG_SCALE;                 // hmm.c:521-524
-#pragma unroll
-                for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
-                if (!RECS) {
-                    reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 0)] = make_double2(b[0], b[1]);
-                    reinterpret_cast<double2*>(B)[fb_slot<L>(tile, lane, i, 1)] = make_double2(b[2], b[3]);
-                }
-                {
-                    const double fi[4] = {FW(i, 0), FW(i, 1), FW(i, 2), FW(i, 3)};
-                    label[t] = (int8_t) posterior_label(fi, b, sc);
-                }
-                if (RECS) {
-#pragma unroll
-                    for (int s = 0; s < 4; s++) FW(i, s) = b[s];
-                }
-            }
-            if (i >= 1) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) Er[k] = Enext[k];
-            }
-        }
-    }
-    if (BWD && RECS) HF_COOP_HALF(2, 0)   // b_t goes into record t
-#undef HF_COOP_HALF
-#undef FW
-#undef SCW
-    if (bad) atomicOr(flags, bad);
 }

@@ -204,6 +204,7 @@ int hf_last_kernel_ms(hf_ctx *ctx, float *ms);
  * the LAST pass in milliseconds (0 for kernels not selected or not run).  Call after hf_finish/hf_check.
  * Each selected kernel adds two event packets to the stream, so select only what is being measured. */
 #define HF_NKERNELS 16
+/* HF_K_PROD_TILE, HF_K_CARRY, HF_K_FB_TILE: round 1's tile kernels, retired (never run; the indices stay) */
 enum { HF_K_TABLES = 0, HF_K_PROD_TILE, HF_K_CARRY, HF_K_FB_TILE, HF_K_STATS_TILE, HF_K_CHUNK_STATS, HF_K_REDUCE,
        HF_K_EMIT_ROWS, HF_K_FWD_SEQ, HF_K_BWD_SEQ, HF_K_PAIR_SUMS, HF_K_ROW_STATS, HF_K_ROWS_TOTAL, HF_K_SEG_PROD, HF_K_SEG_FB, HF_K_AROWS };
 #define HF_PROF_PASS 0x80000000u   /* in kernel_mask: also bracket the whole pass (hf_last_kernel_ms) */
@@ -215,7 +216,7 @@ int hf_kernel_times(hf_ctx *ctx, float ms[HF_NKERNELS]);
 /* Sum of the durations (ms) and number of timed launches of every selected kernel over all passes finished by
  * hf_finish / hf_em_iterate since the last hf_set_profiling: one call after a timed loop instead of one per pass. */
 int hf_kernel_time_sums(hf_ctx *ctx, double sum_ms[HF_NKERNELS], int64_t launches[HF_NKERNELS]);
-const char *hf_kernel_name(int k);   /* "k_tables", "k_prod_tile", ... as they appear in a rocprofv3 kernel trace */
+const char *hf_kernel_name(int k);   /* "k_tables", "k_seg_fb", ... as they appear in a rocprofv3 kernel trace */
 
 /* Self-test hook: fast[i] = a[i] / d[i] through the shared-denominator form the statistics kernel uses (hf_device.h
  * prediv / divp), exact[i] = the plain division, safe[i] = whether the kernel's guard would take the fast form.
