@@ -1,32 +1,32 @@
-// hf_seg.h — HF_ALGO_SCAN, second generation: one WORKGROUP per chunk segment, the whole forward / backward / decode of
-// the segment in one kernel (BASELINE north_star: "one contig-chunk per workgroup ... wavefront prefix-scan for the
-// forward/backward recurrences").
+// hf_seg.h — HF_ALGO_SCAN: one WORKGROUP per chunk segment, the whole forward / backward / decode of the segment in two
+// launches (BASELINE north_star: "one contig-chunk per workgroup ... wavefront prefix-scan for the forward/backward
+// recurrences").
 //
-// A chunk of T windows (hmm.c:333-545 runs it strictly sequentially) is cut into n = ceil(T / (NL*LMAX)) equal SEGMENTS
-// (NL = 64*NW lanes per workgroup); chunks of up to NL*LMAX windows are ONE segment.  Inside a segment lane j owns the
-// L = ceil(n_windows / NL) consecutive windows j*L .. j*L+L-1, in both directions:
-//   A  lane product Q_j = A_{jL} ... A_{jL+L-1}, A_t = T_t∘E_t (rows from this iteration's tables, k_tables);
-//   B  prefix and suffix scans of Q over the 64 lanes of a wavefront (DPP row shifts / broadcasts, no LDS traffic inside a
-//      row of 16 lanes), the NW wave totals through LDS, and — chunks of several segments only — the products of the
-//      chunk's other segments (k_seg_prod, a separate, cheap launch): every lane gets the normalised forward vector
-//      entering its first window and the direction of b at its last one;
-//   C  forward REPLAY of the lane's windows in the reference's exact operation order ((f·T)·e, pre-inner sums, division by
-//      the scale, log): only the carried-in vector differs from a sequential run, in the last ulp;
+// A chunk of T windows (hmm.c:333-545 runs it strictly sequentially) is cut into n = ceil(T / HF_SEG_SPLIT) equal SEGMENTS of
+// at most NL*LMAX windows (NL = 64*NW lanes per workgroup; NW = 1 by default: a CU is busy for the sum of its workgroups'
+// steps, and one-wavefront workgroups spread most evenly).  Inside a segment lane j owns the L = ceil(n_windows / NL)
+// consecutive windows j*L .. j*L+L-1, in both directions:
+//   A  (k_seg_prod) lane product Q_j = A_{jL} ... A_{jL+L-1}, A_t = T_t∘e_t: ONE precomputed 128-byte row per window (below);
+//      the product of the whole segment for the chunk's other segments;
+//   B  (k_seg_fb) prefix and suffix scans of Q over the 64 lanes of a wavefront (DPP row shifts / broadcasts, no LDS traffic
+//      inside a row of 16 lanes), the wave totals through LDS when NW > 1, and the products of the chunk's other segments:
+//      every lane gets the normalised forward vector entering its first window and the direction of b at its last one;
+//   C  forward REPLAY of the lane's windows (f·A, pre-inner sums, division by the scale, log: hmm.c:366-434): the carried-in
+//      vector differs from a sequential run in the last ulp, and so may a term f·(T·e) from the reference's (f·T)·e;
 //   D  backward replay + posterior argmax (hmm.c:470-529, 671-692); the magnitude of the carried-in b from the invariant
 //      sum_s f_t[s]·b_t[s]·scale_t = terminationProb of the scaled forward-backward.
-// No lane product, tile product or carry vector ever goes through HBM, and nothing is computed twice for one-segment chunks.
 //
-// Emission rows: every lane needs ITS OWN 128-byte row per window.  A lane reading its row with eight 16-byte loads touches
+// Rows: every lane needs ITS OWN 128-byte row per window.  A lane reading its row with eight 16-byte loads touches
 // 64 different cache lines per instruction and depends on the 32 KiB L1 keeping each line for the seven loads that follow —
 // it does not (measured: ~1 000 cycles per wavefront and row).  Here the 64 rows of a step are fetched COOPERATIVELY with
 // LDS-DMA (global_load_lds_dwordx4: instruction q moves rows 8q..8q+7 complete, 8 lanes x 16 bytes each, straight into the
 // wavefront's 8 KiB LDS block — no staging registers) and every lane then reads its row with eight conflict-free
 // ds_read_b128; the piece rotation that makes the reads conflict-free is applied on the SOURCE side of the DMA.
 //
-// Output = the PAIR RECORDS the statistics by emission row read (hf_rows.h): record(t) = { f_{t-1}[4], b_t[4] }, 64 bytes,
-// and the scales — both in SLOT order: window w of a segment (w = j*L + i) lives in slot slot0 + i*NL + j, so that at every
-// step the lanes of a wavefront write 64 consecutive records (the statistics plan addresses records by slot; the host
-// getters apply the same map).  Labels leave through LDS, coalesced.
+// Output = the PAIR RECORDS the statistics read (hf_rows.h by emission row, hf_chunks.h per chunk): record(t) = { f_{t-1}[4],
+// b_t[4] }, 64 bytes, and the scales — both in SLOT order: window w of a segment (w = j*L + i) lives in slot
+// slot0 + i*NL + j, so that at every step the lanes of a wavefront write 64 consecutive records (the statistics address
+// records by slot; the host getters apply the same map).  Labels leave through LDS, coalesced.
 #pragma once
 #include "hf_scan.h"
 
