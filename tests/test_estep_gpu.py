@@ -263,6 +263,33 @@ def test_scale_underflow_is_reported():
         orc.close()
 
 
+def test_nan_emission_is_reported():
+    """The reference exits with '[Error] prob is NAN' (hmm_utils.c:782-786); the ABI returns HF_E_NAN.  A negative variance
+    makes sqrt(var*2*PI) NaN for every window; full and forward-only passes, both statistics paths, both algorithms."""
+    store = synth.synthesize([400_000, 150_000], 1000, 200_000, [20], seed=3)
+    K = 3
+    for algo in (N.HF_ALGO_SEQ, N.HF_ALGO_SCAN):
+        model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+        v = model.param_vector()
+        km = (v.size - 27) // 12                 # [trans 25 | lambda | trunc | mean 4*KM | var 4*KM | weight 4*KM]
+        v[27 + 4 * km + 2 * km] = -1.0           # variance of the Hap state
+        model.set_param_vector(v)
+        orc = Oracle(store, 0, K, synth.HIFI_ALPHA)
+        orc.set_param_vector(model.param_vector())
+        assert orc.run_iteration() < 0
+        orc.close()
+        for mode in ((N.HF_STATS_CHUNKS,) if algo == N.HF_ALGO_SEQ else (N.HF_STATS_ROWS, N.HF_STATS_CHUNKS)):
+            em = make_em(store, model, algo=algo)
+            em.set_stats_mode(mode)
+            with pytest.raises(N.HFError) as ei:
+                hmm.EM_runOneIterationForList(em, model)
+            assert ei.value.code == N.HF_E_NAN
+            with pytest.raises(N.HFError) as ei:
+                hmm.EM_runForwardForList(em, model)
+            assert ei.value.code == N.HF_E_NAN
+            em.close()
+
+
 def test_full_size_cfg2_one_pass_and_invariants():
     """BASELINE configs[2] at full size (1.5 M windows, 286 chunks): one E-pass against the oracle plus
     size-independent properties of the scaled forward-backward."""
