@@ -23,12 +23,16 @@ int squarem_iteration(hfm_model** model, std::vector<double>& stats, double tol,
     const double ll0 = hfm_loglikelihood(m0);
     hfm_model* prime = hfm_squarem_model_prime(acc);
     rc = estep(prime, HF_MODE_FORWARD_ONLY, stats.data());
-    while (rc == HF_OK && stats[0] < ll0) {
-        // alpha == -1: prime IS model 0 (hmm.c:871-884), whose likelihood is ll0 by definition.  The reference compares the
-        // same code path's sums on both sides; here ll0 comes from a FULL pass and stats[0] from a FORWARD_ONLY pass, whose
-        // summation orders are matched by construction but not by contract — never shrink past the fixed point.
-        if (hfm_squarem_alpha(acc) == -1.0) break;
+    // hmm.c:904-914: shrink alpha until the likelihood is not below model 0's.  A shrink that comes within 1e-2 of -1 sets
+    // alpha = -1 and makes prime a COPY OF MODEL 0 (hmm.c:871-884) — the loop's fixed point: its likelihood is ll0 by
+    // definition, and the reference leaves the loop there because both sides come from the same code path.  Here ll0 comes
+    // from a FULL pass and stats[0] from a FORWARD_ONLY pass, whose summation orders are matched by construction but not by
+    // contract: never shrink again once the fixed point is reached.  (An alpha that STARTS at -1, hmm.c:1095-1097, is not
+    // the fixed point: prime is then the extrapolation with alpha = -1, i.e. model 2, and must still be tested and shrunk.)
+    bool fixed_point = false;
+    while (rc == HF_OK && stats[0] < ll0 && !fixed_point) {
         prime = hfm_squarem_shrink(acc);
+        fixed_point = hfm_squarem_alpha(acc) == -1.0;
         rc = estep(prime, HF_MODE_FORWARD_ONLY, stats.data());
     }
     if (rc == HF_OK) {

@@ -1,3 +1,4 @@
+#include <stdio.h>
 /*
  * ohf_squarem.c — ORACLE (test infrastructure, not product code).
  * SQUAREM acceleration restated from /root/reference/programs/submodules/hmm/hmm.c:820-1098 and
@@ -140,6 +141,7 @@ int ohf_squarem_iteration(ohf_chunks *cc, ohf_model *m, const ohf_run_opts *o, d
         model_assign(m, a.prime);
     }
     if (alpha_out) *alpha_out = a.alpha;
+    if (!st) fprintf(stderr, "Computed alpha rate for accelerating EM = %.4f\n", a.alpha);   /* hmm.c:916 */
     ohf_model_destroy(a.m0); ohf_model_destroy(a.rr); ohf_model_destroy(a.rv); ohf_model_destroy(a.prime); ohf_model_destroy(m1);
     return st;
 }

@@ -40,4 +40,11 @@ for seed in range(first, first + count):
     diff = [f for f in FILES if not filecmp.cmp(os.path.join(outs[0][1], f), os.path.join(outs[1][1], f), shallow=False)]
     if diff:
         bad += 1; print("seed", seed, model, extra, "windows", store.n_windows, "DIFFERENT:", diff)
+        if os.environ.get("FUZZ_SHOW"):          # the lines that differ (first 6 per file)
+            for f in diff:
+                a = open(os.path.join(outs[0][1], f)).read().splitlines(); b = open(os.path.join(outs[1][1], f)).read().splitlines()
+                shown = 0
+                for x, y in zip(a, b):
+                    if x != y and shown < 6:
+                        print("   ", f, "|", x[:150], "|", y[:150]); shown += 1
 print("seeds", first, "..", first + count - 1, "runs with a difference:", bad)

@@ -75,6 +75,26 @@ def test_cli_negative_binomial_model_matches_oracle_cli(extra, tmp_path):
     assert "Negative Binomial" in (tmp_path / "gpu" / "emission_final.tsv").read_text()
 
 
+@pytest.mark.parametrize("seed", [9010, 9040, 9270, 9280, 9330])
+def test_squarem_on_small_inputs_where_the_rate_starts_at_minus_one(seed, tmp_path):
+    """Short inputs make SQUAREM's alpha start at (or shrink to) -1 in most accelerated iterations (hmm.c:871-884, 904-914,
+    1095-1097): an alpha that STARTS at -1 is the extrapolation to model 2 and must still be shrunk to the fixed point
+    (prime = model 0) when its likelihood is lower.  Inputs of profiles/tools/fuzz_cli.py (found by it in round 2)."""
+    rng = np.random.default_rng(9000 + seed)
+    window_len = int(rng.choice([1000, 4000]))
+    lengths = [int(rng.integers(50, 3000)) * window_len + int(rng.integers(0, window_len)) for _ in range(int(rng.integers(1, 5)))]
+    R = int(rng.integers(1, 4))
+    store = synth.synthesize(lengths, window_len, int(rng.choice([50, 300])) * window_len, [int(rng.integers(10, 40)) for _ in range(R)],
+                             seed=seed, avg_alignment_len=int(rng.choice([0, 15_000])), region_run_bases=(5 * window_len, 300 * window_len))
+    binp = tmp_path / "in.bin"
+    store.write_bin(str(binp))
+    model = ["trunc_exp_gaussian", "gaussian", "negative_binomial"][seed % 3]
+    args = ["-i", str(binp), "-n", "15", "-W", str(window_len), "-m", model] + ([] if model == "negative_binomial" else ["-A", ALPHA]) + ["--accelerate"]
+    _run(CLI, args, tmp_path / "gpu")
+    _run(ORACLE, args + ["--threads", "8"], tmp_path / "cpu")
+    _same_files(tmp_path / "gpu", tmp_path / "cpu", OUTPUTS)
+
+
 def test_cli_diploid_em_with_minimum_lengths(tmp_path):
     store = synth.config(2, scale=0.01)
     binp = tmp_path / "d.bin"
