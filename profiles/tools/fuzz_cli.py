@@ -27,6 +27,13 @@ for seed in range(first, first + count):
     store.write_bin(os.path.join(d, "in.bin"))
     model = ["trunc_exp_gaussian", "gaussian", "negative_binomial"][seed % 3]
     extra = ["--accelerate"] if seed % 5 == 0 else []
+    if os.environ.get("FUZZ_OPTIONS"):           # second axis: the options that change the E-step's inputs
+        if rng.random() < 0.25: extra += ["-e"]
+        if rng.random() < 0.3: extra += ["-q", "%.2f" % rng.uniform(0.1, 0.9), "--minHighMapqRatio", "%.2f" % rng.uniform(0.1, 0.9)]   # the reference has no short -Q
+        if rng.random() < 0.3: extra += ["-p", str(int(rng.integers(2, 9)))]
+        if rng.random() < 0.3: extra += ["-f", "%.2f" % rng.uniform(0.5, 1.0)]
+        if rng.random() < 0.3: extra += ["-P"]
+        if rng.random() < 0.2: extra += ["-M", "%d,%d,%d" % tuple(int(x) * window_len for x in rng.integers(1, 6, 3))]
     args = ["-i", os.path.join(d, "in.bin"), "-n", "15", "-W", str(window_len), "-m", model] + ([] if model == "negative_binomial" else ["-A", ALPHA]) + extra
     outs = []
     for exe, name in ((CLI, "p"), (ORC, "o")):
@@ -37,7 +44,9 @@ for seed in range(first, first + count):
         bad += 1; print("seed", seed, model, extra, "return codes differ", outs[0][0], outs[1][0]); continue
     if outs[0][0] != 0:
         continue
-    diff = [f for f in FILES if not filecmp.cmp(os.path.join(outs[0][1], f), os.path.join(outs[1][1], f), shallow=False)]
+    names = FILES + [f for f in sorted(os.listdir(outs[1][1])) if f not in FILES and ("posterior" in f or f.startswith("prediction_summary"))]
+    diff = [f for f in names if not (os.path.exists(os.path.join(outs[0][1], f)) and
+                                     filecmp.cmp(os.path.join(outs[0][1], f), os.path.join(outs[1][1], f), shallow=False))]
     if diff:
         bad += 1; print("seed", seed, model, extra, "windows", store.n_windows, "DIFFERENT:", diff)
         if os.environ.get("FUZZ_SHOW"):          # the lines that differ (first 6 per file)
