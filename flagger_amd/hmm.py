@@ -476,7 +476,7 @@ def HMM_resetEstimators(model: HMM) -> None:
 def runHMMFlagger(emList, model: HMM, numberOfIterations: int = 100, convergenceTol: float = 0.001,
                   outputDir: Optional[str] = None, writeParameterStatsPerIteration: bool = False,
                   is_writer: bool = True) -> List[float]:
-    """EM outer loop of hmm_flagger.c:285-488 (no --accelerate here; see squarem.py).  Returns the
+    """EM outer loop of hmm_flagger.c:285-488 (no --accelerate here: that loop is flagger_amd/csrc/hf_squarem.h, driven by the command line).  Returns the
     log-likelihood of every E-pass (the rows of loglikelihood.tsv)."""
     lls: List[float] = []
     llf = None
