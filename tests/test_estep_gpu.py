@@ -239,6 +239,28 @@ def test_full_em_against_oracle(algo, tmp_path):
     orc.close()
 
 
+@pytest.mark.parametrize("model_type", [hmm.MODEL_TRUNC_EXP_GAUSSIAN, hmm.MODEL_NEGATIVE_BINOMIAL])
+def test_forward_only_loglikelihood_equals_the_full_pass_bit_for_bit(model_type):
+    """SQUAREM's line search (hmm.c:904-914) ends when EM_runForwardForList on a copy of model 0 returns model 0's
+    log-likelihood from EM_runOneIterationForList: the reference — and the re-pointed reference (integration/hmm_hip_shim.c) —
+    relies on the two passes summing alike.  Both statistics paths, both algorithms, several shapes."""
+    for seed, scale in ((1, 0.004), (2, 0.013), (3, 0.05)):
+        store = synth.config(2 if seed < 3 else 4, scale=scale)
+        K = 4
+        alpha = np.zeros((4, 4)) if model_type == hmm.MODEL_NEGATIVE_BINOMIAL else synth.HIFI_ALPHA
+        model = hmm.createModel(model_type, K, store, alpha)
+        for algo in (N.HF_ALGO_SEQ, N.HF_ALGO_SCAN):
+            for mode in ((N.HF_STATS_CHUNKS,) if algo == N.HF_ALGO_SEQ else (N.HF_STATS_ROWS, N.HF_STATS_CHUNKS)):
+                em = make_em(store, model, algo=algo)
+                em.set_stats_mode(mode)
+                hmm.EM_runOneIterationForList(em, model)
+                full = model.loglikelihood
+                hmm.HMM_resetEstimators(model)
+                hmm.EM_runForwardForList(em, model)
+                assert model.loglikelihood == full, (seed, algo, mode)
+                em.close()
+
+
 def test_scale_underflow_is_reported():
     """The reference exits with 'scale ... is very low!' (hmm.c:412-415); the ABI returns HF_E_SCALE.
     Emissions are floored at 1e-40, so the scale only underflows through the transition matrix: put almost all

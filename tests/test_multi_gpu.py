@@ -147,7 +147,7 @@ def test_one_process_per_gpu_rank_object_with_one_rank():
                 assert np.array_equal(m.local_labels(), ref_labels)
                 assert np.array_equal(m.rank_stats(0), got)
                 fwd = m.run_sharded(model, N.HF_MODE_FORWARD_ONLY)
-                assert fwd[0] == got[0] or abs(fwd[0] - got[0]) <= 1e-11 * abs(got[0])
+                assert fwd[0] == got[0]                          # forward-only and full passes sum alike (SQUAREM relies on it)
                 m.em.set_profiling(True)                         # the borrowed context view answers
                 m.run_sharded(model, N.HF_MODE_FULL)
                 assert m.em.kernel_times()["k_tables"] > 0.0
