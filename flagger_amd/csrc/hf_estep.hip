@@ -653,6 +653,10 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             } else { slot_of.clear(); slot_f.clear(); }
             cphase("segments");
         }
+        if (algo == HF_ALGO_SCAN && N > 0 && C > 0 && ctx->nseg == 0) {
+            hf_destroy(ctx);
+            return set_err(HF_E_ARG, "hf_create: HF_ALGO_SCAN holds at most 2^30 windows per context (shard the chunk list: hmm_flagger_multi.h)");
+        }
         // ---- plan of the statistics by emission row (hf_rows.h) ----
         if (N > 0 && C > 0 && ctx->nseg > 0) {
             const size_t n_rows_all = (size_t) ctx->n_lut + slow.size();
