@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--no-weak-leg", action="store_true",
                     help="with --gpus N > 1 and strong scaling the line also carries a `weak_scaling` object (one whole genome per "
                          "GPU, timed after the main region); this switch skips it")
+    ap.add_argument("--force-weak-leg", action="store_true",
+                    help="run the weak-scaling leg even with one rank (exercises that code path on a 1-GPU box; with --dist-path)")
     ap.add_argument("--dist-path", action="store_true",
                     help="take the multi-GPU code path (process group, all-gather, indexed reduction) even with one GPU")
     args = ap.parse_args()
@@ -228,7 +230,7 @@ def main():
 
     # second leg at N > 1: the same exchange with one WHOLE genome per GPU (weak scaling), outside the timed region above
     weak = None
-    if world > 1 and args.scaling == "strong" and not args.no_weak_leg:
+    if (world > 1 or (args.force_weak_leg and dist_path)) and args.scaling == "strong" and not args.no_weak_leg:
         try:
             wstore = base_store.subset_chunks(list(range(base_store.n_chunks)) * world)
             wmodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, wstore, alpha)
