@@ -130,6 +130,7 @@ struct hf_ctx {
     double* d_scale_s = nullptr; int64_t n_slots = 0;
     std::vector<int32_t> h_slot_of, h_slot_f;   // window -> record slot of its b half / of its f half (host getters)
     bool pass_seg = false;             // the last pass ran the segment kernels (log-likelihood partials per segment)
+    unsigned long long* d_seg_trace = nullptr;   // -DHF_SEG_TRACE builds only
     int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_Es = nullptr; double* d_Cs = nullptr;
 };
 
@@ -208,7 +209,11 @@ __global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __res
 #include "hf_chunks.h"
 #include "hf_rows.h"
 #include "hf_nb_rows.h"
+#ifdef HF_SEG_R2          // temporary: round 2's segment kernels, for same-box A/B runs
+#include "hf_seg_r2.h"
+#else
 #include "hf_seg.h"
+#endif
 
 
 // ------------------------------------------------------------------------------------------
@@ -530,8 +535,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         std::vector<int32_t>& slot_of = ctx->h_slot_of;
         std::vector<int32_t>& slot_f = ctx->h_slot_f;
         if (N > 0 && C > 0 && N < (size_t) INT32_MAX / 2) {
-            constexpr int64_t NL = 64 * HF_SEG_WAVES;
-            static_assert(HF_SEG_SPLIT <= 64 * HF_SEG_WAVES * HF_SEG_LMAX, "a segment has at most HF_SEG_LMAX windows per lane");
+            constexpr int64_t NL = 64;
+            static_assert(HF_SEG_SPLIT <= 64 * HF_SEG_LMAX, "a segment has at most HF_SEG_LMAX windows per lane");
             // (cutting small inputs finer than this was tried: more, shorter workgroups are slower — the scans are a fixed cost)
             constexpr int64_t SMAX = HF_SEG_SPLIT;
             // ---- rows of A = T∘e: the (key, transition class) pairs that occur, then the slow windows ----
@@ -788,6 +793,13 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         const char* e = std::getenv("HF_STATS");
         ctx->stats_mode = (e && std::strcmp(e, "chunks") == 0) ? HF_STATS_CHUNKS : HF_STATS_ROWS;
     }
+#ifdef HF_SEG_TRACE
+    if (ctx->nseg > 0 && std::getenv("HF_SEG_TRACE_FILE")) {
+        DMALLOC(ctx->d_seg_trace, (size_t) ctx->nseg * HF_SEG_TRACE_N * 8);
+        hipMemset(ctx->d_seg_trace, 0, (size_t) ctx->nseg * HF_SEG_TRACE_N * 8);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_seg_trace), &ctx->d_seg_trace, sizeof(void*));
+    }
+#endif
     *out = ctx;
     return HF_OK;
 }
@@ -795,6 +807,17 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
 void hf_destroy(hf_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+#ifdef HF_SEG_TRACE
+    if (ctx->d_seg_trace) {
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t) ctx->nseg * HF_SEG_TRACE_N);
+        hipMemcpy(h.data(), ctx->d_seg_trace, h.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE* fp = std::fopen(std::getenv("HF_SEG_TRACE_FILE"), "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
+        unsigned long long* null_p = nullptr;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_seg_trace), &null_p, sizeof(void*));
+        hipFree(ctx->d_seg_trace);
+    }
+#endif
     if (ctx->host_trace && ctx->ht_n)
         std::fprintf(stderr, "[hf host trace] %ld EM steps: enqueue %.1f us, wait %.1f us, m-step %.1f us, gpu span (first launch .. reduction) %.1f us\n",
                      ctx->ht_n, ctx->ht[0] / ctx->ht_n, ctx->ht[1] / ctx->ht_n, ctx->ht[2] / ctx->ht_n, ctx->ht[3] / ctx->ht_n);
@@ -957,14 +980,22 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 }
             } else if (seg_pass(ctx)) {
                 // one workgroup per chunk segment does the whole forward-backward (hf_seg.h)
+#ifdef HF_SEG_R2
                 constexpr int NW = HF_SEG_WAVES;
                 const size_t lds = seg_lds_bytes<NW>();
+#define HF_SEG_PROD k_seg_prod<NW>
+#define HF_SEG_FB(B) k_seg_fb<NW, B>
+#else
+                const size_t lds = seg_lds_bytes();
+#define HF_SEG_PROD k_seg_prod
+#define HF_SEG_FB(B) k_seg_fb<B>
+#endif
                 if (ctx->host_trace && !ctx->ht_n) {
                     int o1 = 0, o2 = 0;
-                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_seg_prod<NW>, NW * 64, lds);
-                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_seg_fb<NW, true>, NW * 64, lds);
-                    std::fprintf(stderr, "[hf host trace] segment kernels: %d workgroups of %d threads, %zu B of LDS; resident per CU: k_seg_prod %d, k_seg_fb %d\n",
-                                 ctx->nseg, NW * 64, lds, o1, o2);
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, HF_SEG_PROD, 64, lds);
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, HF_SEG_FB(true), 64, lds);
+                    std::fprintf(stderr, "[hf host trace] segment kernels: %d workgroups of 64 threads, %zu B of LDS; resident per CU: k_seg_prod %d, k_seg_fb %d\n",
+                                 ctx->nseg, lds, o1, o2);
                 }
                 if (nbm) {   // k_tables_nb leaves the emission rows; the Gaussian k_tables writes the rows of A itself
                     KTimer t(ctx, st, HF_K_AROWS);
@@ -973,15 +1004,15 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 }
                 {
                     KTimer t(ctx, st, HF_K_SEG_PROD);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_prod<NW>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_arow,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(HF_SEG_PROD), dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow,
                                        ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
                 }
                 KTimer t(ctx, st, HF_K_SEG_FB);
                 if (full)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, true>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_arow,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(HF_SEG_FB(true)), dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow,
                                        ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
                 else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<NW, false>), dim3((unsigned) ctx->nseg), dim3(NW * 64), lds, st, ctx->d_seg, ctx->d_arow,
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(HF_SEG_FB(false)), dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow,
                                        ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
                 ctx->pass_seg = true;
                 if (full) ctx->fb_recs = true;

@@ -1,49 +1,69 @@
-// hf_seg.h — HF_ALGO_SCAN: one WORKGROUP per chunk segment, the whole forward / backward / decode of the segment in two
-// launches (BASELINE north_star: "one contig-chunk per workgroup ... wavefront prefix-scan for the forward/backward
-// recurrences").
+// hf_seg.h — HF_ALGO_SCAN: one WORKGROUP (one wavefront) per chunk segment, the whole forward / backward / decode of the
+// segment in two launches (BASELINE north_star: "one contig-chunk per workgroup ... wavefront prefix-scan for the
+// forward/backward recurrences").
 //
 // A chunk of T windows (hmm.c:333-545 runs it strictly sequentially) is cut into n = ceil(T / HF_SEG_SPLIT) equal SEGMENTS of
-// at most NL*LMAX windows (NL = 64*NW lanes per workgroup; NW = 1 by default: a CU is busy for the sum of its workgroups'
-// steps, and one-wavefront workgroups spread most evenly).  Inside a segment lane j owns the L = ceil(n_windows / NL)
-// consecutive windows j*L .. j*L+L-1, in both directions:
+// at most 64*LMAX windows (one-wavefront workgroups: a CU is busy for the sum of its workgroups' steps, and they spread most
+// evenly).  Inside a segment lane j owns the L = ceil(n_windows / 64) consecutive windows j*L .. j*L+L-1, in both directions:
 //   A  (k_seg_prod) lane product Q_j = A_{jL} ... A_{jL+L-1}, A_t = T_t∘e_t: ONE precomputed 128-byte row per window (below);
 //      the product of the whole segment for the chunk's other segments;
-//   B  (k_seg_fb) prefix and suffix scans of Q over the 64 lanes of a wavefront (DPP row shifts / broadcasts, no LDS traffic
-//      inside a row of 16 lanes), the wave totals through LDS when NW > 1, and the products of the chunk's other segments:
-//      every lane gets the normalised forward vector entering its first window and the direction of b at its last one;
+//   B  (k_seg_fb) prefix and suffix scans of Q over the 64 lanes (DPP row shifts / broadcasts, no LDS traffic inside a row of
+//      16 lanes) and the products of the chunk's other segments (staged in LDS once, then two short chains): every lane gets
+//      the normalised forward vector entering its first window and the direction of b at its last one;
 //   C  forward REPLAY of the lane's windows (f·A, pre-inner sums, division by the scale, log: hmm.c:366-434): the carried-in
-//      vector differs from a sequential run in the last ulp, and so may a term f·(T·e) from the reference's (f·T)·e;
-//   D  backward replay + posterior argmax (hmm.c:470-529, 671-692); the magnitude of the carried-in b from the invariant
-//      sum_s f_t[s]·b_t[s]·scale_t = terminationProb of the scaled forward-backward.
+//      vector differs from a sequential run in the last ulp, and so may a term f·(T·e) from the reference's (f·T)·e.  The
+//      lane's forward vectors and scales STAY IN REGISTERS (round 3: the loop is unrolled over the step index, <= 8 x 5
+//      doubles) — nothing is written in this phase;
+//   D  backward replay + posterior argmax (hmm.c:470-529, 671-692) reading f and the scales from those registers; the
+//      magnitude of the carried-in b from the invariant sum_s f_t[s]·b_t[s]·scale_t = terminationProb of the scaled
+//      forward-backward.  Every step writes one WHOLE pair record and one scale, fire and forget.
 //
 // Rows: every lane needs ITS OWN 128-byte row per window.  A lane reading its row with eight 16-byte loads touches
 // 64 different cache lines per instruction and depends on the 32 KiB L1 keeping each line for the seven loads that follow —
 // it does not (measured: ~1 000 cycles per wavefront and row).  Here the 64 rows of a step are fetched COOPERATIVELY with
 // LDS-DMA (global_load_lds_dwordx4: instruction q moves rows 8q..8q+7 complete, 8 lanes x 16 bytes each, straight into the
 // wavefront's 8 KiB LDS block — no staging registers) and every lane then reads its row with eight conflict-free
-// ds_read_b128; the piece rotation that makes the reads conflict-free is applied on the SOURCE side of the DMA.
+// ds_read_b128; the piece rotation that makes the reads conflict-free is applied on the SOURCE side of the DMA.  The row
+// offsets a lane needs for the DMA (those of eight OTHER lanes) come from a per-segment LDS table written once, arranged
+// [step][lane & 7][lane >> 3]: two ds_read_b128 per step (round 2 moved them with eight dependent ds_bpermute per step).
 //
 // Output = the PAIR RECORDS the statistics read (hf_rows.h by emission row, hf_chunks.h per chunk): record(t) = { f_{t-1}[4],
 // b_t[4] }, 64 bytes, and the scales — both in SLOT order: window w of a segment (w = j*L + i) lives in slot
-// slot0 + i*NL + j, so that at every step the lanes of a wavefront write 64 consecutive records (the statistics address
-// records by slot; the host getters apply the same map).  Labels leave through LDS, coalesced.
+// slot0 + i*64 + j, so that at every step the lanes of a wavefront write 64 consecutive records (the statistics address
+// records by slot; the host getters apply the same map).  f_{t-1} of a lane's first window is the previous lane's last
+// forward vector (one DPP-free shuffle), of a segment's first window the carried-in vector.  Labels leave through LDS.
 #pragma once
 #include "hf_scan.h"
 
-#ifndef HF_SEG_WAVES
-#define HF_SEG_WAVES 1      // wavefronts per workgroup (1: the finest load balance over the CUs; measured best or equal from 0.2 M to 6 M windows)
+#ifndef HF_ABL
+#define HF_ABL 0
 #endif
-#ifndef HF_SEG_LMAX
-#define HF_SEG_LMAX 8       // windows per lane at most: a chunk longer than 64*HF_SEG_WAVES*HF_SEG_LMAX windows is split
-#endif
-#ifndef HF_SEG_SPLIT
-#define HF_SEG_SPLIT (64 * HF_SEG_WAVES * HF_SEG_LMAX)   // windows per segment a chunk is cut by (equal parts of at most this)
-#endif
+#define HF_SEG_LMAX 8                        // windows per lane at most: a chunk longer than 64*HF_SEG_LMAX windows is split
+#define HF_SEG_SPLIT (64 * HF_SEG_LMAX)      // windows per segment a chunk is cut by (equal parts of at most this)
+#define HF_SEG_PSTAGE 24                     // segment products of a chunk staged in LDS by k_seg_fb (the rest: global loads)
 #ifndef HF_SEG_OCC
-#define HF_SEG_OCC 4        // wavefronts per SIMD the register allocation aims at
+#define HF_SEG_OCC 3        // wavefronts per SIMD the register allocation of k_seg_fb aims at (168 VGPRs: the lane's 8 x 5 doubles stay in registers)
 #endif
 
 // SegDesc: hf_device.h
+
+// -DHF_SEG_TRACE: s_memtime stamps of k_seg_fb<true>'s phases, one row of HF_SEG_TRACE_N words per workgroup, dumped by
+// hf_destroy to $HF_SEG_TRACE_FILE (profiles/tools/seg_trace.sh / seg_trace.py).  Not in a normal build.
+#define HF_SEG_TRACE_N 24
+#ifdef HF_SEG_TRACE
+__device__ unsigned long long* g_seg_trace = nullptr;
+#define TR_DECL unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tr_t = clock64(); (void) tr_acc; (void) tr_t
+#define TR_STAMP(k) do { if (BWD && g_seg_trace && lane == 0) g_seg_trace[(size_t) g * HF_SEG_TRACE_N + (k)] = clock64(); } while (0)
+#define TR_LAP(k) do { const unsigned long long n_ = clock64(); tr_acc[k] += n_ - tr_t; tr_t = n_; } while (0)
+#define TR_RESET() do { tr_t = clock64(); } while (0)
+#define TR_FLUSH(k0, n) do { if (BWD && g_seg_trace && lane == 0) for (int q_ = 0; q_ < (n); q_++) g_seg_trace[(size_t) g * HF_SEG_TRACE_N + (k0) + q_] = tr_acc[q_]; } while (0)
+#else
+#define TR_DECL
+#define TR_STAMP(k)
+#define TR_LAP(k)
+#define TR_RESET()
+#define TR_FLUSH(k0, n)
+#endif
 
 __device__ __forceinline__ void v4_renorm(double v[4]) {
     int e;
@@ -138,33 +158,92 @@ __device__ __forceinline__ void m4_scan_suffix(M4& Sq, int lane) {
     if (lane < 32) { m4_mul(R, Sq, Rgt); Sq = R; m4_renorm_tree(Sq); }
 }
 
+// ---- LDS of a segment workgroup: the 8 KiB row block | the offset table [LMAX][8][8] u32 | the labels [64*LMAX] ----
+// 10.5 KiB: at least twelve workgroups per CU (3 per SIMD, what k_seg_fb's registers allow); 13 KiB was measured to admit only
+// eleven.  k_seg_fb's prologue stages the chunk's segment products in the row block, which is idle until the scans.
+__host__ __device__ constexpr size_t seg_lds_bytes() { return 8192 + (size_t) 64 * HF_SEG_LMAX * 5; }
+static_assert((size_t) HF_SEG_PSTAGE * 128 <= 8192, "the staged segment products fit the row block");
+
+// the segment's row indices, read coalesced (lane l takes windows l, 64 + l, ...)
+__device__ __forceinline__ void seg_load_arows(const int32_t* __restrict__ arow_seg, int n, int L, int lane, int32_t rr[HF_SEG_LMAX]) {
+#pragma unroll
+    for (int c = 0; c < HF_SEG_LMAX; c++) { const int w = c * 64 + lane; rr[c] = (c < L && w < n) ? arow_seg[w] : 0; }
+}
+// ... and filed as BYTE OFFSETS of the rows (index << 7; hf_create keeps n_arows < 2^25) where the cooperative fetch reads
+// them: window w = j*L + i (lane j's i-th) at [i][j & 7][j >> 3]; windows past the segment's end point at row 0
+__device__ __forceinline__ void seg_offsets_store(const int32_t rr[HF_SEG_LMAX], int L, int lane, uint32_t* __restrict__ s_off) {
+    const uint32_t inv = (65536u + (uint32_t) L - 1u) / (uint32_t) L;   // w / L for w < 512, L <= 8: (w * inv) >> 16, exact
+#pragma unroll
+    for (int c = 0; c < HF_SEG_LMAX; c++)
+        if (c < L) {
+            const uint32_t w = (uint32_t) (c * 64 + lane), j = (w * inv) >> 16, i = w - j * (uint32_t) L;
+            s_off[(i * 8 + (j & 7u)) * 8 + (j >> 3)] = ((uint32_t) rr[c] & 0x7fffffffu) << 7;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- cooperative row fetch through the wavefront's 8 KiB LDS block (see the header) ----
 // Row r of the step (the row lane r needs) occupies bytes r*128 .. r*128+127 of the block; piece p of the row sits in slot
 // (p + (r >> 1)) & 7: the eight ds_read_b128 of a lane group then cover all 64 banks exactly once.
-__device__ __forceinline__ void rows_issue(const double* __restrict__ rows, int32_t ridx, int lane, double* __restrict__ blk) {
+struct RowFetch {
+    const char* __restrict__ base;          // the table of rows of A (wave-uniform)
+    const uint32_t* __restrict__ my_off;    // this lane's eight offsets of step 0: s_off + (lane >> 3) * 8; step i: + i * 64
+    uint32_t lds_blk;                       // LDS byte address of the row block (wave-uniform)
+    uint32_t off_even, off_odd;             // the 16-byte piece this lane moves, for even / odd instructions
+};
+__device__ __forceinline__ RowFetch rowfetch_init(const double* __restrict__ rows, const uint32_t* __restrict__ s_off, double* __restrict__ blk, int lane) {
     // lane (sub, part) of instruction q moves 16 bytes of row r = 8q + sub: piece (part - (r >> 1)) & 7 = (c0 - 4q) & 7, i.e.
     // one of two values; 32-bit byte offsets from the (wave-uniform) table base
     const int part = lane & 7, sub = lane >> 3;
     const uint32_t c0 = (uint32_t) (part - (sub >> 1));
-    const uint32_t off_even = (c0 & 7u) << 4, off_odd = ((c0 + 4u) & 7u) << 4;
-    const char* __restrict__ base = reinterpret_cast<const char*>(rows);
+    RowFetch F;
+    F.base = reinterpret_cast<const char*>(rows); F.my_off = s_off + sub * 8;
+    F.lds_blk = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) (__attribute__((address_space(3))) char*) blk);
+    F.off_even = (c0 & 7u) << 4; F.off_odd = ((c0 + 4u) & 7u) << 4;
+    return F;
+}
+__device__ __forceinline__ void rows_issue(const RowFetch& F, int step) {
+    const uint4* __restrict__ t = reinterpret_cast<const uint4*>(F.my_off + step * 64);
+    const uint4 o0 = t[0], o1 = t[1];
+    uint32_t o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+#if HF_ABL == 1
+    if (step != 0) return;
+#elif HF_ABL == 2
+    for (int q = 0; q < 8; q++) o[q] = 0;
+#elif HF_ABL == 3
+    for (int q = 0; q < 8; q++) o[q] = (uint32_t) (q * 8 + (threadIdx.x >> 3)) << 7;
+#elif HF_ABL == 4
+    for (int q = 0; q < 8; q++) o[q] = (uint32_t) (((q * 8 + (threadIdx.x >> 3)) * 37 + blockIdx.x * 64) % 8000) << 7;
+#endif
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        const uint32_t idx = (uint32_t) __shfl(ridx, q * 8 + sub);
-        const uint32_t off = (idx << 7) + ((q & 1) ? off_odd : off_even);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (base + off),
-                                         (__attribute__((address_space(3))) void*) (blk + q * 128), 16, 0, 0);
+#if HF_ABL == 5
+        if (step != 0 && q >= 4) break;
+#endif
+        const uint32_t off = o[q] | ((q & 1) ? F.off_odd : F.off_even);
+        // The DMA is inline assembly on purpose: with the builtin, hipcc (ROCm 7.2) keeps a pending LDS write on its vmcnt
+        // scoreboard and turns every wait before a later ds_read into vmcnt(0) — which would also wait for the backward
+        // replay's record stores (rows_read<NEWER>).  M0 = LDS address of the instruction's 1 KiB; nothing else in these
+        // kernels uses M0.  Unknown to the scoreboard, the DMA can only make the compiler's own counted waits longer.
+        const uint32_t la = F.lds_blk + (uint32_t) q * 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(la), "v"(off), "s"(F.base) : "memory");
     }
 }
+// NEWER = vector-memory instructions issued AFTER the row fetch that may stay in flight (the backward replay's record stores:
+// vmcnt counts loads and stores in issue order, so "at most NEWER outstanding" means the older DMA has landed)
+template <int NEWER = 0>
 __device__ __forceinline__ void rows_read(const double* __restrict__ blk, int lane, double E[16]) {
-    __builtin_amdgcn_s_waitcnt(0);          // the wavefront's own LDS-DMA has landed (vmcnt) — nothing else orders it
+    static_assert(NEWER >= 0 && NEWER < 16, "vmcnt immediate");
+    __builtin_amdgcn_s_waitcnt(NEWER | (7 << 4));   // vmcnt(NEWER) lgkmcnt(0): the wavefront's own LDS-DMA has landed — nothing else orders it
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const double2* __restrict__ row = reinterpret_cast<const double2*>(blk) + lane * 8;
 #pragma unroll
     for (int k = 0; k < 8; k++) { const double2 d = row[(k + (lane >> 1)) & 7]; E[2 * k] = d.x; E[2 * k + 1] = d.y; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0);          // the reads have returned before the block is refilled
+    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0) only: the reads have returned before the block is refilled
     __builtin_amdgcn_wave_barrier();
 }
 // park / fetch a lane's matrix in the same block, same rotation (the block is idle during the scans)
@@ -209,8 +288,9 @@ __device__ __forceinline__ int posterior_label_fast(const double f[4], const dou
 // with the emission key (region, x, x_prev) of hf_scan.h that makes a few thousand distinct 4x4 matrices per pass.
 // They are multiplied out once per pass (row = class table ∘ emission row of this iteration's tables; one row per
 // (key, class) that occurs at an interior window, one per slow window: by k_tables itself, hf_scan.h, or — after
-// k_tables_nb — by k_arows), and the segment kernels fetch ONE 128-byte row per window and step: no transition-table lookup, no second factor, no region tables in LDS, and the row of a window is a
-// precomputed index (hf_create: d_arow, bit 31 = chunk-first) instead of a function of two records and a slow-list rank.
+// k_tables_nb — by k_arows), and the segment kernels fetch ONE 128-byte row per window and step: no transition-table
+// lookup, no second factor, no region tables in LDS, and the row of a window is a precomputed index (hf_create: d_arow,
+// bit 31 = chunk-first) instead of a function of two records and a slow-list rank.
 // The product f·(T·e) differs from the reference's (f·T)·e in the last bit of a term; the segment kernels never were
 // bit-identical to a sequential run (the carried-in vectors differ in the last bit already).
 // A NaN in a row (hmm_utils.c:783-786) reaches the scale of the window that uses it: k_seg_fb raises HF_FLAG_NAN there.
@@ -227,24 +307,37 @@ __global__ void __launch_bounds__(256) k_arows(int n_rows, const int32_t* __rest
     lutA[(int64_t) id * 16 + o] = t * lutE[(int64_t) src[id] * 16 + o];
 }
 
-#define HF_AROW_ID(r) ((r) & 0x7fffffff)
-
-// the lane's product of A_t over its m windows (a chunk-first window is left out: it belongs to the start vector).  All 64
-// lanes run all L steps (the row fetch is cooperative); lanes past their last window fetch row 0 and skip the arithmetic.
-__device__ __forceinline__ void seg_lane_product(const int32_t* __restrict__ arow_seg, int a, int m, int L,
-                                                 const double* __restrict__ lutA, double* __restrict__ blk, int lane, M4& Q) {
+// ------------------------------------------------------------------------------------------
+// k_seg_prod: phase A for every segment: the lane products (lane-minor: 1 KiB per store instruction; k_seg_fb's scans start
+// from them) and the product of the whole segment (used by the chunk's OTHER segments only).  A chunk-first window is left
+// out of its lane's product: it belongs to the start vector.  All 64 lanes run all L steps (the row fetch is cooperative);
+// lanes past their last window fetch row 0 and skip the arithmetic.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64, 4) k_seg_prod(const SegDesc* __restrict__ sd, const int32_t* __restrict__ arow,
+                                                    const double* __restrict__ lutA, double* __restrict__ Qs, double* __restrict__ Pseg) {
+    extern __shared__ __attribute__((aligned(16))) double s_W[];
+    double* __restrict__ blk = s_W;
+    uint32_t* __restrict__ s_off = reinterpret_cast<uint32_t*>(s_W + 1024);
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const SegDesc d = sd[g];
+    const int L = d.L, a = lane * L;
+    const int m = d.n - a < L ? (d.n - a > 0 ? d.n - a : 0) : L;
+    {
+        int32_t rr[HF_SEG_LMAX];
+        seg_load_arows(arow + d.t0, d.n, L, lane, rr);
+        seg_offsets_store(rr, L, lane, s_off);
+    }
+    const RowFetch F = rowfetch_init(lutA, s_off, blk, lane);
+    const int i0 = (a == 0 && d.k == 0) ? 1 : 0;               // the chunk's first window starts the chain (hmm.c:333-364)
+    M4 Q;
     m4_identity(Q);
-    int32_t r = m > 0 ? arow_seg[a] : 0;
-    int32_t r1 = m > 1 ? arow_seg[a + 1] : 0;              // row indices are fetched two steps ahead
-    rows_issue(lutA, HF_AROW_ID(r), lane, blk);
+    rows_issue(F, 0);
 #pragma unroll 1
     for (int i = 0; i < L; i++) {
         double E[16];
         rows_read(blk, lane, E);
-        const int32_t rn = r1;
-        if (i + 1 < L) rows_issue(lutA, HF_AROW_ID(rn), lane, blk);   // in flight during this step
-        r1 = i + 2 < m ? arow_seg[a + i + 2] : 0;
-        if (i < m && r >= 0) {
+        if (i + 1 < L) rows_issue(F, i + 1);                     // in flight during this step
+        if (i < m && i >= i0) {
             M4 A, R;
 #pragma unroll
             for (int k = 0; k < 16; k++) A.m[k] = E[HF_PS(k >> 2, k & 3)];
@@ -252,57 +345,15 @@ __device__ __forceinline__ void seg_lane_product(const int32_t* __restrict__ aro
             Q = R;
             m4_renorm_tree(Q);
         }
-        r = rn;
     }
-}
-
-// bytes of dynamic LDS of the segment kernels: wave totals | ll partials (+ padding) | labels | row blocks
-template <int NW>
-__host__ __device__ constexpr size_t seg_lds_bytes() {
-    return (NW * 16 + 2 * NW) * 8 + (size_t) 64 * NW * HF_SEG_LMAX + (size_t) NW * 8192;
-}
-
-// ------------------------------------------------------------------------------------------
-// k_seg_prod: phase A for every segment: the lane products (lane-minor: 1 KiB per store instruction; k_seg_fb's scans start
-// from them) and the product of the whole segment (used by the chunk's OTHER segments only).
-// ------------------------------------------------------------------------------------------
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_prod(const SegDesc* __restrict__ sd, const int32_t* __restrict__ arow,
-                                                                   const double* __restrict__ lutA,
-                                                                   double* __restrict__ Qs, double* __restrict__ Pseg) {
-    constexpr int NL = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) double s_W[];
-    const int g = blockIdx.x;
-    const SegDesc d = sd[g];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = wave * 64 + lane;
-    double* __restrict__ blk = s_W + NW * 16 + 2 * NW + (64 * NW * HF_SEG_LMAX) / 8 + wave * 1024;
-    const int a = j * d.L;
-    const int m = d.n - a < d.L ? (d.n - a > 0 ? d.n - a : 0) : d.L;
-    M4 Q;
-    seg_lane_product(arow + d.t0, a, m, d.L, lutA, blk, lane, Q);
     {
-        double2* __restrict__ dst = reinterpret_cast<double2*>(Qs) + (int64_t) g * 8 * NL + j;
+        double2* __restrict__ dst = reinterpret_cast<double2*>(Qs) + (int64_t) g * 8 * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < 8; k++) dst[k * NL] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
+        for (int k = 0; k < 8; k++) dst[k * 64] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
     }
     if (d.nseg == 1) return;                                  // nobody reads the product of a one-segment chunk
-    m4_scan_prefix(Q, lane);                                  // lane 63: the product of the wavefront
+    m4_scan_prefix(Q, lane);                                  // lane 63: the product of the segment
     if (lane == 63) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) s_W[wave * 16 + k] = Q.m[k];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) Q.m[k] = s_W[k];
-        for (int w = 1; w < NW; w++) {
-            M4 B, R;
-#pragma unroll
-            for (int k = 0; k < 16; k++) B.m[k] = s_W[w * 16 + k];
-            m4_mul(R, Q, B);
-            Q = R;
-            m4_renorm_tree(Q);
-        }
         double2* dst = reinterpret_cast<double2*>(Pseg + (int64_t) g * 16);
 #pragma unroll
         for (int k = 0; k < 8; k++) dst[k] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
@@ -313,60 +364,94 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_prod(const SegDesc*
 // k_seg_fb: one workgroup per segment: phases B-D of the header.  BWD = false: forward only (EM_runForwardForList,
 // hmm.c:790-816): log-likelihood and error flags, nothing else is written.
 // ------------------------------------------------------------------------------------------
-template <int NW, bool BWD>
-__global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* __restrict__ sd, const int32_t* __restrict__ arow,
-                                                                 const double* __restrict__ lutA, const DevParams* __restrict__ P,
-                                                                 const double* __restrict__ Qs, const double* __restrict__ Pseg,
-                                                                 double* __restrict__ recs,
-                                                                 double* __restrict__ scale_s, int8_t* __restrict__ label,
-                                                                 double* __restrict__ seg_ll, unsigned* __restrict__ flags) {
-    constexpr int NL = NW * 64;
-    extern __shared__ __attribute__((aligned(16))) double s_W[];           // [NW][16] wave totals
-    double* __restrict__ s_red = s_W + NW * 16;                           // [NW] log-likelihood partials (+ NW of padding)
-    int8_t* __restrict__ s_lab = reinterpret_cast<int8_t*>(s_red + 2 * NW);   // [NL * LMAX] labels of the segment
-    const int g = blockIdx.x;
+template <bool BWD>
+__global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __restrict__ sd, const int32_t* __restrict__ arow,
+                                                           const double* __restrict__ lutA, const DevParams* __restrict__ P,
+                                                           const double* __restrict__ Qs, const double* __restrict__ Pseg,
+                                                           double* __restrict__ recs, double* __restrict__ scale_s,
+                                                           int8_t* __restrict__ label, double* __restrict__ seg_ll,
+                                                           unsigned* __restrict__ flags) {
+    constexpr int LM = HF_SEG_LMAX;
+    extern __shared__ __attribute__((aligned(16))) double s_W[];
+    double* __restrict__ blk = s_W;                                           // the 8 KiB row block
+    uint32_t* __restrict__ s_off = reinterpret_cast<uint32_t*>(s_W + 1024);   // the row offsets of the replay
+    int8_t* __restrict__ s_lab = reinterpret_cast<int8_t*>(s_W + 1024) + 64 * LM * 4;   // [64 * LM] labels of the segment
+    double* __restrict__ s_P = s_W;                                           // prologue: the chunk's segment products, in the (still idle) row block
+    const int g = blockIdx.x, lane = threadIdx.x;
     const SegDesc d = sd[g];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, j = wave * 64 + lane;
-    double* __restrict__ blk = s_red + 2 * NW + (64 * NW * HF_SEG_LMAX) / 8 + wave * 1024;   // this wavefront's 8 KiB row block
     const int L = d.L, n = d.n;
-    const int a = j * L;
+    const int a = lane * L;
     const int m = n - a < L ? (n - a > 0 ? n - a : 0) : L;
-    const int32_t* __restrict__ arow_seg = arow + d.t0;
     const bool chunk_first = a == 0 && d.k == 0;                           // this lane's first window starts the chunk
     unsigned bad = 0;
     double fin[4], bdir[4];
+    TR_DECL;
+    TR_STAMP(0);
     {
-        // ---- A: the lane product, from k_seg_prod ----
-        M4 Q;
-        {
-            const double2* __restrict__ src = reinterpret_cast<const double2*>(Qs) + (int64_t) g * 8 * NL + j;
+        // ---- A: loads, in the order they are consumed (vmcnt counts in order): row indices, the products of the chunk's other
+        // segments, the start row; LAST the lane product of k_seg_prod — the offset table and the two chains over the other
+        // segments run while it is still in flight ----
+        int32_t rr[LM];
+        seg_load_arows(arow + d.t0, n, L, lane, rr);
+        const int nst = d.nseg < HF_SEG_PSTAGE ? d.nseg : HF_SEG_PSTAGE;
+        double2 pst[(HF_SEG_PSTAGE * 8 + 63) / 64];
+        if (d.nseg > 1) {
+            const double2* __restrict__ src = reinterpret_cast<const double2*>(Pseg + (int64_t) d.seg0 * 16);
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const double2 v = src[k * NL]; Q.m[2 * k] = v.x; Q.m[2 * k + 1] = v.y; }
+            for (int c = 0; c < (HF_SEG_PSTAGE * 8 + 63) / 64; c++) if (c * 64 + lane < nst * 8) pst[c] = src[c * 64 + lane];
         }
-        // ---- B: scans over the lanes of the wavefront; Q waits for the second scan in the (idle) row block ----
-        if (BWD) m4_park(Q, lane, blk);
-        m4_scan_prefix(Q, lane);
-        if (lane == 63) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) s_W[wave * 16 + k] = Q.m[k];
-        }
-        double xv[16];                                          // exclusive prefix: the product of lanes 0..lane-1
-#pragma unroll
-        for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);
-        __syncthreads();
-        // forward vector entering the segment: start∘e of the chunk's first window (row (0, s) of its row of A), through the
-        // products of the chunk's earlier segments and of the earlier wavefronts
-        double v[4];
+        // forward vector entering the chunk: start∘e of its first window = row (0, s) of that window's row of A
+        double v[4], u[4];
         {
             const double* __restrict__ A0 = lutA + (int64_t) d.chunk_slow0 * 16;
-            double sv = 0.0;
 #pragma unroll
-            for (int s = 0; s < 4; s++) { v[s] = A0[HF_PS(0, s)]; sv += v[s]; }
+            for (int s = 0; s < 4; s++) v[s] = A0[HF_PS(0, s)];
+        }
+        const DevRegion* __restrict__ Rl = &P->reg[d.reg_last];
+#pragma unroll
+        for (int s = 0; s < 4; s++) u[s] = Rl->trans[s][4];     // the end vector (hmm.c:452-467)
+        M4 Q;
+        {
+            const double2* __restrict__ src = reinterpret_cast<const double2*>(Qs) + (int64_t) g * 8 * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const double2 q2 = src[k * 64]; Q.m[2 * k] = q2.x; Q.m[2 * k + 1] = q2.y; }
+        }
+        seg_offsets_store(rr, L, lane, s_off);
+        TR_STAMP(1);
+        if (d.nseg > 1) {
+#pragma unroll
+            for (int c = 0; c < (HF_SEG_PSTAGE * 8 + 63) / 64; c++) if (c * 64 + lane < nst * 8) reinterpret_cast<double2*>(s_P)[c * 64 + lane] = pst[c];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        {
+            const double sv = ((v[0] + v[1]) + v[2]) + v[3];
 #pragma unroll
             for (int s = 0; s < 4; s++) v[s] /= sv;
         }
-        for (int q = 0; q < d.k; q++) { v4_mul_right(v, Pseg + (int64_t) (d.seg0 + q) * 16); v4_renorm(v); }
-        for (int w = 0; w < wave; w++) { v4_mul_right(v, s_W + w * 16); v4_renorm(v); }
+        for (int q = 0; q < d.k; q++) {                          // through the chunk's earlier segments
+            if (q < HF_SEG_PSTAGE) v4_mul_right(v, s_P + q * 16); else v4_mul_right(v, Pseg + (int64_t) (d.seg0 + q) * 16);
+            v4_renorm(v);
+        }
+        TR_STAMP(2);
+        if (BWD) {                                               // ... and back through the later ones
+            v4_renorm(u);
+            for (int q = d.nseg - 1; q > d.k; q--) {
+                if (q < HF_SEG_PSTAGE) v4_mul_left(u, s_P + q * 16); else v4_mul_left(u, Pseg + (int64_t) (d.seg0 + q) * 16);
+                v4_renorm(u);
+            }
+        }
+        TR_STAMP(3);
+        // ---- B: scans over the lanes of the wavefront; Q waits for the second scan in the (idle) row block ----
+        if (BWD) m4_park(Q, lane, blk);
+        TR_STAMP(4);
+#if HF_ABL != 6
+        m4_scan_prefix(Q, lane);
+#endif
+        double xv[16];                                          // exclusive prefix: the product of lanes 0..lane-1
+#pragma unroll
+        for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);
         if (lane > 0) v4_mul_right(v, xv);
         {
             const double su = ((v[0] + v[1]) + v[2]) + v[3];
@@ -374,53 +459,39 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* _
             for (int s = 0; s < 4; s++) fin[s] = v[s] / su;
         }
         if (chunk_first) { fin[0] = 1.0; fin[1] = 0.0; fin[2] = 0.0; fin[3] = 0.0; }   // (1,0,0,0)·A_first = start∘e
+        TR_STAMP(5);
         if (BWD) {
             m4_unpark(Q, lane, blk);
+#if HF_ABL != 6
             m4_scan_suffix(Q, lane);
+#endif
 #pragma unroll
             for (int k = 0; k < 16; k++) xv[k] = __shfl_down(Q.m[k], 1);   // exclusive suffix: lanes lane+1..63
-            // direction of b at the lane's last window: everything after it applied to the end vector (hmm.c:452-467)
-            double u[4];
-            const DevRegion* __restrict__ Rl = &P->reg[d.reg_last];
-#pragma unroll
-            for (int s = 0; s < 4; s++) u[s] = Rl->trans[s][4];
-            v4_renorm(u);
-            for (int q = d.nseg - 1; q > d.k; q--) { v4_mul_left(u, Pseg + (int64_t) (d.seg0 + q) * 16); v4_renorm(u); }
-            for (int w = NW - 1; w > wave; w--) { v4_mul_left(u, s_W + w * 16); v4_renorm(u); }
+            // direction of b at the lane's last window: everything after it applied to the end vector
 #pragma unroll
             for (int s = 0; s < 4; s++) bdir[s] = u[s];
             if (lane < 63) v4_mul_left(bdir, xv);
         }
     }
-    // ---- C: forward replay (hmm.c:333-434) ----
+    const RowFetch F = rowfetch_init(lutA, s_off, blk, lane);
+    TR_STAMP(6);
+    // ---- C: forward replay (hmm.c:333-434).  fs[i], ss[i]: forward vector and scale of the lane's i-th window (registers) ----
     double f[4] = {fin[0], fin[1], fin[2], fin[3]};
+    double fs[LM][4], ss[LM];
+    double A[16];
     // log-likelihood of the lane's windows: sum of log(scale) (hmm.c:428) as log(product of the mantissas) + (sum of the
     // exponents)·ln 2 — one log per lane instead of one (~95 instructions) per window; <= HF_SEG_LMAX mantissas in [0.5, 1)
     double lm = 1.0, scl = 1.0;
     int le = 0;
-    const int64_t slot_ij = (int64_t) d.slot0 + j;                         // + i*NL
-    // The outputs of step i (scale, f) are STORED at the top of step i+1, after the wait for that step's rows: a store issued
-    // right before the wait would make every step pay the full store latency (vmcnt counts loads and stores alike).
-    auto store_fwd = [&](int i) {
-        scale_s[slot_ij + (int64_t) i * NL] = scl;
-        // f_t is the first half of record t+1: the lane's next slot, the next lane's first slot, or the next segment's
-        int64_t sf = i + 1 < L ? slot_ij + (int64_t) (i + 1) * NL : slot_ij + 1;
-        if (a + i + 1 == n) sf = d.next_slot;
-        double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + sf * 4;
-        dst[0] = make_double2(f[0], f[1]); dst[1] = make_double2(f[2], f[3]);
-    };
-    {
-        int32_t r = m > 0 ? arow_seg[a] : 0;
-        int32_t r1 = m > 1 ? arow_seg[a + 1] : 0;                          // row indices are fetched two steps ahead
-        rows_issue(lutA, HF_AROW_ID(r), lane, blk);
-#pragma unroll 1
-        for (int i = 0; i < L; i++) {
-            double A[16];
+    rows_issue(F, 0);
+    TR_RESET();
+#pragma unroll
+    for (int i = 0; i < LM; i++) {
+        if (i < L) {                                            // wave-uniform
             rows_read(blk, lane, A);
-            if (BWD && i >= 1 && i - 1 < m) store_fwd(i - 1);
-            const int32_t rn = r1;
-            if (i + 1 < L) rows_issue(lutA, HF_AROW_ID(rn), lane, blk);
-            r1 = i + 2 < m ? arow_seg[a + i + 2] : 0;
+            TR_LAP(0);
+            if (i + 1 < L) rows_issue(F, i + 1);                // in flight during this step
+            TR_LAP(1);
             if (i < m) {
                 double nf[4];
 #pragma unroll
@@ -431,29 +502,39 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* _
                     nf[s] = acc;
                 }
                 const double sc = ((nf[0] + nf[1]) + nf[2]) + nf[3];
-                if (r >= 0 && sc < 1e-50) bad |= HF_FLAG_SCALE;           // hmm.c:412-415 (not at the chunk's first window)
+                if (!(chunk_first && i == 0) && sc < 1e-50) bad |= HF_FLAG_SCALE;   // hmm.c:412-415 (not at the chunk's first window)
                 if (!(sc == sc)) bad |= HF_FLAG_NAN;                      // a NaN emission value (hmm_utils.c:783-786)
 #pragma unroll
-                for (int s = 0; s < 4; s++) f[s] = nf[s] / sc;
+                for (int s = 0; s < 4; s++) { f[s] = nf[s] / sc; fs[i][s] = f[s]; }
                 { int e2; lm *= frexp(sc, &e2); le += e2; }                // hmm.c:428, see above
-                scl = sc;
+                scl = sc; ss[i] = sc;
             }
-            r = rn;
+            TR_LAP(2);
         }
-        if (BWD && L - 1 < m) store_fwd(L - 1);
     }
-    double ll = log(lm) + (double) le * 0.693147180559945309417232121458;
-    for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
-    if (lane == 0) s_red[wave] = ll;
+    TR_STAMP(7);
+    {
+        double ll = log(lm) + (double) le * 0.693147180559945309417232121458;
+        for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
+        if (lane == 0) seg_ll[g] = ll;
+    }
+    TR_STAMP(8);
     // ---- D: backward replay + labels (hmm.c:452-545, 671-692) ----
     if (BWD) {
         const int jl = m - 1;                                   // the lane's last window (< 0: none)
         const DevRegion* __restrict__ Rl = &P->reg[d.reg_last];
+        const int64_t slot_ij = (int64_t) d.slot0 + lane;       // + i*64
+        // f of the window before the lane's first one: the previous lane's last forward vector, the carried-in vector for lane 0
+        double fp[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) { fp[s] = __shfl_up(f[s], 1); if (lane == 0) fp[s] = fin[s]; }
         double b[4] = {0.0, 0.0, 0.0, 0.0};
         if (jl >= 0) {
             if (d.k == d.nseg - 1 && a + jl == n - 1) {         // the chunk's last window, hmm.c:452-467
 #pragma unroll
                 for (int s = 0; s < 4; s++) b[s] = Rl->trans[s][4] / scl;
+                double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + (int64_t) d.next_slot * 4;   // its f: the chunk's spare slot
+                dst[0] = make_double2(f[0], f[1]); dst[1] = make_double2(f[2], f[3]);
             } else {                                            // direction from the scans, magnitude from the invariant at this window
                 const double term = Rl->trans[0][4];
                 double dot = 0.0;
@@ -465,66 +546,79 @@ __global__ void __launch_bounds__(NW * 64, HF_SEG_OCC) k_seg_fb(const SegDesc* _
             }
             s_lab[a + jl] = (int8_t) posterior_label_fast(f, b, scl);
         }
-        // b_k is stored at the top of the step that consumes it (see store_fwd); scale and f of a step are loaded one step ahead
-        auto store_bwd = [&](int k) {
-            double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + (slot_ij + (int64_t) k * NL) * 4 + 2;
-            dst[0] = make_double2(b[0], b[1]); dst[1] = make_double2(b[2], b[3]);
+        // record k = { f_{k-1}, b_k } and scale k leave at the top of the step that consumes b_k; window k's row turns b_k into
+        // b_{k-1}.  All lanes run k = L-1 .. 1 (cooperative fetch), a lane joins at its last window.  The first step still
+        // holds the row of window L-1 from the forward replay (a lane that joins there has m = L).
+        // Through the (momentarily idle) row block, so that every store instruction writes 1 KiB CONTIGUOUS (16 whole records):
+        // written lane by lane as 16-byte pieces at a 64-byte stride, the same bytes cost 13 us more per launch (partial-line
+        // writes: measured, profiles/r03_notes).  All 64 lanes store; the slots of lanes without a window k are padding.
+        auto store_rec = [&](int k, bool act, const double* __restrict__ fk, double sck) {
+            double2* __restrict__ mine = reinterpret_cast<double2*>(blk) + lane * 4;
+            mine[0] = make_double2(fk[0], fk[1]); mine[1] = make_double2(fk[2], fk[3]);
+            mine[2] = make_double2(b[0], b[1]); mine[3] = make_double2(b[2], b[3]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + lane;
+            const double2 v0 = img[0], v1 = img[64], v2 = img[128], v3 = img[192];
+            double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + ((int64_t) d.slot0 + (int64_t) k * 64) * 4 + lane;
+            dst[0] = v0; dst[64] = v1; dst[128] = v2; dst[192] = v3;
+            if (act) scale_s[slot_ij + (int64_t) k * 64] = sck;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                    // the block has been read out: the next row fetch may land
         };
-        // window k's row turns b_k into b_{k-1}; all lanes run k = L-1 .. 1 (cooperative fetch), a lane joins at its last window
-        auto row_of = [&](int k) { return (k >= 1 && k <= jl) ? HF_AROW_ID(arow_seg[a + k]) : 0; };
-        int32_t rkm1 = row_of(L - 2);                           // the row of the NEXT step, fetched one step ahead
-        rows_issue(lutA, row_of(L - 1), lane, blk);
-        double nsc = 1.0;
-        double2 nf01 = make_double2(0.0, 0.0), nf23 = nf01;
-        if (jl >= 1 && jl == L - 1) {
-            nsc = scale_s[slot_ij + (int64_t) (jl - 1) * NL];
-            const double2* __restrict__ fsrc = reinterpret_cast<const double2*>(recs) + (slot_ij + (int64_t) jl * NL) * 4;
-            nf01 = fsrc[0]; nf23 = fsrc[1];
-        }
-#pragma unroll 1
-        for (int k = L - 1; k >= 1; k--) {
-            double A[16];
-            rows_read(blk, lane, A);
-            const bool act = k <= jl;                           // this lane has a window k
-            if (act) store_bwd(k);
-            const double sc = nsc;
-            const double2 f01 = nf01, f23 = nf23;
-            if (k >= 2) {
-                rows_issue(lutA, rkm1, lane, blk);
-                rkm1 = row_of(k - 2);
-                if (k - 1 <= jl) {                              // scale and f of step k-1, in flight during this step
-                    nsc = scale_s[slot_ij + (int64_t) (k - 2) * NL];
-                    const double2* __restrict__ fsrc = reinterpret_cast<const double2*>(recs) + (slot_ij + (int64_t) (k - 1) * NL) * 4;
-                    nf01 = fsrc[0]; nf23 = fsrc[1];
+        TR_STAMP(9);
+        TR_RESET();
+#pragma unroll
+        for (int k = LM - 1; k >= 1; k--) {
+            if (k < L) {                                        // wave-uniform
+                if (k < L - 1) rows_read(blk, lane, A);
+                TR_LAP(3);
+                const bool act = k <= jl;                       // this lane has a window k
+                store_rec(k, act, fs[k - 1], ss[k]);
+                TR_LAP(4);
+                if (k >= 2) rows_issue(F, k - 1);
+                TR_LAP(5);
+                if (act) {
+                    double nb[4];
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        double acc = A[HF_PS(p, 0)] * b[0];
+#pragma unroll
+                        for (int s = 1; s < 4; s++) acc = fma(A[HF_PS(p, s)], b[s], acc);
+                        nb[p] = acc;
+                    }
+                    const double sc = ss[k - 1];
+                    if (sc < 1e-50) bad |= HF_FLAG_SCALE;                     // hmm.c:521-524
+#pragma unroll
+                    for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
+                    s_lab[a + k - 1] = (int8_t) posterior_label_fast(fs[k - 1], b, sc);
                 }
-            }
-            if (act) {
-                double nb[4];
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    double acc = A[HF_PS(p, 0)] * b[0];
-#pragma unroll
-                    for (int s = 1; s < 4; s++) acc = fma(A[HF_PS(p, s)], b[s], acc);
-                    nb[p] = acc;
-                }
-                if (sc < 1e-50) bad |= HF_FLAG_SCALE;                     // hmm.c:521-524
-#pragma unroll
-                for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
-                const double fi[4] = {f01.x, f01.y, f23.x, f23.y};
-                s_lab[a + k - 1] = (int8_t) posterior_label_fast(fi, b, sc);
+                TR_LAP(6);
             }
         }
-        if (jl >= 0) store_bwd(0);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
-        for (int w = 0; w < NW; w++) s += s_red[w];
-        seg_ll[g] = s;
-    }
-    if (BWD) {
+        TR_STAMP(10);
+        store_rec(0, jl >= 0, fp, ss[0]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int8_t* __restrict__ dst = label + d.t0;
-        for (int w = threadIdx.x; w < n; w += NL) dst[w] = s_lab[w];
+        for (int w = lane; w < n; w += 64) dst[w] = s_lab[w];
     }
+    TR_STAMP(11);
+    TR_FLUSH(12, 7);
+#ifdef HF_SEG_TRACE
+    if (BWD && g_seg_trace && lane == 0) {
+        g_seg_trace[(size_t) g * HF_SEG_TRACE_N + 19] = (unsigned long long) L;
+        g_seg_trace[(size_t) g * HF_SEG_TRACE_N + 20] = (unsigned long long) n;
+        g_seg_trace[(size_t) g * HF_SEG_TRACE_N + 21] = wall_clock64();
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_seg_trace[(size_t) g * HF_SEG_TRACE_N + 22] = hw; g_seg_trace[(size_t) g * HF_SEG_TRACE_N + 23] = xcc;
+    }
+#endif
+#if HF_ABL != 0
+    bad = 0;
+#endif
     if (bad) atomicOr(flags, bad);
 }

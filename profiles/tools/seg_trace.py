@@ -1,21 +1,32 @@
 #!/usr/bin/env python
-"""k_seg_fb from a -DHF_SEG_TRACE build (profiles/tools/seg_trace.sh; HF_SEG_TRACE_FILE=<file>): where a forward step goes
-(s_memtime, wavefront 0 of every workgroup), how long workgroups live and how they spread over the CUs (s_memrealtime, HW_ID)."""
+"""k_seg_fb<true> from a -DHF_SEG_TRACE build (profiles/tools/seg_trace.sh; HF_SEG_TRACE_FILE=<file>): s_memtime stamps of the
+phases of every workgroup (one wavefront), the per-step laps of both replays, workgroup lifetimes (s_memrealtime) and how
+the workgroups spread over the CUs (HW_ID)."""
 import sys
 import numpy as np
-t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 10).astype(np.int64)
-L = t[:, 4].astype(float)
-print("workgroups", len(t), " windows per lane: mean %.2f" % L.mean(), " windows per segment: mean %.0f" % t[:, 5].mean())
-for k, nm in enumerate(["wait for the DMA + read the rows out of LDS", "deferred stores", "issue the next step's row fetch", "arithmetic"]):
-    print("forward step, %-46s %6.0f cycles" % (nm, (t[:, k] / L).mean()))
-s, e = t[:, 6], t[:, 7]
-t0 = s.min()
-life = (e - s) / 100.0
-print("kernel span %.1f us; workgroup life: p10 %.1f, median %.1f, p90 %.1f us; sum of lives / span = %.0f workgroups busy on average"
-      % ((e.max() - t0) / 100.0, np.percentile(life, 10), np.median(life), np.percentile(life, 90), life.sum() / ((e.max() - t0) / 100.0)))
-print("start (us after the first):", [round((np.percentile(s, q) - t0) / 100.0, 1) for q in (50, 90, 100)],
-      " end:", [round((np.percentile(e, q) - t0) / 100.0, 1) for q in (0, 10, 50, 90, 100)])
-hw, xcc = t[:, 8], t[:, 9]
+N = 24
+t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, N).astype(np.int64)
+t = t[t[:, 19] > 0]
+L = t[:, 19].astype(float)
+print("workgroups", len(t), " windows per lane: mean %.2f" % L.mean(), " windows per segment: mean %.0f" % t[:, 20].mean())
+names = ["loads (lane product, row indices, segment products), park", "prefix scan", "carry-in: forward chain", "unpark + suffix scan",
+         "carry-in: backward chain", "offset table", "forward replay", "log-likelihood", "b at the last window, label", "backward replay",
+         "last record, labels out"]
+life = (t[:, 11] - t[:, 0]).astype(float)
+print("cycles per workgroup (mean), total %.0f:" % life.mean())
+for k, nm in enumerate(names):
+    d = (t[:, k + 1] - t[:, k]).astype(float)
+    print("  %-58s %8.0f  %5.1f %%" % (nm, d.mean(), 100 * d.mean() / life.mean()))
+laps = ["fwd: wait for the DMA + read the rows out of LDS", "fwd: issue the next step's row fetch", "fwd: arithmetic",
+        "bwd: wait + read", "bwd: stores", "bwd: issue", "bwd: arithmetic + label"]
+for k, nm in enumerate(laps):
+    per = t[:, 12 + k] / np.maximum(L - (1 if k >= 3 else 0), 1)
+    print("  per step, %-48s %6.0f cycles" % (nm, per.mean()))
+hw, xcc = t[:, 22], t[:, 23]
 key = (xcc & 0xf) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 20 + ((hw >> 8) & 0xf)
 u, c = np.unique(key, return_counts=True)
-print("CUs used", len(u), " workgroups per CU: histogram", dict(enumerate(np.bincount(c))))
+print("CUs used", len(u), " workgroups per CU: histogram", {int(k): int(v) for k, v in enumerate(np.bincount(c)) if v})
+e = t[:, 21]
+print("workgroup end (s_memrealtime, us after the first end): p10 %.1f  p50 %.1f  p90 %.1f  max %.1f" %
+      tuple((np.percentile(e, q) - e.min()) / 100.0 for q in (10, 50, 90, 100)))
+print("lifetime cycles: p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % tuple(np.percentile(life, q) for q in (10, 50, 90, 100)))
