@@ -108,6 +108,7 @@ struct hf_ctx {
     // statistics by emission row (hf_rows.h): the static plan and its work arrays
     int stats_mode = HF_STATS_CHUNKS; bool rows_ready = false, pass_rows = false; int pass_kc = 0, pass_wpb = 4;
     double poll_seq = 0.0;         // completion stamp of the last polled pass (hf_finish)
+    bool pass_polled = false;      // the last rows-mode pass carried a stamp (decided at launch: k_row_stats writes the total itself)
     unsigned* d_done = nullptr;    // k_reduce / k_rows_total: blocks finished (the last one stamps the host block)
     unsigned long long* d_cks = nullptr;   // k_reduce: XOR of the words written (checksum of a polled pass)
     int poll_kind = 0;             // what the last polled kernel was: 1 k_rows_total (a checksum per region), 2 k_reduce (one)
@@ -277,6 +278,22 @@ static bool seg_pass(const hf_ctx* ctx) { return ctx->algo == HF_ALGO_SCAN && ct
 // does a full pass of the Gaussian models take the statistics-by-row path?
 static bool rows_pass(const hf_ctx* ctx) { return ctx->stats_mode == HF_STATS_ROWS && ctx->rows_ready && ctx->algo == HF_ALGO_SCAN; }
 
+// polled completion of a pass: see wait_total
+static int poll_mode() {
+    static const int mode = [] {
+        const char* e = std::getenv("HF_POLL");
+        if (!e) return 0;
+        if (!std::strcmp(e, "debug")) return 2;
+        return e[0] == '1' ? 1 : 0;
+    }();
+    return mode;
+}
+static bool poll_ok(const hf_ctx* ctx, int last_kernel) {
+    return poll_mode() != 0 && ctx->d_total_host && !((ctx->prof_mask >> last_kernel) & 1u) && !(ctx->prof_mask & HF_PROF_PASS) &&
+           !ctx->host_trace;
+}
+static double next_stamp(hf_ctx* ctx) { ctx->poll_seq += 1.0; ctx->h_total[ctx->V + 1] = 0.0; return ctx->poll_seq; }
+
 template <int KT>
 static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
     ctx->pass_rows = false;
@@ -296,9 +313,14 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         if (g.threads == 192) { g.threads = 128; g.lds = g.lds / 3 * 2; }   // 4, 2 or 1 wavefronts: a block stays inside one region
         const int wpb = (int) g.threads / 64;
         const int n_rw_blocks = (ctx->n_rowwaves + wpb - 1) / wpb, n_ll_blocks = (ctx->C + wpb - 1) / wpb;
+        // the launch's last block also sums the partials (rows_total): into d_total and straight into the pinned host block
+        const bool polled = poll_ok(ctx, HF_K_ROW_STATS);
+        const double seq = polled ? next_stamp(ctx) : 0.0;
+        ctx->pass_polled = polled;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_stats<KT>), dim3((unsigned) (n_rw_blocks + n_ll_blocks)), dim3(g.threads), g.lds, st,
                            ctx->n_rowwaves, n_rw_blocks, ctx->d_rw_region, ctx->d_rowslots, ctx->d_grp_sums, row_src(ctx), ctx->d_params,
-                           ctx->d_rw_stats, ctx->C, ll_off(ctx), ll_part(ctx), ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll);
+                           ctx->d_rw_stats, ctx->C, ll_off(ctx), ll_part(ctx), ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll,
+                           ctx->d_rw_off, ctx->K, ctx->d_total, ctx->d_total_host, ctx->d_flags, seq, ctx->d_done);
         ctx->pass_wpb = wpb;
         ctx->pass_rows = true;
         ctx->pass_kc = ncol;
@@ -318,23 +340,15 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
                        full);
 }
 
-// the last kernel of a pass in HF_STATS_ROWS mode: total vector (+ flag word) into `out`
-static int launch_rows_total(hf_ctx* ctx, hipStream_t st, double* out, bool with_flags = true, double seq = 0.0) {
+// the last kernel of a negative_binomial pass in HF_STATS_ROWS mode: total vector (+ flag word) into `out`
+// (the Gaussian models' total is written by the last block of k_row_stats itself: hf_rows.h rows_total)
+static int launch_nb_total(hf_ctx* ctx, hipStream_t st, double* out, bool with_flags = true, double seq = 0.0) {
     KTimer t(ctx, st, HF_K_ROWS_TOTAL);
-    if (ctx->pass_nb) {
-        NbTables nt;
-        nt.E = ctx->d_nbE; nt.P = ctx->d_nbP; nt.dig = ctx->d_nbDig; nt.r = ctx->d_nbR; nt.beta = ctx->d_nbBeta;
-        hipLaunchKernelGGL(k_nb_total, dim3((unsigned) ctx->R), dim3(1024), 0, st, ctx->d_rw_off, ctx->pass_wpb, ctx->d_rw_stats, ctx->d_H,
-                           ctx->d_params, nt, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out,
-                           with_flags ? ctx->d_flags : (const unsigned*) nullptr, seq, ctx->d_done);
-        HIPCHK(hipGetLastError());
-        return 0;
-    }
-    const int kc = ctx->pass_kc;
-#define ROWS_TOTAL(KT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_total<KT>), dim3((unsigned) ctx->R), dim3(1024), 0, st, ctx->d_rw_off, ctx->pass_wpb, ctx->d_rw_stats, \
-        ctx->d_params, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out, with_flags ? ctx->d_flags : (const unsigned*) nullptr, seq, ctx->d_done)
-    if (kc <= 4) ROWS_TOTAL(4); else if (kc <= 8) ROWS_TOTAL(8); else ROWS_TOTAL(16);
-#undef ROWS_TOTAL
+    NbTables nt;
+    nt.E = ctx->d_nbE; nt.P = ctx->d_nbP; nt.dig = ctx->d_nbDig; nt.r = ctx->d_nbR; nt.beta = ctx->d_nbBeta;
+    hipLaunchKernelGGL(k_nb_total, dim3((unsigned) ctx->R), dim3(1024), 0, st, ctx->d_rw_off, ctx->pass_wpb, ctx->d_rw_stats, ctx->d_H,
+                       ctx->d_params, nt, ctx->d_chunk_ll, (int64_t) ctx->C, ctx->V, ctx->K, out,
+                       with_flags ? ctx->d_flags : (const unsigned*) nullptr, seq, ctx->d_done);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1109,7 +1123,12 @@ int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
 int hf_rank_total(hf_ctx* ctx, double* out_dev, void* stream) {
     if (!ctx || !out_dev) return set_err(HF_E_ARG, "hf_rank_total: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
-    if (ctx->pass_rows) return launch_rows_total(ctx, (hipStream_t) stream, out_dev, false);
+    if (ctx->pass_rows && ctx->pass_nb) return launch_nb_total(ctx, (hipStream_t) stream, out_dev, false);
+    if (ctx->pass_rows) {   // the pass left its total in d_total
+        hipLaunchKernelGGL(k_copy_total, dim3(1), dim3(256), 0, (hipStream_t) stream, ctx->d_total, out_dev, ctx->V);
+        HIPCHK(hipGetLastError());
+        return HF_OK;
+    }
     return hf_reduce_chunks_indexed(ctx, ctx->d_chunk_stats, nullptr, ctx->C, out_dev, stream);
 }
 
@@ -1178,20 +1197,6 @@ int hf_check(hf_ctx* ctx, void* stream) {
 // profiles/tools/poll_soak.py), and the memory must be coherent host memory (HIP_HOST_COHERENT=0 falls back to the
 // stream after the 2 s bail-out).  HF_POLL=debug additionally synchronises after acceptance and reports any word
 // that still changed.  It stays off by default: no EM step should depend on a probabilistic check.
-static int poll_mode() {
-    static const int mode = [] {
-        const char* e = std::getenv("HF_POLL");
-        if (!e) return 0;
-        if (!std::strcmp(e, "debug")) return 2;
-        return e[0] == '1' ? 1 : 0;
-    }();
-    return mode;
-}
-static bool poll_ok(const hf_ctx* ctx, int last_kernel) {
-    return poll_mode() != 0 && ctx->d_total_host && !((ctx->prof_mask >> last_kernel) & 1u) && !(ctx->prof_mask & HF_PROF_PASS) &&
-           !ctx->host_trace;
-}
-static double next_stamp(hf_ctx* ctx) { ctx->poll_seq += 1.0; ctx->h_total[ctx->V + 1] = 0.0; return ctx->poll_seq; }
 // The stamp alone is not enough: the device's writes to host memory may become visible out of order (a soak test saw a
 // stale element once in ~2 000 passes).  So the kernel also writes a checksum of everything it wrote (hf_cks_term: bit
 // pattern x position weight, summed mod 2^64) plus the pass's stamp value; the host accepts the block only when what it
@@ -1251,11 +1256,13 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
     HIPCHK(hipSetDevice(ctx->device));
     // the reduction writes the V+1 doubles into pinned host memory over PCIe: no device-to-host copy afterwards
     double* out = ctx->d_total_host ? ctx->d_total_host : ctx->d_total;
-    const bool polled = poll_ok(ctx, ctx->pass_rows ? HF_K_ROWS_TOTAL : HF_K_REDUCE);
-    const double seq = polled ? next_stamp(ctx) : 0.0;
+    const bool own_total = ctx->pass_rows && !ctx->pass_nb;   // k_row_stats already wrote the total (and the stamp, when polled)
+    const bool polled = own_total ? ctx->pass_polled : poll_ok(ctx, ctx->pass_rows ? HF_K_ROWS_TOTAL : HF_K_REDUCE);
+    const double seq = own_total ? 0.0 : (polled ? next_stamp(ctx) : 0.0);
     ctx->poll_kind = ctx->pass_rows ? 1 : 2;
-    int rc = ctx->pass_rows ? launch_rows_total(ctx, st, out, true, seq)
-                            : reduce_chunks_seq(ctx, ctx->d_chunk_stats, nullptr, ctx->C, out, stream, seq);
+    int rc = own_total ? HF_OK
+                       : (ctx->pass_rows ? launch_nb_total(ctx, st, out, true, seq)
+                                         : reduce_chunks_seq(ctx, ctx->d_chunk_stats, nullptr, ctx->C, out, stream, seq));
     if (rc) return rc;
     if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev1, st));
     if (!ctx->d_total_host)

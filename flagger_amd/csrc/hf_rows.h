@@ -104,12 +104,135 @@ __global__ void __launch_bounds__(256) k_pair_sums(int n_groups, const PairIdx* 
 }
 
 // ------------------------------------------------------------------------------------------
+// rows_total: the total of a pass from the block partials of k_row_stats — run by the LAST block of that launch to finish
+// (round 3: one launch and one kernel boundary less per pass than the separate k_rows_total of rounds 1-2).
+// Element 0 = sum of the chunks' log-likelihoods in k_reduce's order (the same bits as the per-chunk path), by the block's
+// last wavefront; per region, the block partials in plan order by NQ interleaved accumulators per element (fixed by the launch
+// geometry), expanded into the estimator layout of include/hmm_flagger_hip.h exactly as k_chunk_stats does.  A region's block
+// of the vector is assembled in LDS and written once: to `out_dev` (V + 1 doubles, the flag word last) and, when the
+// context has a pinned host block, to `out_host`, followed there by a per-region checksum word bound to the pass
+// (out[V+2+r]) and the completion stamp (out[V+1]): see wait_total.  rw_off[r]..rw_off[r+1]: the wavefronts of region r.
+// ------------------------------------------------------------------------------------------
+// cross-CU hand-off of a few doubles without cache-wide fences: write-through stores (sc0 sc1), drained by the producer before
+// its ticket, and cache-bypassing loads on the reader's side (MI355X_MICROARCH.md, workgroup dispatch & visibility)
+__device__ __forceinline__ void xcu_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double xcu_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+template <int KT>
+__device__ void rows_total(const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_stats,
+                           const DevParams* __restrict__ P, const double* __restrict__ chunk_ll, int64_t C, int64_t V, int Kctx,
+                           double* __restrict__ out_dev, double* __restrict__ out_host, const unsigned* __restrict__ flags, double seq) {
+    constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
+    constexpr int NQMAX = 16;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    __shared__ double part[NQMAX][NA];
+    __shared__ double red[NA];
+    __shared__ double blockv[24 * HF_MAXCOMP + 16];   // one region's block of the vector, assembled in LDS
+    __shared__ double s_ll;
+    __shared__ unsigned long long s_x[16];
+    const unsigned fl = (tid == 0 && flags) ? *flags : 0u;
+    if (tid >= nt - 64) {   // k_reduce's order over the chunk list
+        const int lane = tid - (nt - 64);
+        double acc = 0.0;
+        int64_t c = lane;
+        for (; c + 64 * 3 < C; c += 64 * 4) {
+            const double x0 = xcu_load(chunk_ll + c), x1 = xcu_load(chunk_ll + c + 64), x2 = xcu_load(chunk_ll + c + 128), x3 = xcu_load(chunk_ll + c + 192);
+            acc += x0; acc += x1; acc += x2; acc += x3;
+        }
+        for (; c < C; c += 64) acc += xcu_load(chunk_ll + c);
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+        if (lane == 0) { out_dev[0] = acc; if (out_host) out_host[0] = acc; s_ll = acc; }
+    }
+    const int nreg = P->n_regions, ncol = P->ncomp[3];
+    const bool te = hf_err_is_truncexp(P);
+    const int rstride = 24 * Kctx + 16;
+    int nq = nt / NA;                              // interleaved accumulators per element: one (element, accumulator) item per thread
+    nq = nq < 1 ? 1 : (nq > NQMAX ? NQMAX : nq);
+    for (int r = 0; r < nreg; r++) {
+        const int w0 = rw_off[r] / wpb, w1 = rw_off[r + 1] / wpb;   // rw_off counts wavefronts, a multiple of 4 per region
+        for (int v = tid; v < rstride; v += nt) blockv[v] = 0.0;
+        for (int w = tid; w < nq * NA; w += nt) {
+            const int q = w / NA, i = w - q * NA;
+            double v = 0.0;
+            int k = w0 + q;
+            for (; k < w1; k += nq * 32) {   // 32 loads in flight (the partials come from other CUs: every load is a miss), adds in plan order
+                double xk[32];
+#pragma unroll
+                for (int u = 0; u < 32; u++) xk[u] = k + nq * u < w1 ? xcu_load(blk_stats + (int64_t) (k + nq * u) * NA + i) : 0.0;
+#pragma unroll
+                for (int u = 0; u < 32; u++) if (k + nq * u < w1) v += xk[u];
+            }
+            part[q][i] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < NA; i += nt) {
+            double v = 0.0;
+            for (int u = 0; u < nq; u++) v += part[u][i];
+            red[i] = v;
+        }
+        __syncthreads();
+        if (w1 > w0 && tid < 64) {
+            double* __restrict__ dst = blockv;
+            const StatAcc<KT>* __restrict__ Sa = reinterpret_cast<const StatAcc<KT>*>(red);
+            if (tid < 16) dst[24 * Kctx + tid] = Sa->trans[tid];
+            if (tid == 16 && te) { dst[(0 * 2 + 0) * Kctx] = Sa->te_num; dst[(0 * 2 + 1) * Kctx] = Sa->te_den; }
+            if (tid >= 20 && tid < 23) {
+                const int s = tid - 20;
+                if (!(s == 0 && te)) {
+                    double* dd = dst + (s * 3) * 2 * Kctx;
+                    dd[(0 * 2 + 0) * Kctx] = Sa->g_mnum[s]; dd[(0 * 2 + 1) * Kctx] = Sa->g_den[s];
+                    dd[(1 * 2 + 0) * Kctx] = Sa->g_vnum[s]; dd[(1 * 2 + 1) * Kctx] = Sa->g_den[s];
+                    dd[(2 * 2 + 0) * Kctx] = Sa->g_den[s];  dd[(2 * 2 + 1) * Kctx] = Sa->g_den[s];
+                }
+            }
+            if (tid >= 32 && tid < 32 + KT && (tid - 32) < ncol) {
+                const int cc = tid - 32;
+                double* dd = dst + (3 * 3) * 2 * Kctx;
+                dd[(0 * 2 + 0) * Kctx + cc] = Sa->c_mnum[cc]; dd[(0 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
+                dd[(1 * 2 + 0) * Kctx + cc] = Sa->c_vnum[cc]; dd[(1 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
+                dd[(2 * 2 + 0) * Kctx + cc] = Sa->c_den[cc];  dd[(2 * 2 + 1) * Kctx + cc] = Sa->c_wden;
+            }
+        }
+        __syncthreads();
+        unsigned long long x = 0ull;           // checksum of what is written (hf_cks_term): the host verifies what it read
+        for (int v = tid; v < rstride; v += nt) {
+            const double dv = blockv[v];
+            const int64_t at = 1 + (int64_t) r * rstride + v;
+            out_dev[at] = dv;
+            if (out_host) out_host[at] = dv;
+            x += hf_cks_term((unsigned long long) __double_as_longlong(dv), at);
+        }
+        if (seq != 0.0 && out_host) {
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+            if ((tid & 63) == 0) s_x[tid >> 6] = x;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long c = (unsigned long long) __double_as_longlong(seq);
+                for (int w = 0; w < (nt >> 6); w++) c += s_x[w];
+                if (r == 0) c += hf_cks_term((unsigned long long) __double_as_longlong(s_ll), 0) +
+                                 hf_cks_term((unsigned long long) __double_as_longlong((double) fl), V);
+                out_host[V + 2 + r] = __longlong_as_double((long long) c);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && flags) { out_dev[V] = (double) fl; if (out_host) out_host[V] = (double) fl; }
+    if (seq != 0.0 && out_host) {   // completion stamp for a host that polls the pinned block: after every write above is visible
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) { out_host[V + 1] = seq; __threadfence_system(); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_row_stats: FOUR lanes per row slot — lane p takes the previous state p: its row of the transition counts and its
 // term of every estimator update of k_stats_tile (hmm_utils.c:812-839, 1027-1034), with the slot's summed counts in the
 // place of one window's counts — 16 row slots of ONE region per wavefront.  The 64 lanes are summed in lane order out of
 // LDS (as k_stats_tile does), the wavefronts of a block in wave order: one partial vector per BLOCK, StatAcc<KT> order.
 // The blocks after the first n_rw_blocks do a second job that has to happen once per pass anyway: the log-likelihood of
 // every chunk (one wavefront per chunk, the same sum as k_chunk_stats) into element 0 of the chunk's vector.
+// The last block of the launch to finish (a ticket behind an agent-scope release; the reader takes an agent-scope acquire)
+// then sums everybody's partials: rows_total above.
 // ------------------------------------------------------------------------------------------
 template <int KT>
 __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_blocks, const int32_t* __restrict__ rw_region,
@@ -117,22 +240,25 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
                                                       const RowSrc S, const DevParams* __restrict__ P, double* __restrict__ blk_stats,
                                                       int C, const int32_t* __restrict__ chunk_tile0,
                                                       const double* __restrict__ tile_ll, double* __restrict__ chunk_stats, int64_t V,
-                                                      double* __restrict__ chunk_ll) {
+                                                      double* __restrict__ chunk_ll, const int32_t* __restrict__ rw_off, int Kctx,
+                                                      double* __restrict__ out_dev, double* __restrict__ out_host,
+                                                      const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NS = 16 + 9 + 2;
     constexpr int RS = 65;
     extern __shared__ __attribute__((aligned(16))) double s_rows[];
     const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ bool s_last;
     if ((int) blockIdx.x >= n_rw_blocks) {
         const int c = ((int) blockIdx.x - n_rw_blocks) * wpb + wave;
-        if (c >= C) return;
-        const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
-        double s = 0.0;
-        for (int k = lane; k < nt; k += 64) s += tile_ll[k0 + k];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        if (lane == 0) { chunk_stats[(int64_t) c * V] = s; chunk_ll[c] = s; }
-        return;
-    }
+        if (c < C) {
+            const int k0 = chunk_tile0[c], nt = chunk_tile0[c + 1] - k0;
+            double s = 0.0;
+            for (int k = lane; k < nt; k += 64) s += tile_ll[k0 + k];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+            if (lane == 0) { chunk_stats[(int64_t) c * V] = s; xcu_store(chunk_ll + c, s); }
+        }
+    } else {
     const int rw = (int) blockIdx.x * wpb + wave;
     const int ncol = P->ncomp[3];
     const bool te = hf_err_is_truncexp(P);
@@ -238,123 +364,28 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
         wsum[lane < NS ? lane : NS + 3 * KT] = v;
     }
     __syncthreads();
-    if ((int) threadIdx.x < NA) {   // the block's wavefronts in wave order
+    for (int i = threadIdx.x; i < NA; i += blockDim.x) {   // the block's wavefronts in wave order
         double v = 0.0;
-        for (int w = 0; w < wpb; w++) v += s_blk[w * NA + threadIdx.x];
-        blk_stats[(int64_t) blockIdx.x * NA + threadIdx.x] = v;
+        for (int w = 0; w < wpb; w++) v += s_blk[w * NA + i];
+        xcu_store(blk_stats + (int64_t) blockIdx.x * NA + i, v);
     }
+    }
+    // ---- the last block to get here sums everything (producer: write-through stores, drained, block barrier, the ticket;
+    // consumer: the ticket, cache-bypassing loads) ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == gridDim.x - 1;
+        if (s_last) *done = 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    rows_total<KT>(rw_off, wpb, blk_stats, P, chunk_ll, (int64_t) C, V, Kctx, out_dev, out_host, flags, seq);
 }
 
-// ------------------------------------------------------------------------------------------
-// k_rows_total: one block per region (block 0 also sums the log-likelihoods).  Element 0 = sum of the chunks' log-likelihoods (k_row_stats) in k_reduce's order (the same
-// bits as the per-chunk path); per region, the block partials of k_row_stats summed in plan order by 960/NA interleaved
-// accumulators per element (fixed), expanded into the estimator layout of include/hmm_flagger_hip.h exactly as
-// k_chunk_stats does; a region's block of the vector is assembled in LDS and written to `out` (the pinned host block) once, followed by a
-// per-region checksum word bound to the pass (out[V+2+r]) and the completion stamp (out[V+1]): see wait_total.
-// blk_off[r]..blk_off[r+1]: the partials of region r.
-// ------------------------------------------------------------------------------------------
-template <int KT>
-__global__ void __launch_bounds__(1024) k_rows_total(const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_stats,
-                                                     const DevParams* __restrict__ P, const double* __restrict__ chunk_ll, int64_t C,
-                                                     int64_t V, int Kctx, double* __restrict__ out, const unsigned* __restrict__ flags, double seq,
-                                                     unsigned* __restrict__ done) {
-    constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
-    constexpr int NQ = 960 / NA;                  // interleaved accumulators per element (the last wavefront sums the log-likelihoods)
-    const int tid = threadIdx.x;
-    __shared__ double part[NQ][NA];
-    __shared__ double red[NA];
-    __shared__ double blockv[24 * HF_MAXCOMP + 16];   // one region's block of the vector, assembled in LDS
-    __shared__ double s_ll;
-    __shared__ unsigned long long s_x[16];
-    const unsigned fl = (tid == 0 && flags) ? *flags : 0u;
-    if (tid >= 960 && blockIdx.x == 0) {   // k_reduce's order over the chunk list
-        const int lane = tid - 960;
-        double acc = 0.0;
-        int64_t c = lane;
-        for (; c + 64 * 3 < C; c += 64 * 4) {
-            const double x0 = chunk_ll[c], x1 = chunk_ll[c + 64], x2 = chunk_ll[c + 128], x3 = chunk_ll[c + 192];
-            acc += x0; acc += x1; acc += x2; acc += x3;
-        }
-        for (; c < C; c += 64) acc += chunk_ll[c];
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-        if (lane == 0) { out[0] = acc; s_ll = acc; }
-    }
-    const int nreg = P->n_regions, ncol = P->ncomp[3];
-    const bool te = hf_err_is_truncexp(P);
-    const int rstride = 24 * Kctx + 16;
-    for (int r = blockIdx.x; r < nreg; r += gridDim.x) {
-        const int w0 = rw_off[r] / wpb, w1 = rw_off[r + 1] / wpb;   // rw_off counts wavefronts, a multiple of 4 per region
-        for (int v = tid; v < rstride; v += 1024) blockv[v] = 0.0;
-        const int q = tid / NA, i = tid % NA;
-        if (q < NQ) {
-            double v = 0.0;
-            int k = w0 + q;
-            for (; k + NQ * 7 < w1; k += NQ * 8) {   // 8 loads in flight, adds in plan order
-                double xk[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) xk[u] = blk_stats[(int64_t) (k + NQ * u) * NA + i];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v += xk[u];
-            }
-            for (; k < w1; k += NQ) v += blk_stats[(int64_t) k * NA + i];
-            part[q][i] = v;
-        }
-        __syncthreads();
-        if (tid < NA) {
-            double v = 0.0;
-#pragma unroll
-            for (int u = 0; u < NQ; u++) v += part[u][tid];
-            red[tid] = v;
-        }
-        __syncthreads();
-        if (w1 > w0) {
-            double* __restrict__ dst = blockv;
-            const StatAcc<KT>* __restrict__ Sa = reinterpret_cast<const StatAcc<KT>*>(red);
-            if (tid < 16) dst[24 * Kctx + tid] = Sa->trans[tid];
-            if (tid == 32 && te) { dst[(0 * 2 + 0) * Kctx] = Sa->te_num; dst[(0 * 2 + 1) * Kctx] = Sa->te_den; }
-            if (tid >= 64 && tid < 67) {
-                const int s = tid - 64;
-                if (!(s == 0 && te)) {
-                    double* dd = dst + (s * 3) * 2 * Kctx;
-                    dd[(0 * 2 + 0) * Kctx] = Sa->g_mnum[s]; dd[(0 * 2 + 1) * Kctx] = Sa->g_den[s];
-                    dd[(1 * 2 + 0) * Kctx] = Sa->g_vnum[s]; dd[(1 * 2 + 1) * Kctx] = Sa->g_den[s];
-                    dd[(2 * 2 + 0) * Kctx] = Sa->g_den[s];  dd[(2 * 2 + 1) * Kctx] = Sa->g_den[s];
-                }
-            }
-            if (tid >= 96 && tid < 96 + KT && (tid - 96) < ncol) {
-                const int cc = tid - 96;
-                double* dd = dst + (3 * 3) * 2 * Kctx;
-                dd[(0 * 2 + 0) * Kctx + cc] = Sa->c_mnum[cc]; dd[(0 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
-                dd[(1 * 2 + 0) * Kctx + cc] = Sa->c_vnum[cc]; dd[(1 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
-                dd[(2 * 2 + 0) * Kctx + cc] = Sa->c_den[cc];  dd[(2 * 2 + 1) * Kctx + cc] = Sa->c_wden;
-            }
-        }
-        __syncthreads();
-        unsigned long long x = 0ull;           // checksum of what this block writes (hf_cks_term): the host verifies what it read
-        for (int v = tid; v < rstride; v += 1024) {
-            const double d = blockv[v];
-            const int64_t at = 1 + (int64_t) r * rstride + v;
-            out[at] = d;
-            x += hf_cks_term((unsigned long long) __double_as_longlong(d), at);
-        }
-        if (seq != 0.0) {
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            if ((tid & 63) == 0) s_x[tid >> 6] = x;
-            __syncthreads();
-            if (tid == 0) {
-                unsigned long long c = (unsigned long long) __double_as_longlong(seq);
-                for (int w = 0; w < 16; w++) c += s_x[w];
-                if (r == 0) c += hf_cks_term((unsigned long long) __double_as_longlong(s_ll), 0) +
-                                 hf_cks_term((unsigned long long) __double_as_longlong((double) fl), V);
-                out[V + 2 + r] = __longlong_as_double((long long) c);
-            }
-        }
-        __syncthreads();
-    }
-    if (tid == 0 && flags && blockIdx.x == 0) out[V] = (double) fl;
-    if (seq != 0.0) {   // completion stamp for a host that polls the pinned block: after every write of every block is visible
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0 && atomicAdd(done, 1u) == gridDim.x - 1) { *done = 0u; out[V + 1] = seq; __threadfence_system(); }
-    }
+// what ranks exchange (hf_rank_total): the total the pass left on the device, without the flag word
+__global__ void k_copy_total(const double* __restrict__ src, double* __restrict__ dst, int64_t V) {
+    for (int64_t v = threadIdx.x; v < V; v += blockDim.x) dst[v] = src[v];
 }
+
