@@ -8,8 +8,10 @@
 #include "hmm.h"
 #include "hmm_flagger_hip.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 static hf_ctx *g_ctx = NULL;             /* windows stay resident in HBM for the whole run */
 static int64_t *g_off; static int g_K;
@@ -43,9 +45,49 @@ static void flatten_and_create(stList *emList, HMM *model) {
     free(cov); free(mapq); free(clip); free(annot); free(cs); free(ce); free(cl);
 }
 
+/* negative_binomial: every emission quantity depends on the coverage value alone, so the library takes per-x tables that the
+ * HOST fills with the reference's own functions (hf_params.nb_*, include/hmm_flagger_hip.h:84-95) — here literally
+ * NegativeBinomial_getComponentProbs / NegativeBinomial_getR (hmm_utils.c:497-520, 458-461) and nb->digammaTable (:394-408) */
+#define NB_NX (HF_NB_MAX_COVERAGE + 1)
+static double *g_nbE, *g_nbP, *g_nbDig, *g_nbR, *g_nbBeta;
+
+static void fill_nb_tables(HMM *model, hf_params *p, int K) {
+    const int R = model->numberOfRegions;
+    if (!g_nbE) {
+        g_nbE = calloc((size_t) R * 4 * NB_NX, 8); g_nbP = calloc((size_t) R * 4 * K * NB_NX, 8);
+        g_nbDig = calloc((size_t) R * 4 * K * NB_NX, 8); g_nbR = calloc((size_t) R * 4 * K, 8); g_nbBeta = calloc((size_t) R * 4 * K, 8);
+    }
+    for (int r = 0; r < R; r++)
+        for (int s = 0; s < 4; s++) {
+            NegativeBinomial *nb = model->emissionDistSeriesPerRegion[r]->emissionDists[s]->dist;
+            for (int c = 0; c < nb->numberOfComps; c++) {
+                const size_t pc = ((size_t) r * 4 + s) * K + c;
+                g_nbR[pc] = NegativeBinomial_getR(nb->theta[c], nb->lambda[c]);
+                g_nbBeta[pc] = -1 * nb->theta[c] / (1 - nb->theta[c]) - 1 / log(nb->theta[c]);           /* hmm_utils.c:547 */
+                for (int x = 0; x < NB_NX; x++) g_nbDig[pc * NB_NX + x] = nb->digammaTable[c][x];
+            }
+            for (int x = 0; x < NB_NX; x++) {
+                double *probs = NegativeBinomial_getComponentProbs(nb, (uint8_t) x), tot = 0.0;
+                for (int c = 0; c < nb->numberOfComps; c++) {                                           /* Double_sum1DArray: index order */
+                    g_nbP[(((size_t) r * 4 + s) * K + c) * NB_NX + x] = probs[c]; tot += probs[c];
+                }
+                g_nbE[((size_t) r * 4 + s) * NB_NX + x] = tot;                                           /* NegativeBinomial_getProb */
+                free(probs);
+            }
+        }
+    p->nb_E = g_nbE; p->nb_P = g_nbP; p->nb_dig = g_nbDig; p->nb_r = g_nbR; p->nb_beta = g_nbBeta;
+    p->nb_max_x = 0;                                              /* the tables are filled for every x = 0..250 */
+}
+
 static void pack_params(HMM *model, hf_params *p, double *trans, double *lam, double *trunc,
                         double *mean, double *var, double *weight) {
-    p->model_type = model->modelType == MODEL_GAUSSIAN ? HF_MODEL_GAUSSIAN : HF_MODEL_TRUNC_EXP_GAUSSIAN;
+    memset(p, 0, sizeof *p);
+    switch (model->modelType) {
+        case MODEL_GAUSSIAN: p->model_type = HF_MODEL_GAUSSIAN; break;
+        case MODEL_TRUNC_EXP_GAUSSIAN: p->model_type = HF_MODEL_TRUNC_EXP_GAUSSIAN; break;
+        case MODEL_NEGATIVE_BINOMIAL: p->model_type = HF_MODEL_NEGATIVE_BINOMIAL; break;
+        default: fprintf(stderr, "[hmm_flagger] model type %d has no HIP E-step\n", (int) model->modelType); exit(EXIT_FAILURE);
+    }
     p->n_regions = model->numberOfRegions;
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) p->alpha[i][j] = model->alpha->data[i][j];
     for (int r = 0; r < model->numberOfRegions; r++) {
@@ -57,6 +99,14 @@ static void pack_params(HMM *model, hf_params *p, double *trans, double *lam, do
             if (d->distType == DIST_TRUNC_EXPONENTIAL) {
                 lam[r] = ((TruncExponential *) d->dist)->lambda; trunc[r] = ((TruncExponential *) d->dist)->truncPoint;
                 p->ncomp[s] = 1;
+            } else if (d->distType == DIST_NEGATIVE_BINOMIAL) {          /* theta / lambda / weights in the mean / var / weight slots */
+                NegativeBinomial *nb = d->dist; p->ncomp[s] = nb->numberOfComps;
+                for (int c = 0; c < nb->numberOfComps; c++) {
+                    size_t o = ((size_t) r * 4 + s) * HF_MAXCOMP + c;
+                    mean[o] = nb->theta[c]; var[o] = nb->lambda[c]; weight[o] = nb->weights[c];
+                }
+            } else if (d->distType != DIST_GAUSSIAN) {
+                fprintf(stderr, "[hmm_flagger] emission distribution %d has no HIP E-step\n", (int) d->distType); exit(EXIT_FAILURE);
             } else {
                 Gaussian *g = d->dist; p->ncomp[s] = g->numberOfComps;
                 for (int c = 0; c < g->numberOfComps; c++) {
@@ -67,6 +117,7 @@ static void pack_params(HMM *model, hf_params *p, double *trans, double *lam, do
         }
     }
     p->trans = trans; p->lambda = lam; p->trunc_point = trunc; p->mean = mean; p->var = var; p->weight = weight;
+    if (model->modelType == MODEL_NEGATIVE_BINOMIAL) fill_nb_tables(model, p, model->maxNumberOfComps);
 }
 
 static void run(stList *emList, HMM *model, int mode) {
@@ -90,7 +141,9 @@ static void run(stList *emList, HMM *model, int mode) {
                 EmissionDist *d = eds->emissionDists[s];
                 ParameterEstimator *pe[3]; int np = 3;
                 if (d->distType == DIST_TRUNC_EXPONENTIAL) { pe[0] = ((TruncExponential *) d->dist)->lambdaEstimator; np = 1; }
-                else { Gaussian *g = d->dist; pe[0] = g->meanEstimator; pe[1] = g->varEstimator; pe[2] = g->weightsEstimator; }
+                else if (d->distType == DIST_NEGATIVE_BINOMIAL) {        /* parameter slots 0 / 1 / 2 = theta / lambda / weights */
+                    NegativeBinomial *nb = d->dist; pe[0] = nb->thetaEstimator; pe[1] = nb->lambdaEstimator; pe[2] = nb->weightsEstimator;
+                } else { Gaussian *g = d->dist; pe[0] = g->meanEstimator; pe[1] = g->varEstimator; pe[2] = g->weightsEstimator; }
                 for (int q = 0; q < np; q++) for (int c = 0; c < pe[q]->numberOfComps; c++) {
                     pe[q]->numeratorPerComp[c]   += b[((s * 3 + q) * 2 + 0) * K + c];
                     pe[q]->denominatorPerComp[c] += b[((s * 3 + q) * 2 + 1) * K + c];

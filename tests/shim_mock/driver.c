@@ -21,6 +21,7 @@ static ParameterEstimator *est(int n) {
     p->numberOfComps = n; p->numeratorPerComp = calloc(n, 8); p->denominatorPerComp = calloc(n, 8);
     return p;
 }
+void mock_nb_fill_digamma_table(NegativeBinomial *nb);      /* mock_nb.c */
 #define RD(ptr, n) do { if (fread(ptr, 1, (n), f) != (size_t) (n)) { fprintf(stderr, "short dump\n"); return 2; } } while (0)
 
 int main(int argc, char **argv) {
@@ -68,7 +69,14 @@ int main(int argc, char **argv) {
         for (int s = 0; s < 4; s++) {
             EmissionDist *e = calloc(1, sizeof *e);
             const int nc = s == 3 ? K : 1;
-            if (s == 0 && model.modelType == MODEL_TRUNC_EXP_GAUSSIAN) {
+            if (model.modelType == MODEL_NEGATIVE_BINOMIAL) {    /* theta / lambda / weights travel in the mean / var / weight slots */
+                NegativeBinomial *nb = calloc(1, sizeof *nb);
+                nb->numberOfComps = nc; nb->theta = calloc(nc, 8); nb->lambda = calloc(nc, 8); nb->weights = calloc(nc, 8);
+                for (int c = 0; c < nc; c++) { nb->theta[c] = p[27 + s * 16 + c]; nb->lambda[c] = p[27 + 64 + s * 16 + c]; nb->weights[c] = p[27 + 128 + s * 16 + c]; }
+                nb->thetaEstimator = est(nc); nb->lambdaEstimator = est(nc); nb->weightsEstimator = est(nc);
+                mock_nb_fill_digamma_table(nb);
+                e->dist = nb; e->distType = DIST_NEGATIVE_BINOMIAL;
+            } else if (s == 0 && model.modelType == MODEL_TRUNC_EXP_GAUSSIAN) {
                 TruncExponential *te = calloc(1, sizeof *te);
                 te->lambda = p[25]; te->truncPoint = p[26]; te->lambdaEstimator = est(1);
                 e->dist = te; e->distType = DIST_TRUNC_EXPONENTIAL;
@@ -94,6 +102,7 @@ int main(int argc, char **argv) {
             EmissionDist *e = model.emissionDistSeriesPerRegion[r]->emissionDists[s];
             ParameterEstimator *pe[3] = {NULL, NULL, NULL};
             if (e->distType == DIST_TRUNC_EXPONENTIAL) pe[0] = ((TruncExponential *) e->dist)->lambdaEstimator;
+            else if (e->distType == DIST_NEGATIVE_BINOMIAL) { NegativeBinomial *nb = e->dist; pe[0] = nb->thetaEstimator; pe[1] = nb->lambdaEstimator; pe[2] = nb->weightsEstimator; }
             else { Gaussian *g = e->dist; pe[0] = g->meanEstimator; pe[1] = g->varEstimator; pe[2] = g->weightsEstimator; }
             for (int q = 0; q < 3; q++)
                 for (int k = 0; k < 2; k++)

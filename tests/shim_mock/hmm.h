@@ -1,10 +1,11 @@
 /* tests/shim_mock/hmm.h — TEST INFRASTRUCTURE.  Mock of the declarations of mobinasri/flagger that integration/hmm_hip_shim.c
  * touches, so that the documented binding is compiled, linked and run: the struct FIELDS (names, types, order of the ones
  * used) are the reference's — hmm.h:14-25 (HMM), :65-80 (EM); hmm_utils.h:36-48 (DistType, ModelType), :86-89 (EmissionDist),
- * :93-105 (ParameterEstimator), :312-320 (Gaussian), :393-397 (TruncExponential), :547-555 (EmissionDistSeries), :713-717
+ * :93-105 (ParameterEstimator), :213-222 (NegativeBinomial), :312-320 (Gaussian), :393-397 (TruncExponential), :547-555 (EmissionDistSeries), :713-717
  * (TransitionRequirements), :768-771 (TransitionCountData), :826-834 (Transition); chunk.h:11-34 (Chunk); ptBlock.h:50-55
  * (Inference), :79-92 (CoverageInfo); data_types.h:26-30 (MatrixDouble) — and sonLib's stList is reduced to an array with
- * the two accessors the shim calls.  Nothing here is reference code: no function bodies, no algorithm. */
+ * the two accessors the shim calls.  Nothing here is reference code: no function bodies, no algorithm (the two NegativeBinomial
+ * functions the shim calls for --modelType negative_binomial get test-only bodies in mock_nb.c, on top of the oracle). */
 #ifndef SHIM_MOCK_HMM_H
 #define SHIM_MOCK_HMM_H
 #include <stdbool.h>
@@ -27,6 +28,13 @@ typedef struct Gaussian {
     int numberOfComps;
 } Gaussian;
 typedef struct TruncExponential { double lambda; double truncPoint; ParameterEstimator *lambdaEstimator; } TruncExponential;
+typedef struct NegativeBinomial {                               /* hmm_utils.h:213-222 */
+    double *theta; double *lambda; double *weights;
+    ParameterEstimator *lambdaEstimator; ParameterEstimator *thetaEstimator; ParameterEstimator *weightsEstimator;
+    int numberOfComps; double **digammaTable;
+} NegativeBinomial;
+double NegativeBinomial_getR(double theta, double lambda);                       /* hmm_utils.h:255; mock body: mock_nb.c */
+double *NegativeBinomial_getComponentProbs(NegativeBinomial *nb, uint8_t x);     /* hmm_utils.h:275 */
 typedef struct EmissionDistSeries {
     EmissionDist **emissionDists; void **countDataPerDist; void **parameterBindingPerDist;
     int numberOfDists; ModelType modelType; int numberOfCollapsedComps; bool excludeMisjoin;

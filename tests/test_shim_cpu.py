@@ -18,9 +18,11 @@ CSRC = os.path.join(ROOT, "flagger_amd", "csrc")
 
 def build_driver(tmp_path):
     exe = str(tmp_path / "shim_driver")
+    ORC = os.path.join(ROOT, "oracle")     # the mock's NegativeBinomial functions sit on the oracle (test infrastructure only)
     cmd = ["gcc", "-std=gnu11", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "tests", "shim_mock"),
-           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "integration", "hmm_hip_shim.c"),
-           os.path.join(ROOT, "tests", "shim_mock", "driver.c"), "-L" + CSRC, "-lhmmflagger_hip", "-Wl,-rpath," + CSRC, "-o", exe]
+           "-I" + os.path.join(ROOT, "include"), "-I" + ORC, os.path.join(ROOT, "integration", "hmm_hip_shim.c"),
+           os.path.join(ROOT, "tests", "shim_mock", "driver.c"), os.path.join(ROOT, "tests", "shim_mock", "mock_nb.c"),
+           "-L" + CSRC, "-lhmmflagger_hip", "-Wl,-rpath," + CSRC, "-L" + ORC, "-loracle_hf", "-Wl,-rpath," + ORC, "-lm", "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe

@@ -12,7 +12,7 @@ from test_shim_cpu import build_driver, write_dump
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("model_type,cfg", [(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 2), (hmm.MODEL_GAUSSIAN, 4)])
+@pytest.mark.parametrize("model_type,cfg", [(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 2), (hmm.MODEL_GAUSSIAN, 4), (hmm.MODEL_NEGATIVE_BINOMIAL, 2)])
 def test_shim_scatters_what_the_abi_returns(model_type, cfg, tmp_path):
     import subprocess
     store = synth.config(cfg, scale=0.01)
