@@ -96,6 +96,10 @@ def main():
     ap.add_argument("--no-weak-leg", action="store_true",
                     help="with --gpus N > 1 and strong scaling the line also carries a `weak_scaling` object (one whole genome per "
                          "GPU, timed after the main region); this switch skips it")
+    ap.add_argument("--no-second-exchange", action="store_true",
+                    help="on the multi-GPU path the line also carries `other_exchange` (the exchange that was not timed as the headline) "
+                         "and `n_invariance` (a 5 % copy of the workload through --exchange chunks on all ranks against one context on "
+                         "rank 0: log-likelihoods bit-identical, labels identical); this switch skips both")
     ap.add_argument("--force-weak-leg", action="store_true",
                     help="run the weak-scaling leg even with one rank (exercises that code path on a 1-GPU box; with --dist-path)")
     ap.add_argument("--dist-path", action="store_true",
@@ -154,14 +158,17 @@ def main():
     torch.cuda.set_device(local_rank)
     collective_used = {"name": args.collective if dist_path else "none"}
 
-    def make_sharded(st, mdl):
+    def make_sharded(st, mdl, exchange=None):
+        exchange = exchange or args.exchange
         if dist_path and collective_used["name"] == "native":
             uid = [hmm.comm_unique_id() if rank == 0 else None]
             tdist.broadcast_object_list(uid, src=0, device=torch.device("cuda", local_rank))
             sh, err = None, ""
             try:
+                # (hf_multi_create_rank agrees on the outcome of every rank's set-up through the new communicator; what can fail
+                # BEFORE a communicator exists — no visible device for this rank — was checked above, on every rank)
                 sh = hmm.RankEMList(st, mdl, world, rank, local_rank, uid[0], True, 0.95, algo,
-                                    exchange=N.HF_EXCHANGE_RANKS if args.exchange == "ranks" else N.HF_EXCHANGE_CHUNKS)
+                                    exchange=N.HF_EXCHANGE_RANKS if exchange == "ranks" else N.HF_EXCHANGE_CHUNKS)
             except Exception as e:          # never seen; N > 1 cannot be tried on the 1-GPU development boxes
                 err = repr(e)
             ok = torch.tensor([1 if sh is not None else 0], dtype=torch.int32, device="cuda")
@@ -171,7 +178,7 @@ def main():
             if sh is not None:
                 sh.close()
             collective_used["name"] = "torch (native set-up failed on some rank: %s)" % (err or "another rank")
-        sh = fdist.make_sharded_hip(st, mdl, rank, world, local_rank, True, 0.95, algo, exchange=args.exchange)
+        sh = fdist.make_sharded_hip(st, mdl, rank, world, local_rank, True, 0.95, algo, exchange=exchange)
         return sh, sh.local.em
 
     sharded, em = make_sharded(store, model)
@@ -186,6 +193,8 @@ def main():
     def step():
         if not dist_path:
             em.em_iterate(model, True, 1e-3)                      # E-step + decode + ordered reduce + M-step, one native call
+        elif hasattr(target, "em_iterate"):
+            target.em_iterate(model, True, 1e-3)                  # the same + the RCCL all-gather, one native call (hf_multi_em_iterate)
         else:
             hmm.EM_runOneIterationForList(target, model)          # E-step + decode + all-gather + ordered reduce
             hmm.HMM_estimateParameters(model, 1e-3)               # M-step on the host (replicated on every rank)
@@ -196,7 +205,7 @@ def main():
             tdist.barrier()
         torch.cuda.synchronize()
 
-    dom = "k_fb_tile"                      # the dominant kernel unless the warm-up passes say otherwise
+    dom = "k_seg_fb"                       # the dominant kernel unless the warm-up passes say otherwise
     for _ in range(args.warmup):
         step()
         kt = em.kernel_times()
@@ -256,6 +265,90 @@ def main():
         except Exception as e:              # the headline number above stays valid
             weak = {"error": repr(e)}
 
+    # how many ranks RCCL itself counts in the communicator of the timed region (ncclCommCount), not what was asked for
+    rccl_ranks = None
+    if dist_path and collective_used["name"] == "native":
+        rccl_ranks = int(N.lib().hf_multi_comm_ranks(sharded._h))
+        if rccl_ranks != world:
+            sys.exit(f"bench.py: RCCL reports {rccl_ranks} ranks in the communicator, --gpus {world}: refusing to print a line")
+    elif dist_path:
+        rccl_ranks = tdist.get_world_size()
+
+    # at N > 1 (or --dist-path): the OTHER exchange, timed the same way, and a proof that the sharded run is the one-GPU run:
+    # a small copy of the workload through `--exchange chunks` on all ranks against a single context on rank 0
+    other, invariance = None, None
+    if dist_path and not args.no_second_exchange:
+        try:
+            oex = "chunks" if args.exchange == "ranks" else "ranks"
+            omodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
+            osh, _ = make_sharded(store, omodel, oex)
+            osh.force_collective = args.dist_path
+
+            def ostep():
+                hmm.EM_runOneIterationForList(osh, omodel)
+                hmm.HMM_estimateParameters(omodel, 1e-3)
+                hmm.HMM_resetEstimators(omodel)
+            for _ in range(max(args.warmup, 1)):
+                ostep()
+            barrier()
+            o0 = time.perf_counter()
+            for _ in range(args.steps):
+                ostep()
+            barrier()
+            ot = torch.tensor([time.perf_counter() - o0], dtype=torch.float64, device="cuda")
+            tdist.all_reduce(ot, op=tdist.ReduceOp.MAX)
+            odt = float(ot.item())
+            other = {"exchange": oex, "value": n_windows * args.steps / odt, "unit": "windows/s", "ms_per_step": odt / args.steps * 1e3,
+                     "loglikelihood_after_last_step": omodel.loglikelihood}
+            getattr(osh, 'close', lambda: None)()
+        except Exception as e:
+            other = {"error": repr(e)}
+        try:
+            sscale = min(args.scale, 0.05)
+            sstore = synth.config(args.config, scale=sscale)
+            smodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, sstore, alpha)
+            ssh, _ = make_sharded(sstore, smodel, "chunks")
+            ssh.force_collective = args.dist_path
+            iters, lls = 5, []
+            for _ in range(iters):
+                hmm.EM_runOneIterationForList(ssh, smodel)
+                lls.append(smodel.loglikelihood)
+                hmm.HMM_estimateParameters(smodel, 1e-3)
+                hmm.HMM_resetEstimators(smodel)
+            hmm.EM_runOneIterationForList(ssh, smodel)          # the final inference pass (hmm_flagger.c:464)
+            lls.append(smodel.loglikelihood)
+            mine = ssh.local_labels() if hasattr(ssh, "local_labels") else ssh.local.labels()
+            first = ssh.first_window if hasattr(ssh, "first_window") else int(sstore.chunk_off[ssh.bounds[rank]])
+            parts = [None] * world
+            tdist.all_gather_object(parts, (first, mine.tobytes()))
+            getattr(ssh, 'close', lambda: None)()
+            if rank == 0:
+                import numpy as np
+                lab_n = np.full(sstore.n_windows, -1, dtype=np.int8)
+                for f0, b in parts:
+                    a = np.frombuffer(b, dtype=np.int8)
+                    lab_n[f0:f0 + a.size] = a
+                rmodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, sstore, alpha)
+                rem = hmm.EMList(sstore, rmodel, True, 0.95, device=local_rank, algo=algo)
+                rem.set_stats_mode(N.HF_STATS_CHUNKS)
+                rlls = []
+                for _ in range(iters):
+                    hmm.EM_runOneIterationForList(rem, rmodel)
+                    rlls.append(rmodel.loglikelihood)
+                    hmm.HMM_estimateParameters(rmodel, 1e-3)
+                    hmm.HMM_resetEstimators(rmodel)
+                hmm.EM_runOneIterationForList(rem, rmodel)
+                rlls.append(rmodel.loglikelihood)
+                lab_1 = rem.labels()
+                rem.close()
+                invariance = {"what": f"{iters} EM iterations + final pass, exchange chunks over {world} rank(s) vs one context (per-chunk statistics) on rank 0",
+                              "scale": sscale, "n_windows": sstore.n_windows, "loglikelihoods_bit_identical": lls == rlls,
+                              "labels_identical": bool((lab_n == lab_1).all()), "label_mismatches": int((lab_n != lab_1).sum()),
+                              "final_loglikelihood": lls[-1]}
+            barrier()
+        except Exception as e:
+            invariance = {"error": repr(e)}
+
     if rank == 0:
         kavg = {k: v / extra for k, v in ksum.items() if v > 0}
         if args.no_kernel_events:
@@ -282,7 +375,7 @@ def main():
         out = {
             "metric": "coverage windows/sec through EM+decode; achieved HBM GB/s vs roofline",
             "value": n_windows * args.steps / dt, "unit": "windows/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("BASELINE.json configs[2]: synthetic 2x3.03 Gb diploid HiFi-like coverage, "
@@ -313,6 +406,10 @@ def main():
         }
         if weak is not None:
             out["weak_scaling"] = weak
+        if other is not None:
+            out["other_exchange"] = other
+        if invariance is not None:
+            out["n_invariance"] = invariance
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(store, K, alpha, effective_cores())
         print(json.dumps(out))

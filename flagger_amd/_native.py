@@ -135,6 +135,9 @@ def lib() -> C.CDLL:
     sig("hf_multi_get_labels", C.c_int, vp, C.POINTER(C.c_int8))
     sig("hf_multi_get_posterior", C.c_int, vp, i64, i64, pd)
     sig("hf_multi_world", C.c_int, vp)
+    sig("hf_multi_comm_ranks", C.c_int, vp)
+    sig("hf_multi_em_iterate", C.c_int, vp, vp, C.c_int, C.c_int, C.c_double, pd, C.POINTER(C.c_int))
+    sig("hf_bind_rank_total", C.c_int, vp, vp, vp)
     sig("hf_multi_stats_len", i64, vp)
     sig("hf_multi_shard_windows", i64, vp, C.c_int)
     sig("hf_multi_shard_chunks", i32, vp, C.c_int)

@@ -108,6 +108,8 @@ struct hf_ctx {
     // statistics by emission row (hf_rows.h): the static plan and its work arrays
     int stats_mode = HF_STATS_CHUNKS; bool rows_ready = false, pass_rows = false; int pass_kc = 0, pass_wpb = 4;
     double poll_seq = 0.0;         // completion stamp of the last polled pass (hf_finish)
+    double* d_rank_out = nullptr; double* d_rank_flag = nullptr;   // hf_bind_rank_total: where a rows-mode pass writes its total / flag word
+    bool pass_bound = false;       // the last pass wrote them there
     bool pass_polled = false;      // the last rows-mode pass carried a stamp (decided at launch: k_row_stats writes the total itself)
     unsigned* d_done = nullptr;    // k_reduce / k_rows_total: blocks finished (the last one stamps the host block)
     unsigned long long* d_cks = nullptr;   // k_reduce: XOR of the words written (checksum of a polled pass)
@@ -314,13 +316,15 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         const int wpb = (int) g.threads / 64;
         const int n_rw_blocks = (ctx->n_rowwaves + wpb - 1) / wpb, n_ll_blocks = (ctx->C + wpb - 1) / wpb;
         // the launch's last block also sums the partials (rows_total): into d_total and straight into the pinned host block
-        const bool polled = poll_ok(ctx, HF_K_ROW_STATS);
+        const bool bound = ctx->d_rank_out != nullptr;    // multi-GPU `ranks` exchange: the total goes into the exchange buffer, not to the host
+        const bool polled = !bound && poll_ok(ctx, HF_K_ROW_STATS);
         const double seq = polled ? next_stamp(ctx) : 0.0;
-        ctx->pass_polled = polled;
+        ctx->pass_polled = polled; ctx->pass_bound = bound;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_stats<KT>), dim3((unsigned) (n_rw_blocks + n_ll_blocks)), dim3(g.threads), g.lds, st,
                            ctx->n_rowwaves, n_rw_blocks, ctx->d_rw_region, ctx->d_rowslots, ctx->d_grp_sums, row_src(ctx), ctx->d_params,
                            ctx->d_rw_stats, ctx->C, ll_off(ctx), ll_part(ctx), ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll,
-                           ctx->d_rw_off, ctx->K, ctx->d_total, ctx->d_total_host, ctx->d_flags, seq, ctx->d_done);
+                           ctx->d_rw_off, ctx->K, bound ? ctx->d_rank_out : ctx->d_total, bound ? (double*) nullptr : ctx->d_total_host,
+                           bound ? ctx->d_rank_flag : (double*) nullptr, ctx->d_flags, seq, ctx->d_done);
         ctx->pass_wpb = wpb;
         ctx->pass_rows = true;
         ctx->pass_kc = ncol;
@@ -552,6 +556,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             constexpr int64_t NL = 64;
             static_assert(HF_SEG_SPLIT <= 64 * HF_SEG_LMAX, "a segment has at most HF_SEG_LMAX windows per lane");
             // (cutting small inputs finer than this was tried: more, shorter workgroups are slower — the scans are a fixed cost)
+            // (shorter segments for small inputs were measured again in round 3, 128..384 windows at 0.19 M .. 1.5 M windows: never
+            // faster — a workgroup's life is mostly the scans and the carried-in chains, not the replay; profiles/r03f_split_sweep.txt)
             constexpr int64_t SMAX = HF_SEG_SPLIT;
             // ---- rows of A = T∘e: the (key, transition class) pairs that occur, then the slow windows ----
             hrec.resize(N);
@@ -929,7 +935,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
     HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
     for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
     ctx->prof_now = ctx->prof_stride <= 1 || (ctx->prof_pass++ % ctx->prof_stride) == 0;
-    ctx->pass_rows = false;
+    ctx->pass_rows = false; ctx->pass_bound = false;
     ctx->pass_seg = false;
     if (ctx->C == 0) HIPCHK(hipMemsetAsync(ctx->d_flags, 0, 4, st));
     if (ctx->C > 0) {
@@ -1124,8 +1130,9 @@ int hf_rank_total(hf_ctx* ctx, double* out_dev, void* stream) {
     if (!ctx || !out_dev) return set_err(HF_E_ARG, "hf_rank_total: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->pass_rows && ctx->pass_nb) return launch_nb_total(ctx, (hipStream_t) stream, out_dev, false);
-    if (ctx->pass_rows) {   // the pass left its total in d_total
-        hipLaunchKernelGGL(k_copy_total, dim3(1), dim3(256), 0, (hipStream_t) stream, ctx->d_total, out_dev, ctx->V);
+    if (ctx->pass_rows && ctx->pass_bound && out_dev == ctx->d_rank_out) return HF_OK;   // hf_bind_rank_total: already there
+    if (ctx->pass_rows) {   // the pass left its total in d_total (or where it was bound to)
+        hipLaunchKernelGGL(k_copy_total, dim3(1), dim3(256), 0, (hipStream_t) stream, ctx->pass_bound ? ctx->d_rank_out : ctx->d_total, out_dev, ctx->V);
         HIPCHK(hipGetLastError());
         return HF_OK;
     }
@@ -1265,7 +1272,10 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
                                          : reduce_chunks_seq(ctx, ctx->d_chunk_stats, nullptr, ctx->C, out, stream, seq));
     if (rc) return rc;
     if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev1, st));
-    if (!ctx->d_total_host)
+    if (own_total && ctx->pass_bound) {   // the pass wrote its total into a bound exchange slot (hf_bind_rank_total): fetch it from there
+        HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_rank_out, (size_t) ctx->V * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(ctx->h_total + ctx->V, ctx->d_rank_flag, 8, hipMemcpyDeviceToHost, st));
+    } else if (!ctx->d_total_host)
         HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
     return wait_total(ctx, st, polled, stats_host);
 }
@@ -1319,9 +1329,16 @@ int hf_bind_chunk_stats(hf_ctx* ctx, double* rows_dev) {
     return HF_OK;
 }
 
+int hf_bind_rank_total(hf_ctx* ctx, double* total_dev, double* flag_row_dev) {
+    if (!ctx || ((total_dev == nullptr) != (flag_row_dev == nullptr))) return set_err(HF_E_ARG, "hf_bind_rank_total: bad argument");
+    ctx->d_rank_out = total_dev; ctx->d_rank_flag = flag_row_dev;
+    return HF_OK;
+}
+
 int hf_write_flag_row(hf_ctx* ctx, double* row_dev, void* stream) {
     if (!ctx || !row_dev) return set_err(HF_E_ARG, "hf_write_flag_row: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->pass_rows && !ctx->pass_nb && ctx->pass_bound && row_dev == ctx->d_rank_flag) return HF_OK;   // written by the pass itself
     hipLaunchKernelGGL(k_flag_row, dim3(1), dim3(64), 0, (hipStream_t) stream, ctx->d_flags, row_dev);
     HIPCHK(hipGetLastError());
     return HF_OK;

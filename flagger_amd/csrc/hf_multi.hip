@@ -6,10 +6,13 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include "../../include/hmm_flagger_multi.h"
+#include "../../include/hmm_flagger_model.h"
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <thread>
 #include <vector>
@@ -131,7 +134,11 @@ void hf_comm_destroy(hf_comm* c) {
 }
 
 int hf_comm_rank(const hf_comm* c) { return c ? c->rank : -1; }
-int hf_comm_size(const hf_comm* c) { return c ? c->size : 0; }
+int hf_comm_size(const hf_comm* c) {   // what the communicator itself says (RCCL), not what it was asked for
+    if (!c) return 0;
+    if (c->nccl) { int n = 0; if (ncclCommCount(c->nccl, &n) == ncclSuccess) return n; return -1; }
+    return c->size;
+}
 
 int hf_comm_allgather(hf_comm* c, const double* send_dev, double* recv_dev, int64_t count, void* stream) {
     if (!c || !send_dev || !recv_dev || count < 0) return merr(HF_E_ARG, "hf_comm_allgather: bad argument");
@@ -204,6 +211,7 @@ struct RankState {
     std::vector<double> stats;
     int rc = HF_OK; std::string err;
     std::thread th;
+    hipEvent_t xe0 = nullptr, xe1 = nullptr; double x_us = 0.0; long x_n = 0;   // HF_HOST_TRACE=1: the all-gather, bracketed by events
 };
 }  // namespace
 
@@ -255,6 +263,8 @@ int rank_create(hf_multi* M, RankState& R) {
     } else {
         for (int k = 0; k < M->world; k++) rows.push_back(k * M->rows_per_rank);
         rc = hf_set_stats_mode(R.ctx, HF_STATS_ROWS);
+        // a full pass then writes its total and its flag word straight into this rank's slot: no copy kernels before the all-gather
+        if (rc == HF_OK) rc = hf_bind_rank_total(R.ctx, R.xbuf + (size_t) R.r * slot, R.xbuf + (size_t) R.r * slot + (size_t) M->flag_row * (size_t) M->V);
     }
     if (rc != HF_OK) { R.err = hf_last_error(); return rc; }
     if (rows.empty()) rows.push_back(0);
@@ -263,7 +273,31 @@ int rank_create(hf_multi* M, RankState& R) {
         R.err = "row index upload failed"; return HF_E_HIP;
     }
     R.stats.assign((size_t) M->V, 0.0);
+    {
+        const char* e = std::getenv("HF_HOST_TRACE");
+        if (e && e[0] == '1') {
+            hipEventCreate(&R.xe0); hipEventCreate(&R.xe1);
+            std::fprintf(stderr, "[hf_multi] rank %d of %d on GPU %d: chunks %d..%d (%d), windows %lld..%lld (%lld), exchange %s, %d RCCL ranks\n", R.r, M->world,
+                         R.device, R.c0, R.c0 + R.nc - 1, R.nc, (long long) R.w0, (long long) (R.w0 + R.nw - 1), (long long) R.nw,
+                         M->exchange == HF_EXCHANGE_CHUNKS ? "chunks" : "ranks", hf_comm_size(R.comm));
+        }
+    }
     return HF_OK;
+}
+
+// everything a rank owns (hf_multi_destroy and every failure path of the two constructors)
+void rank_release(RankState& R) {
+    if (R.th.joinable()) R.th.join();
+    hipSetDevice(R.device);
+    if (R.xe0) {
+        if (R.x_n) std::fprintf(stderr, "[hf_multi] rank %d: %ld passes, all-gather %.1f us per pass (events on the pass's stream)\n", R.r, R.x_n, R.x_us / R.x_n);
+        hipEventDestroy(R.xe0); hipEventDestroy(R.xe1); R.xe0 = R.xe1 = nullptr;
+    }
+    if (R.ctx) { hf_bind_chunk_stats(R.ctx, nullptr); hf_destroy(R.ctx); R.ctx = nullptr; }
+    if (R.xbuf) { hipFree(R.xbuf); R.xbuf = nullptr; }
+    if (R.d_row_index) { hipFree(R.d_row_index); R.d_row_index = nullptr; }
+    if (R.st) { hipStreamDestroy(R.st); R.st = nullptr; }
+    if (R.comm) { hf_comm_destroy(R.comm); R.comm = nullptr; }
 }
 
 int rank_estep(hf_multi* M, RankState& R) {
@@ -279,15 +313,17 @@ int rank_estep(hf_multi* M, RankState& R) {
         if (rc != HF_OK) first_err = hf_last_error();
     }
     int rc2 = hf_write_flag_row(R.ctx, mine + (size_t) M->flag_row * (size_t) M->V, R.st);
-    if (rc2 == HF_OK) {
-        rc2 = hf_comm_allgather(R.comm, mine, R.xbuf, (int64_t) slot, R.st);
-        if (rc2 != HF_OK && first_err.empty()) first_err = hf_comm_last_error();
-    } else if (first_err.empty()) first_err = hf_last_error();
-    if (rc == HF_OK) rc = rc2;
+    if (rc2 != HF_OK && first_err.empty()) first_err = hf_last_error();
+    if (R.xe0) hipEventRecord(R.xe0, R.st);
+    const int rc3 = hf_comm_allgather(R.comm, mine, R.xbuf, (int64_t) slot, R.st);   // whatever happened above: the peers are waiting in it
+    if (R.xe0) hipEventRecord(R.xe1, R.st);
+    if (rc3 != HF_OK && first_err.empty()) first_err = hf_comm_last_error();
+    if (rc == HF_OK) rc = rc2 != HF_OK ? rc2 : rc3;
     if (rc != HF_OK) { R.err = first_err; hipStreamSynchronize(R.st); return rc; }
     const int64_t n_rows = M->exchange == HF_EXCHANGE_CHUNKS ? (int64_t) M->C : (int64_t) M->world;
     rc = hf_finish_exchange(R.ctx, R.xbuf, R.d_row_index, n_rows, M->world, M->rows_per_rank, M->flag_row, R.stats.data(), R.st);
     if (rc != HF_OK) R.err = hf_last_error();
+    if (R.xe0 && rc == HF_OK) { float ms = 0.f; if (hipEventElapsedTime(&ms, R.xe0, R.xe1) == hipSuccess) { R.x_us += ms * 1e3; R.x_n++; } }
     return rc;
 }
 
@@ -400,7 +436,7 @@ int hf_multi_create(const hf_windows* w, int n_regions, int max_comps, int n_dev
             const int code = R.rc;
             merr(code, "rank " + std::to_string(R.r) + " (GPU " + std::to_string(R.device) + "): " + R.err);
             const std::string keep = g_merr;
-            for (auto& Q : M->ranks) { if (Q.ctx) hf_destroy(Q.ctx); if (Q.comm) hf_comm_destroy(Q.comm); }
+            for (auto& Q : M->ranks) rank_release(Q);
             delete M;
             g_merr = keep;
             return code;
@@ -419,6 +455,10 @@ int hf_multi_create_rank(const hf_windows* w, int n_regions, int max_comps, int 
     if (!w || !out || !unique_id || world < 1 || world > 4096 || rank < 0 || rank >= world ||
         (exchange != HF_EXCHANGE_CHUNKS && exchange != HF_EXCHANGE_RANKS))
         return merr(HF_E_ARG, "hf_multi_create_rank: bad argument");
+    // A rank that returns before ncclCommInitRank leaves its peers blocked inside it: only the checks every rank evaluates
+    // identically (the arguments above) and the one without which no communicator can exist (a device) come first — the
+    // LAUNCHER must agree on those (bench.py / hmm.RankEMList all-reduce a go / no-go before this call).  Everything else is
+    // checked after the communicator exists, and the ranks then agree on the outcome through it (below).
     const int visible = hf_device_count();
     if (visible <= 0) return merr(HF_E_NOGPU, "hf_multi_create_rank: no HIP device (there is no CPU fallback)");
     if (device < 0 || device >= visible) return merr(HF_E_NOGPU, "hf_multi_create_rank: device " + std::to_string(device) + " is not visible");
@@ -426,30 +466,48 @@ int hf_multi_create_rank(const hf_windows* w, int n_regions, int max_comps, int 
     M->world = world; M->exchange = exchange; M->transport = HF_TRANSPORT_RCCL; M->algo = algo; M->local_rank = rank;
     M->n_regions = n_regions; M->max_comps = max_comps;
     M->V = hf_stats_len(n_regions, max_comps); M->N = w->n_windows; M->C = w->n_chunks;
-    M->bounds.assign((size_t) world + 1, 0);
-    int rc = hf_shard_bounds(w->chunk_off, w->n_chunks, world, M->bounds.data());
-    if (rc != HF_OK) { delete M; return rc; }
-    M->maxc = 1;
-    for (int r = 0; r < world; r++) { const int n = M->bounds[(size_t) r + 1] - M->bounds[(size_t) r]; if (n > M->maxc) M->maxc = n; }
-    for (int r = 0; r < world; r++) M->shard_nw.push_back(w->chunk_off[M->bounds[(size_t) r + 1]] - w->chunk_off[M->bounds[(size_t) r]]);
-    if (exchange == HF_EXCHANGE_CHUNKS) { M->rows_per_rank = M->maxc + 1; M->flag_row = M->maxc; }
-    else { M->rows_per_rank = 2; M->flag_row = 1; }
     M->ranks.resize(1);
     RankState& R = M->ranks[0];
     R.r = rank; R.device = device;
-    R.c0 = M->bounds[(size_t) rank]; R.nc = M->bounds[(size_t) rank + 1] - R.c0;
-    R.w0 = w->chunk_off[R.c0] - w->chunk_off[0]; R.nw = w->chunk_off[R.c0 + R.nc] - w->chunk_off[R.c0];
-    rc = hf_comm_init_rank(world, rank, device, unique_id, &R.comm);
+    int rc = hf_comm_init_rank(world, rank, device, unique_id, &R.comm);      // collective: first
+    if (rc != HF_OK) { const std::string keep = g_merr; rank_release(R); delete M; g_merr = keep; return rc; }
+    M->bounds.assign((size_t) world + 1, 0);
+    rc = hf_shard_bounds(w->chunk_off, w->n_chunks, world, M->bounds.data());
     if (rc == HF_OK) {
+        M->maxc = 1;
+        for (int r = 0; r < world; r++) { const int n = M->bounds[(size_t) r + 1] - M->bounds[(size_t) r]; if (n > M->maxc) M->maxc = n; }
+        for (int r = 0; r < world; r++) M->shard_nw.push_back(w->chunk_off[M->bounds[(size_t) r + 1]] - w->chunk_off[M->bounds[(size_t) r]]);
+        if (exchange == HF_EXCHANGE_CHUNKS) { M->rows_per_rank = M->maxc + 1; M->flag_row = M->maxc; }
+        else { M->rows_per_rank = 2; M->flag_row = 1; }
+        R.c0 = M->bounds[(size_t) rank]; R.nc = M->bounds[(size_t) rank + 1] - R.c0;
+        R.w0 = w->chunk_off[R.c0] - w->chunk_off[0]; R.nw = w->chunk_off[R.c0 + R.nc] - w->chunk_off[R.c0];
         M->w = w;
         rc = rank_create(M, R);
         M->w = nullptr;
         if (rc != HF_OK) merr(rc, "rank " + std::to_string(rank) + " (GPU " + std::to_string(device) + "): " + R.err);
     }
+    // every rank learns whether every rank's set-up worked: one status word each, all-gathered over the new communicator
+    // (a rank that failed above still takes part, so nobody waits for it in the first EM pass)
+    {
+        double* d_status = nullptr;
+        std::vector<double> h_status((size_t) world, 0.0);
+        bool agreed = hipSetDevice(device) == hipSuccess && hipMalloc((void**) &d_status, (size_t) world * 8) == hipSuccess;
+        if (agreed) {
+            const double mine = (double) rc;
+            agreed = hipMemcpy(d_status + rank, &mine, 8, hipMemcpyHostToDevice) == hipSuccess &&
+                     hf_comm_allgather(R.comm, d_status + rank, d_status, 1, nullptr) == HF_OK &&
+                     hipDeviceSynchronize() == hipSuccess &&
+                     hipMemcpy(h_status.data(), d_status, (size_t) world * 8, hipMemcpyDeviceToHost) == hipSuccess;
+        }
+        if (d_status) hipFree(d_status);
+        if (!agreed && rc == HF_OK) rc = merr(HF_E_HIP, "hf_multi_create_rank: the ranks could not exchange their set-up status");
+        if (rc == HF_OK)
+            for (int r = 0; r < world; r++)
+                if (h_status[(size_t) r] != 0.0) { rc = merr((int) h_status[(size_t) r], "hf_multi_create_rank: the set-up of rank " + std::to_string(r) + " failed"); break; }
+    }
     if (rc != HF_OK) {
         const std::string keep = g_merr;
-        if (R.ctx) hf_destroy(R.ctx);
-        if (R.comm) hf_comm_destroy(R.comm);
+        rank_release(R);
         delete M;
         g_merr = keep;
         return rc;
@@ -461,15 +519,7 @@ int hf_multi_create_rank(const hf_windows* w, int n_regions, int max_comps, int 
 void hf_multi_destroy(hf_multi* M) {
     if (!M) return;
     if (M->local_rank < 0) (void) run_all(M, CMD_EXIT);
-    for (auto& R : M->ranks) {
-        if (R.th.joinable()) R.th.join();
-        hipSetDevice(R.device);
-        if (R.ctx) { hf_bind_chunk_stats(R.ctx, nullptr); hf_destroy(R.ctx); }
-        if (R.xbuf) hipFree(R.xbuf);
-        if (R.d_row_index) hipFree(R.d_row_index);
-        if (R.st) hipStreamDestroy(R.st);
-        if (R.comm) hf_comm_destroy(R.comm);
-    }
+    for (auto& R : M->ranks) rank_release(R);
     delete M;
 }
 
@@ -487,6 +537,21 @@ int hf_multi_estep(hf_multi* M, const hf_params* p, int mode, double* stats_host
     const int rc = run_all(M, CMD_ESTEP);
     if (rc != HF_OK) return rc;
     std::memcpy(stats_host, M->ranks[0].stats.data(), (size_t) M->V * 8);
+    return HF_OK;
+}
+
+// One EM step in one call, the multi-GPU counterpart of hf_em_iterate: sharded E-step + exchange, then the (replicated) M-step.
+int hf_multi_em_iterate(hf_multi* M, hfm_model* model, int mode, int do_mstep, double tol, double* stats_host, int* converged) {
+    if (!M || !model || !stats_host) return merr(HF_E_ARG, "hf_multi_em_iterate: bad argument");
+    hf_params p;
+    hfm_params(model, &p);
+    const int rc = hf_multi_estep(M, &p, mode, stats_host);
+    if (rc != HF_OK) return rc;
+    hfm_set_loglikelihood(model, stats_host[0]);
+    if (do_mstep && mode == HF_MODE_FULL) {
+        const int cv = hfm_estimate(model, stats_host, tol);
+        if (converged) *converged = cv;
+    }
     return HF_OK;
 }
 
@@ -516,6 +581,7 @@ int hf_multi_get_posterior(hf_multi* M, int64_t first, int64_t n, double* post_h
 }
 
 int hf_multi_world(const hf_multi* M) { return M ? M->world : 0; }
+int hf_multi_comm_ranks(const hf_multi* M) { return (M && !M->ranks.empty()) ? hf_comm_size(M->ranks[0].comm) : 0; }
 int64_t hf_multi_stats_len(const hf_multi* M) { return M ? M->V : 0; }
 static const RankState* rank_of(const hf_multi* M, int r) {
     if (!M || r < 0 || r >= M->world) return nullptr;

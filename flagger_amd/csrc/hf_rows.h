@@ -121,7 +121,8 @@ __device__ __forceinline__ double xcu_load(const double* p) { return __hip_atomi
 template <int KT>
 __device__ void rows_total(const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_stats,
                            const DevParams* __restrict__ P, const double* __restrict__ chunk_ll, int64_t C, int64_t V, int Kctx,
-                           double* __restrict__ out_dev, double* __restrict__ out_host, const unsigned* __restrict__ flags, double seq) {
+                           double* __restrict__ out_dev, double* __restrict__ out_host, double* __restrict__ flag_row,
+                           const unsigned* __restrict__ flags, double seq) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NQMAX = 16;
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -216,7 +217,10 @@ __device__ void rows_total(const int32_t* __restrict__ rw_off, int wpb, const do
         }
         __syncthreads();
     }
-    if (tid == 0 && flags) { out_dev[V] = (double) fl; if (out_host) out_host[V] = (double) fl; }
+    if (tid == 0 && flags) {   // the flag word: element V of the vector, or element 0 of a row of an exchange buffer (hf_bind_rank_total)
+        if (flag_row) flag_row[0] = (double) fl; else out_dev[V] = (double) fl;
+        if (out_host) out_host[V] = (double) fl;
+    }
     if (seq != 0.0 && out_host) {   // completion stamp for a host that polls the pinned block: after every write above is visible
         __threadfence_system();
         __syncthreads();
@@ -241,7 +245,7 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
                                                       int C, const int32_t* __restrict__ chunk_tile0,
                                                       const double* __restrict__ tile_ll, double* __restrict__ chunk_stats, int64_t V,
                                                       double* __restrict__ chunk_ll, const int32_t* __restrict__ rw_off, int Kctx,
-                                                      double* __restrict__ out_dev, double* __restrict__ out_host,
+                                                      double* __restrict__ out_dev, double* __restrict__ out_host, double* __restrict__ flag_row,
                                                       const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NS = 16 + 9 + 2;
@@ -381,7 +385,7 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
     }
     __syncthreads();
     if (!s_last) return;
-    rows_total<KT>(rw_off, wpb, blk_stats, P, chunk_ll, (int64_t) C, V, Kctx, out_dev, out_host, flags, seq);
+    rows_total<KT>(rw_off, wpb, blk_stats, P, chunk_ll, (int64_t) C, V, Kctx, out_dev, out_host, flag_row, flags, seq);
 }
 
 // what ranks exchange (hf_rank_total): the total the pass left on the device, without the flag word

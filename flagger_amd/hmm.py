@@ -208,6 +208,16 @@ class MultiEMList:
             raise MultiHFError(rc, "hf_multi_estep")
         return self._stats.copy()
 
+    def em_iterate(self, model: "HMM", do_mstep: bool = True, tol: float = 1e-3, mode: int = N.HF_MODE_FULL) -> bool:
+        """Sharded EM_runOneIterationForList + exchange + HMM_estimateParameters in one native call (hf_multi_em_iterate)."""
+        cv = C.c_int(0)
+        rc = self._L.hf_multi_em_iterate(self._h, model._h, mode, int(do_mstep), float(tol), _dptr(self._stats), C.byref(cv))
+        if rc != N.HF_OK:
+            raise MultiHFError(rc, "hf_multi_em_iterate")
+        model.estimators = self._stats
+        model.loglikelihood = float(self._stats[0])
+        return bool(cv.value)
+
     def rank_stats(self, r: int) -> np.ndarray:
         out = np.empty(self.stats_len, dtype=np.float64)
         N.check(self._L.hf_multi_rank_stats(self._h, r, _dptr(out)), "hf_multi_rank_stats")
@@ -275,6 +285,24 @@ class RankEMList(MultiEMList):
         if getattr(self, "em", None) is not None:
             self.em._h = None
         super().close()
+
+    def labels(self) -> np.ndarray:
+        """Labels of ALL windows' positions, but only this rank's range is known here: the others are -1 (hf_multi_get_labels
+        fills this rank's windows at their global positions).  Use local_labels() for the rank's own slice."""
+        out = np.full(self.store.n_windows, -1, dtype=np.int8)
+        rc = self._L.hf_multi_get_labels(self._h, out.ctypes.data_as(C.POINTER(C.c_int8)))
+        if rc != N.HF_OK:
+            raise MultiHFError(rc, "hf_multi_get_labels")
+        return out
+
+    def posterior(self, first: int = 0, n: Optional[int] = None) -> np.ndarray:
+        """Posteriors of windows first .. first + n; rows of windows that other ranks hold are NaN."""
+        n = self.store.n_windows - first if n is None else n
+        out = np.full((n, 4), np.nan, dtype=np.float64)
+        rc = self._L.hf_multi_get_posterior(self._h, first, n, _dptr(out))
+        if rc != N.HF_OK:
+            raise MultiHFError(rc, "hf_multi_get_posterior")
+        return out
 
     def local_labels(self) -> np.ndarray:
         """Labels of this rank's windows (global positions first_window .. first_window + n_local_windows)."""

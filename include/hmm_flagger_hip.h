@@ -156,6 +156,11 @@ int hf_finish_exchange(hf_ctx *ctx, const double *rows_dev, const int32_t *row_i
 /* Let the pass write its per-chunk vectors straight into caller-owned device memory (>= n_chunks rows), e.g. this rank's
  * slot of an in-place all-gather buffer: no device-to-device copy per pass.  NULL: back to a buffer of the context. */
 int hf_bind_chunk_stats(hf_ctx *ctx, double *rows_dev);
+/* The same for the `ranks` exchange: a full pass in HF_STATS_ROWS mode (Gaussian / trunc-exp models) writes its total (V
+ * doubles) straight to `total_dev` and its error-flag word to element 0 of `flag_row_dev`; hf_rank_total(total_dev) and
+ * hf_write_flag_row(flag_row_dev) after such a pass then launch nothing.  Passes that do not produce a total of their own
+ * (forward-only, negative_binomial, per-chunk statistics) are unaffected.  NULL, NULL: unbind. */
+int hf_bind_rank_total(hf_ctx *ctx, double *total_dev, double *flag_row_dev);
 /* This context's device error-flag word as element 0 of `row_dev` (device memory, one row of the exchange buffer);
  * asynchronous on `stream`, after the pass. */
 int hf_write_flag_row(hf_ctx *ctx, double *row_dev, void *stream);

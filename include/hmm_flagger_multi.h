@@ -81,9 +81,14 @@ void hf_multi_destroy(hf_multi *m);
  * EM_runForwardForList (HF_MODE_FORWARD_ONLY) for the whole chunk list.  stats_host gets the reduced vector
  * (hf_stats_len doubles; every rank computed the same bits).  Returns HF_OK or the HF_E_* every rank agreed on. */
 int hf_multi_estep(hf_multi *m, const hf_params *p, int mode, double *stats_host);
+/* hf_multi_estep with the model's current parameters + HMM_estimateParameters on the returned vector (every rank: the same
+ * vector, the same M-step): what hf_em_iterate is for one context.  struct hfm_model: include/hmm_flagger_model.h */
+struct hfm_model;
+int hf_multi_em_iterate(hf_multi *m, struct hfm_model *model, int mode, int do_mstep, double tol, double *stats_host, int *converged);
 int hf_multi_get_labels(hf_multi *m, int8_t *labels_host);                              /* [n_windows], list order */
 int hf_multi_get_posterior(hf_multi *m, int64_t first, int64_t n, double *post_host);   /* [n][4] */
 int hf_multi_world(const hf_multi *m);
+int hf_multi_comm_ranks(const hf_multi *m);   /* ranks of the RCCL communicator, as ncclCommCount reports them (loopback: the group size) */
 int64_t hf_multi_stats_len(const hf_multi *m);
 /* windows / chunks of rank r's shard (reporting) */
 int64_t hf_multi_shard_windows(const hf_multi *m, int r);

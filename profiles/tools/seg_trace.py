@@ -9,16 +9,16 @@ t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, N).astype(np.int64)
 t = t[t[:, 19] > 0]
 L = t[:, 19].astype(float)
 print("workgroups", len(t), " windows per lane: mean %.2f" % L.mean(), " windows per segment: mean %.0f" % t[:, 20].mean())
-names = ["loads (lane product, row indices, segment products), park", "prefix scan", "carry-in: forward chain", "unpark + suffix scan",
-         "carry-in: backward chain", "offset table", "forward replay", "log-likelihood", "b at the last window, label", "backward replay",
-         "last record, labels out"]
+names = ["first loads (row indices) + offset table", "segment products staged + forward chain", "backward chain",
+         "lane product arrives, park", "prefix scan + carried-in f", "unpark + suffix scan + direction of b", "forward replay",
+         "log-likelihood", "b at the last window, label", "backward replay", "last record, labels out"]
 life = (t[:, 11] - t[:, 0]).astype(float)
 print("cycles per workgroup (mean), total %.0f:" % life.mean())
 for k, nm in enumerate(names):
     d = (t[:, k + 1] - t[:, k]).astype(float)
     print("  %-58s %8.0f  %5.1f %%" % (nm, d.mean(), 100 * d.mean() / life.mean()))
 laps = ["fwd: wait for the DMA + read the rows out of LDS", "fwd: issue the next step's row fetch", "fwd: arithmetic",
-        "bwd: wait + read", "bwd: stores", "bwd: issue", "bwd: arithmetic + label"]
+        "bwd: wait + read", "bwd: record through LDS + stores", "bwd: issue", "bwd: arithmetic + label"]
 for k, nm in enumerate(laps):
     per = t[:, 12 + k] / np.maximum(L - (1 if k >= 3 else 0), 1)
     print("  per step, %-48s %6.0f cycles" % (nm, per.mean()))
@@ -27,6 +27,7 @@ key = (xcc & 0xf) * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 20 + ((hw
 u, c = np.unique(key, return_counts=True)
 print("CUs used", len(u), " workgroups per CU: histogram", {int(k): int(v) for k, v in enumerate(np.bincount(c)) if v})
 e = t[:, 21]
+print("first workgroup starts .. last ends: %.0f cycles (s_memtime)" % float(t[:, 11].max() - t[:, 0].min()))
 print("workgroup end (s_memrealtime, us after the first end): p10 %.1f  p50 %.1f  p90 %.1f  max %.1f" %
       tuple((np.percentile(e, q) - e.min()) / 100.0 for q in (10, 50, 90, 100)))
 print("lifetime cycles: p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % tuple(np.percentile(life, q) for q in (10, 50, 90, 100)))
