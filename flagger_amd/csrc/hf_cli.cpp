@@ -50,11 +50,12 @@ static struct option long_options[] = {                    // hmm_flagger.c:578-
     {"initialRandomDev", required_argument, nullptr, 'D'}, {"trackName", required_argument, nullptr, 'N'},
     {"dumpBin", no_argument, nullptr, 'B'}, {"accelerate", no_argument, nullptr, 's'},
     {"minimumLengths", required_argument, nullptr, 'M'},
-    {"device", required_argument, nullptr, 1001},          // additions of this build (not in the reference)
-    {"algo", required_argument, nullptr, 1002},
+    // additions of this build (not in the reference), named so that every unique prefix the reference's getopt_long accepted
+    // still resolves to the same option (tests/test_cli_prefix_cpu.py): nothing new starts like an existing name's prefix
+    {"device", required_argument, nullptr, 1001},
+    {"hipAlgo", required_argument, nullptr, 1002},         // scan (default) | seq (the on-device sequential cross-check)
     {"gpus", required_argument, nullptr, 1003},            // chunks sharded over GPUs device..device+N-1, one RCCL all-gather per pass
     {"exchange", required_argument, nullptr, 1004},        // chunks (bit-identical for every N, default) | ranks
-    {"loopbackRanks", required_argument, nullptr, 1005},   // TEST: N ranks sharing one GPU (no RCCL): the multi-GPU path on a 1-GPU box
     {nullptr, 0, nullptr, 0}};
 
 static void usage(const char* program) {
@@ -81,7 +82,7 @@ static void usage(const char* program) {
             "         --minimumLengths, -M         Err,Dup,Col minimum lengths [0,0,0]\n"
             "         --threads, -@                accepted for compatibility (the E-step runs on the GPU)\n"
             "         --labelNames -l, --binArrayFile -a, --overlapRatioThreshold -v, -k: summary tables (prediction_summary_*.tsv)\n"
-            "         --device                     (first) GPU index [0]        --algo scan|seq [scan]\n"
+            "         --device                     (first) GPU index [0]        --hipAlgo scan|seq [scan]\n"
             "         --gpus N                     shard the chunks over GPUs device..device+N-1 (one process, one thread + one RCCL\n"
             "                                      rank per GPU, one all-gather of statistics per EM pass)\n"
             "         --exchange chunks|ranks      what the GPUs exchange: per-chunk vectors summed in chunk-list order (default with\n"
@@ -236,7 +237,6 @@ int main(int argc, char* argv[]) {
                 else if (!strcmp(optarg, "ranks")) exchange = HF_EXCHANGE_RANKS;
                 else { fprintf(stderr, "[%s] Error: --exchange can be chunks or ranks.\n", ts()); return EXIT_FAILURE; }
                 break;
-            case 1005: loopbackRanks = atoi(optarg); break;
             default:
                 if (c != 'h') fprintf(stderr, "[E::%s] undefined option %c\n", __func__, c);
                 usage(program);
@@ -253,8 +253,10 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "[phase] %-28s %8.1f ms\n", name, (now - phaseStart) * 1e3);
         phaseStart = now;
     };
+    // test transport, not an option: HF_LOOPBACK_RANKS=N runs N ranks that share ONE GPU (no RCCL) through the multi-GPU path
+    if (const char* e = getenv("HF_LOOPBACK_RANKS")) loopbackRanks = atoi(e);
     if (nGpus < 0 || nGpus > 64 || loopbackRanks < 0 || loopbackRanks > 64) { fprintf(stderr, "[%s] Error: --gpus should be between 1 and 64.\n", ts()); return EXIT_FAILURE; }
-    if (nGpus > 0 && loopbackRanks > 0) { fprintf(stderr, "[%s] Error: --gpus and --loopbackRanks exclude each other.\n", ts()); return EXIT_FAILURE; }
+    if (nGpus > 0 && loopbackRanks > 0) { fprintf(stderr, "[%s] Error: --gpus and HF_LOOPBACK_RANKS exclude each other.\n", ts()); return EXIT_FAILURE; }
     if (!inputPath) { fprintf(stderr, "[%s] Error: Input path cannot be NULL.\n", ts()); return EXIT_FAILURE; }
     if (convergenceTol <= 0.0 || convergenceTol > 1.0) {
         fprintf(stderr, "[%s] Error: convergence tol = %2.f should be between 0 and 1.\n", ts(), convergenceTol);

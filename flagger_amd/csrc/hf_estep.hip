@@ -434,7 +434,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     DMALLOC(ctx->d_rec, N * 4); DMALLOC(ctx->d_beta, N * 8); DMALLOC(ctx->d_regmask, C * 8);
 
     if (algo == HF_ALGO_SEQ) DMALLOC(ctx->d_E, N * 16 * 8);
-    DMALLOC(ctx->d_scale, N * 8); DMALLOC(ctx->d_label, N);
+    if (algo == HF_ALGO_SEQ) DMALLOC(ctx->d_scale, N * 8);   // window-order scales: the sequential cross-check only (hf_seg.h keeps them by slot)
+    DMALLOC(ctx->d_label, N);
     DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, ((size_t) ctx->V + 1) * 8);
     DMALLOC(ctx->d_flags, 4);
     DMALLOC(ctx->d_done, 4);
@@ -612,6 +613,10 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     }
                 });
                 ctx->n_combo = n_combo; ctx->n_arows = (int) a_src.size();
+                if (a_src.size() >= ((size_t) 1 << 25)) {   // the segment kernels address a row by a 32-bit BYTE offset (index << 7)
+                    hf_destroy(ctx);
+                    return set_err(HF_E_ARG, "hf_create: more than 2^25 distinct rows of A (contig-end windows included): shard the chunk list (hmm_flagger_multi.h)");
+                }
                 TRY(dev_upload(&ctx->d_arow, arow.data(), arow.size()));
                 TRY(dev_upload(&ctx->d_arow_src, a_src.data(), a_src.size()));
                 TRY(dev_upload(&ctx->d_arow_cls, a_cls.data(), a_cls.size()));
@@ -1379,6 +1384,7 @@ int hf_em_iterate(hf_ctx* ctx, hfm_model* model, int mode, int do_mstep, double 
 
 int hf_get_labels(hf_ctx* ctx, int8_t* labels_host) {
     if (!ctx || !labels_host) return set_err(HF_E_ARG, "hf_get_labels: bad argument");
+    if (!ctx->have_full) return set_err(HF_E_ARG, "hf_get_labels: the last pass was not HF_MODE_FULL (a forward-only pass decodes nothing)");
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpy(labels_host, ctx->d_label, (size_t) ctx->N, hipMemcpyDeviceToHost));
     return HF_OK;
@@ -1386,8 +1392,8 @@ int hf_get_labels(hf_ctx* ctx, int8_t* labels_host) {
 
 int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_host, double* b_host, double* scales_host) {
     if (!ctx || first < 0 || n < 0 || first + n > ctx->N) return set_err(HF_E_ARG, "hf_get_forward_backward: bad range");
-    if (!ctx->have_full && (f_host || b_host))
-        return set_err(HF_E_ARG, "hf_get_forward_backward: the last pass was not HF_MODE_FULL (backward values would be stale)");
+    if (!ctx->have_full)   // a forward-only pass of the segment kernels keeps everything in registers: nothing of THIS pass to return
+        return set_err(HF_E_ARG, "hf_get_forward_backward: the last pass was not HF_MODE_FULL (forward, backward and scale values would be stale)");
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return HF_OK;
     if (scales_host && !ctx->fb_recs) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
@@ -1487,9 +1493,11 @@ int hf_kernel_times(hf_ctx* ctx, float ms[HF_NKERNELS]) {
 }
 
 const char* hf_kernel_name(int k) {
-    static const char* names[HF_NKERNELS] = {"k_tables", "k_prod_tile", "k_carry", "k_fb_tile", "k_stats_tile", "k_chunk_stats",
+    // slots 1-3 belonged to round 1's tile kernels (never launched since round 2); k_nb_total is the only kernel left in the
+    // HF_K_ROWS_TOTAL slot (the Gaussian models' total is part of k_row_stats since round 3)
+    static const char* names[HF_NKERNELS] = {"k_tables", "(retired)", "(retired)", "(retired)", "k_stats_tile", "k_chunk_stats",
                                              "k_reduce", "k_emit_rows", "k_fwd_seq", "k_bwd_seq", "k_pair_sums", "k_row_stats",
-                                             "k_rows_total", "k_seg_prod", "k_seg_fb", "k_arows"};
+                                             "k_nb_total", "k_seg_prod", "k_seg_fb", "k_arows"};
     return k >= 0 && k < HF_NKERNELS ? names[k] : "?";
 }
 

@@ -44,14 +44,14 @@ def test_cli_reproduces_committed_golden_outputs(name, args, tmp_path):
         assert open(os.path.join(exp, f)).read() == (tmp_path / "o" / f).read_text(), f
 
 
-@pytest.mark.parametrize("extra", [[], ["--accelerate"], ["--algo", "seq"]], ids=["em", "squarem", "seq"])
+@pytest.mark.parametrize("extra", [[], ["--accelerate"], ["--hipAlgo", "seq"]], ids=["em", "squarem", "seq"])
 def test_cli_on_simulated_cov_gz_matches_oracle_cli(extra, tmp_path):
     """configs[0]: the docs/hmm_test recipe on the .cov.gz written by the reference's simulator."""
     cov = os.path.join(GOLD, "sim_gaussian_30k.cov.gz")
     common = ["-i", cov, "--modelType", "gaussian", "--chunkLen", "1000", "--windowLen", "1", "--collapsedComps", "4",
               "--convergenceTol", "1e-4", "--minHighMapqRatio", "0", "-e", "-n", "25", "--trackName", "gaussian_30k",
               "--writePosteriorProbs", "--dumpBin", "-w"]
-    oextra = [x for x in extra if x not in ("--algo", "seq")]
+    oextra = [x for x in extra if x not in ("--hipAlgo", "seq")]
     _run(CLI, common + extra, tmp_path / "gpu")
     _run(ORACLE, common + oextra, tmp_path / "cpu")
     names = OUTPUTS + ["posterior_prediction_final.bed", "chunks.c_1000.w_1.bin"]

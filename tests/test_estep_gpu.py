@@ -148,8 +148,9 @@ def test_empty_chunk_list(algo):
 
 @pytest.mark.parametrize("algo", ALGOS)
 def test_one_long_chunk_spanning_many_tiles(algo):
-    """A 45 000-window chunk = 176 tiles: the carry sweep of a chunk goes through more than one LDS batch of tile
-    products (HF_CARRY_BATCH = 128), next to a chunk of exactly one tile and one of exactly 128 tiles."""
+    """A 45 000-window chunk = 88 segments of the segment kernels (hf_seg.h): more products of OTHER segments than k_seg_fb
+    stages in LDS (HF_SEG_PSTAGE = 24; the rest are read from global memory), next to a chunk of one half-filled segment
+    and one of exactly 64 full segments."""
     store = synth.synthesize([45_000_000, 256_000, 32_768_000], 1000, 60_000_000, [20], seed=21)
     assert sorted(np.diff(store.chunk_off).tolist()) == [256, 32768, 45000]
     _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, synth.HIFI_ALPHA, algo, n_iter=1)

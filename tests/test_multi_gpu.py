@@ -206,7 +206,7 @@ OUTPUTS = ["final_flagger_prediction.bed", "loglikelihood.tsv", "emission_final.
 
 @pytest.mark.parametrize("extra", [[], ["--accelerate"]], ids=["em", "squarem"])
 def test_command_line_gpus_option(extra, tmp_path):
-    """`hmm_flagger --gpus 1 --exchange chunks` (RCCL, one rank), `--loopbackRanks 3` and a one-context run of the per-chunk
+    """`hmm_flagger --gpus 1 --exchange chunks` (RCCL, one rank), `HF_LOOPBACK_RANKS=3` and a one-context run of the per-chunk
     statistics write identical files; `--gpus N` beyond the visible devices exits non-zero with a clear message."""
     store = synth.config(2, scale=0.01)
     binp = tmp_path / "d.bin"
@@ -217,7 +217,7 @@ def test_command_line_gpus_option(extra, tmp_path):
     r1 = _cli(args + ["--gpus", "1", "--exchange", "chunks"], tmp_path / "rccl1")
     assert r1.returncode == 0, r1.stderr[-2000:]
     assert "GPU 0: %d chunks" % store.n_chunks in r1.stderr
-    r3 = _cli(args + ["--loopbackRanks", "3"], tmp_path / "loop3")
+    r3 = _cli(args, tmp_path / "loop3", env={"HF_LOOPBACK_RANKS": "3"})
     assert r3.returncode == 0, r3.stderr[-2000:]
     for name in OUTPUTS + ["posterior_prediction_final.bed"]:
         a = (tmp_path / "one" / name).read_text()
