@@ -38,17 +38,17 @@ struct TileDesc { long long t0; int T; int base; int chunk; int slow0; };
 struct SegDesc {
     long long t0;            // global index of the segment's first window
     int n, L;                // windows of the segment, windows per lane
-    int slot0, next_slot;    // first record slot; the slot whose f half takes f of the segment's LAST window
+    int slot0, next_slot;    // first slot (scales, lane products: slot0 + step*64 + lane); first slot of the chunk's next segment
     int slow0;               // slow-list position of the first slow window at or after t0 (hf_scan.h)
     int chunk_slow0;         // row of A (hf_seg.h) of the chunk's first window: start∘e
     int seg0, k, nseg;       // first segment of the chunk, this segment's position in it, segments of the chunk
     int reg_first, reg_last; // region of the chunk's first / last window
     int chunk;               // chunk index
-    int pad0, pad1;
+    int spare_pos;           // record position whose f half takes f of the CHUNK's last window
+    int pad1;
 };
 static_assert(sizeof(SegDesc) == 64, "SegDesc is one 64-byte load");
 // statistics by emission row (hf_rows.h): one pair (t-1, t) of the plan, one row slot
-struct PairIdx { int32_t t; uint32_t rec; };                     // global window t of the pair (t-1, t) (< 0: empty slot), its record
 struct RowSlot { int32_t row, g0, ng, xpx; };                    // row < 0: padding; xpx = x | x_prev << 8
 
 // Layout of the forward / backward arrays f, b (double2 units): tile-major, lane-minor —

@@ -120,18 +120,20 @@ struct hf_ctx {
     double* d_chunk_ll = nullptr;  // [C] log-likelihood per chunk (rows mode)
     double* d_recs = nullptr;      // [n_slots] pair records { f_{t-1}, b_t } of k_seg_fb, slot order; fb_recs: the last full pass wrote them
     bool fb_recs = false;
-    PairIdx* d_pairs = nullptr; int32_t* d_grp_row = nullptr; double* d_grp_sums = nullptr;
+    int32_t* d_grp_ar = nullptr; int32_t* d_grp_n = nullptr; double* d_grp_sums = nullptr;   // per group: its row of A, its pairs
+    int32_t* d_pos_f = nullptr; int32_t* d_slot_of = nullptr;   // device copies of h_pos_f / h_slot_of, uploaded by the first getter call
+    int32_t* d_pos = nullptr; int64_t n_pos = 0;   // [N] position of every window's pair record in d_recs (plan order; slot order without a plan)
     RowSlot* d_rowslots = nullptr; int32_t* d_rw_region = nullptr; int32_t* d_rw_off = nullptr; double* d_rw_stats = nullptr;
     // segment kernels (hf_seg.h): the forward-backward of the statistics-by-row path
     SegDesc* d_seg = nullptr; int nseg = 0; int32_t* d_chunk_seg0 = nullptr; double* d_seg_ll = nullptr; double* d_Pseg = nullptr;
     double* d_segQ = nullptr;          // [nseg][8][NL] double2: lane products, lane-minor
     // rows of A_t = T_t∘e_t (hf_seg.h): one per (emission key, transition class) that occurs at an interior window, then one
     // per slow window; d_arow[t] = the row of window t (bit 31: chunk-first), d_arow_src / d_arow_cls = where a row comes from
-    int32_t* d_slot_of = nullptr;      // [N] record slot of every window (the per-chunk statistics kernels read pair records by window)
     int32_t* d_arow = nullptr; int32_t* d_arow_src = nullptr; int32_t* d_arow_cls = nullptr; double* d_lutA = nullptr;
     int n_arows = 0, n_combo = 0;
     double* d_scale_s = nullptr; int64_t n_slots = 0;
-    std::vector<int32_t> h_slot_of, h_slot_f;   // window -> record slot of its b half / of its f half (host getters)
+    std::vector<int32_t> h_slot_of;             // window -> slot (the scales are kept in slot order)
+    std::vector<int32_t> h_pos, h_pos_f;        // window -> position of the record with its b / with its f (host getters)
     bool pass_seg = false;             // the last pass ran the segment kernels (log-likelihood partials per segment)
     unsigned long long* d_seg_trace = nullptr;   // -DHF_SEG_TRACE builds only
     int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_Es = nullptr; double* d_Cs = nullptr;
@@ -303,10 +305,8 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         // statistics by emission row (hf_rows.h); hf_finish launches k_rows_total
         {
             KTimer t(ctx, st, HF_K_PAIR_SUMS);
-            const TileGeom g = tile_geom(ctx, k_pair_sums, 0);
-            TILE_GEOM_OR_FAIL(g);
-            hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) (((int64_t) ctx->n_groups * 16 + 255) / 256)), dim3(256), g.lds, st, ctx->n_groups,
-                               ctx->d_pairs, ctx->d_grp_row, ctx->d_lutE, ctx->d_params, ctx->d_recs, ctx->d_grp_sums);
+            hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) ((ctx->n_groups + 15) / 16)), dim3(256), 0, st, ctx->n_groups, ctx->d_grp_ar, ctx->d_grp_n,
+                               ctx->d_lutA, ctx->d_recs, ctx->d_grp_sums);
         }
         KTimer t(ctx, st, HF_K_ROW_STATS);
         constexpr size_t NA = 16 + 9 + 2 + 3 * KT + 1;
@@ -336,7 +336,7 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         TILE_GEOM_OR_FAIL(g);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
                            ctx->d_tile_desc, ctx->d_rec, row_src(ctx), ctx->d_params, ctx->pass_seg ? ctx->d_recs : ctx->d_f, ctx->d_b, ctx->d_regmask,
-                           ctx->d_tile_stats, ctx->pass_seg ? ctx->d_slot_of : (const int32_t*) nullptr);
+                           ctx->d_tile_stats, ctx->pass_seg ? ctx->d_pos : (const int32_t*) nullptr);
     }
     KTimer t(ctx, st, HF_K_CHUNK_STATS);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_chunk_stats<KT>), dim3((unsigned) ctx->C), dim3(128), 0, st, ctx->d_chunk_tile0, ll_off(ctx),
@@ -355,6 +355,20 @@ static int launch_nb_total(hf_ctx* ctx, hipStream_t st, double* out, bool with_f
                        with_flags ? ctx->d_flags : (const unsigned*) nullptr, seq, ctx->d_done);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// host getters (hf_get_forward_backward): f, b and the scale of windows first .. first + n, gathered from the pair records
+__global__ void k_gather_fb(int64_t first, int64_t n, const int32_t* __restrict__ pos, const int32_t* __restrict__ pos_f,
+                            const int32_t* __restrict__ slot_of, const double* __restrict__ recs, const double* __restrict__ scale_s,
+                            double* __restrict__ f, double* __restrict__ b, double* __restrict__ sc) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t t = first + i;
+    const double* __restrict__ rf = recs + (int64_t) pos_f[t] * 8;
+    const double* __restrict__ rb = recs + (int64_t) pos[t] * 8 + 4;
+#pragma unroll
+    for (int s = 0; s < 4; s++) { f[i * 4 + s] = rf[s]; b[i * 4 + s] = rb[s]; }
+    sc[i] = scale_s[slot_of[t]];
 }
 
 extern "C" {
@@ -552,7 +566,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         // ---- segments of the workgroup-per-segment forward-backward (hf_seg.h) and the record slot of every window ----
         std::vector<uint32_t> hrec;
         std::vector<int32_t>& slot_of = ctx->h_slot_of;
-        std::vector<int32_t>& slot_f = ctx->h_slot_f;
+        std::vector<int32_t> h_arow, h_arow_src;        // window -> row of A; row of A -> emission row (both also on the device)
         if (N > 0 && C > 0 && N < (size_t) INT32_MAX / 2) {
             constexpr int64_t NL = 64;
             static_assert(HF_SEG_SPLIT <= 64 * HF_SEG_LMAX, "a segment has at most HF_SEG_LMAX windows per lane");
@@ -585,7 +599,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         }
                     }
                 });
-                std::vector<int32_t> a_src, a_cls;
+                std::vector<int32_t>& a_src = h_arow_src;
+                std::vector<int32_t> a_cls;
                 for (size_t k = 0; k < combo_id.size(); k++)
                     if (combo_id[k]) {
                         combo_id[k] = (int32_t) a_src.size() + 1;            // id + 1
@@ -594,7 +609,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     }
                 const int32_t n_combo = (int32_t) a_src.size();
                 a_src.resize((size_t) n_combo + slow.size()); a_cls.resize((size_t) n_combo + slow.size());
-                std::vector<int32_t> arow(N);
+                std::vector<int32_t>& arow = h_arow;
+                arow.resize(N);
                 par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
                     for (size_t c = c0; c < c1; c++) {
                         const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
@@ -626,7 +642,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             }
             std::vector<SegDesc> segs;
             std::vector<int32_t> cseg0(C + 1, 0);
-            slot_of.assign(N, 0); slot_f.assign(N, 0);
+            slot_of.assign(N, 0);
             int64_t nslots = 0;
             for (size_t c = 0; c < C; c++) {
                 const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
@@ -665,118 +681,106 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         for (int64_t l = 0, x = 0; x < d.n; l++)                  // window x = lane l's x % L-th
                             for (int64_t i = 0; i < d.L && x < d.n; i++, x++) so[x] = d.slot0 + (int32_t) (i * NL + l);
                     }
-                    const int32_t spare = segs[(size_t) cseg0[c + 1] - 1].next_slot;
-                    for (int64_t x = 0; x + 1 < T; x++) slot_f[(size_t) (t0 + x)] = slot_of[(size_t) (t0 + x + 1)];
-                    slot_f[(size_t) (t0 + T - 1)] = spare;
                 }
             });
             if (nslots < INT32_MAX) {
                 ctx->nseg = (int) segs.size(); ctx->n_slots = nslots;
                 TRY(dev_upload(&ctx->d_seg, segs.data(), segs.size()));
-                TRY(dev_upload(&ctx->d_slot_of, slot_of.data(), slot_of.size()));
                 TRY(dev_upload(&ctx->d_chunk_seg0, cseg0.data(), cseg0.size()));
                 DMALLOC(ctx->d_segQ, segs.size() * (size_t) NL * 16 * 8);
                 DMALLOC(ctx->d_seg_ll, segs.size() * 8);
                 DMALLOC(ctx->d_Pseg, segs.size() * 16 * 8);
-                DMALLOC(ctx->d_recs, (size_t) ctx->n_slots * 64);
                 DMALLOC(ctx->d_scale_s, (size_t) ctx->n_slots * 8);
-            } else { slot_of.clear(); slot_f.clear(); }
+            } else slot_of.clear();
             cphase("segments");
         }
         if (algo == HF_ALGO_SCAN && N > 0 && C > 0 && ctx->nseg == 0) {
             hf_destroy(ctx);
             return set_err(HF_E_ARG, "hf_create: HF_ALGO_SCAN holds at most 2^30 windows per context (shard the chunk list: hmm_flagger_multi.h)");
         }
-        // ---- plan of the statistics by emission row (hf_rows.h) ----
+        // ---- plan of the statistics by emission row (hf_rows.h) and the POSITION of every window's pair record ----
+        // Pairs (x-1, x), x = 2..T-1 of every chunk (hmm.c:638-642), grouped by the row of A of window x (emission key x
+        // transition class, or a contig-end window's own row): up to 64 pairs per group, record of the group's i-th pair at
+        // position group*64 + i — k_pair_sums STREAMS the records, k_seg_fb scatters them (whole 64-byte records).  Windows
+        // without a pair (the first two of a chunk) and the f of a chunk's last window get positions after the groups.
         if (N > 0 && C > 0 && ctx->nseg > 0) {
-            const size_t n_rows_all = (size_t) ctx->n_lut + slow.size();
-            std::vector<int32_t> cnt(n_rows_all + 1, 0);
-            std::vector<int32_t> prow(N); std::vector<PairIdx> pidx(N);
-            std::vector<size_t> pair0(C + 1, 0);                  // pairs (x-1, x), x = 2..T-1 (hmm.c:638-642)
+            const size_t n_ar = h_arow_src.size();
+            std::vector<int32_t> cnt(n_ar + 1, 0);
+            std::vector<size_t> pair0(C + 1, 0);
             for (size_t c = 0; c < C; c++) {
                 const int64_t T = w->chunk_off[c + 1] - w->chunk_off[c];
                 pair0[c + 1] = pair0[c] + (size_t) (T > 2 ? T - 2 : 0);
             }
             const size_t np = pair0[C];
-            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
-                for (size_t c = c0; c < c1; c++) {
-                    const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-                    size_t q = pair0[c], sp = (size_t) soff[c];
-                    for (int64_t x = 2; x < T; x++) {
-                        const size_t t = (size_t) (t0 + x);
-                        int64_t row;
-                        if (hb[t] != ctx->beta_star) {
-                            while (sp < slow.size() && (size_t) slow[sp] < t) sp++;
-                            row = ctx->n_lut + (int64_t) sp;
-                        } else {
-                            const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
-                            row = (int64_t) ((reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu));
-                        }
-                        pidx[q].t = slot_of[t]; pidx[q].rec = hrec[t];        // the pair's record, by slot (hf_seg.h)
-                        prow[q++] = (int32_t) row;
-                    }
-                }
-            });
-            for (size_t q = 0; q < np; q++) cnt[(size_t) prow[q]]++;       // popular rows: one thread, no contended atomics
-            prow.resize(np); pidx.resize(np);
-            // a plan is padded to 64 slots per group: when most pairs sit in rows of their own (reads longer than the contigs:
-            // every window is a contig-end window) it would cost 64 slots per window — then the per-chunk statistics stay
+            for (size_t c = 0; c < C; c++) {                      // popular rows: one thread, no contended atomics
+                const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                for (int64_t x = 2; x < T; x++) cnt[(size_t) (h_arow[(size_t) (t0 + x)] & 0x7fffffff)]++;
+            }
+            // a plan is padded to 64 positions per group: when most pairs sit in rows of their own (reads longer than the contigs:
+            // every window is a contig-end window) it would cost 64 positions per window — then the per-chunk statistics stay
             int64_t n_groups_all = 0;
-            for (size_t r = 0; r < n_rows_all; r++) n_groups_all += (cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS;
-            const bool dense = n_groups_all * HF_GRP_PAIRS <= 4 * (int64_t) pidx.size() + (4 << 20);   // 32 MiB of slack
+            for (size_t r = 0; r < n_ar; r++) n_groups_all += (cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS;
+            const bool dense = n_groups_all * HF_GRP_PAIRS <= 4 * (int64_t) np + (4 << 20);   // 32 MiB of slack
             cphase("plan: pairs");
-            if (!pidx.empty() && dense && ctx->n_lut + (int64_t) slow.size() < INT32_MAX && N < (size_t) INT32_MAX) {
-                // counting sort by row (pairs of a row stay in window order)
-                std::vector<int64_t> start(n_rows_all + 1, 0);
-                for (size_t r = 0; r < n_rows_all; r++) start[r + 1] = start[r] + cnt[r];
-                std::vector<PairIdx> sorted(pidx.size());
-                {
-                    std::vector<int64_t> fill(start.begin(), start.end() - 1);
-                    for (size_t i = 0; i < pidx.size(); i++) sorted[(size_t) fill[(size_t) prow[i]]++] = pidx[i];
-                }
-                cphase("plan: sort");
-                // occurring rows ordered by (region, row)
-                struct OccRow { int32_t region, row; };
-                std::vector<OccRow> occ;
-                for (size_t r = 0; r < n_rows_all; r++) {
+            std::vector<int32_t> pos(N, 0), pos_f(N, 0);
+            int64_t n_pos = 0;
+            if (np > 0 && dense && n_groups_all * HF_GRP_PAIRS + 3 * (int64_t) C < INT32_MAX && N < (size_t) INT32_MAX) {
+                // rows of A that occur, ordered by (region, row of A): combos are numbered by (emission key, class), keys are
+                // region-major; the contig-end windows' rows follow in window order
+                struct Occ { int32_t region, ar; };
+                std::vector<Occ> occ;
+                const size_t MMr = (size_t) ctx->M * ctx->M;
+                for (size_t r = 0; r < n_ar; r++) {
                     if (!cnt[r]) continue;
+                    const int64_t er = h_arow_src[r];            // emission row: a key, or n_lut + slow index
                     int32_t reg;
-                    if ((int64_t) r < ctx->n_lut) reg = (int32_t) (r / ((size_t) ctx->M * ctx->M));
-                    else reg = (int32_t) ((w->annot[(size_t) slow[r - (size_t) ctx->n_lut]] & 0xFC00000000000000ULL) >> 58);
+                    if (er < ctx->n_lut) reg = (int32_t) ((size_t) er / MMr);
+                    else reg = (int32_t) ((w->annot[(size_t) slow[(size_t) (er - ctx->n_lut)]] & 0xFC00000000000000ULL) >> 58);
                     occ.push_back({reg, (int32_t) r});
                 }
-                std::stable_sort(occ.begin(), occ.end(), [](const OccRow& a, const OccRow& b) { return a.region < b.region; });
-                std::vector<PairIdx> gp; std::vector<int32_t> grow;
-                gp.reserve((size_t) n_groups_all * HF_GRP_PAIRS); grow.reserve((size_t) n_groups_all);
+                std::stable_sort(occ.begin(), occ.end(), [](const Occ& a, const Occ& b) { return a.region < b.region; });
+                std::vector<int32_t> g_first(n_ar, 0);            // first group of every row of A
+                std::vector<int32_t> grp_ar, grp_n;
+                grp_ar.reserve((size_t) n_groups_all); grp_n.reserve((size_t) n_groups_all);
                 std::vector<RowSlot> rslots; std::vector<int32_t> rwreg, rwoff((size_t) n_regions + 1, 0);
-                const PairIdx empty = {-1, 0u};
                 size_t oi = 0;
                 for (int reg = 0; reg < n_regions; reg++) {
                     rwoff[(size_t) reg] = (int32_t) (rslots.size() / 16);
+                    int64_t open_row = -1;                         // emission row of the row slot being filled
                     for (; oi < occ.size() && occ[oi].region == reg; oi++) {
-                        const size_t r = (size_t) occ[oi].row;
-                        const int64_t n = cnt[r], s0 = start[r];
-                        const int32_t g_first = (int32_t) grow.size();
-                        for (int64_t b = 0; b < n; b += HF_GRP_PAIRS) {
-                            const int64_t m = n - b < HF_GRP_PAIRS ? n - b : HF_GRP_PAIRS;
-                            gp.insert(gp.end(), sorted.begin() + (s0 + b), sorted.begin() + (s0 + b + m));
-                            if (m < HF_GRP_PAIRS) gp.insert(gp.end(), (size_t) (HF_GRP_PAIRS - m), empty);
-                            grow.push_back((int32_t) r);
-                        }
-                        const int32_t ng_all = (int32_t) grow.size() - g_first;
+                        const size_t r = (size_t) occ[oi].ar;
+                        const int64_t er = h_arow_src[r];
+                        g_first[r] = (int32_t) grp_ar.size();
                         int32_t xpx;
-                        if ((int64_t) r < ctx->n_lut) xpx = (int32_t) ((r / (size_t) ctx->M) % (size_t) ctx->M) | ((int32_t) (r % (size_t) ctx->M) << 8);
-                        else { const size_t t = (size_t) slow[r - (size_t) ctx->n_lut]; xpx = (int32_t) (w->cov[t] & 0xffu) | ((int32_t) (w->cov[t - 1] & 0xffu) << 8); }
-                        for (int32_t g = 0; g < ng_all; g += HF_ROWSLOT_GROUPS) {
-                            RowSlot sl; sl.row = (int32_t) r; sl.g0 = g_first + g;
-                            sl.ng = ng_all - g < HF_ROWSLOT_GROUPS ? ng_all - g : HF_ROWSLOT_GROUPS; sl.xpx = xpx;
-                            rslots.push_back(sl);
+                        if (er < ctx->n_lut) xpx = (int32_t) (((size_t) er / (size_t) ctx->M) % (size_t) ctx->M) | ((int32_t) ((size_t) er % (size_t) ctx->M) << 8);
+                        else { const size_t t = (size_t) slow[(size_t) (er - ctx->n_lut)]; xpx = (int32_t) (w->cov[t] & 0xffu) | ((int32_t) (w->cov[t - 1] & 0xffu) << 8); }
+                        for (int64_t b = 0; b < cnt[r]; b += HF_GRP_PAIRS) {
+                            const int32_t g = (int32_t) grp_ar.size();
+                            grp_ar.push_back((int32_t) r);
+                            grp_n.push_back((int32_t) (cnt[r] - b < HF_GRP_PAIRS ? cnt[r] - b : HF_GRP_PAIRS));
+                            // a row slot = up to 4 consecutive groups of one EMISSION row (its transition classes are adjacent)
+                            if (open_row == er && rslots.back().ng < HF_ROWSLOT_GROUPS) rslots.back().ng++;
+                            else { RowSlot sl; sl.row = (int32_t) er; sl.g0 = g; sl.ng = 1; sl.xpx = xpx; rslots.push_back(sl); open_row = er; }
                         }
                     }
                     while (rslots.size() % 64) rslots.push_back({-1, 0, 0, 0});
                     for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / 16; k++) rwreg.push_back(reg);
                 }
                 rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / 16);
+                n_pos = (int64_t) grp_ar.size() * HF_GRP_PAIRS;
+                // positions: pairs of a row of A in window order
+                {
+                    std::vector<int64_t> fill(n_ar, 0);           // pairs of the row placed so far
+                    for (size_t c = 0; c < C; c++) {
+                        const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                        for (int64_t x = 2; x < T; x++) {
+                            const size_t r = (size_t) (h_arow[(size_t) (t0 + x)] & 0x7fffffff);
+                            const int64_t k = fill[r]++;
+                            pos[(size_t) (t0 + x)] = (int32_t) (((int64_t) g_first[r] + k / HF_GRP_PAIRS) * HF_GRP_PAIRS + k % HF_GRP_PAIRS);
+                        }
+                    }
+                }
+                cphase("plan: groups, row slots, positions");
                 // negative_binomial count data: the row slots of every (region, min(x, 249)) bin, in plan order
                 {
                     std::vector<int32_t> boff((size_t) n_regions * 256 + 1, 0), blist;
@@ -798,19 +802,51 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     DMALLOC(ctx->d_slot_h, rslots.size() * 4 * 8);
                     DMALLOC(ctx->d_H, (size_t) n_regions * 4 * 256 * 8);
                 }
-                cphase("plan: groups, row slots");
-                ctx->n_groups = (int) grow.size(); ctx->n_rowwaves = (int) (rslots.size() / 16);   // 16 slots per wavefront, 64 per region pad
-                TRY(dev_upload(&ctx->d_pairs, gp.data(), gp.size()));
-                TRY(dev_upload(&ctx->d_grp_row, grow.data(), grow.size()));
+                ctx->n_groups = (int) grp_ar.size(); ctx->n_rowwaves = (int) (rslots.size() / 16);   // 16 slots per wavefront, 64 per region pad
+                while (grp_ar.size() % 4) { grp_ar.push_back(0); grp_n.push_back(0); }   // k_pair_sums: four groups per wavefront
+                TRY(dev_upload(&ctx->d_grp_ar, grp_ar.data(), grp_ar.size()));
+                TRY(dev_upload(&ctx->d_grp_n, grp_n.data(), grp_n.size()));
                 TRY(dev_upload(&ctx->d_rowslots, rslots.data(), rslots.size()));
                 TRY(dev_upload(&ctx->d_rw_region, rwreg.data(), rwreg.size()));
                 TRY(dev_upload(&ctx->d_rw_off, rwoff.data(), rwoff.size()));
-                DMALLOC(ctx->d_grp_sums, (size_t) ctx->n_groups * 16 * 8);
+                DMALLOC(ctx->d_grp_sums, (size_t) grp_ar.size() * 16 * 8);
                 DMALLOC(ctx->d_chunk_ll, C * 8);
                 DMALLOC(ctx->d_rw_stats, (size_t) ctx->n_rowwaves * (16 + 9 + 2 + 3 * 16 + 1) * 8);
+                n_pos = (int64_t) grp_ar.size() * HF_GRP_PAIRS;
                 ctx->rows_ready = true;
-                cphase("plan: uploads, allocations");
+            } else {
+                // no plan (sparse rows): the per-chunk statistics read the records by window; positions in slot order
+                for (size_t t = 0; t < N; t++) pos[t] = slot_of[t];
+                n_pos = ctx->n_slots;
             }
+            // windows without a pair of their own (x = 0, 1), and the f of every chunk's last window
+            for (size_t c = 0; c < C; c++) {
+                const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                if (T <= 0) continue;
+                if (ctx->rows_ready) for (int64_t x = 0; x < T && x < 2; x++) pos[(size_t) (t0 + x)] = (int32_t) n_pos++;
+                for (int64_t x = 0; x + 1 < T; x++) pos_f[(size_t) (t0 + x)] = pos[(size_t) (t0 + x + 1)];
+                pos_f[(size_t) (t0 + T - 1)] = (int32_t) n_pos++;   // == SegDesc.spare_pos of the chunk's last segment (below)
+            }
+            // the chunk's spare position goes into the descriptors of its segments
+            {
+                std::vector<SegDesc> segs((size_t) ctx->nseg);
+                if (hipMemcpy(segs.data(), ctx->d_seg, segs.size() * sizeof(SegDesc), hipMemcpyDeviceToHost) != hipSuccess) {
+                    hf_destroy(ctx); return set_err(HF_E_HIP, "segment descriptor download failed");
+                }
+                for (auto& d : segs) {
+                    const int64_t t_last = w->chunk_off[d.chunk + 1] - 1;
+                    d.spare_pos = pos_f[(size_t) t_last];
+                }
+                if (hipMemcpy(ctx->d_seg, segs.data(), segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice) != hipSuccess) {
+                    hf_destroy(ctx); return set_err(HF_E_HIP, "segment descriptor upload failed");
+                }
+            }
+            ctx->n_pos = n_pos;
+            TRY(dev_upload(&ctx->d_pos, pos.data(), pos.size()));
+            hipFree(ctx->d_recs); ctx->d_recs = nullptr;
+            DMALLOC(ctx->d_recs, (size_t) n_pos * 64);
+            ctx->h_pos.swap(pos); ctx->h_pos_f.swap(pos_f);
+            cphase("plan: uploads, allocations");
         }
     }
     { const char* e = std::getenv("HF_HOST_TRACE"); ctx->host_trace = e && e[0] == '1'; }
@@ -852,9 +888,9 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0);
-    hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_pairs); hipFree(ctx->d_grp_row); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
+    hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_grp_ar); hipFree(ctx->d_grp_n); hipFree(ctx->d_pos); hipFree(ctx->d_pos_f); hipFree(ctx->d_slot_of); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
     hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_scale_s);
-    hipFree(ctx->d_slot_of); hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
+    hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats);
     hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats);
     if (ctx->h_params) hipHostFree(ctx->h_params);
@@ -1035,10 +1071,10 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 KTimer t(ctx, st, HF_K_SEG_FB);
                 if (full)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(HF_SEG_FB(true)), dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow,
-                                       ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
+                                       ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_pos, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
                 else
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(HF_SEG_FB(false)), dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow,
-                                       ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
+                                       ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_pos, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
                 ctx->pass_seg = true;
                 if (full) ctx->fb_recs = true;
             } else
@@ -1050,10 +1086,8 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         if (nbm && fl && rows_pass(ctx)) {   // statistics by emission row, negative_binomial (hf_nb_rows.h)
             {
                 KTimer t(ctx, st, HF_K_PAIR_SUMS);
-                const TileGeom g = tile_geom(ctx, k_pair_sums, 0);
-                if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
-                hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) (((int64_t) ctx->n_groups * 16 + 255) / 256)), dim3(256), g.lds, st, ctx->n_groups,
-                                   ctx->d_pairs, ctx->d_grp_row, ctx->d_lutE, ctx->d_params, ctx->d_recs, ctx->d_grp_sums);
+                hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) ((ctx->n_groups + 15) / 16)), dim3(256), 0, st, ctx->n_groups, ctx->d_grp_ar, ctx->d_grp_n,
+                                   ctx->d_lutA, ctx->d_recs, ctx->d_grp_sums);
             }
             {
                 KTimer t(ctx, st, HF_K_ROW_STATS);
@@ -1074,7 +1108,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile_nb<HF_SCAN_L>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles, ctx->d_tile_desc,
                                    ctx->d_rec, S, ctx->d_params, ctx->pass_seg ? ctx->d_recs : ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_hist,
-                                   ctx->pass_seg ? ctx->d_slot_of : (const int32_t*) nullptr);
+                                   ctx->pass_seg ? ctx->d_pos : (const int32_t*) nullptr);
             }
             NbTables nt;
             nt.E = ctx->d_nbE; nt.P = ctx->d_nbP; nt.dig = ctx->d_nbDig; nt.r = ctx->d_nbR; nt.beta = ctx->d_nbBeta;
@@ -1398,23 +1432,24 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
     if (n == 0) return HF_OK;
     if (scales_host && !ctx->fb_recs) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
     if (!f_host && !b_host && !ctx->fb_recs) return HF_OK;
-    if (ctx->fb_recs) {   // pair records in slot order (hf_seg.h): b_t is the second half of record slot_of[t], f_t the first half of slot_f[t]
-        int64_t lo = INT64_MAX, hi = -1;
-        for (int64_t i = 0; i < n; i++) {
-            const int64_t a = ctx->h_slot_of[(size_t) (first + i)], b = ctx->h_slot_f[(size_t) (first + i)];
-            lo = std::min(lo, std::min(a, b)); hi = std::max(hi, std::max(a, b));
+    if (ctx->fb_recs) {   // pair records (hf_seg.h): b_t is the second half of the record at pos[t], f_t the first half of the one at pos_f[t]
+        // the positions of a range are scattered over the plan: gathered on the device, one copy back (maps uploaded on first use)
+        if (!ctx->d_pos_f) {
+            HIPCHK(hipMalloc((void**) &ctx->d_pos_f, (size_t) ctx->N * 4));
+            HIPCHK(hipMemcpy(ctx->d_pos_f, ctx->h_pos_f.data(), (size_t) ctx->N * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMalloc((void**) &ctx->d_slot_of, (size_t) ctx->N * 4));
+            HIPCHK(hipMemcpy(ctx->d_slot_of, ctx->h_slot_of.data(), (size_t) ctx->N * 4, hipMemcpyHostToDevice));
         }
-        std::vector<double> buf((size_t) (hi - lo + 1) * 8), sbuf((size_t) (hi - lo + 1));
-        HIPCHK(hipMemcpy(buf.data(), ctx->d_recs + (size_t) lo * 8, buf.size() * 8, hipMemcpyDeviceToHost));
-        if (scales_host) HIPCHK(hipMemcpy(sbuf.data(), ctx->d_scale_s + lo, sbuf.size() * 8, hipMemcpyDeviceToHost));
-        for (int64_t i = 0; i < n; i++) {
-            const size_t sb = (size_t) (ctx->h_slot_of[(size_t) (first + i)] - lo), sf = (size_t) (ctx->h_slot_f[(size_t) (first + i)] - lo);
-            for (int s = 0; s < 4; s++) {
-                if (f_host) f_host[i * 4 + s] = buf[sf * 8 + s];
-                if (b_host) b_host[i * 4 + s] = buf[sb * 8 + 4 + s];
-            }
-            if (scales_host) scales_host[i] = sbuf[sb];
-        }
+        double* d_out = nullptr;
+        HIPCHK(hipMalloc((void**) &d_out, (size_t) n * 9 * 8));
+        hipLaunchKernelGGL(k_gather_fb, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, first, n, ctx->d_pos, ctx->d_pos_f, ctx->d_slot_of,
+                           ctx->d_recs, ctx->d_scale_s, d_out, d_out + n * 4, d_out + n * 8);
+        hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
+        if (f_host) e1 = hipMemcpy(f_host, d_out, (size_t) n * 32, hipMemcpyDeviceToHost);
+        if (b_host) e2 = hipMemcpy(b_host, d_out + n * 4, (size_t) n * 32, hipMemcpyDeviceToHost);
+        if (scales_host) e3 = hipMemcpy(scales_host, d_out + n * 8, (size_t) n * 8, hipMemcpyDeviceToHost);
+        hipFree(d_out);
+        HIPCHK(e1); HIPCHK(e2); HIPCHK(e3);
         return HF_OK;
     }
     // f and b live tile-major / lane-minor on the device (hf_scan.h fb_slot): fetch the tiles that cover the range and

@@ -11,10 +11,11 @@
 // path (hf_chunks.h k_stats_tile), i.e. the results agree to rounding (tests: 1e-12 relative against each other, 1e-9
 // against the oracle).  The order is fixed by the plan built in hf_create, so a run is reproducible bit for bit.
 //
-// Plan (static, hf_create): the pairs (t-1, t), t = 2..T-1 of every chunk, sorted by (region, row, t); a GROUP is up to 64
-// consecutive pairs of one row, worked on by 16 lanes; a ROW SLOT is up to 4 consecutive groups of one row (a
-// popular row has many slots: linearity again), worked on by four lanes of k_row_stats; row slots are padded to 64 per
-// region (four wavefronts of 16 slots: the wavefronts of a block always belong to one region).
+// Plan (static, hf_create): the pairs (t-1, t), t = 2..T-1 of every chunk, sorted by (region, row of A, t); a GROUP is up to
+// 64 consecutive pairs of one row of A (= emission row x transition class), their records consecutive in memory; a ROW SLOT
+// is up to 4 consecutive groups of one EMISSION row (a popular row has many slots: linearity again), worked on by four lanes
+// of k_row_stats; row slots are padded to 64 per region (four wavefronts of 16 slots: the wavefronts of a block always
+// belong to one region).
 #pragma once
 #include "hf_scan.h"
 
@@ -24,11 +25,14 @@
 // PairIdx, RowSlot: hf_device.h
 
 // ------------------------------------------------------------------------------------------
-// k_pair_sums: sum over a group's pairs of the counts f[pre]·T[pre][s]·e[pre][s]·b[s] (before the division).
-// 16 lanes per group (4 groups per wavefront), FOUR lanes per pair: lane q of a quad loads 16-byte piece q of the pair
-// record (k_seg_fb: f01 f23 b01 b23) — one load instruction covers 16 whole records — takes the f piece and the b
-// piece of its 2x2 block of the 4x4 count matrix from its quad by DPP, and accumulates the block; the four quads of a
-// group take the pairs round-robin and are summed by a fixed butterfly at the end.
+// k_pair_sums: per group, sum over its pairs of the counts f[pre]·A[pre][s]·b[s] (before the division), A = T∘e = the
+// group's row of A (hf_seg.h): the sum of the outer products f ⊗ b is multiplied by A once per group.  (The reference
+// multiplies f·T·e·b per pair, hmm.c:612: same value up to the rounding of the order; rounds 1-2 did that per pair.)
+// The records of a group are CONSECUTIVE (hf_create: position = group*64 + i; k_seg_fb scatters whole records), so the
+// kernel streams: a wavefront takes 4 consecutive groups = 16 KiB, every load instruction reads 1 KiB contiguous = 16 whole
+// records, FOUR lanes per record — lane q of a quad holds 16-byte piece q (f01 f23 b01 b23), takes the f piece and the b
+// piece of its 2x2 block of the 4x4 count matrix from its quad by DPP, and accumulates the block; the 16 quads are summed by
+// a fixed butterfly at the end of every group.  Positions past a group's last pair are not loaded (never written either).
 // ------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ double quad_perm_f64(double v) {   // quad_perm within each group of four lanes
@@ -37,82 +41,52 @@ __device__ __forceinline__ double quad_perm_f64(double v) {   // quad_perm withi
     return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(256) k_pair_sums(int n_groups, const PairIdx* __restrict__ pairs, const int32_t* __restrict__ grp_row,
-                                                   const double* __restrict__ lutE, const DevParams* __restrict__ P,
-                                                   const double* __restrict__ recs, double* __restrict__ grp_sums) {
-    extern __shared__ __attribute__((aligned(16))) double s_tab[];
-    fill_tab(P, s_tab);
-    const int grp = (int) ((blockIdx.x * 256u + threadIdx.x) >> 4);
-    if (grp >= n_groups) return;   // whole groups leave together; DPP and the butterfly stay inside a group
-    const int ql = threadIdx.x & 3, qd = (threadIdx.x >> 2) & 3;
+__global__ void __launch_bounds__(256) k_pair_sums(int n_groups, const int32_t* __restrict__ grp_ar, const int32_t* __restrict__ grp_n,
+                                                   const double* __restrict__ lutA, const double* __restrict__ recs,
+                                                   double* __restrict__ grp_sums) {
+    const int wave = (int) ((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    const int g0 = wave * 4;
+    if (g0 >= n_groups) return;
+    const int ql = lane & 3, qd = lane >> 2;            // piece of the record, record of the instruction
     const int pi = ql & 1, si = ql >> 1;                // this lane's block: pre in {2pi, 2pi+1}, s in {2si, 2si+1}
-    int kk[4];                                          // state-major positions of the block's four entries
+    const double2* __restrict__ R2 = reinterpret_cast<const double2*>(recs) + (int64_t) g0 * HF_GRP_PAIRS * 4 + lane;
+    int ng[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) kk[u] = HF_PS(2 * pi + (u & 1), 2 * si + (u >> 1));
-    double ev[4];
-    {
-        const double* __restrict__ er = lutE + (int64_t) grp_row[grp] * 16;
+    for (int g = 0; g < 4; g++) ng[g] = g0 + g < n_groups ? grp_n[g0 + g] : 0;   // (the arrays are padded to a multiple of 4 groups)
 #pragma unroll
-        for (int u = 0; u < 4; u++) ev[u] = er[kk[u]];
-    }
-    const PairIdx* __restrict__ pp = pairs + (int64_t) grp * HF_GRP_PAIRS + qd;
-    const double2* __restrict__ R2 = reinterpret_cast<const double2*>(recs);
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 1
-    for (int it0 = 0; it0 < HF_GRP_PAIRS / 4; it0 += 4) {
-        PairIdx q[4];
+    for (int g = 0; g < 4; g++) {
         double2 v[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            q[j] = pp[(it0 + j) * 4];
-            v[j] = R2[(int64_t) (q[j].t < 0 ? 0 : q[j].t) * 4 + ql];
+        for (int j = 0; j < 4; j++) {                    // records j*16 + qd of group g: four 1 KiB loads in flight (all sixteen of the
+            const bool have = j * 16 + qd < ng[g];       // wavefront at once was measured 25 % slower, same box)
+            v[j] = have ? R2[(g * 4 + j) * 64] : make_double2(0.0, 0.0);
         }
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             // quad_perm [0,1,0,1]: the f piece of this lane's rows; [2,2,3,3]: the b piece of its columns
             const double f0 = quad_perm_f64<0x44>(v[j].x), f1 = quad_perm_f64<0x44>(v[j].y);
             const double b0 = quad_perm_f64<0xFA>(v[j].x), b1 = quad_perm_f64<0xFA>(v[j].y);
-            if (q[j].t >= 0) {
-                const uint32_t r = q[j].rec;
-                double tm[4];
-                if (REC_REGCHG(r)) {                      // region change => 1/(S+1), hmm.c:398-400
+            acc[0] += f0 * b0; acc[1] += f1 * b0; acc[2] += f0 * b1; acc[3] += f1 * b1;
+        }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) tm[u] = 1.0 / (HF_NSTATES + 1);
-                } else {
-                    const double* __restrict__ tt = s_tab + REC_REGION(r) * HF_TAB_STRIDE + REC_VMASK(r) * 16;
+        for (int u = 0; u < 4; u++) {                    // the 16 quads, fixed order
+            double x = acc[u];
+            x += __shfl_xor(x, 4); x += __shfl_xor(x, 8); x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+            acc[u] = x;
+        }
+        if (qd == 0 && g0 + g < n_groups) {
+            const double* __restrict__ A = lutA + (int64_t) grp_ar[g0 + g] * 16;
+            double* __restrict__ dst = grp_sums + (int64_t) (g0 + g) * 16;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) tm[u] = tt[kk[u]];
-                }
-                acc[0] += f0 * tm[0] * ev[0] * b0;        // count before the division, hmm.c:612
-                acc[1] += f1 * tm[1] * ev[1] * b0;
-                acc[2] += f0 * tm[2] * ev[2] * b1;
-                acc[3] += f1 * tm[3] * ev[3] * b1;
+            for (int u = 0; u < 4; u++) {                // state-major position of entry (pre, s) = (2pi + (u & 1), 2si + (u >> 1))
+                const int kk = HF_PS(2 * pi + (u & 1), 2 * si + (u >> 1));
+                dst[kk] = acc[u] * A[kk];
             }
         }
     }
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        double v = acc[u];
-        v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16);
-        acc[u] = v;
-    }
-    if (qd == 0) {
-        double* __restrict__ dst = grp_sums + (int64_t) grp * 16;
-#pragma unroll
-        for (int u = 0; u < 4; u++) dst[kk[u]] = acc[u];
-    }
 }
 
-// ------------------------------------------------------------------------------------------
-// rows_total: the total of a pass from the block partials of k_row_stats — run by the LAST block of that launch to finish
-// (round 3: one launch and one kernel boundary less per pass than the separate k_rows_total of rounds 1-2).
-// Element 0 = sum of the chunks' log-likelihoods in k_reduce's order (the same bits as the per-chunk path), by the block's
-// last wavefront; per region, the block partials in plan order by NQ interleaved accumulators per element (fixed by the launch
-// geometry), expanded into the estimator layout of include/hmm_flagger_hip.h exactly as k_chunk_stats does.  A region's block
-// of the vector is assembled in LDS and written once: to `out_dev` (V + 1 doubles, the flag word last) and, when the
-// context has a pinned host block, to `out_host`, followed there by a per-region checksum word bound to the pass
-// (out[V+2+r]) and the completion stamp (out[V+1]): see wait_total.  rw_off[r]..rw_off[r+1]: the wavefronts of region r.
-// ------------------------------------------------------------------------------------------
 // cross-CU hand-off of a few doubles without cache-wide fences: write-through stores (sc0 sc1), drained by the producer before
 // its ticket, and cache-bypassing loads on the reader's side (MI355X_MICROARCH.md, workgroup dispatch & visibility)
 __device__ __forceinline__ void xcu_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }

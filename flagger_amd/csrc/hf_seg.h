@@ -368,7 +368,7 @@ template <bool BWD>
 __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __restrict__ sd, const int32_t* __restrict__ arow,
                                                            const double* __restrict__ lutA, const DevParams* __restrict__ P,
                                                            const double* __restrict__ Qs, const double* __restrict__ Pseg,
-                                                           double* __restrict__ recs, double* __restrict__ scale_s,
+                                                           const int32_t* __restrict__ pos, double* __restrict__ recs, double* __restrict__ scale_s,
                                                            int8_t* __restrict__ label, double* __restrict__ seg_ll,
                                                            unsigned* __restrict__ flags) {
     constexpr int LM = HF_SEG_LMAX;
@@ -533,7 +533,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             if (d.k == d.nseg - 1 && a + jl == n - 1) {         // the chunk's last window, hmm.c:452-467
 #pragma unroll
                 for (int s = 0; s < 4; s++) b[s] = Rl->trans[s][4] / scl;
-                double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + (int64_t) d.next_slot * 4;   // its f: the chunk's spare slot
+                double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + (int64_t) d.spare_pos * 4;   // its f: the chunk's spare record
                 dst[0] = make_double2(f[0], f[1]); dst[1] = make_double2(f[2], f[3]);
             } else {                                            // direction from the scans, magnitude from the invariant at this window
                 const double term = Rl->trans[0][4];
@@ -549,10 +549,12 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
         // record k = { f_{k-1}, b_k } and scale k leave at the top of the step that consumes b_k; window k's row turns b_k into
         // b_{k-1}.  All lanes run k = L-1 .. 1 (cooperative fetch), a lane joins at its last window.  The first step still
         // holds the row of window L-1 from the forward replay (a lane that joins there has m = L).
-        // Through the (momentarily idle) row block, so that every store instruction writes 1 KiB CONTIGUOUS (16 whole records):
-        // written lane by lane as 16-byte pieces at a 64-byte stride, the same bytes cost 13 us more per launch (partial-line
-        // writes: measured, profiles/r03_notes).  All 64 lanes store; the slots of lanes without a window k are padding.
-        auto store_rec = [&](int k, bool act, const double* __restrict__ fk, double sck) {
+        // Record k = { f_{k-1}, b_k } goes to the POSITION hf_create planned for the window (the statistics then stream the
+        // records of a row of A; positions are scattered).  Through the (momentarily idle) row block, so that four adjacent lanes
+        // write one WHOLE 64-byte record: written lane by lane as 16-byte pieces, the same bytes cost 13 us more per launch
+        // (measured: partial-line writes, profiles/r03c_ablation.txt).  Lanes without a window k write nothing.
+        const int32_t* __restrict__ pos_seg = pos + d.t0;
+        auto store_rec = [&](int k, bool act, int32_t pk, const double* __restrict__ fk, double sck) {
             double2* __restrict__ mine = reinterpret_cast<double2*>(blk) + lane * 4;
             mine[0] = make_double2(fk[0], fk[1]); mine[1] = make_double2(fk[2], fk[3]);
             mine[2] = make_double2(b[0], b[1]); mine[3] = make_double2(b[2], b[3]);
@@ -561,12 +563,18 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + lane;
             const double2 v0 = img[0], v1 = img[64], v2 = img[128], v3 = img[192];
-            double2* __restrict__ dst = reinterpret_cast<double2*>(recs) + ((int64_t) d.slot0 + (int64_t) k * 64) * 4 + lane;
-            dst[0] = v0; dst[64] = v1; dst[128] = v2; dst[192] = v3;
+            const int32_t pact = act ? pk : -1;             // the record of lane r goes to position pact(r): lanes 4r .. 4r+3 of instruction r >> 4
+            double2* __restrict__ R2 = reinterpret_cast<double2*>(recs) + (lane & 3);
+            const int32_t p0 = __shfl(pact, lane >> 2), p1 = __shfl(pact, 16 + (lane >> 2)), p2 = __shfl(pact, 32 + (lane >> 2)), p3 = __shfl(pact, 48 + (lane >> 2));
+            if (p0 >= 0) R2[(int64_t) p0 * 4] = v0;
+            if (p1 >= 0) R2[(int64_t) p1 * 4] = v1;
+            if (p2 >= 0) R2[(int64_t) p2 * 4] = v2;
+            if (p3 >= 0) R2[(int64_t) p3 * 4] = v3;
             if (act) scale_s[slot_ij + (int64_t) k * 64] = sck;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                    // the block has been read out: the next row fetch may land
         };
+        int32_t pk_next = jl >= 0 ? pos_seg[a + jl] : 0;        // position of the record of the lane's last window (the first step's, when that is window L-1)
         TR_STAMP(9);
         TR_RESET();
 #pragma unroll
@@ -575,7 +583,9 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 if (k < L - 1) rows_read(blk, lane, A);
                 TR_LAP(3);
                 const bool act = k <= jl;                       // this lane has a window k
-                store_rec(k, act, fs[k - 1], ss[k]);
+                const int32_t pk = pk_next;
+                pk_next = (k - 1 <= jl && k - 1 >= 0) ? pos_seg[a + k - 1] : 0;   // in flight during this step
+                store_rec(k, act, pk, fs[k - 1], ss[k]);
                 TR_LAP(4);
                 if (k >= 2) rows_issue(F, k - 1);
                 TR_LAP(5);
@@ -598,7 +608,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             }
         }
         TR_STAMP(10);
-        store_rec(0, jl >= 0, fp, ss[0]);
+        store_rec(0, jl >= 0, pk_next, fp, ss[0]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
