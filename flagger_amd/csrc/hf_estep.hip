@@ -114,7 +114,7 @@ struct hf_ctx {
     unsigned* d_done = nullptr;    // k_reduce / k_rows_total: blocks finished (the last one stamps the host block)
     unsigned long long* d_cks = nullptr;   // k_reduce: XOR of the words written (checksum of a polled pass)
     int poll_kind = 0;             // what the last polled kernel was: 1 k_rows_total (a checksum per region), 2 k_reduce (one)
-    int n_groups = 0, n_rowwaves = 0;
+    int n_groups = 0, n_rowwaves = 0, n_parts = 1;   // n_parts: regions that have a row, + 1 (the log-likelihood blocks): hf_rows.h hand-offs
     bool pass_nb = false;          // the last rows-mode pass ran the negative_binomial kernels (hf_nb_rows.h)
     int32_t* d_bin_off = nullptr; int32_t* d_bin_list = nullptr; double* d_slot_h = nullptr; double* d_H = nullptr;   // count-data plan
     double* d_chunk_ll = nullptr;  // [C] log-likelihood per chunk (rows mode)
@@ -324,7 +324,7 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
                            ctx->n_rowwaves, n_rw_blocks, ctx->d_rw_region, ctx->d_rowslots, ctx->d_grp_sums, row_src(ctx), ctx->d_params,
                            ctx->d_rw_stats, ctx->C, ll_off(ctx), ll_part(ctx), ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll,
                            ctx->d_rw_off, ctx->K, bound ? ctx->d_rank_out : ctx->d_total, bound ? (double*) nullptr : ctx->d_total_host,
-                           bound ? ctx->d_rank_flag : (double*) nullptr, ctx->d_flags, seq, ctx->d_done);
+                           bound ? ctx->d_rank_flag : (double*) nullptr, ctx->d_flags, seq, ctx->d_done, ctx->n_parts);
         ctx->pass_wpb = wpb;
         ctx->pass_rows = true;
         ctx->pass_kc = ncol;
@@ -452,8 +452,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     DMALLOC(ctx->d_label, N);
     DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, ((size_t) ctx->V + 1) * 8);
     DMALLOC(ctx->d_flags, 4);
-    DMALLOC(ctx->d_done, 4);
-    hipMemset(ctx->d_done, 0, 4);
+    DMALLOC(ctx->d_done, HF_DONE_BYTES);         // tickets and scratch of the in-launch hand-offs (hf_rows.h)
+    hipMemset(ctx->d_done, 0, HF_DONE_BYTES);
     DMALLOC(ctx->d_cks, 8);
     hipMemset(ctx->d_cks, 0, 8);
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
@@ -767,6 +767,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / 16; k++) rwreg.push_back(reg);
                 }
                 rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / 16);
+                ctx->n_parts = 1;
+                for (int reg = 0; reg < n_regions; reg++) if (rwoff[(size_t) reg + 1] > rwoff[(size_t) reg]) ctx->n_parts++;
                 n_pos = (int64_t) grp_ar.size() * HF_GRP_PAIRS;
                 // positions: pairs of a row of A in window order
                 {

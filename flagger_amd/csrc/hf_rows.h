@@ -87,119 +87,132 @@ __global__ void __launch_bounds__(256) k_pair_sums(int n_groups, const int32_t* 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The total of a pass from the block partials of k_row_stats, by the blocks of that same launch (round 3: one launch and one
+// kernel boundary less per pass than the separate k_rows_total of rounds 1-2):
+//   * the LAST block of every region to finish sums that region's partials (rows_total_region): in plan order by NQ
+//     interleaved accumulators per element (fixed by the launch geometry), expanded into the estimator layout of
+//     include/hmm_flagger_hip.h exactly as k_chunk_stats does, assembled in LDS and written once — regions in parallel;
+//   * the last of the blocks that sum the chunks' log-likelihoods adds those up in k_reduce's order (the same bits as the
+//     per-chunk path) and zero-fills the blocks of regions without a row (rows_total_ll);
+//   * the last of THOSE parts to finish writes the flag word and, for a host that polls, a per-region checksum word bound
+//     to the pass (out[V+2+r]) and the completion stamp (out[V+1]): see wait_total.
+// Every hand-off goes through write-through stores, a drained queue and a ticket (xcu_store / xcu_load below).
+// Results go to `out_dev` (V + 1 doubles, the flag word last — or to element 0 of `flag_row`, hf_bind_rank_total) and, when
+// the context has a pinned host block, to `out_host`.  rw_off[r]..rw_off[r+1]: the wavefronts of region r.
+// ------------------------------------------------------------------------------------------
 // cross-CU hand-off of a few doubles without cache-wide fences: write-through stores (sc0 sc1), drained by the producer before
 // its ticket, and cache-bypassing loads on the reader's side (MI355X_MICROARCH.md, workgroup dispatch & visibility)
 __device__ __forceinline__ void xcu_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double xcu_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
+// scratch of the hand-offs (hf_ctx.d_done): tickets, then the parts' checksum sums and the log-likelihood for the finalizer
+#define HF_DONE_REGION0 1                                    // tickets of region r at HF_DONE_REGION0 + r, r = n_regions: the log-likelihood blocks
+#define HF_DONE_PARTS (HF_DONE_REGION0 + HF_MAXREGIONS + 1)  // ticket of the finished parts
+#define HF_DONE_WORDS (HF_DONE_PARTS + 1)                    // unsigned words; then (8-byte aligned) HF_MAXREGIONS + 1 doubles
+__device__ __forceinline__ double* done_scratch(unsigned* done) { return reinterpret_cast<double*>(done + ((HF_DONE_WORDS + 1) & ~1)); }
+#define HF_DONE_BYTES ((((HF_DONE_WORDS + 1) & ~1) * 4) + (HF_MAXREGIONS + 1) * 8)
+
+// one region; returns (thread 0) the checksum sum of what was written
 template <int KT>
-__device__ void rows_total(const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_stats,
-                           const DevParams* __restrict__ P, const double* __restrict__ chunk_ll, int64_t C, int64_t V, int Kctx,
-                           double* __restrict__ out_dev, double* __restrict__ out_host, double* __restrict__ flag_row,
-                           const unsigned* __restrict__ flags, double seq) {
+__device__ unsigned long long rows_total_region(int r, const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_stats,
+                                                const DevParams* __restrict__ P, int Kctx, double* __restrict__ out_dev,
+                                                double* __restrict__ out_host) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NQMAX = 16;
     const int tid = threadIdx.x, nt = blockDim.x;
     __shared__ double part[NQMAX][NA];
     __shared__ double red[NA];
-    __shared__ double blockv[24 * HF_MAXCOMP + 16];   // one region's block of the vector, assembled in LDS
-    __shared__ double s_ll;
+    __shared__ double blockv[24 * HF_MAXCOMP + 16];   // the region's block of the vector, assembled in LDS
     __shared__ unsigned long long s_x[16];
-    const unsigned fl = (tid == 0 && flags) ? *flags : 0u;
-    if (tid >= nt - 64) {   // k_reduce's order over the chunk list
-        const int lane = tid - (nt - 64);
-        double acc = 0.0;
-        int64_t c = lane;
+    const int ncol = P->ncomp[3];
+    const bool te = hf_err_is_truncexp(P);
+    const int rstride = 24 * Kctx + 16;
+    int nq = nt / NA;                              // interleaved accumulators per element: one (element, accumulator) item per thread
+    nq = nq < 1 ? 1 : (nq > NQMAX ? NQMAX : nq);
+    const int w0 = rw_off[r] / wpb, w1 = rw_off[r + 1] / wpb;   // rw_off counts wavefronts, a multiple of 4 per region
+    for (int v = tid; v < rstride; v += nt) blockv[v] = 0.0;
+    for (int w = tid; w < nq * NA; w += nt) {
+        const int q = w / NA, i = w - q * NA;
+        double v = 0.0;
+        for (int k = w0 + q; k < w1; k += nq * 32) {   // 32 loads in flight (the partials come from other CUs: every load is a miss), adds in plan order
+            double xk[32];
+#pragma unroll
+            for (int u = 0; u < 32; u++) xk[u] = k + nq * u < w1 ? xcu_load(blk_stats + (int64_t) (k + nq * u) * NA + i) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 32; u++) if (k + nq * u < w1) v += xk[u];
+        }
+        part[q][i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < NA; i += nt) {
+        double v = 0.0;
+        for (int u = 0; u < nq; u++) v += part[u][i];
+        red[i] = v;
+    }
+    __syncthreads();
+    if (w1 > w0 && tid < 64) {
+        double* __restrict__ dst = blockv;
+        const StatAcc<KT>* __restrict__ Sa = reinterpret_cast<const StatAcc<KT>*>(red);
+        if (tid < 16) dst[24 * Kctx + tid] = Sa->trans[tid];
+        if (tid == 16 && te) { dst[(0 * 2 + 0) * Kctx] = Sa->te_num; dst[(0 * 2 + 1) * Kctx] = Sa->te_den; }
+        if (tid >= 20 && tid < 23) {
+            const int s = tid - 20;
+            if (!(s == 0 && te)) {
+                double* dd = dst + (s * 3) * 2 * Kctx;
+                dd[(0 * 2 + 0) * Kctx] = Sa->g_mnum[s]; dd[(0 * 2 + 1) * Kctx] = Sa->g_den[s];
+                dd[(1 * 2 + 0) * Kctx] = Sa->g_vnum[s]; dd[(1 * 2 + 1) * Kctx] = Sa->g_den[s];
+                dd[(2 * 2 + 0) * Kctx] = Sa->g_den[s];  dd[(2 * 2 + 1) * Kctx] = Sa->g_den[s];
+            }
+        }
+        if (tid >= 32 && tid < 32 + KT && (tid - 32) < ncol) {
+            const int cc = tid - 32;
+            double* dd = dst + (3 * 3) * 2 * Kctx;
+            dd[(0 * 2 + 0) * Kctx + cc] = Sa->c_mnum[cc]; dd[(0 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
+            dd[(1 * 2 + 0) * Kctx + cc] = Sa->c_vnum[cc]; dd[(1 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
+            dd[(2 * 2 + 0) * Kctx + cc] = Sa->c_den[cc];  dd[(2 * 2 + 1) * Kctx + cc] = Sa->c_wden;
+        }
+    }
+    __syncthreads();
+    unsigned long long x = 0ull;           // checksum of what is written (hf_cks_term): the host verifies what it read
+    for (int v = tid; v < rstride; v += nt) {
+        const double dv = blockv[v];
+        const int64_t at = 1 + (int64_t) r * rstride + v;
+        out_dev[at] = dv;
+        if (out_host) out_host[at] = dv;
+        x += hf_cks_term((unsigned long long) __double_as_longlong(dv), at);
+    }
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if ((tid & 63) == 0) s_x[tid >> 6] = x;
+    __syncthreads();
+    unsigned long long c = 0ull;
+    if (tid == 0) for (int w = 0; w < (nt >> 6); w++) c += s_x[w];
+    return c;
+}
+
+// the log-likelihood (element 0) in k_reduce's order over the chunk list, by the block's first wavefront; zeros for the
+// regions that have no row at all.  Returns (thread 0) the log-likelihood.
+__device__ double rows_total_ll(const int32_t* __restrict__ rw_off, int nreg, int Kctx, const double* __restrict__ chunk_ll, int64_t C,
+                                double* __restrict__ out_dev, double* __restrict__ out_host, double* __restrict__ scratch) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    double acc = 0.0;
+    if (tid < 64) {
+        int64_t c = tid;
         for (; c + 64 * 3 < C; c += 64 * 4) {
             const double x0 = xcu_load(chunk_ll + c), x1 = xcu_load(chunk_ll + c + 64), x2 = xcu_load(chunk_ll + c + 128), x3 = xcu_load(chunk_ll + c + 192);
             acc += x0; acc += x1; acc += x2; acc += x3;
         }
         for (; c < C; c += 64) acc += xcu_load(chunk_ll + c);
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-        if (lane == 0) { out_dev[0] = acc; if (out_host) out_host[0] = acc; s_ll = acc; }
+        if (tid == 0) { out_dev[0] = acc; if (out_host) out_host[0] = acc; }
     }
-    const int nreg = P->n_regions, ncol = P->ncomp[3];
-    const bool te = hf_err_is_truncexp(P);
     const int rstride = 24 * Kctx + 16;
-    int nq = nt / NA;                              // interleaved accumulators per element: one (element, accumulator) item per thread
-    nq = nq < 1 ? 1 : (nq > NQMAX ? NQMAX : nq);
-    for (int r = 0; r < nreg; r++) {
-        const int w0 = rw_off[r] / wpb, w1 = rw_off[r + 1] / wpb;   // rw_off counts wavefronts, a multiple of 4 per region
-        for (int v = tid; v < rstride; v += nt) blockv[v] = 0.0;
-        for (int w = tid; w < nq * NA; w += nt) {
-            const int q = w / NA, i = w - q * NA;
-            double v = 0.0;
-            int k = w0 + q;
-            for (; k < w1; k += nq * 32) {   // 32 loads in flight (the partials come from other CUs: every load is a miss), adds in plan order
-                double xk[32];
-#pragma unroll
-                for (int u = 0; u < 32; u++) xk[u] = k + nq * u < w1 ? xcu_load(blk_stats + (int64_t) (k + nq * u) * NA + i) : 0.0;
-#pragma unroll
-                for (int u = 0; u < 32; u++) if (k + nq * u < w1) v += xk[u];
-            }
-            part[q][i] = v;
+    for (int r = 0; r < nreg; r++)
+        if (rw_off[r + 1] == rw_off[r]) {
+            for (int v = tid; v < rstride; v += nt) { const int64_t at = 1 + (int64_t) r * rstride + v; out_dev[at] = 0.0; if (out_host) out_host[at] = 0.0; }
+            if (tid == 0) xcu_store(scratch + r, 0.0);       // checksum sum of a block of zeros
         }
-        __syncthreads();
-        for (int i = tid; i < NA; i += nt) {
-            double v = 0.0;
-            for (int u = 0; u < nq; u++) v += part[u][i];
-            red[i] = v;
-        }
-        __syncthreads();
-        if (w1 > w0 && tid < 64) {
-            double* __restrict__ dst = blockv;
-            const StatAcc<KT>* __restrict__ Sa = reinterpret_cast<const StatAcc<KT>*>(red);
-            if (tid < 16) dst[24 * Kctx + tid] = Sa->trans[tid];
-            if (tid == 16 && te) { dst[(0 * 2 + 0) * Kctx] = Sa->te_num; dst[(0 * 2 + 1) * Kctx] = Sa->te_den; }
-            if (tid >= 20 && tid < 23) {
-                const int s = tid - 20;
-                if (!(s == 0 && te)) {
-                    double* dd = dst + (s * 3) * 2 * Kctx;
-                    dd[(0 * 2 + 0) * Kctx] = Sa->g_mnum[s]; dd[(0 * 2 + 1) * Kctx] = Sa->g_den[s];
-                    dd[(1 * 2 + 0) * Kctx] = Sa->g_vnum[s]; dd[(1 * 2 + 1) * Kctx] = Sa->g_den[s];
-                    dd[(2 * 2 + 0) * Kctx] = Sa->g_den[s];  dd[(2 * 2 + 1) * Kctx] = Sa->g_den[s];
-                }
-            }
-            if (tid >= 32 && tid < 32 + KT && (tid - 32) < ncol) {
-                const int cc = tid - 32;
-                double* dd = dst + (3 * 3) * 2 * Kctx;
-                dd[(0 * 2 + 0) * Kctx + cc] = Sa->c_mnum[cc]; dd[(0 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
-                dd[(1 * 2 + 0) * Kctx + cc] = Sa->c_vnum[cc]; dd[(1 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
-                dd[(2 * 2 + 0) * Kctx + cc] = Sa->c_den[cc];  dd[(2 * 2 + 1) * Kctx + cc] = Sa->c_wden;
-            }
-        }
-        __syncthreads();
-        unsigned long long x = 0ull;           // checksum of what is written (hf_cks_term): the host verifies what it read
-        for (int v = tid; v < rstride; v += nt) {
-            const double dv = blockv[v];
-            const int64_t at = 1 + (int64_t) r * rstride + v;
-            out_dev[at] = dv;
-            if (out_host) out_host[at] = dv;
-            x += hf_cks_term((unsigned long long) __double_as_longlong(dv), at);
-        }
-        if (seq != 0.0 && out_host) {
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            if ((tid & 63) == 0) s_x[tid >> 6] = x;
-            __syncthreads();
-            if (tid == 0) {
-                unsigned long long c = (unsigned long long) __double_as_longlong(seq);
-                for (int w = 0; w < (nt >> 6); w++) c += s_x[w];
-                if (r == 0) c += hf_cks_term((unsigned long long) __double_as_longlong(s_ll), 0) +
-                                 hf_cks_term((unsigned long long) __double_as_longlong((double) fl), V);
-                out_host[V + 2 + r] = __longlong_as_double((long long) c);
-            }
-        }
-        __syncthreads();
-    }
-    if (tid == 0 && flags) {   // the flag word: element V of the vector, or element 0 of a row of an exchange buffer (hf_bind_rank_total)
-        if (flag_row) flag_row[0] = (double) fl; else out_dev[V] = (double) fl;
-        if (out_host) out_host[V] = (double) fl;
-    }
-    if (seq != 0.0 && out_host) {   // completion stamp for a host that polls the pinned block: after every write above is visible
-        __threadfence_system();
-        __syncthreads();
-        if (tid == 0) { out_host[V + 1] = seq; __threadfence_system(); }
-    }
+    return acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -209,8 +222,7 @@ __device__ void rows_total(const int32_t* __restrict__ rw_off, int wpb, const do
 // LDS (as k_stats_tile does), the wavefronts of a block in wave order: one partial vector per BLOCK, StatAcc<KT> order.
 // The blocks after the first n_rw_blocks do a second job that has to happen once per pass anyway: the log-likelihood of
 // every chunk (one wavefront per chunk, the same sum as k_chunk_stats) into element 0 of the chunk's vector.
-// The last block of the launch to finish (a ticket behind an agent-scope release; the reader takes an agent-scope acquire)
-// then sums everybody's partials: rows_total above.
+// The last block of every part of the launch to finish then sums the part's partials: rows_total_region / rows_total_ll above.
 // ------------------------------------------------------------------------------------------
 template <int KT>
 __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_blocks, const int32_t* __restrict__ rw_region,
@@ -220,7 +232,7 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
                                                       const double* __restrict__ tile_ll, double* __restrict__ chunk_stats, int64_t V,
                                                       double* __restrict__ chunk_ll, const int32_t* __restrict__ rw_off, int Kctx,
                                                       double* __restrict__ out_dev, double* __restrict__ out_host, double* __restrict__ flag_row,
-                                                      const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done) {
+                                                      const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done, int n_parts) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NS = 16 + 9 + 2;
     constexpr int RS = 65;
@@ -348,18 +360,56 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
         xcu_store(blk_stats + (int64_t) blockIdx.x * NA + i, v);
     }
     }
-    // ---- the last block to get here sums everything (producer: write-through stores, drained, block barrier, the ticket;
-    // consumer: the ticket, cache-bypassing loads) ----
+    // ---- hand-offs: the last block of a part (a region / the log-likelihood blocks) sums the part; the last part writes flag
+    // word, checksums and stamp (producer: write-through stores, drained, block barrier, ticket; consumer: cache-bypassing loads) ----
+    const int nreg = P->n_regions;
+    const int part_id = (int) blockIdx.x < n_rw_blocks ? rw_region[(int) blockIdx.x * wpb] : nreg;
+    const unsigned part_blocks = part_id < nreg ? (unsigned) ((rw_off[part_id + 1] - rw_off[part_id]) / wpb) : gridDim.x - (unsigned) n_rw_blocks;
+    double* __restrict__ scratch = done_scratch(done);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned ticket = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == gridDim.x - 1;
-        if (s_last) *done = 0u;
+        const unsigned ticket = __hip_atomic_fetch_add(done + HF_DONE_REGION0 + part_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == part_blocks - 1;
+        if (s_last) done[HF_DONE_REGION0 + part_id] = 0u;
     }
     __syncthreads();
     if (!s_last) return;
-    rows_total<KT>(rw_off, wpb, blk_stats, P, chunk_ll, (int64_t) C, V, Kctx, out_dev, out_host, flag_row, flags, seq);
+    if (part_id < nreg) {
+        const unsigned long long x = rows_total_region<KT>(part_id, rw_off, wpb, blk_stats, P, Kctx, out_dev, out_host);
+        if (threadIdx.x == 0) xcu_store(scratch + part_id, __longlong_as_double((long long) x));
+    } else {
+        const double ll = rows_total_ll(rw_off, nreg, Kctx, chunk_ll, (int64_t) C, out_dev, out_host, scratch);
+        if (threadIdx.x == 0) xcu_store(scratch + HF_MAXREGIONS, ll);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(done + HF_DONE_PARTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == (unsigned) n_parts - 1;
+        if (s_last) done[HF_DONE_PARTS] = 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        const unsigned fl = flags ? *flags : 0u;
+        if (flags) {   // the flag word: element V of the vector, or element 0 of a row of an exchange buffer (hf_bind_rank_total)
+            if (flag_row) flag_row[0] = (double) fl; else out_dev[V] = (double) fl;
+            if (out_host) out_host[V] = (double) fl;
+        }
+        if (seq != 0.0 && out_host) {   // for a host that polls the pinned block: checksums bound to the pass, then the stamp
+            const double ll = xcu_load(scratch + HF_MAXREGIONS);
+            for (int r = 0; r < nreg; r++) {
+                unsigned long long c = (unsigned long long) __double_as_longlong(seq) + (unsigned long long) __double_as_longlong(xcu_load(scratch + r));
+                if (r == 0) c += hf_cks_term((unsigned long long) __double_as_longlong(ll), 0) +
+                                 hf_cks_term((unsigned long long) __double_as_longlong((double) fl), V);
+                out_host[V + 2 + r] = __longlong_as_double((long long) c);
+            }
+            __threadfence_system();
+            out_host[V + 1] = seq;
+            __threadfence_system();
+        }
+    }
 }
 
 // what ranks exchange (hf_rank_total): the total the pass left on the device, without the flag word
