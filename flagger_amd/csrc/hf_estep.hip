@@ -443,6 +443,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     TRY(dev_upload(&d_cov, w->cov, N)); TRY(dev_upload(&d_mapq, w->mapq, N)); TRY(dev_upload(&d_clip, w->clip, N));
     TRY(dev_upload(&d_annot, w->annot, N));
     TRY(dev_upload(&d_cs, w->chunk_s, C)); TRY(dev_upload(&d_ce, w->chunk_e, C)); TRY(dev_upload(&d_cl, w->chunk_ctg_len, C));
+    cphase("window arrays up");
 #define DMALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void**) &(p), (bytes) ? (bytes) : 8); \
     if (e_ != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e_)); } } while (0)
     DMALLOC(ctx->d_rec, N * 4); DMALLOC(ctx->d_beta, N * 8); DMALLOC(ctx->d_regmask, C * 8);
@@ -458,16 +459,20 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     hipMemset(ctx->d_cks, 0, 8);
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
     DMALLOC(ctx->d_params, ctx->params_bytes);
-    if (hipHostMalloc((void**) &ctx->h_params, ctx->params_bytes) != hipSuccess ||
-        hipHostMalloc((void**) &ctx->h_flags, 4) != hipSuccess ||
-        hipHostMalloc((void**) &ctx->h_total, ((size_t) ctx->V + 2 + HF_MAXREGIONS) * 8) != hipSuccess) {
-        hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed");
+    {   // one pinned block: the result vector (+ flag word, stamp, checksums) | the flag word of hf_check | the parameter block
+        const size_t tot_bytes = ((size_t) ctx->V + 2 + HF_MAXREGIONS) * 8;
+        char* pin = nullptr;
+        if (hipHostMalloc((void**) &pin, tot_bytes + 64 + ctx->params_bytes) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed"); }
+        ctx->h_total = reinterpret_cast<double*>(pin);
+        ctx->h_flags = reinterpret_cast<unsigned*>(pin + tot_bytes);
+        ctx->h_params = reinterpret_cast<DevParams*>(pin + tot_bytes + 64);
     }
     {
         void* dp = nullptr;
         if (hipHostGetDevicePointer(&dp, ctx->h_total, 0) == hipSuccess) ctx->d_total_host = (double*) dp;
         else (void) hipGetLastError();
     }
+    cphase("device + pinned allocations");
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     hipMemset(ctx->d_flags, 0, 4);
     hipMemset(ctx->d_label, 0xff, N ? N : 1);
@@ -479,10 +484,11 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                            ctx->beta_star, ctx->d_rec, ctx->d_beta, ctx->d_flags);
         hipLaunchKernelGGL(k_regmask, dim3((unsigned) C), dim3(256), 0, 0, ctx->d_off, ctx->d_rec, ctx->d_regmask);
     }
-    cphase("uploads + window records");
+    cphase("events, memsets, k_setup enqueued");
     hipError_t e = hipDeviceSynchronize();
     hipFree(d_cov); hipFree(d_mapq); hipFree(d_clip); hipFree(d_annot); hipFree(d_cs); hipFree(d_ce); hipFree(d_cl);
     if (e != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("setup: ") + hipGetErrorString(e)); }
+    cphase("k_setup done, temporaries freed");
     unsigned fl = 0;
     hipMemcpy(&fl, ctx->d_flags, 4, hipMemcpyDeviceToHost);
     if (fl & HF_FLAG_REGION) { hf_destroy(ctx); return set_err(HF_E_REGION, "a window's region index is >= n_regions"); }
@@ -491,10 +497,11 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         for (size_t t = 0; t < N; t++) { const unsigned x = w->cov[t] & 0xffu; if (x > maxx) maxx = x; }
         ctx->M = (int) maxx + 1;
         const size_t MM = (size_t) ctx->M * ctx->M;
-        // slow windows: chunk-first, or beta differs from beta_star (the same test as k_setup's REC_SLOW bit)
-        std::vector<double> hb(N);
-        if (N) { hipError_t e2 = hipMemcpy(hb.data(), ctx->d_beta, N * 8, hipMemcpyDeviceToHost);
-                 if (e2 != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "beta download failed"); } }
+        // slow windows: chunk-first, or beta differs from beta_star: k_setup's REC_SLOW bit of the packed records (4 B per window
+        // come back once; round 2 also fetched the 8-byte beta of every window for the same test)
+        std::vector<uint32_t> hrec(N);
+        if (N) { hipError_t e2 = hipMemcpy(hrec.data(), ctx->d_rec, N * 4, hipMemcpyDeviceToHost);
+                 if (e2 != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "record download failed"); } }
         std::vector<int64_t> slow;
         std::vector<int32_t> soff(C + 1, 0), keys;
         std::vector<uint8_t> seen((size_t) n_regions * MM, 0);
@@ -509,7 +516,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
                     for (int64_t x = 0; x < T; x++) {
                         const size_t t = (size_t) (t0 + x);
-                        if (x == 0 || hb[t] != ctx->beta_star) { mine.push_back((int64_t) t); continue; }
+                        if (REC_SLOW(hrec[t])) { mine.push_back((int64_t) t); continue; }
                         const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
                         uint8_t* cell = seen_p + (reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu);
                         if (!__atomic_load_n(cell, __ATOMIC_RELAXED)) __atomic_store_n(cell, (uint8_t) 1, __ATOMIC_RELAXED);   // a few thousand cells, all threads: read-mostly
@@ -564,7 +571,6 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
         cphase("tiles + work arrays");
         // ---- segments of the workgroup-per-segment forward-backward (hf_seg.h) and the record slot of every window ----
-        std::vector<uint32_t> hrec;
         std::vector<int32_t>& slot_of = ctx->h_slot_of;
         std::vector<int32_t> h_arow, h_arow_src;        // window -> row of A; row of A -> emission row (both also on the device)
         if (N > 0 && C > 0 && N < (size_t) INT32_MAX / 2) {
@@ -575,10 +581,6 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             // faster — a workgroup's life is mostly the scans and the carried-in chains, not the replay; profiles/r03f_split_sweep.txt)
             constexpr int64_t SMAX = HF_SEG_SPLIT;
             // ---- rows of A = T∘e: the (key, transition class) pairs that occur, then the slow windows ----
-            hrec.resize(N);
-            if (hipMemcpy(hrec.data(), ctx->d_rec, N * 4, hipMemcpyDeviceToHost) != hipSuccess) {
-                hf_destroy(ctx); return set_err(HF_E_HIP, "record download failed");
-            }
             {
                 constexpr int NC = HF_AROW_CLASSES;
                 auto cls_of = [](uint32_t r) { return REC_REGCHG(r) ? 8 : (int) REC_VMASK(r); };
@@ -593,7 +595,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
                         for (int64_t x = 1; x < T; x++) {
                             const size_t t = (size_t) (t0 + x);
-                            if (hb[t] != ctx->beta_star) continue;
+                            if (REC_SLOW(hrec[t])) continue;
                             int32_t* cell = cid + key_of(t) * NC + cls_of(hrec[t]);
                             if (!__atomic_load_n(cell, __ATOMIC_RELAXED)) __atomic_store_n(cell, 1, __ATOMIC_RELAXED);
                         }
@@ -618,7 +620,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         for (int64_t x = 0; x < T; x++) {
                             const size_t t = (size_t) (t0 + x);
                             const uint32_t r = hrec[t];
-                            if (x == 0 || hb[t] != ctx->beta_star) {
+                            if (REC_SLOW(r)) {
                                 const size_t id = (size_t) n_combo + (size_t) sp;
                                 a_src[id] = (int32_t) (ctx->n_lut + sp);
                                 a_cls[id] = (x == 0 ? 9 : cls_of(r)) | (int32_t) (REC_REGION(r) << 8);
@@ -895,9 +897,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats);
     hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats);
-    if (ctx->h_params) hipHostFree(ctx->h_params);
-    if (ctx->h_flags) hipHostFree(ctx->h_flags);
-    if (ctx->h_total) hipHostFree(ctx->h_total);
+    if (ctx->h_total) hipHostFree(ctx->h_total);   // one pinned block: h_flags and h_params live in it
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 2 * HF_NKERNELS; i++) if (ctx->kev[i]) hipEventDestroy(ctx->kev[i]);
