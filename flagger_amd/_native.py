@@ -19,7 +19,7 @@ HF_STATS_CHUNKS, HF_STATS_ROWS = 0, 1
 HF_EXCHANGE_CHUNKS, HF_EXCHANGE_RANKS = 0, 1
 HF_TRANSPORT_RCCL, HF_TRANSPORT_LOOPBACK = 0, 1
 HF_PROF_PASS = 0x80000000
-HF_OK, HF_E_ARG, HF_E_HIP, HF_E_SCALE, HF_E_NAN, HF_E_REGION, HF_E_NOGPU = 0, -1, -2, -3, -4, -5, -6
+HF_OK, HF_E_ARG, HF_E_HIP, HF_E_SCALE, HF_E_NAN, HF_E_REGION, HF_E_NOGPU, HF_E_RETRY = 0, -1, -2, -3, -4, -5, -6, -7
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhmmflagger_hip.so")
 

@@ -14,6 +14,7 @@
 #define HF_FLAG_SCALE 1u
 #define HF_FLAG_NAN 2u
 #define HF_FLAG_REGION 4u
+#define HF_FLAG_SYNC 8u     // one-launch segment kernel: a segment waited too long for another segment's product (hf_seg.h)
 
 // ---- packed window record (4 B/window), built once by k_setup ----
 //   bits 0..7  x      = (uint8_t) coverage             hmm.c:345,384

@@ -126,7 +126,11 @@ struct hf_ctx {
     RowSlot* d_rowslots = nullptr; int32_t* d_rw_region = nullptr; int32_t* d_rw_off = nullptr; double* d_rw_stats = nullptr;
     // segment kernels (hf_seg.h): the forward-backward of the statistics-by-row path
     SegDesc* d_seg = nullptr; int nseg = 0; int32_t* d_chunk_seg0 = nullptr; double* d_seg_ll = nullptr; double* d_Pseg = nullptr;
-    double* d_segQ = nullptr;          // [nseg][8][NL] double2: lane products, lane-minor
+    double* d_segQ = nullptr;          // [nseg][8][64] double2: lane products, lane-minor (two-launch mode only: allocated on first use)
+    // one-launch mode (hf_seg.h): k_seg_fb computes the lane products itself and the segments of a chunk hand their products to
+    // each other inside the launch (flags stamped with the launch's epoch); a timed-out wait switches the context to two launches
+    unsigned* d_seg_ready = nullptr; unsigned seg_epoch = 0; bool seg_fused = true, seg_test_timeout = false;
+    hf_params last_p{}; int last_mode = HF_MODE_FULL;   // what the last hf_estep was given (the fallback re-runs the pass)
     // rows of A_t = T_t∘e_t (hf_seg.h): one per (emission key, transition class) that occurs at an interior window, then one
     // per slow window; d_arow[t] = the row of window t (bit 31: chunk-first), d_arow_src / d_arow_cls = where a row comes from
     int32_t* d_arow = nullptr; int32_t* d_arow_src = nullptr; int32_t* d_arow_cls = nullptr; double* d_lutA = nullptr;
@@ -214,11 +218,7 @@ __global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __res
 #include "hf_chunks.h"
 #include "hf_rows.h"
 #include "hf_nb_rows.h"
-#ifdef HF_SEG_R2          // temporary: round 2's segment kernels, for same-box A/B runs
-#include "hf_seg_r2.h"
-#else
 #include "hf_seg.h"
-#endif
 
 
 // ------------------------------------------------------------------------------------------
@@ -689,7 +689,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 ctx->nseg = (int) segs.size(); ctx->n_slots = nslots;
                 TRY(dev_upload(&ctx->d_seg, segs.data(), segs.size()));
                 TRY(dev_upload(&ctx->d_chunk_seg0, cseg0.data(), cseg0.size()));
-                DMALLOC(ctx->d_segQ, segs.size() * (size_t) NL * 16 * 8);
+                DMALLOC(ctx->d_seg_ready, segs.size() * 4);
+                hipMemset(ctx->d_seg_ready, 0, segs.size() * 4);
                 DMALLOC(ctx->d_seg_ll, segs.size() * 8);
                 DMALLOC(ctx->d_Pseg, segs.size() * 16 * 8);
                 DMALLOC(ctx->d_scale_s, (size_t) ctx->n_slots * 8);
@@ -854,6 +855,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         }
     }
     { const char* e = std::getenv("HF_HOST_TRACE"); ctx->host_trace = e && e[0] == '1'; }
+    { const char* e = std::getenv("HF_SEG_LAUNCHES"); ctx->seg_fused = !(e && e[0] == '2'); }   // HF_SEG_LAUNCHES=2: k_seg_prod + k_seg_fb
+    ctx->seg_test_timeout = std::getenv("HF_SEG_TEST_TIMEOUT") != nullptr;
     {
         const char* e = std::getenv("HF_STATS");
         ctx->stats_mode = (e && std::strcmp(e, "chunks") == 0) ? HF_STATS_CHUNKS : HF_STATS_ROWS;
@@ -893,7 +896,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0);
     hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_grp_ar); hipFree(ctx->d_grp_n); hipFree(ctx->d_pos); hipFree(ctx->d_pos_f); hipFree(ctx->d_slot_of); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
-    hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_scale_s);
+    hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_seg_ready); hipFree(ctx->d_scale_s);
     hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats);
     hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats);
@@ -1043,40 +1046,36 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 }
             } else if (seg_pass(ctx)) {
                 // one workgroup per chunk segment does the whole forward-backward (hf_seg.h)
-#ifdef HF_SEG_R2
-                constexpr int NW = HF_SEG_WAVES;
-                const size_t lds = seg_lds_bytes<NW>();
-#define HF_SEG_PROD k_seg_prod<NW>
-#define HF_SEG_FB(B) k_seg_fb<NW, B>
-#else
                 const size_t lds = seg_lds_bytes();
-#define HF_SEG_PROD k_seg_prod
-#define HF_SEG_FB(B) k_seg_fb<B>
-#endif
                 if (ctx->host_trace && !ctx->ht_n) {
                     int o1 = 0, o2 = 0;
-                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, HF_SEG_PROD, 64, lds);
-                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, HF_SEG_FB(true), 64, lds);
-                    std::fprintf(stderr, "[hf host trace] segment kernels: %d workgroups of 64 threads, %zu B of LDS; resident per CU: k_seg_prod %d, k_seg_fb %d\n",
-                                 ctx->nseg, lds, o1, o2);
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_seg_prod, 64, lds);
+                    if (ctx->seg_fused) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_seg_fb<true, true>, 64, lds);
+                    else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_seg_fb<true, false>, 64, lds);
+                    std::fprintf(stderr, "[hf host trace] segment kernels (%s): %d workgroups of 64 threads, %zu B of LDS; resident per CU: k_seg_prod %d, k_seg_fb %d\n",
+                                 ctx->seg_fused ? "one launch" : "two launches", ctx->nseg, lds, o1, o2);
                 }
                 if (nbm) {   // k_tables_nb leaves the emission rows; the Gaussian k_tables writes the rows of A itself
                     KTimer t(ctx, st, HF_K_AROWS);
                     hipLaunchKernelGGL(k_arows, dim3((unsigned) (((int64_t) ctx->n_arows * 16 + 255) / 256)), dim3(256), 0, st, ctx->n_arows,
                                        ctx->d_arow_src, ctx->d_arow_cls, ctx->d_lutE, ctx->d_params, ctx->d_lutA);
                 }
-                {
+                if (!ctx->seg_fused) {
+                    if (!ctx->d_segQ) HIPCHK(hipMalloc((void**) &ctx->d_segQ, (size_t) ctx->nseg * 64 * 16 * 8));   // lane products: two-launch mode only
                     KTimer t(ctx, st, HF_K_SEG_PROD);
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(HF_SEG_PROD), dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow,
-                                       ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
+                    hipLaunchKernelGGL(k_seg_prod, dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
                 }
                 KTimer t(ctx, st, HF_K_SEG_FB);
-                if (full)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(HF_SEG_FB(true)), dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow,
-                                       ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_pos, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
-                else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(HF_SEG_FB(false)), dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow,
-                                       ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_pos, ctx->d_recs, ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags);
+                const unsigned epoch = ++ctx->seg_epoch;
+                // HF_SEG_TEST_TIMEOUT=1 (tests/test_estep_gpu.py): the first one-launch pass waits for flags nobody writes, so that
+                // the time-out, HF_E_RETRY and the fall-back to two launches are exercised
+                const unsigned wait_epoch = (ctx->seg_test_timeout && epoch == 1) ? 0xffffffffu : epoch;
+#define HF_SEG_FB_LAUNCH(B, F) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow, \
+                        ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_seg_ready, epoch, wait_epoch, ctx->d_pos, ctx->d_recs, ctx->d_scale_s, ctx->d_label, \
+                        ctx->d_seg_ll, ctx->d_flags)
+                if (full) { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(true, true); else HF_SEG_FB_LAUNCH(true, false); }
+                else { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(false, true); else HF_SEG_FB_LAUNCH(false, false); }
+#undef HF_SEG_FB_LAUNCH
                 ctx->pass_seg = true;
                 if (full) ctx->fb_recs = true;
             } else
@@ -1133,6 +1132,7 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
     HIPCHK(hipSetDevice(ctx->device));
     int rc = pack_params(ctx, p);
     if (rc) return rc;
+    ctx->last_p = *p; ctx->last_mode = mode;
     if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev0, st));
     rc = enqueue_pass(ctx, p, mode, st);
     if (rc) return rc;
@@ -1220,6 +1220,7 @@ static void accumulate_kernel_times(hf_ctx* ctx) {
 
 static int flags_to_code(unsigned fl) {
     if (fl & HF_FLAG_REGION) return set_err(HF_E_REGION, "a window's region index is >= n_regions");
+    if (fl & HF_FLAG_SYNC) return set_err(HF_E_HIP, "a chunk segment waited too long for another segment's product (one-launch segment kernel)");
     if (fl & HF_FLAG_NAN) return set_err(HF_E_NAN, "[Error] prob is NAN");
     if (fl & HF_FLAG_SCALE) return set_err(HF_E_SCALE, "scale is very low!");
     return HF_OK;
@@ -1295,7 +1296,13 @@ static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_ho
     }
     accumulate_kernel_times(ctx);   // events of the kernels before the last one have completed
     std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
-    return flags_to_code((unsigned) ctx->h_total[ctx->V]);
+    const unsigned fl = (unsigned) ctx->h_total[ctx->V];
+    if ((fl & HF_FLAG_SYNC) && ctx->seg_fused) {   // the one-launch segment kernel gave up a wait: this context runs two launches from now on
+        ctx->seg_fused = false;
+        std::fprintf(stderr, "[hmm_flagger_hip] one-launch segment kernel: a hand-off timed out; this context falls back to k_seg_prod + k_seg_fb\n");
+        return HF_E_RETRY;
+    }
+    return flags_to_code(fl);
 }
 
 int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
@@ -1318,7 +1325,14 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
         HIPCHK(hipMemcpyAsync(ctx->h_total + ctx->V, ctx->d_rank_flag, 8, hipMemcpyDeviceToHost, st));
     } else if (!ctx->d_total_host)
         HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
-    return wait_total(ctx, st, polled, stats_host);
+    rc = wait_total(ctx, st, polled, stats_host);
+    if (rc == HF_E_RETRY) {   // the pass again, in two launches (the packed parameters are still in the pinned block)
+        if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev0, st));
+        rc = enqueue_pass(ctx, &ctx->last_p, ctx->last_mode, st);
+        if (rc) return rc;
+        return hf_finish(ctx, stats_host, stream);
+    }
+    return rc;
 }
 
 // Multi-GPU counterpart of hf_finish: the rows of ALL chunks are in `rows_dev` (all-gathered, row_index_dev maps list

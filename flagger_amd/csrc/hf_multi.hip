@@ -300,7 +300,13 @@ void rank_release(RankState& R) {
     if (R.comm) { hf_comm_destroy(R.comm); R.comm = nullptr; }
 }
 
+int rank_estep_once(hf_multi* M, RankState& R);
 int rank_estep(hf_multi* M, RankState& R) {
+    int rc = rank_estep_once(M, R);
+    if (rc == HF_E_RETRY) rc = rank_estep_once(M, R);   // every rank got it together (the flag words are OR-ed): all run the pass again
+    return rc;
+}
+int rank_estep_once(hf_multi* M, RankState& R) {
     const size_t slot = (size_t) M->rows_per_rank * (size_t) M->V;
     double* mine = R.xbuf + (size_t) R.r * slot;
     int rc = hf_estep(R.ctx, M->p, M->mode, R.st);

@@ -47,6 +47,12 @@
 
 // SegDesc: hf_device.h
 
+// one-launch mode (k_seg_fb<., true>): hand-off of a segment's product to the chunk's other segments — write-through stores,
+// a drained queue, then the flag (= the launch's epoch); readers poll the flag and read past their caches
+#define HF_SEG_SPIN_MAX (1 << 16)            // polls of one flag before the wait is given up (HF_FLAG_SYNC: the host falls back to two launches)
+__device__ __forceinline__ void seg_xcu_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double seg_xcu_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // -DHF_SEG_TRACE: s_memtime stamps of k_seg_fb<true>'s phases, one row of HF_SEG_TRACE_N words per workgroup, dumped by
 // hf_destroy to $HF_SEG_TRACE_FILE (profiles/tools/seg_trace.sh / seg_trace.py).  Not in a normal build.
 #define HF_SEG_TRACE_N 24
@@ -364,10 +370,10 @@ __global__ void __launch_bounds__(64, 4) k_seg_prod(const SegDesc* __restrict__ 
 // k_seg_fb: one workgroup per segment: phases B-D of the header.  BWD = false: forward only (EM_runForwardForList,
 // hmm.c:790-816): log-likelihood and error flags, nothing else is written.
 // ------------------------------------------------------------------------------------------
-template <bool BWD>
+template <bool BWD, bool FUSED>
 __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __restrict__ sd, const int32_t* __restrict__ arow,
                                                            const double* __restrict__ lutA, const DevParams* __restrict__ P,
-                                                           const double* __restrict__ Qs, const double* __restrict__ Pseg,
+                                                           const double* __restrict__ Qs, double* Pseg, unsigned* ready, unsigned epoch, unsigned wait_epoch,
                                                            const int32_t* __restrict__ pos, double* __restrict__ recs, double* __restrict__ scale_s,
                                                            int8_t* __restrict__ label, double* __restrict__ seg_ll,
                                                            unsigned* __restrict__ flags) {
@@ -387,19 +393,10 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     double fin[4], bdir[4];
     TR_DECL;
     TR_STAMP(0);
+    const RowFetch F = rowfetch_init(lutA, s_off, blk, lane);
     {
-        // ---- A: loads, in the order they are consumed (vmcnt counts in order): row indices, the products of the chunk's other
-        // segments, the start row; LAST the lane product of k_seg_prod — the offset table and the two chains over the other
-        // segments run while it is still in flight ----
         int32_t rr[LM];
         seg_load_arows(arow + d.t0, n, L, lane, rr);
-        const int nst = d.nseg < HF_SEG_PSTAGE ? d.nseg : HF_SEG_PSTAGE;
-        double2 pst[(HF_SEG_PSTAGE * 8 + 63) / 64];
-        if (d.nseg > 1) {
-            const double2* __restrict__ src = reinterpret_cast<const double2*>(Pseg + (int64_t) d.seg0 * 16);
-#pragma unroll
-            for (int c = 0; c < (HF_SEG_PSTAGE * 8 + 63) / 64; c++) if (c * 64 + lane < nst * 8) pst[c] = src[c * 64 + lane];
-        }
         // forward vector entering the chunk: start∘e of its first window = row (0, s) of that window's row of A
         double v[4], u[4];
         {
@@ -411,6 +408,98 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
 #pragma unroll
         for (int s = 0; s < 4; s++) u[s] = Rl->trans[s][4];     // the end vector (hmm.c:452-467)
         M4 Q;
+        double xv[16];
+        if constexpr (FUSED) {
+            // ---- A (one launch): the lane product is computed here (k_seg_prod's loop); the segment's product is what the prefix
+            // scan leaves in lane 63: it is PUBLISHED for the chunk's other segments, theirs are awaited (seg_gather) ----
+            seg_offsets_store(rr, L, lane, s_off);
+            const int i0 = chunk_first ? 1 : 0;
+            m4_identity(Q);
+            rows_issue(F, 0);
+#pragma unroll 1
+            for (int i = 0; i < L; i++) {
+                double E[16];
+                rows_read(blk, lane, E);
+                if (i + 1 < L) rows_issue(F, i + 1);
+                if (i < m && i >= i0) {
+                    M4 A2, R2;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) A2.m[k] = E[HF_PS(k >> 2, k & 3)];
+                    m4_mul(R2, Q, A2);
+                    Q = R2;
+                    m4_renorm_tree(Q);
+                }
+            }
+            TR_STAMP(1);
+            if (BWD) m4_park(Q, lane, blk);
+            m4_scan_prefix(Q, lane);
+            if (d.nseg > 1) {
+                if (lane == 63) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) seg_xcu_store(Pseg + (int64_t) g * 16 + k, Q.m[k]);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the product has left this CU before the flag does
+                if (lane == 63) __hip_atomic_store(ready + g, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            TR_STAMP(2);
+#pragma unroll
+            for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);   // exclusive prefix: the product of lanes 0..lane-1
+            {
+                const double sv = ((v[0] + v[1]) + v[2]) + v[3];
+#pragma unroll
+                for (int s = 0; s < 4; s++) v[s] /= sv;
+            }
+            if (BWD) v4_renorm(u);
+            if (d.nseg > 1) {
+                // lane l takes the product of segment base + l of the chunk (waits for its flag: bounded), a chain step reads it
+                // from that lane (v_readlane: wave-uniform index)
+                double Tm[16];
+                int have_base = -1;
+                auto gather = [&](int base) {
+                    if (base == have_base) return;
+                    have_base = base;
+                    const int q = base + lane;
+                    if (q < d.nseg && q != d.k) {
+                        const unsigned* r = ready + d.seg0 + q;
+                        int spins = 0;
+                        while (__hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != wait_epoch) {   // wait_epoch == epoch (tests: a value nobody publishes)
+                            if (++spins > HF_SEG_SPIN_MAX) { bad |= HF_FLAG_SYNC; break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 16; k++) Tm[k] = seg_xcu_load(Pseg + (int64_t) (d.seg0 + q) * 16 + k);
+                    }
+                };
+                auto from_lane = [&](int src, double M[16]) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        M[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Tm[k]), src), __builtin_amdgcn_readlane(__double2loint(Tm[k]), src));
+                };
+                for (int base = 0; base < d.k; base += 64) {                  // through the chunk's earlier segments
+                    gather(base);
+                    const int hi = d.k < base + 64 ? d.k : base + 64;
+                    for (int q = base; q < hi; q++) { double M[16]; from_lane(q - base, M); v4_mul_right(v, M); v4_renorm(v); }
+                }
+                if (BWD)                                                      // ... and back through the later ones
+                    for (int base = ((d.nseg - 1) >> 6) << 6; base >= 0 && base + 64 > d.k + 1; base -= 64) {
+                        gather(base);
+                        const int lo = d.k + 1 > base ? d.k + 1 : base;
+                        for (int q = (d.nseg - 1 < base + 63 ? d.nseg - 1 : base + 63); q >= lo; q--) { double M[16]; from_lane(q - base, M); v4_mul_left(u, M); v4_renorm(u); }
+                    }
+            }
+            TR_STAMP(3);
+            TR_STAMP(4);
+        } else {
+        // ---- A (two launches): loads, in the order they are consumed (vmcnt counts in order): row indices, the products of the
+        // chunk's other segments, the start row; LAST the lane product of k_seg_prod — the offset table and the two chains over the
+        // other segments run while it is still in flight ----
+        const int nst = d.nseg < HF_SEG_PSTAGE ? d.nseg : HF_SEG_PSTAGE;
+        double2 pst[(HF_SEG_PSTAGE * 8 + 63) / 64];
+        if (d.nseg > 1) {
+            const double2* __restrict__ src = reinterpret_cast<const double2*>(Pseg + (int64_t) d.seg0 * 16);
+#pragma unroll
+            for (int c = 0; c < (HF_SEG_PSTAGE * 8 + 63) / 64; c++) if (c * 64 + lane < nst * 8) pst[c] = src[c * 64 + lane];
+        }
         {
             const double2* __restrict__ src = reinterpret_cast<const double2*>(Qs) + (int64_t) g * 8 * 64 + lane;
 #pragma unroll
@@ -446,12 +535,10 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
         // ---- B: scans over the lanes of the wavefront; Q waits for the second scan in the (idle) row block ----
         if (BWD) m4_park(Q, lane, blk);
         TR_STAMP(4);
-#if HF_ABL != 6
         m4_scan_prefix(Q, lane);
-#endif
-        double xv[16];                                          // exclusive prefix: the product of lanes 0..lane-1
 #pragma unroll
-        for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);
+        for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);   // exclusive prefix: the product of lanes 0..lane-1
+        }
         if (lane > 0) v4_mul_right(v, xv);
         {
             const double su = ((v[0] + v[1]) + v[2]) + v[3];
@@ -462,9 +549,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
         TR_STAMP(5);
         if (BWD) {
             m4_unpark(Q, lane, blk);
-#if HF_ABL != 6
             m4_scan_suffix(Q, lane);
-#endif
 #pragma unroll
             for (int k = 0; k < 16; k++) xv[k] = __shfl_down(Q.m[k], 1);   // exclusive suffix: lanes lane+1..63
             // direction of b at the lane's last window: everything after it applied to the end vector
@@ -473,7 +558,6 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             if (lane < 63) v4_mul_left(bdir, xv);
         }
     }
-    const RowFetch F = rowfetch_init(lutA, s_off, blk, lane);
     TR_STAMP(6);
     // ---- C: forward replay (hmm.c:333-434).  fs[i], ss[i]: forward vector and scale of the lane's i-th window (registers) ----
     double f[4] = {fin[0], fin[1], fin[2], fin[3]};

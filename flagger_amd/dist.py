@@ -82,6 +82,12 @@ class ShardedEMList:
         self.total = torch.zeros((self.V,), dtype=torch.float64, device=self.device)
 
     def run_sharded(self, model, mode: int) -> np.ndarray:
+        out = self._run_sharded_once(model, mode)
+        if out is None:                   # HF_E_RETRY on every rank (include/hmm_flagger_hip.h): the pass again, in two launches
+            out = self._run_sharded_once(model, mode)
+        return out
+
+    def _run_sharded_once(self, model, mode: int):
         import torch.distributed as dist
         self.local.launch(model, mode)
         if self.exchange == "ranks":
@@ -98,7 +104,8 @@ class ShardedEMList:
         # every rank sums ALL rows in the fixed order straight out of the gathered buffer
         rows = self.recv.view(self.world * self.rpr, self.V)
         if hip:      # sum into pinned host memory, one sync; the flags of ALL ranks are checked: every rank raises together
-            return self.local.finish_exchange(rows, self.row_index, self.n_rows, self.world, self.rpr, self.flag_row).copy()
+            st = self.local.finish_exchange(rows, self.row_index, self.n_rows, self.world, self.rpr, self.flag_row)
+            return None if st is None else st.copy()
         self.local.reduce_into(rows, self.row_index, self.n_rows, self.total)
         stats = self.total.cpu().numpy().copy()           # device->host copy synchronises the stream
         self.local.check()

@@ -380,8 +380,11 @@ class EMList:
         """hf_finish_exchange: hf_finish_gathered + the error flags of every rank (row `flag_row` of each rank's rows)."""
         if not hasattr(self, "_stats_buf"):
             self._stats_buf = np.empty(self.stats_len, dtype=np.float64)
-        N.check(self._L.hf_finish_exchange(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr), n_rows, world,
-                                           rows_per_rank, flag_row, _dptr(self._stats_buf), self.stream), "hf_finish_exchange")
+        rc = self._L.hf_finish_exchange(self._h, C.c_void_p(rows_dev_ptr), C.c_void_p(row_index_dev_ptr), n_rows, world,
+                                        rows_per_rank, flag_row, _dptr(self._stats_buf), self.stream)
+        if rc == N.HF_E_RETRY:          # every rank gets it together: the caller runs the pass again (ShardedEMList.run_sharded)
+            return None
+        N.check(rc, "hf_finish_exchange")
         return self._stats_buf
 
     def bind_chunk_stats(self, rows_dev_ptr: int) -> None:

@@ -43,7 +43,10 @@ enum {
     HF_E_SCALE = -3,      /* "scale (= ...) is very low!"      hmm.c:412-415, 521-524 */
     HF_E_NAN = -4,        /* "[Error] prob is NAN"             hmm_utils.c:782-786 */
     HF_E_REGION = -5,     /* a window's region index >= n_regions */
-    HF_E_NOGPU = -6       /* no HIP device: there is no CPU fallback */
+    HF_E_NOGPU = -6,      /* no HIP device: there is no CPU fallback */
+    HF_E_RETRY = -7       /* hf_finish_exchange / hf_finish_gathered only: the context changed its launch mode (a hand-off inside the
+                           * one-launch segment kernel timed out on some rank) and the pass has to be run again: hf_estep, exchange,
+                           * finish — every rank gets this code together.  hf_finish and hf_em_iterate re-run the pass themselves. */
 };
 
 typedef struct hf_ctx hf_ctx;

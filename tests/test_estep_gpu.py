@@ -4,8 +4,12 @@ Bar (BASELINE.json north_star): labels bit-exact; log-likelihood within 1e-6 rel
 1e-9); the fp64 sufficient statistics / forward / backward within 1e-9 relative — the only
 permitted difference is the last-ulp behaviour of exp()/log() on the device vs glibc.
 """
+import os
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from flagger_amd import _native as N
 from flagger_amd import hmm, synth
@@ -544,3 +548,55 @@ def test_completion_never_returns_a_stale_vector(poll):
     r = subprocess.run([sys.executable, "-c", _ALTERNATE % root], capture_output=True, text=True, env=dict(os.environ, HF_POLL=poll))
     assert r.returncode == 0 and "alternation ok" in r.stdout, r.stderr[-2000:]
     assert "[poll debug]" not in r.stderr, r.stderr[-2000:]
+
+
+def _pass_in_subprocess(env, scale, passes=2, multi=False):
+    """One or more EM passes of configs[2] x scale in a fresh process (the segment-kernel mode is read at hf_create):
+    returns (log-likelihoods, statistics of the last pass, sha1 of the labels, stderr)."""
+    import subprocess, sys, json as _json
+    code = r"""
+import sys, json, hashlib, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from flagger_amd import hmm, synth, _native as N
+store = synth.config(2, scale=%r)
+K = hmm.getBestNumberOfCollapsedComps(store)
+model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+em = hmm.MultiEMList(store, model, 1, exchange=N.HF_EXCHANGE_RANKS) if %r else hmm.EMList(store, model, True, 0.95)
+lls = []
+for _ in range(%d):
+    hmm.EM_runOneIterationForList(em, model)
+    lls.append(model.loglikelihood)
+    st = np.array(model.estimators, dtype=np.float64).copy()
+    hmm.HMM_estimateParameters(model, 1e-3); hmm.HMM_resetEstimators(model)
+hmm.EM_runForwardForList(em, model); lls.append(model.loglikelihood)
+hmm.EM_runOneIterationForList(em, model)
+print(json.dumps({"ll": lls, "stats": st.tolist(), "labels": hashlib.sha1(em.labels().tobytes()).hexdigest()}))
+em.close()
+""" % (ROOT, os.path.join(ROOT, "tests"), scale, multi, passes)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    return d["ll"], np.array(d["stats"]), d["labels"], r.stderr
+
+
+@pytest.mark.parametrize("scale", [0.02, 1.0, 3.0], ids=["small", "full", "3x: four rounds of workgroups"])
+def test_one_launch_segment_kernel_equals_two_launches(scale):
+    """Default: k_seg_fb computes the lane products itself and the segments of a chunk hand their products to each other inside
+    the launch (flags, bounded waits: hf_seg.h).  HF_SEG_LAUNCHES=2 is the older k_seg_prod + k_seg_fb pair.  Same arithmetic in
+    the same order: log-likelihoods, statistics and labels must be IDENTICAL, also when the grid is several times what the chip
+    holds at once (the waits then span dispatch rounds), and nothing may time out."""
+    a = _pass_in_subprocess({"HF_SEG_LAUNCHES": "1"}, scale)
+    b = _pass_in_subprocess({"HF_SEG_LAUNCHES": "2"}, scale)
+    assert "falls back" not in a[3]
+    assert a[0] == b[0] and a[2] == b[2] and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("multi", [False, True], ids=["one context", "hf_multi"])
+def test_hand_off_time_out_falls_back_to_two_launches(multi):
+    """HF_SEG_TEST_TIMEOUT=1 makes the first one-launch pass wait for flags nobody writes: every wait is given up after its bounded
+    number of polls, the flag word carries HF_FLAG_SYNC, the host re-runs the pass with two launches (hf_finish itself; hf_multi
+    on HF_E_RETRY) and stays there — the caller sees the results of an ordinary run."""
+    a = _pass_in_subprocess({"HF_SEG_TEST_TIMEOUT": "1"}, 0.05, multi=multi)
+    b = _pass_in_subprocess({"HF_SEG_LAUNCHES": "2"}, 0.05, multi=multi)
+    assert "falls back to k_seg_prod + k_seg_fb" in a[3]
+    assert a[0] == b[0] and a[2] == b[2] and np.array_equal(a[1], b[1])
