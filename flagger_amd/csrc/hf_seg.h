@@ -35,9 +35,6 @@
 #pragma once
 #include "hf_scan.h"
 
-#ifndef HF_ABL
-#define HF_ABL 0
-#endif
 #define HF_SEG_LMAX 8                        // windows per lane at most: a chunk longer than 64*HF_SEG_LMAX windows is split
 #define HF_SEG_SPLIT (64 * HF_SEG_LMAX)      // windows per segment a chunk is cut by (equal parts of at most this)
 #define HF_SEG_PSTAGE 24                     // segment products of a chunk staged in LDS by k_seg_fb (the rest: global loads)
@@ -213,21 +210,9 @@ __device__ __forceinline__ RowFetch rowfetch_init(const double* __restrict__ row
 __device__ __forceinline__ void rows_issue(const RowFetch& F, int step) {
     const uint4* __restrict__ t = reinterpret_cast<const uint4*>(F.my_off + step * 64);
     const uint4 o0 = t[0], o1 = t[1];
-    uint32_t o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-#if HF_ABL == 1
-    if (step != 0) return;
-#elif HF_ABL == 2
-    for (int q = 0; q < 8; q++) o[q] = 0;
-#elif HF_ABL == 3
-    for (int q = 0; q < 8; q++) o[q] = (uint32_t) (q * 8 + (threadIdx.x >> 3)) << 7;
-#elif HF_ABL == 4
-    for (int q = 0; q < 8; q++) o[q] = (uint32_t) (((q * 8 + (threadIdx.x >> 3)) * 37 + blockIdx.x * 64) % 8000) << 7;
-#endif
+    const uint32_t o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-#if HF_ABL == 5
-        if (step != 0 && q >= 4) break;
-#endif
         const uint32_t off = o[q] | ((q & 1) ? F.off_odd : F.off_even);
         // The DMA is inline assembly on purpose: with the builtin, hipcc (ROCm 7.2) keeps a pending LDS write on its vmcnt
         // scoreboard and turns every wait before a later ds_read into vmcnt(0) — which would also wait for the backward
@@ -347,8 +332,8 @@ __global__ void __launch_bounds__(64, 4) k_seg_prod(const SegDesc* __restrict__ 
             M4 A, R;
 #pragma unroll
             for (int k = 0; k < 16; k++) A.m[k] = E[HF_PS(k >> 2, k & 3)];
-            m4_mul(R, Q, A);
-            Q = R;
+            if (i == i0) Q = A;                                  // the first factor: no product with the identity
+            else { m4_mul(R, Q, A); Q = R; }
             m4_renorm_tree(Q);
         }
     }
@@ -425,8 +410,8 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                     M4 A2, R2;
 #pragma unroll
                     for (int k = 0; k < 16; k++) A2.m[k] = E[HF_PS(k >> 2, k & 3)];
-                    m4_mul(R2, Q, A2);
-                    Q = R2;
+                    if (i == i0) Q = A2;                         // the first factor: no product with the identity
+                    else { m4_mul(R2, Q, A2); Q = R2; }
                     m4_renorm_tree(Q);
                 }
             }
@@ -710,9 +695,6 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         g_seg_trace[(size_t) g * HF_SEG_TRACE_N + 22] = hw; g_seg_trace[(size_t) g * HF_SEG_TRACE_N + 23] = xcc;
     }
-#endif
-#if HF_ABL != 0
-    bad = 0;
 #endif
     if (bad) atomicOr(flags, bad);
 }
