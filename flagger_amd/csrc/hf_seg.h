@@ -122,6 +122,13 @@ __device__ __forceinline__ double dpp_f64(double v) {
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// the same move with 0.0 for lanes without a source (row shifts: bound_ctrl; broadcasts: rows outside the mask)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp0_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ void m4_dpp(M4& dst, const M4& src) {
 #pragma unroll
@@ -584,8 +591,11 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     TR_STAMP(7);
     {
         double ll = log(lm) + (double) le * 0.693147180559945309417232121458;
-        for (int o = 32; o > 0; o >>= 1) ll += __shfl_down(ll, o);
-        if (lane == 0) seg_ll[g] = ll;
+        // sum over the 64 lanes without LDS traffic: inclusive row scan (lanes without a source add 0), then the row totals
+        ll += dpp0_f64<HF_DPP_ROW_SHR(1), 0xf>(ll); ll += dpp0_f64<HF_DPP_ROW_SHR(2), 0xf>(ll);
+        ll += dpp0_f64<HF_DPP_ROW_SHR(4), 0xf>(ll); ll += dpp0_f64<HF_DPP_ROW_SHR(8), 0xf>(ll);
+        ll += dpp0_f64<HF_DPP_ROW_BCAST15, 0xa>(ll); ll += dpp0_f64<HF_DPP_ROW_BCAST31, 0xc>(ll);
+        if (lane == 63) seg_ll[g] = ll;
     }
     TR_STAMP(8);
     // ---- D: backward replay + labels (hmm.c:452-545, 671-692) ----
