@@ -110,6 +110,7 @@ struct hf_ctx {
     double poll_seq = 0.0;         // completion stamp of the last polled pass (hf_finish)
     double* d_rank_out = nullptr; double* d_rank_flag = nullptr;   // hf_bind_rank_total: where a rows-mode pass writes its total / flag word
     bool pass_bound = false;       // the last pass wrote them there
+    bool stream_stamp_ok = true; uint32_t stream_stamp = 0;   // wait_total: completion through hipStreamWriteValue32 (HF_STREAM_STAMP=0: off)
     bool pass_polled = false;      // the last rows-mode pass carried a stamp (decided at launch: k_row_stats writes the total itself)
     unsigned* d_done = nullptr;    // k_reduce / k_rows_total: blocks finished (the last one stamps the host block)
     unsigned long long* d_cks = nullptr;   // k_reduce: XOR of the words written (checksum of a polled pass)
@@ -857,6 +858,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     { const char* e = std::getenv("HF_HOST_TRACE"); ctx->host_trace = e && e[0] == '1'; }
     { const char* e = std::getenv("HF_SEG_LAUNCHES"); ctx->seg_fused = !(e && e[0] == '2'); }   // HF_SEG_LAUNCHES=2: k_seg_prod + k_seg_fb
     ctx->seg_test_timeout = std::getenv("HF_SEG_TEST_TIMEOUT") != nullptr;
+    { const char* e = std::getenv("HF_STREAM_STAMP"); if (e && e[0] == '0') ctx->stream_stamp_ok = false; }
     {
         const char* e = std::getenv("HF_STATS");
         ctx->stats_mode = (e && std::strcmp(e, "chunks") == 0) ? HF_STATS_CHUNKS : HF_STATS_ROWS;
@@ -1283,6 +1285,35 @@ static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_ho
             }
             __builtin_ia32_pause();
             if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;   // let the stream report
+        }
+    }
+    if (!seen && ctx->stream_stamp_ok) {
+        // Completion through the stream itself: a 32-bit value that the command processor writes into the pinned block AFTER
+        // everything enqueued before it has completed (hipStreamWriteValue32: a stream-ordered memory operation, so — unlike a
+        // stamp written by the kernel, HF_POLL — its order against the kernel's own writes is defined), polled by the host.
+        // Measured 4-5 us less per EM step than hipStreamSynchronize.  Bail-out: the stream after 2 s.
+        volatile uint32_t* word = reinterpret_cast<volatile uint32_t*>(ctx->h_flags) + 1;
+        const uint32_t want = ++ctx->stream_stamp;
+        if (hipStreamWriteValue32(st, (void*) word, want, 0) == hipSuccess) {
+            const auto t0 = std::chrono::steady_clock::now();
+            long spins = 0;
+            while (*word != want) {
+                __builtin_ia32_pause();
+                if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            seen = *word == want;
+        } else { (void) hipGetLastError(); ctx->stream_stamp_ok = false; }
+        if (seen) {
+            accumulate_kernel_times(ctx);
+            std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
+            const unsigned fl2 = (unsigned) ctx->h_total[ctx->V];
+            if ((fl2 & HF_FLAG_SYNC) && ctx->seg_fused) {
+                ctx->seg_fused = false;
+                std::fprintf(stderr, "[hmm_flagger_hip] one-launch segment kernel: a hand-off timed out; this context falls back to k_seg_prod + k_seg_fb\n");
+                return HF_E_RETRY;
+            }
+            return flags_to_code(fl2);
         }
     }
     if (!seen) HIPCHK(hipStreamSynchronize(st));
