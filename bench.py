@@ -72,9 +72,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink contig lengths (testing only; 1.0 = BASELINE workload)")
     ap.add_argument("--algo", choices=["scan", "seq"], default="scan")
-    ap.add_argument("--config", type=int, choices=[2, 4, 5], default=2,
+    ap.add_argument("--config", type=int, choices=[2, 4, 5, 6], default=2,
                     help="BASELINE.json configs[n]: 2 = the headline workload (default); 4 = ONT-R10 preset, 7 bias regions, 8 kb windows; "
-                         "5 = not a BASELINE config: configs[4] with coverage spread over 0..250 (worst case for the emission tables)")
+                         "5 = not a BASELINE config: configs[4] with coverage spread over 0..250 (worst case for the emission tables); "
+                         "6 = not a BASELINE config: configs[2] with over-dispersed (negative-binomial, variance = 3 x mean) coverage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-stride", type=int, default=4,
                     help="the dominant kernel is bracketed by a pair of HIP events in every n-th timed step (default 4; 1 = every step)")
@@ -152,7 +153,7 @@ def main():
     if args.scaling == "weak" and world > 1:      # one whole genome per rank: the chunk list of `world` genomes
         store = store.subset_chunks(list(range(store.n_chunks)) * world)
     K = hmm.getBestNumberOfCollapsedComps(store)
-    alpha = synth.HIFI_ALPHA if args.config == 2 else synth.ONT_R10_ALPHA
+    alpha = synth.HIFI_ALPHA if args.config in (2, 6) else synth.ONT_R10_ALPHA
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
     algo = N.HF_ALGO_SCAN if args.algo == "scan" else N.HF_ALGO_SEQ
     torch.cuda.set_device(local_rank)
@@ -383,6 +384,7 @@ def main():
                                     "(E-step+decode on GPU, M-step on host)" if args.config == 2 else
                                     "BASELINE.json configs[4]: synthetic 2x3.03 Gb diploid, ONT-R10 preset (8 kb windows), 7 bias "
                                     "regions with their own emission parameters, ONT-R10 v1.1.0 alpha, full EM step" if args.config == 4 else
+                                    "configs[2] with over-dispersed coverage (not a BASELINE config): negative binomial, variance = 3 x mean" if args.config == 6 else
                                     "worst case for the emission tables (not a BASELINE config): configs[4] with coverage spread over "
                                     "0..250, ~1 window per (region, x, x_prev) key, K = 10")
                                    + ("" if args.scale == 1.0 else f" [scale {args.scale}]")

@@ -239,9 +239,10 @@ def _sticky_states(rng: np.random.Generator, n: int, stay: np.ndarray, start_sta
 
 def synthesize(contig_lengths: Sequence[int], window_len: int, chunk_len: int, region_coverages: Sequence[int],
                seed: int, stay=(0.9, 0.9, 0.9975, 0.9), avg_alignment_len: int = 15000,
-               region_run_bases=(100_000, 5_000_000), contig_prefix: str = "ctg") -> WindowStore:
+               region_run_bases=(100_000, 5_000_000), contig_prefix: str = "ctg", overdispersion: float = 0.0) -> WindowStore:
     """cfg-2..5 style input: per contig a sticky hidden chain, cov ~ round(N(mu_s, 1.2*mu_s)) clipped
-    to [0,250] with mu = (0.1, 0.5, 1, 2..) x region coverage, mapq = cov except Dup (~0), clip = 0."""
+    to [0,250] with mu = (0.1, 0.5, 1, 2..) x region coverage, mapq = cov except Dup (~0), clip = 0.
+    overdispersion > 1: cov ~ negative binomial with mean mu_s and variance overdispersion * mu_s instead (heavy right tail)."""
     rng = np.random.default_rng(seed)
     stay = np.asarray(stay, dtype=np.float64)
     R = len(region_coverages)
@@ -269,7 +270,10 @@ def synthesize(contig_lengths: Sequence[int], window_len: int, chunk_len: int, r
         mu = np.where(states == 0, 0.1 * base,
              np.where(states == 1, 0.5 * base,
              np.where(states == 2, base, (k + 1) * base)))
-        cov = np.rint(rng.normal(mu, np.sqrt(1.2 * mu))).clip(0, 250).astype(np.uint16)
+        if overdispersion > 1.0:   # mean mu, variance od * mu: n = mu / (od - 1), p = 1 / od
+            cov = rng.negative_binomial(np.maximum(mu, 1e-9) / (overdispersion - 1.0), 1.0 / overdispersion).clip(0, 250).astype(np.uint16)
+        else:
+            cov = np.rint(rng.normal(mu, np.sqrt(1.2 * mu))).clip(0, 250).astype(np.uint16)
         mapq = np.where(states == 1, (cov * rng.uniform(0.0, 0.1, size=nwin_ctg)).astype(np.uint16), cov)
         annot = np.uint64(1) | (region.astype(np.uint64) << np.uint64(58))   # annotation index 1 = bit 0 (ptBlock.c:225-228)
         cov_l.append(cov); mapq_l.append(mapq.astype(np.uint16)); ann_l.append(annot); truth_l.append(states)
@@ -308,4 +312,8 @@ def config(n: int, scale: float = 1.0) -> WindowStore:
         st.cov = np.where(rng.random(nwin) < 0.5, rng.integers(0, 251, size=nwin), heavy).astype(np.uint16)
         st.mapq = st.cov.copy()
         return st
+    if n == 6:   # NOT a BASELINE config: configs[2] with over-dispersed coverage (negative binomial, variance = 3 x mean: what real
+        # sequencing coverage looks like next to the Gaussian of SURVEY §8d), VERDICT r02 #5
+        lens = [int(x * scale) for x in _HUMAN_CHROMS] * 2
+        return synthesize(lens, 4000, 20_000_000, [20], seed, contig_prefix="hap_ctg", overdispersion=3.0)
     raise ValueError("configs[0] is generated by tests/golden/make_golden.py (simulated .cov)")

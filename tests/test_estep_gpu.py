@@ -135,6 +135,17 @@ def test_wide_coverage_support_worst_case_for_the_tables(algo):
     _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, synth.ONT_R10_ALPHA, algo, n_iter=2)
 
 
+def test_over_dispersed_coverage():
+    """synth.config(6): configs[2] with negative-binomial coverage (variance = 3 x mean, a heavy right tail): more emission keys
+    and more collapsed components than the Gaussian workload, still on the statistics-by-row path; all three model types."""
+    store = synth.config(6, scale=0.02)
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    assert int(store.cov.max()) > 100
+    for mt, alpha in ((hmm.MODEL_TRUNC_EXP_GAUSSIAN, synth.HIFI_ALPHA), (hmm.MODEL_GAUSSIAN, synth.HIFI_ALPHA),
+                      (hmm.MODEL_NEGATIVE_BINOMIAL, np.zeros((4, 4)))):
+        _check_pass(store, mt, min(K, 6), alpha, N.HF_ALGO_SCAN, n_iter=2)
+
+
 @pytest.mark.parametrize("algo", ALGOS)
 def test_empty_chunk_list(algo):
     """No chunk at all (e.g. --contigsList that matches nothing): log-likelihood 0, all-zero statistics, no labels."""
