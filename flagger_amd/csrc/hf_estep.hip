@@ -147,7 +147,9 @@ struct hf_ctx {
 // ------------------------------------------------------------------------------------------
 // setup: packed records + contig-end factor beta (hmm.c:301-316), once per run
 // ------------------------------------------------------------------------------------------
-__global__ void k_setup(const int64_t* __restrict__ off, const uint16_t* __restrict__ cov,
+// packed != nullptr: the four per-window inputs as one word cov | mapq << 8 | clip << 16 | region << 24 (hf_create packs them on the
+// host when every value fits a byte — window values are at most 250, chunk.c:393-441: a quarter of the bytes to upload)
+__global__ void k_setup(const int64_t* __restrict__ off, const uint32_t* __restrict__ packed, const uint16_t* __restrict__ cov,
                         const uint16_t* __restrict__ mapq, const uint16_t* __restrict__ clip,
                         const uint64_t* __restrict__ annot, const int32_t* __restrict__ cs,
                         const int32_t* __restrict__ ce, const int32_t* __restrict__ cl, int window_len,
@@ -159,12 +161,14 @@ __global__ void k_setup(const int64_t* __restrict__ off, const uint16_t* __restr
     const int64_t col = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (col >= T) return;
     const int64_t t = t0 + col;
-    const unsigned cv = cov[t];
-    const unsigned region = (unsigned) ((annot[t] & 0xFC00000000000000ULL) >> 58);
+    const uint32_t pw = packed ? packed[t] : 0u;
+    const unsigned cv = packed ? (pw & 0xffu) : cov[t];
+    const unsigned mq = packed ? ((pw >> 8) & 0xffu) : mapq[t], cp = packed ? ((pw >> 16) & 0xffu) : clip[t];
+    const unsigned region = packed ? (pw >> 24) : (unsigned) ((annot[t] & 0xFC00000000000000ULL) >> 58);
     if ((int) region >= n_regions) atomicOr(flags, HF_FLAG_REGION);
     // validity mask, hmm_utils.c:2229-2254
-    const double ratio_m = (double) mapq[t] / (0.1 + cv);
-    const double ratio_c = (double) clip[t] / (0.1 + cv);
+    const double ratio_m = (double) mq / (0.1 + cv);
+    const double ratio_c = (double) cp / (0.1 + cv);
     unsigned vm = 0;
     if (!(ratio_m > max_mapq)) vm |= 1u;  // Dup valid
     if (!(ratio_m < min_mapq)) vm |= 2u;  // Col valid
@@ -172,7 +176,7 @@ __global__ void k_setup(const int64_t* __restrict__ off, const uint16_t* __restr
     unsigned r = (cv & 0xffu) | (region << 8) | (vm << 16);
     if (col == 0) r |= 1u << 19;
     else {
-        const unsigned pre_region = (unsigned) ((annot[t - 1] & 0xFC00000000000000ULL) >> 58);
+        const unsigned pre_region = packed ? (packed[t - 1] >> 24) : (unsigned) ((annot[t - 1] & 0xFC00000000000000ULL) >> 58);
         if (pre_region != region) r |= 1u << 20;
     }
     // beta, hmm.c:301-316; min/max are the int functions of common.c:142-148
@@ -441,8 +445,37 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     int rc = 0;
 #define TRY(x) do { rc = (x); if (rc) { hf_destroy(ctx); return rc; } } while (0)
     TRY(dev_upload(&ctx->d_off, w->chunk_off, C + 1));
-    TRY(dev_upload(&d_cov, w->cov, N)); TRY(dev_upload(&d_mapq, w->mapq, N)); TRY(dev_upload(&d_clip, w->clip, N));
-    TRY(dev_upload(&d_annot, w->annot, N));
+    cphase("context, chunk offsets up");
+    // The four per-window arrays (16 B per window, pageable host memory: measured at ~1 GB/s) go up as ONE packed word per window
+    // through a pinned staging buffer when every value fits a byte (window values are at most 250); as they are otherwise.
+    uint32_t* d_packed = nullptr;
+    {
+        uint32_t* stage = nullptr;
+        std::atomic<int> wide{0};
+        if (N > 0 && hipHostMalloc((void**) &stage, N * 4) == hipSuccess) {
+            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
+                bool big = false;
+                for (size_t t = (size_t) w->chunk_off[c0], e = (size_t) w->chunk_off[c1]; t < e; t++) {
+                    const unsigned cv = w->cov[t], mq = w->mapq[t], cp = w->clip[t];
+                    big |= (cv | mq | cp) > 0xffu;
+                    stage[t] = cv | (mq << 8) | (cp << 16) | ((uint32_t) (w->annot[t] >> 58) << 24);
+                }
+                if (big) wide.store(1, std::memory_order_relaxed);
+            });
+            cphase("pinned staging + packing");
+            if (w->chunk_off[0] != 0 || (size_t) w->chunk_off[C] != N) wide.store(1);   // (a window outside every chunk: take the plain path)
+            if (!wide.load()) {
+                hipError_t e1 = hipMalloc((void**) &d_packed, N * 4);
+                if (e1 == hipSuccess) e1 = hipMemcpy(d_packed, stage, N * 4, hipMemcpyHostToDevice);
+                if (e1 != hipSuccess) { (void) hipGetLastError(); if (d_packed) hipFree(d_packed); d_packed = nullptr; }
+            }
+            hipHostFree(stage);
+        } else (void) hipGetLastError();
+    }
+    if (!d_packed) {
+        TRY(dev_upload(&d_cov, w->cov, N)); TRY(dev_upload(&d_mapq, w->mapq, N)); TRY(dev_upload(&d_clip, w->clip, N));
+        TRY(dev_upload(&d_annot, w->annot, N));
+    }
     TRY(dev_upload(&d_cs, w->chunk_s, C)); TRY(dev_upload(&d_ce, w->chunk_e, C)); TRY(dev_upload(&d_cl, w->chunk_ctg_len, C));
     cphase("window arrays up");
 #define DMALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void**) &(p), (bytes) ? (bytes) : 8); \
@@ -479,7 +512,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     hipMemset(ctx->d_label, 0xff, N ? N : 1);
     if (N > 0 && C > 0) {
         dim3 grid((unsigned) ((maxT + 255) / 256), (unsigned) C);
-        hipLaunchKernelGGL(k_setup, grid, dim3(256), 0, 0, ctx->d_off, d_cov, d_mapq, d_clip, d_annot, d_cs, d_ce, d_cl,
+        hipLaunchKernelGGL(k_setup, grid, dim3(256), 0, 0, ctx->d_off, d_packed, d_cov, d_mapq, d_clip, d_annot, d_cs, d_ce, d_cl,
                            w->window_len, w->mean_read_len, w->adjust_contig_ends, w->min_read_frac,
                            w->max_high_mapq_ratio, w->min_high_mapq_ratio, w->min_highly_clipped_ratio, n_regions,
                            ctx->beta_star, ctx->d_rec, ctx->d_beta, ctx->d_flags);
@@ -487,7 +520,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     }
     cphase("events, memsets, k_setup enqueued");
     hipError_t e = hipDeviceSynchronize();
-    hipFree(d_cov); hipFree(d_mapq); hipFree(d_clip); hipFree(d_annot); hipFree(d_cs); hipFree(d_ce); hipFree(d_cl);
+    hipFree(d_packed); hipFree(d_cov); hipFree(d_mapq); hipFree(d_clip); hipFree(d_annot); hipFree(d_cs); hipFree(d_ce); hipFree(d_cl);
     if (e != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("setup: ") + hipGetErrorString(e)); }
     cphase("k_setup done, temporaries freed");
     unsigned fl = 0;
@@ -716,10 +749,20 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 pair0[c + 1] = pair0[c] + (size_t) (T > 2 ? T - 2 : 0);
             }
             const size_t np = pair0[C];
-            for (size_t c = 0; c < C; c++) {                      // popular rows: one thread, no contended atomics
-                const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-                for (int64_t x = 2; x < T; x++) cnt[(size_t) (h_arow[(size_t) (t0 + x)] & 0x7fffffff)]++;
-            }
+            // pairs per row of A: one histogram per part of the chunk list (popular rows: no contended atomics), then their sum;
+            // the per-part counts become the parts' starting ranks for the positions below
+            std::vector<std::vector<int32_t>> pcnt(8);
+            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
+                std::vector<int32_t>& h = pcnt[part];
+                h.assign(n_ar, 0);
+                for (size_t c = c0; c < c1; c++) {
+                    const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                    for (int64_t x = 2; x < T; x++) h[(size_t) (h_arow[(size_t) (t0 + x)] & 0x7fffffff)]++;
+                }
+            });
+            for (auto& h : pcnt)
+                if (!h.empty())
+                    for (size_t r = 0; r < n_ar; r++) { const int32_t here = h[r]; h[r] = cnt[r]; cnt[r] += here; }   // exclusive prefix over the parts
             // a plan is padded to 64 positions per group: when most pairs sit in rows of their own (reads longer than the contigs:
             // every window is a contig-end window) it would cost 64 positions per window — then the per-chunk statistics stay
             int64_t n_groups_all = 0;
@@ -775,9 +818,9 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 for (int reg = 0; reg < n_regions; reg++) if (rwoff[(size_t) reg + 1] > rwoff[(size_t) reg]) ctx->n_parts++;
                 n_pos = (int64_t) grp_ar.size() * HF_GRP_PAIRS;
                 // positions: pairs of a row of A in window order
-                {
-                    std::vector<int64_t> fill(n_ar, 0);           // pairs of the row placed so far
-                    for (size_t c = 0; c < C; c++) {
+                par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
+                    std::vector<int32_t>& fill = pcnt[part];      // rank of the part's next pair of every row of A
+                    for (size_t c = c0; c < c1; c++) {
                         const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
                         for (int64_t x = 2; x < T; x++) {
                             const size_t r = (size_t) (h_arow[(size_t) (t0 + x)] & 0x7fffffff);
@@ -785,7 +828,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                             pos[(size_t) (t0 + x)] = (int32_t) (((int64_t) g_first[r] + k / HF_GRP_PAIRS) * HF_GRP_PAIRS + k % HF_GRP_PAIRS);
                         }
                     }
-                }
+                });
                 cphase("plan: groups, row slots, positions");
                 // negative_binomial count data: the row slots of every (region, min(x, 249)) bin, in plan order
                 {
