@@ -324,28 +324,31 @@ def main():
             tdist.all_gather_object(parts, (first, mine.tobytes()))
             getattr(ssh, 'close', lambda: None)()
             if rank == 0:
-                import numpy as np
-                lab_n = np.full(sstore.n_windows, -1, dtype=np.int8)
-                for f0, b in parts:
-                    a = np.frombuffer(b, dtype=np.int8)
-                    lab_n[f0:f0 + a.size] = a
-                rmodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, sstore, alpha)
-                rem = hmm.EMList(sstore, rmodel, True, 0.95, device=local_rank, algo=algo)
-                rem.set_stats_mode(N.HF_STATS_CHUNKS)
-                rlls = []
-                for _ in range(iters):
+                try:                                   # rank-0-only work: whatever happens here, every rank reaches the barrier below
+                    import numpy as np
+                    lab_n = np.full(sstore.n_windows, -1, dtype=np.int8)
+                    for f0, b in parts:
+                        a = np.frombuffer(b, dtype=np.int8)
+                        lab_n[f0:f0 + a.size] = a
+                    rmodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, sstore, alpha)
+                    rem = hmm.EMList(sstore, rmodel, True, 0.95, device=local_rank, algo=algo)
+                    rem.set_stats_mode(N.HF_STATS_CHUNKS)
+                    rlls = []
+                    for _ in range(iters):
+                        hmm.EM_runOneIterationForList(rem, rmodel)
+                        rlls.append(rmodel.loglikelihood)
+                        hmm.HMM_estimateParameters(rmodel, 1e-3)
+                        hmm.HMM_resetEstimators(rmodel)
                     hmm.EM_runOneIterationForList(rem, rmodel)
                     rlls.append(rmodel.loglikelihood)
-                    hmm.HMM_estimateParameters(rmodel, 1e-3)
-                    hmm.HMM_resetEstimators(rmodel)
-                hmm.EM_runOneIterationForList(rem, rmodel)
-                rlls.append(rmodel.loglikelihood)
-                lab_1 = rem.labels()
-                rem.close()
-                invariance = {"what": f"{iters} EM iterations + final pass, exchange chunks over {world} rank(s) vs one context (per-chunk statistics) on rank 0",
-                              "scale": sscale, "n_windows": sstore.n_windows, "loglikelihoods_bit_identical": lls == rlls,
-                              "labels_identical": bool((lab_n == lab_1).all()), "label_mismatches": int((lab_n != lab_1).sum()),
-                              "final_loglikelihood": lls[-1]}
+                    lab_1 = rem.labels()
+                    rem.close()
+                    invariance = {"what": f"{iters} EM iterations + final pass, exchange chunks over {world} rank(s) vs one context (per-chunk statistics) on rank 0",
+                                  "scale": sscale, "n_windows": sstore.n_windows, "loglikelihoods_bit_identical": lls == rlls,
+                                  "labels_identical": bool((lab_n == lab_1).all()), "label_mismatches": int((lab_n != lab_1).sum()),
+                                  "final_loglikelihood": lls[-1]}
+                except Exception as e:
+                    invariance = {"error": repr(e)}
             barrier()
         except Exception as e:
             invariance = {"error": repr(e)}
