@@ -28,18 +28,77 @@
 #include <cstdio>
 #include <cmath>
 #include <atomic>
+#include <functional>
+#include <condition_variable>
+#include <mutex>
+#include <memory>
 #include <chrono>
 #include <cstdlib>
 
 #include <thread>
 static thread_local std::string g_err;
 
-// hf_create's host loops over the windows are independent per chunk: run fn(first chunk, last chunk + 1, part) on up to 8
-// threads, the chunk list cut into parts of about equal window count (1.5 M windows: 6-8 ms per loop on one thread)
+// hf_create's host loops over the windows are independent per chunk: run fn(first chunk, last chunk + 1, part) on up to
+// HF_PARTS threads, the chunk list cut into parts of about equal window count (1.5 M windows: 6-8 ms per loop on one thread).
+// The threads are a process-wide pool (hf_warmup starts it): spawning 16 threads per loop was measured at 1-2 ms a loop, as much
+// as the loops themselves.  A caller that finds the pool busy (hf_multi's ranks create their contexts concurrently) spawns its own.
+constexpr size_t HF_PARTS = 16;
+namespace {
+struct HostPool {
+    std::mutex run_m, m;
+    std::condition_variable cv;
+    std::vector<std::thread> th;
+    const std::function<void(size_t)>* job = nullptr;
+    size_t gen = 0, parts = 0;
+    std::atomic<size_t> next{0}, done{0}, active{0};
+    bool stop = false;
+    void start(size_t n) {
+        std::lock_guard<std::mutex> g(m);
+        while (th.size() < n) th.emplace_back([this] { worker(); });
+    }
+    void worker() {
+        size_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t)>* f;
+            size_t P;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; f = job; P = parts;
+                if (!f) continue;                      // woke after the job was over
+                active.fetch_add(1, std::memory_order_relaxed);   // under m: run() does not reuse the counters while a worker holds a job
+            }
+            for (size_t k; (k = next.fetch_add(1, std::memory_order_relaxed)) < P;) { (*f)(k); done.fetch_add(1, std::memory_order_release); }
+            active.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    // f(k) for k = 0..P-1 (the caller takes parts too); false if another caller holds the pool
+    bool run(size_t P, const std::function<void(size_t)>& f) {
+        std::unique_lock<std::mutex> only(run_m, std::try_to_lock);
+        if (!only.owns_lock()) return false;
+        start(P - 1);
+        next.store(0); done.store(0);
+        { std::lock_guard<std::mutex> g(m); job = &f; parts = P; gen++; }
+        cv.notify_all();
+        for (size_t k; (k = next.fetch_add(1, std::memory_order_relaxed)) < P;) { f(k); done.fetch_add(1, std::memory_order_release); }
+        while (done.load(std::memory_order_acquire) < P) std::this_thread::yield();
+        { std::lock_guard<std::mutex> g(m); job = nullptr; parts = 0; }   // a worker that wakes from here on leaves the counters alone
+        while (active.load(std::memory_order_acquire) != 0) std::this_thread::yield();
+        return true;
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> g(m); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+HostPool& host_pool() { static HostPool p; return p; }
+}
 template <class Fn>
 static void par_chunks(const int64_t* chunk_off, size_t C, Fn fn) {
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t T = C < 16 ? 1 : std::min<size_t>(8, hw ? hw : 1);
+    const size_t T = C < 16 ? 1 : std::min<size_t>(HF_PARTS, hw ? hw : 1);
     if (T <= 1) { fn((size_t) 0, C, (size_t) 0); return; }
     std::vector<size_t> cut(T + 1, 0);
     const int64_t total = chunk_off[C] - chunk_off[0];
@@ -50,10 +109,14 @@ static void par_chunks(const int64_t* chunk_off, size_t C, Fn fn) {
         cut[k] = c;
     }
     cut[T] = C;
+    const std::function<void(size_t)> part = [&](size_t k) { fn(cut[k], cut[k + 1], k); };
+    if (host_pool().run(T, part)) return;
     std::vector<std::thread> th;
-    for (size_t k = 0; k < T; k++) th.emplace_back([&, k] { fn(cut[k], cut[k + 1], k); });
+    for (size_t k = 0; k < T; k++) th.emplace_back([&, k] { part(k); });
     for (auto& t : th) t.join();
 }
+// slot of a segment's x-th window: lane x / L holds it as its x % L-th (hf_seg.h)
+static inline int32_t seg_slot(const SegDesc& d, int64_t x) { return d.slot0 + (int32_t) ((x % d.L) * 64 + x / d.L); }
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) \
     return set_err(HF_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
@@ -122,7 +185,8 @@ struct hf_ctx {
     double* d_recs = nullptr;      // [n_slots] pair records { f_{t-1}, b_t } of k_seg_fb, slot order; fb_recs: the last full pass wrote them
     bool fb_recs = false;
     int32_t* d_grp_ar = nullptr; int32_t* d_grp_n = nullptr; double* d_grp_sums = nullptr;   // per group: its row of A, its pairs
-    int32_t* d_pos_f = nullptr; int32_t* d_slot_of = nullptr;   // device copies of h_pos_f / h_slot_of, uploaded by the first getter call
+    int32_t* d_pos_f = nullptr;    // [N] position of the record that holds every window's f (getters)
+    int32_t* d_slot_of = nullptr;  // window -> slot, built from h_segs and uploaded by the first getter call
     int32_t* d_pos = nullptr; int64_t n_pos = 0;   // [N] position of every window's pair record in d_recs (plan order; slot order without a plan)
     RowSlot* d_rowslots = nullptr; int32_t* d_rw_region = nullptr; int32_t* d_rw_off = nullptr; double* d_rw_stats = nullptr;
     // segment kernels (hf_seg.h): the forward-backward of the statistics-by-row path
@@ -137,8 +201,8 @@ struct hf_ctx {
     int32_t* d_arow = nullptr; int32_t* d_arow_src = nullptr; int32_t* d_arow_cls = nullptr; double* d_lutA = nullptr;
     int n_arows = 0, n_combo = 0;
     double* d_scale_s = nullptr; int64_t n_slots = 0;
-    std::vector<int32_t> h_slot_of;             // window -> slot (the scales are kept in slot order)
-    std::vector<int32_t> h_pos, h_pos_f;        // window -> position of the record with its b / with its f (host getters)
+    std::thread unpin;                          // frees hf_create's pinned staging buffers
+    std::vector<SegDesc> h_segs;                // the segment descriptors (the getters derive a window's slot from them)
     bool pass_seg = false;             // the last pass ran the segment kernels (log-likelihood partials per segment)
     unsigned long long* d_seg_trace = nullptr;   // -DHF_SEG_TRACE builds only
     int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_Es = nullptr; double* d_Cs = nullptr;
@@ -149,6 +213,43 @@ struct hf_ctx {
 // ------------------------------------------------------------------------------------------
 // packed != nullptr: the four per-window inputs as one word cov | mapq << 8 | clip << 16 | region << 24 (hf_create packs them on the
 // host when every value fits a byte — window values are at most 250, chunk.c:393-441: a quarter of the bytes to upload)
+// The packed record of one window (hf_device.h REC_*) and its beta: ONE function for the device (k_setup) and for the host
+// (hf_create's plan reads the same bits without fetching them back; -ffp-contract=off on both sides, plain IEEE divisions and
+// comparisons, so the two agree bit for bit -- HF_CREATE_VERIFY=1, set by the test suite, downloads the device's and compares).
+__host__ __device__ static inline uint32_t window_record(unsigned cv, unsigned mq, unsigned cp, unsigned region, unsigned pre_region,
+                                                         int64_t col, int s, int e, int ctg_len, int window_len, int mean_read_len,
+                                                         int adjust, double min_frac, double max_mapq, double min_mapq,
+                                                         double min_clip, double beta_star, double* beta_out) {
+    // validity mask, hmm_utils.c:2229-2254
+    const double ratio_m = (double) mq / (0.1 + cv);
+    const double ratio_c = (double) cp / (0.1 + cv);
+    unsigned vm = 0;
+    if (!(ratio_m > max_mapq)) vm |= 1u;  // Dup valid
+    if (!(ratio_m < min_mapq)) vm |= 2u;  // Col valid
+    if (!(ratio_c < min_clip)) vm |= 4u;  // End/Msj column valid
+    uint32_t r = (cv & 0xffu) | (region << 8) | (vm << 16);
+    if (col == 0) r |= 1u << 19;
+    else if (pre_region != region) r |= 1u << 20;
+    // beta, hmm.c:301-316; min/max are the int functions of common.c:142-148
+    double bt = 1.0;
+    if (adjust) {
+        const int icol = (int) col;
+        const int a1 = (int) (s + (double) window_len * (icol + 0.5));
+        const int a2 = (int) ((s + (double) window_len * icol + e) / 2);
+        const int mid = a1 < a2 ? a1 : a2;
+        const int L = mean_read_len;
+        const int l1 = mid - L + 1, l2 = (int) (-(1 - min_frac) * L);
+        const int l = l2 < l1 ? l1 : l2;
+        const int u2 = (int) (ctg_len - min_frac * L);
+        const int u = mid < u2 ? mid : u2;
+        bt = (double) (u - l) / L;
+        if (bt <= 0.25) bt = 0.25;
+    }
+    *beta_out = bt;
+    if (col == 0 || bt != beta_star) r |= 1u << 21;   // private emission row (REC_SLOW)
+    return r;
+}
+
 __global__ void k_setup(const int64_t* __restrict__ off, const uint32_t* __restrict__ packed, const uint16_t* __restrict__ cov,
                         const uint16_t* __restrict__ mapq, const uint16_t* __restrict__ clip,
                         const uint64_t* __restrict__ annot, const int32_t* __restrict__ cs,
@@ -166,38 +267,12 @@ __global__ void k_setup(const int64_t* __restrict__ off, const uint32_t* __restr
     const unsigned mq = packed ? ((pw >> 8) & 0xffu) : mapq[t], cp = packed ? ((pw >> 16) & 0xffu) : clip[t];
     const unsigned region = packed ? (pw >> 24) : (unsigned) ((annot[t] & 0xFC00000000000000ULL) >> 58);
     if ((int) region >= n_regions) atomicOr(flags, HF_FLAG_REGION);
-    // validity mask, hmm_utils.c:2229-2254
-    const double ratio_m = (double) mq / (0.1 + cv);
-    const double ratio_c = (double) cp / (0.1 + cv);
-    unsigned vm = 0;
-    if (!(ratio_m > max_mapq)) vm |= 1u;  // Dup valid
-    if (!(ratio_m < min_mapq)) vm |= 2u;  // Col valid
-    if (!(ratio_c < min_clip)) vm |= 4u;  // End/Msj column valid
-    unsigned r = (cv & 0xffu) | (region << 8) | (vm << 16);
-    if (col == 0) r |= 1u << 19;
-    else {
-        const unsigned pre_region = packed ? (packed[t - 1] >> 24) : (unsigned) ((annot[t - 1] & 0xFC00000000000000ULL) >> 58);
-        if (pre_region != region) r |= 1u << 20;
-    }
-    // beta, hmm.c:301-316; min/max are the int functions of common.c:142-148
-    double bt = 1.0;
-    if (adjust) {
-        const int s = cs[c], e = ce[c], ctg_len = cl[c];
-        const int icol = (int) col;
-        const int a1 = (int) (s + (double) window_len * (icol + 0.5));
-        const int a2 = (int) ((s + (double) window_len * icol + e) / 2);
-        const int mid = a1 < a2 ? a1 : a2;
-        const int L = mean_read_len;
-        const int l1 = mid - L + 1, l2 = (int) (-(1 - min_frac) * L);
-        const int l = l2 < l1 ? l1 : l2;
-        const int u2 = (int) (ctg_len - min_frac * L);
-        const int u = mid < u2 ? mid : u2;
-        bt = (double) (u - l) / L;
-        if (bt <= 0.25) bt = 0.25;
-    }
+    unsigned pre_region = region;
+    if (col > 0) pre_region = packed ? (packed[t - 1] >> 24) : (unsigned) ((annot[t - 1] & 0xFC00000000000000ULL) >> 58);
+    double bt;
+    rec[t] = window_record(cv, mq, cp, region, pre_region, col, cs[c], ce[c], cl[c], window_len, mean_read_len, adjust, min_frac,
+                           max_mapq, min_mapq, min_clip, beta_star, &bt);
     beta[t] = bt;
-    if (col == 0 || bt != beta_star) r |= 1u << 21;   // private emission row (REC_SLOW)
-    rec[t] = r;
 }
 
 __global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __restrict__ rec,
@@ -393,11 +468,26 @@ __global__ void k_selftest_div(int64_t n, const double* __restrict__ a, const do
 
 int hf_warmup(int device) {
     if (hf_device_count() <= 0) return set_err(HF_E_NOGPU, "hf_warmup: no HIP device");
+    {   // the host threads of hf_create's passes over the windows
+        const unsigned hw = std::thread::hardware_concurrency();
+        host_pool().start(std::min<size_t>(HF_PARTS, hw ? hw : 1) - 1);
+    }
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));      // forces the context
     hipLaunchKernelGGL(k_selftest_div, dim3(1), dim3(64), 0, 0, (int64_t) 0, (const double*) nullptr, (const double*) nullptr,
                        (double*) nullptr, (double*) nullptr, (int32_t*) nullptr);   // loads this library's code object
     HIPCHK(hipDeviceSynchronize());
+    {   // the first pinned allocation and the first copy in each direction cost several milliseconds each (queues, staging): pay them here
+        void *d = nullptr, *h = nullptr;
+        if (hipMalloc(&d, 8 << 20) == hipSuccess && hipHostMalloc(&h, 8 << 20) == hipSuccess) {   // (large: a 1 MiB copy takes another path)
+            (void) hipMemcpy(d, h, 8 << 20, hipMemcpyHostToDevice);
+            (void) hipMemcpy(h, d, 8 << 20, hipMemcpyDeviceToHost);
+            (void) hipMemset(d, 0, 64);
+        }
+        if (h) hipHostFree(h);
+        if (d) hipFree(d);
+        (void) hipGetLastError();
+    }
     return HF_OK;
 }
 
@@ -448,29 +538,91 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     cphase("context, chunk offsets up");
     // The four per-window arrays (16 B per window, pageable host memory: measured at ~1 GB/s) go up as ONE packed word per window
     // through a pinned staging buffer when every value fits a byte (window values are at most 250); as they are otherwise.
+    // Pinned buffers of 4 bytes per window for everything this function moves between host and device (pageable copies were
+    // measured at ~1 GB/s): P0 packed windows up, then the f-positions up; P1 the rows of A up; P2 the record positions up.  Pinning
+    // costs ~0.2 ms per MB: P0 here, P1 and P2 on a helper thread while the first pass over the windows runs.
+    struct Pinned {
+        char* p = nullptr; bool pinned = false;
+        void get(size_t bytes) {
+            if (hipHostMalloc((void**) &p, bytes) == hipSuccess) pinned = true;
+            else { (void) hipGetLastError(); p = (char*) std::malloc(bytes); }
+        }
+        void release() { if (p) { if (pinned) hipHostFree(p); else std::free(p); } p = nullptr; }
+        ~Pinned() { release(); }
+    };
+    struct Arena { Pinned a, b; std::thread th; ~Arena() { if (th.joinable()) th.join(); } } arena;
+    if (N > 0) {
+        arena.a.get(N * 4);
+        if (!arena.a.p) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of host memory"); }
+        arena.th = std::thread([&arena, device, N] { if (hipSetDevice(device) == hipSuccess) arena.b.get(2 * N * 4); });
+    }
+    cphase("pinned staging buffer");
+    uint32_t* const P0 = reinterpret_cast<uint32_t*>(arena.a.p);
+    int32_t *P1 = nullptr, *P2 = nullptr;                                   // (set when the helper thread is joined)
+    std::unique_ptr<uint32_t[]> hrec_buf(N ? new uint32_t[N] : nullptr);     // the packed records as the host computes them
     uint32_t* d_packed = nullptr;
+    std::vector<std::vector<int64_t>> part_slow(HF_PARTS);
+    std::vector<int32_t> nslow(C, 0);
+    std::vector<uint8_t> seen256((size_t) n_regions << 16, 0), mark256(((size_t) n_regions << 16) * HF_AROW_CLASSES, 0);
+    std::atomic<int> wide{0}, bad_region{0};
     {
-        uint32_t* stage = nullptr;
-        std::atomic<int> wide{0};
-        if (N > 0 && hipHostMalloc((void**) &stage, N * 4) == hipSuccess) {
-            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
-                bool big = false;
-                for (size_t t = (size_t) w->chunk_off[c0], e = (size_t) w->chunk_off[c1]; t < e; t++) {
-                    const unsigned cv = w->cov[t], mq = w->mapq[t], cp = w->clip[t];
-                    big |= (cv | mq | cp) > 0xffu;
-                    stage[t] = cv | (mq << 8) | (cp << 16) | ((uint32_t) (w->annot[t] >> 58) << 24);
+        uint32_t* stage = P0;
+        uint32_t* hrec_w = hrec_buf.get();                      // the packed records, computed here as k_setup computes them
+        std::atomic<unsigned> maxx_all{0};
+        if (N > 0) {
+            // ONE pass over the windows: the packed upload word, the packed record, the largest coverage, the contig-end ("slow")
+            // windows, and which (region, x, x_prev) emission keys and (key, transition class) rows of A occur (tables at a stride
+            // of 256 per coverage value: the largest coverage is only known afterwards)
+            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
+                bool big = false, badr = false;
+                unsigned mx = 0;
+                std::vector<int64_t>& mine = part_slow[part];
+                uint8_t* const seen_p = seen256.data();
+                uint8_t* const mark_p = mark256.data();
+                for (size_t c = c0; c < c1; c++) {
+                    const size_t before = mine.size();
+                    const size_t t0 = (size_t) w->chunk_off[c], te = (size_t) w->chunk_off[c + 1];
+                    const int cs_ = w->chunk_s[c], ce_ = w->chunk_e[c], cl_ = w->chunk_ctg_len[c];
+                    unsigned pre_region = 0, xp = 0;
+                    for (size_t t = t0; t < te; t++) {
+                        const unsigned cv = w->cov[t], mq = w->mapq[t], cp = w->clip[t];
+                        const unsigned region = (unsigned) (w->annot[t] >> 58);
+                        const unsigned x = cv & 0xffu;
+                        big |= (cv | mq | cp) > 0xffu;
+                        if (x > mx) mx = x;
+                        stage[t] = cv | (mq << 8) | (cp << 16) | (region << 24);
+                        double bt;
+                        const uint32_t r = window_record(cv, mq, cp, region, pre_region, (int64_t) (t - t0), cs_, ce_, cl_, w->window_len,
+                                                         w->mean_read_len, w->adjust_contig_ends, w->min_read_frac, w->max_high_mapq_ratio,
+                                                         w->min_high_mapq_ratio, w->min_highly_clipped_ratio, ctx->beta_star, &bt);
+                        hrec_w[t] = r;
+                        if (region >= (unsigned) n_regions) badr = true;
+                        else if (REC_SLOW(r)) mine.push_back((int64_t) t);
+                        else {
+                            const size_t key = ((size_t) region << 16) | (x << 8) | xp;
+                            if (!__atomic_load_n(seen_p + key, __ATOMIC_RELAXED)) __atomic_store_n(seen_p + key, (uint8_t) 1, __ATOMIC_RELAXED);   // a few thousand cells, all threads: read-mostly
+                            uint8_t* const cell = mark_p + key * HF_AROW_CLASSES + (REC_REGCHG(r) ? 8u : REC_VMASK(r));
+                            if (!__atomic_load_n(cell, __ATOMIC_RELAXED)) __atomic_store_n(cell, (uint8_t) 1, __ATOMIC_RELAXED);
+                        }
+                        pre_region = region; xp = x;
+                    }
+                    nslow[c] = (int32_t) (mine.size() - before);
                 }
                 if (big) wide.store(1, std::memory_order_relaxed);
+                if (badr) bad_region.store(1, std::memory_order_relaxed);
+                unsigned cur = maxx_all.load(std::memory_order_relaxed);
+                while (mx > cur && !maxx_all.compare_exchange_weak(cur, mx, std::memory_order_relaxed)) {}
             });
-            cphase("pinned staging + packing");
+            ctx->M = (int) maxx_all.load() + 1;
+            cphase("one pass: packing, records, keys");
+            if (bad_region.load()) { hf_destroy(ctx); return set_err(HF_E_REGION, "a window's region index is >= n_regions"); }
             if (w->chunk_off[0] != 0 || (size_t) w->chunk_off[C] != N) wide.store(1);   // (a window outside every chunk: take the plain path)
             if (!wide.load()) {
                 hipError_t e1 = hipMalloc((void**) &d_packed, N * 4);
                 if (e1 == hipSuccess) e1 = hipMemcpy(d_packed, stage, N * 4, hipMemcpyHostToDevice);
                 if (e1 != hipSuccess) { (void) hipGetLastError(); if (d_packed) hipFree(d_packed); d_packed = nullptr; }
             }
-            hipHostFree(stage);
-        } else (void) hipGetLastError();
+        }
     }
     if (!d_packed) {
         TRY(dev_upload(&d_cov, w->cov, N)); TRY(dev_upload(&d_mapq, w->mapq, N)); TRY(dev_upload(&d_clip, w->clip, N));
@@ -527,42 +679,31 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     hipMemcpy(&fl, ctx->d_flags, 4, hipMemcpyDeviceToHost);
     if (fl & HF_FLAG_REGION) { hf_destroy(ctx); return set_err(HF_E_REGION, "a window's region index is >= n_regions"); }
     {
-        unsigned maxx = 0;
-        for (size_t t = 0; t < N; t++) { const unsigned x = w->cov[t] & 0xffu; if (x > maxx) maxx = x; }
-        ctx->M = (int) maxx + 1;
+        if (N == 0) ctx->M = 1;
         const size_t MM = (size_t) ctx->M * ctx->M;
-        // slow windows: chunk-first, or beta differs from beta_star: k_setup's REC_SLOW bit of the packed records (4 B per window
-        // come back once; round 2 also fetched the 8-byte beta of every window for the same test)
-        std::vector<uint32_t> hrec(N);
-        if (N) { hipError_t e2 = hipMemcpy(hrec.data(), ctx->d_rec, N * 4, hipMemcpyDeviceToHost);
-                 if (e2 != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "record download failed"); } }
+        // slow windows (chunk-first, or beta differs from beta_star) and the transition classes: bits of the packed records, which the
+        // packing loop above computed with k_setup's own function -- nothing comes back from the device (a first 6 MB device-to-host
+        // copy into a fresh pinned block was measured at 7.8 ms, the second at 0.13 ms)
+        const uint32_t* const hrec = hrec_buf.get();
+        if (N && std::getenv("HF_CREATE_VERIFY")) {
+            std::vector<uint32_t> dev(N);
+            bool same = hipMemcpy(dev.data(), ctx->d_rec, N * 4, hipMemcpyDeviceToHost) == hipSuccess;
+            for (size_t c = 0; c < C && same; c++) {
+                const size_t t0 = (size_t) w->chunk_off[c], n = (size_t) (w->chunk_off[c + 1] - w->chunk_off[c]);
+                same = std::memcmp(dev.data() + t0, hrec + t0, n * 4) == 0;
+            }
+            if (!same) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: host and device disagree on a window's packed record"); }
+        }
+        cphase("flags back");
         std::vector<int64_t> slow;
         std::vector<int32_t> soff(C + 1, 0), keys;
-        std::vector<uint8_t> seen((size_t) n_regions * MM, 0);
-        {
-            std::vector<std::vector<int64_t>> part_slow(8);
-            std::vector<int32_t> nslow(C, 0);
-            uint8_t* seen_p = seen.data();
-            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
-                std::vector<int64_t>& mine = part_slow[part];
-                for (size_t c = c0; c < c1; c++) {
-                    const size_t before = mine.size();
-                    const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-                    for (int64_t x = 0; x < T; x++) {
-                        const size_t t = (size_t) (t0 + x);
-                        if (REC_SLOW(hrec[t])) { mine.push_back((int64_t) t); continue; }
-                        const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
-                        uint8_t* cell = seen_p + (reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu);
-                        if (!__atomic_load_n(cell, __ATOMIC_RELAXED)) __atomic_store_n(cell, (uint8_t) 1, __ATOMIC_RELAXED);   // a few thousand cells, all threads: read-mostly
-                    }
-                    nslow[c] = (int32_t) (mine.size() - before);
-                }
-            });
-            for (size_t c = 0; c < C; c++) soff[c + 1] = soff[c] + nslow[c];
-            slow.reserve((size_t) soff[C]);
-            for (auto& v : part_slow) slow.insert(slow.end(), v.begin(), v.end());   // parts are consecutive chunk ranges: ascending
-        }
-        for (size_t k = 0; k < seen.size(); k++) if (seen[k]) keys.push_back((int32_t) k);
+        for (size_t c = 0; c < C; c++) soff[c + 1] = soff[c] + nslow[c];
+        slow.reserve((size_t) soff[C]);
+        for (auto& v : part_slow) slow.insert(slow.end(), v.begin(), v.end());   // parts are consecutive chunk ranges: ascending
+        for (size_t reg = 0; reg < (size_t) n_regions; reg++)                      // keys in (region, x, x_prev) order
+            for (size_t x = 0; x < (size_t) ctx->M; x++)
+                for (size_t xp = 0; xp < (size_t) ctx->M; xp++)
+                    if (seen256[(reg << 16) | (x << 8) | xp]) keys.push_back((int32_t) ((reg * ctx->M + x) * ctx->M + xp));
         ctx->n_slow = (int) slow.size();
         ctx->n_keys = (int) keys.size();
         TRY(dev_upload(&ctx->d_slow_w, slow.data(), slow.size()));
@@ -605,8 +746,13 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
         cphase("tiles + work arrays");
         // ---- segments of the workgroup-per-segment forward-backward (hf_seg.h) and the record slot of every window ----
-        std::vector<int32_t>& slot_of = ctx->h_slot_of;
-        std::vector<int32_t> h_arow, h_arow_src;        // window -> row of A; row of A -> emission row (both also on the device)
+        std::vector<std::vector<int32_t>> pcnt(HF_PARTS);   // pairs per row of A, per part of the chunk list
+        if (arena.th.joinable()) arena.th.join();
+        if (N > 0 && !arena.b.p) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of host memory"); }
+        P1 = reinterpret_cast<int32_t*>(arena.b.p); P2 = reinterpret_cast<int32_t*>(arena.b.p + N * 4);
+        int32_t* const h_arow = P1;                     // window -> row of A (also on the device)
+        std::vector<int32_t> h_arow_src;                // row of A -> emission row (also on the device)
+        std::vector<int32_t> cseg0;                     // first segment of every chunk
         if (N > 0 && C > 0 && N < (size_t) INT32_MAX / 2) {
             constexpr int64_t NL = 64;
             static_assert(HF_SEG_SPLIT <= 64 * HF_SEG_LMAX, "a segment has at most HF_SEG_LMAX windows per lane");
@@ -624,43 +770,46 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
                     return (reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu);
                 };
-                par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
-                    for (size_t c = c0; c < c1; c++) {
-                        const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-                        for (int64_t x = 1; x < T; x++) {
-                            const size_t t = (size_t) (t0 + x);
-                            if (REC_SLOW(hrec[t])) continue;
-                            int32_t* cell = cid + key_of(t) * NC + cls_of(hrec[t]);
-                            if (!__atomic_load_n(cell, __ATOMIC_RELAXED)) __atomic_store_n(cell, 1, __ATOMIC_RELAXED);
-                        }
-                    }
-                });
                 std::vector<int32_t>& a_src = h_arow_src;
                 std::vector<int32_t> a_cls;
-                for (size_t k = 0; k < combo_id.size(); k++)
-                    if (combo_id[k]) {
-                        combo_id[k] = (int32_t) a_src.size() + 1;            // id + 1
-                        a_src.push_back((int32_t) (k / NC));
-                        a_cls.push_back((int32_t) (k % NC) | (int32_t) ((k / NC / MM) << 8));
-                    }
+                // the (key, class) pairs the first pass marked, numbered in (region, x, x_prev, class) order
+                for (size_t reg = 0; reg < (size_t) n_regions; reg++)
+                    for (size_t x = 0; x < (size_t) ctx->M; x++)
+                        for (size_t xp = 0; xp < (size_t) ctx->M; xp++) {
+                            const size_t k256 = (reg << 16) | (x << 8) | xp;
+                            if (!seen256[k256]) continue;
+                            const size_t key = (reg * ctx->M + x) * ctx->M + xp;
+                            for (size_t cl = 0; cl < (size_t) NC; cl++)
+                                if (mark256[k256 * NC + cl]) {
+                                    cid[key * NC + cl] = (int32_t) a_src.size() + 1;            // id + 1
+                                    a_src.push_back((int32_t) key);
+                                    a_cls.push_back((int32_t) cl | (int32_t) (reg << 8));
+                                }
+                        }
                 const int32_t n_combo = (int32_t) a_src.size();
                 a_src.resize((size_t) n_combo + slow.size()); a_cls.resize((size_t) n_combo + slow.size());
-                std::vector<int32_t>& arow = h_arow;
-                arow.resize(N);
-                par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
+                const size_t n_ar_all = a_src.size();
+                int32_t* const arow = h_arow;
+                // second pass: every window's row of A, and the pairs per row of A (x >= 2: hmm.c:638-642) as one histogram per part
+                // of the chunk list (popular rows: no contended atomics)
+                par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
+                    std::vector<int32_t>& h = pcnt[part];
+                    h.assign(n_ar_all, 0);
                     for (size_t c = c0; c < c1; c++) {
                         const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
                         int32_t sp = soff[c];
                         for (int64_t x = 0; x < T; x++) {
                             const size_t t = (size_t) (t0 + x);
                             const uint32_t r = hrec[t];
+                            int32_t id;
                             if (REC_SLOW(r)) {
-                                const size_t id = (size_t) n_combo + (size_t) sp;
-                                a_src[id] = (int32_t) (ctx->n_lut + sp);
-                                a_cls[id] = (x == 0 ? 9 : cls_of(r)) | (int32_t) (REC_REGION(r) << 8);
-                                arow[t] = (int32_t) id | (x == 0 ? (int32_t) 0x80000000 : 0);
+                                id = n_combo + sp;
+                                a_src[(size_t) id] = (int32_t) (ctx->n_lut + sp);
+                                a_cls[(size_t) id] = (x == 0 ? 9 : cls_of(r)) | (int32_t) (REC_REGION(r) << 8);
+                                arow[t] = id | (x == 0 ? (int32_t) 0x80000000 : 0);
                                 sp++;
-                            } else arow[t] = cid[key_of(t) * NC + cls_of(r)] - 1;
+                            } else arow[t] = id = cid[key_of(t) * NC + cls_of(r)] - 1;
+                            if (x >= 2) h[(size_t) id]++;
                         }
                     }
                 });
@@ -669,16 +818,15 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     hf_destroy(ctx);
                     return set_err(HF_E_ARG, "hf_create: more than 2^25 distinct rows of A (contig-end windows included): shard the chunk list (hmm_flagger_multi.h)");
                 }
-                TRY(dev_upload(&ctx->d_arow, arow.data(), arow.size()));
+                TRY(dev_upload(&ctx->d_arow, arow, N));
                 TRY(dev_upload(&ctx->d_arow_src, a_src.data(), a_src.size()));
                 TRY(dev_upload(&ctx->d_arow_cls, a_cls.data(), a_cls.size()));
                 DMALLOC(ctx->d_lutA, (a_src.size() + 1) * 16 * 8);
                 if (ctrace) std::fprintf(stderr, "[hf_create] %d emission keys, %d (key, transition class) rows, %d slow windows\n",
                                          ctx->n_keys, n_combo, ctx->n_slow);
             }
-            std::vector<SegDesc> segs;
-            std::vector<int32_t> cseg0(C + 1, 0);
-            slot_of.assign(N, 0);
+            std::vector<SegDesc>& segs = ctx->h_segs;
+            cseg0.assign(C + 1, 0);
             int64_t nslots = 0;
             for (size_t c = 0; c < C; c++) {
                 const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
@@ -707,28 +855,15 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 }
             }
             cseg0[C] = (int32_t) segs.size();
-            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t) {
-                for (size_t c = c0; c < c1; c++) {
-                    const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-                    if (T <= 0) continue;
-                    for (int k = cseg0[c]; k < cseg0[c + 1]; k++) {
-                        const SegDesc& d = segs[(size_t) k];
-                        int32_t* so = slot_of.data() + d.t0;
-                        for (int64_t l = 0, x = 0; x < d.n; l++)                  // window x = lane l's x % L-th
-                            for (int64_t i = 0; i < d.L && x < d.n; i++, x++) so[x] = d.slot0 + (int32_t) (i * NL + l);
-                    }
-                }
-            });
             if (nslots < INT32_MAX) {
                 ctx->nseg = (int) segs.size(); ctx->n_slots = nslots;
-                TRY(dev_upload(&ctx->d_seg, segs.data(), segs.size()));
-                TRY(dev_upload(&ctx->d_chunk_seg0, cseg0.data(), cseg0.size()));
+                TRY(dev_upload(&ctx->d_chunk_seg0, cseg0.data(), cseg0.size()));   // (the descriptors go up with the plan's positions in them)
                 DMALLOC(ctx->d_seg_ready, segs.size() * 4);
                 hipMemset(ctx->d_seg_ready, 0, segs.size() * 4);
                 DMALLOC(ctx->d_seg_ll, segs.size() * 8);
                 DMALLOC(ctx->d_Pseg, segs.size() * 16 * 8);
                 DMALLOC(ctx->d_scale_s, (size_t) ctx->n_slots * 8);
-            } else slot_of.clear();
+            } else segs.clear();
             cphase("segments");
         }
         if (algo == HF_ALGO_SCAN && N > 0 && C > 0 && ctx->nseg == 0) {
@@ -749,17 +884,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 pair0[c + 1] = pair0[c] + (size_t) (T > 2 ? T - 2 : 0);
             }
             const size_t np = pair0[C];
-            // pairs per row of A: one histogram per part of the chunk list (popular rows: no contended atomics), then their sum;
-            // the per-part counts become the parts' starting ranks for the positions below
-            std::vector<std::vector<int32_t>> pcnt(8);
-            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
-                std::vector<int32_t>& h = pcnt[part];
-                h.assign(n_ar, 0);
-                for (size_t c = c0; c < c1; c++) {
-                    const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-                    for (int64_t x = 2; x < T; x++) h[(size_t) (h_arow[(size_t) (t0 + x)] & 0x7fffffff)]++;
-                }
-            });
+            // pairs per row of A: the sum of the parts' histograms; the per-part counts become the parts' starting ranks for the
+            // positions below
             for (auto& h : pcnt)
                 if (!h.empty())
                     for (size_t r = 0; r < n_ar; r++) { const int32_t here = h[r]; h[r] = cnt[r]; cnt[r] += here; }   // exclusive prefix over the parts
@@ -769,8 +895,14 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             for (size_t r = 0; r < n_ar; r++) n_groups_all += (cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS;
             const bool dense = n_groups_all * HF_GRP_PAIRS <= 4 * (int64_t) np + (4 << 20);   // 32 MiB of slack
             cphase("plan: pairs");
-            std::vector<int32_t> pos(N, 0), pos_f(N, 0);
+            int32_t* const pos = P2;                      // record position of every window (b half) ...
+            int32_t* const pos_f = reinterpret_cast<int32_t*>(P0);   // ... and of the record with its f (the packed records are no longer needed)
+            if (w->chunk_off[0] != 0 || (size_t) w->chunk_off[C] != N) std::memset(pos, 0, N * 4);   // windows outside every chunk
             int64_t n_pos = 0;
+            bool planned = false;
+            std::vector<int32_t> g_first;                         // first group of every row of A
+            std::vector<int32_t> grp_ar, grp_n;
+            std::vector<RowSlot> rslots; std::vector<int32_t> rwreg, rwoff((size_t) n_regions + 1, 0);
             if (np > 0 && dense && n_groups_all * HF_GRP_PAIRS + 3 * (int64_t) C < INT32_MAX && N < (size_t) INT32_MAX) {
                 // rows of A that occur, ordered by (region, row of A): combos are numbered by (emission key, class), keys are
                 // region-major; the contig-end windows' rows follow in window order
@@ -786,10 +918,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     occ.push_back({reg, (int32_t) r});
                 }
                 std::stable_sort(occ.begin(), occ.end(), [](const Occ& a, const Occ& b) { return a.region < b.region; });
-                std::vector<int32_t> g_first(n_ar, 0);            // first group of every row of A
-                std::vector<int32_t> grp_ar, grp_n;
+                g_first.assign(n_ar, 0);
                 grp_ar.reserve((size_t) n_groups_all); grp_n.reserve((size_t) n_groups_all);
-                std::vector<RowSlot> rslots; std::vector<int32_t> rwreg, rwoff((size_t) n_regions + 1, 0);
                 size_t oi = 0;
                 for (int reg = 0; reg < n_regions; reg++) {
                     rwoff[(size_t) reg] = (int32_t) (rslots.size() / 16);
@@ -816,20 +946,45 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / 16);
                 ctx->n_parts = 1;
                 for (int reg = 0; reg < n_regions; reg++) if (rwoff[(size_t) reg + 1] > rwoff[(size_t) reg]) ctx->n_parts++;
+                ctx->n_groups = (int) grp_ar.size();
+                while (grp_ar.size() % 4) { grp_ar.push_back(0); grp_n.push_back(0); }   // k_pair_sums: four groups per wavefront
                 n_pos = (int64_t) grp_ar.size() * HF_GRP_PAIRS;
-                // positions: pairs of a row of A in window order
-                par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
-                    std::vector<int32_t>& fill = pcnt[part];      // rank of the part's next pair of every row of A
-                    for (size_t c = c0; c < c1; c++) {
-                        const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                planned = true;
+            } else n_pos = ctx->n_slots;    // no plan (sparse rows): the per-chunk statistics read the records by window; positions in slot order
+            // third pass: the position of every window's record.  Pairs of a row of A in window order; the windows without a pair
+            // of their own (x = 0, 1) and the f of every chunk's last window after the groups, chunk by chunk
+            std::vector<int64_t> extra0(C + 1, n_pos);
+            for (size_t c = 0; c < C; c++) {
+                const int64_t T = w->chunk_off[c + 1] - w->chunk_off[c];
+                extra0[c + 1] = extra0[c] + (T <= 0 ? 0 : (planned ? (T < 2 ? T : 2) : 0) + 1);
+            }
+            par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
+                int32_t* const fill = pcnt[part].data();      // rank of the part's next pair of every row of A
+                for (size_t c = c0; c < c1; c++) {
+                    const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
+                    if (T <= 0) continue;
+                    if (planned) {
+                        for (int64_t x = 0; x < T && x < 2; x++) pos[(size_t) (t0 + x)] = (int32_t) (extra0[c] + x);
                         for (int64_t x = 2; x < T; x++) {
                             const size_t r = (size_t) (h_arow[(size_t) (t0 + x)] & 0x7fffffff);
                             const int64_t k = fill[r]++;
                             pos[(size_t) (t0 + x)] = (int32_t) (((int64_t) g_first[r] + k / HF_GRP_PAIRS) * HF_GRP_PAIRS + k % HF_GRP_PAIRS);
                         }
+                    } else {
+                        for (int k = cseg0[c]; k < cseg0[c + 1]; k++) {
+                            const SegDesc& d = ctx->h_segs[(size_t) k];
+                            for (int64_t x = 0; x < d.n; x++) pos[(size_t) (d.t0 + x)] = seg_slot(d, x);
+                        }
                     }
-                });
-                cphase("plan: groups, row slots, positions");
+                    const int32_t spare = (int32_t) (extra0[c + 1] - 1);   // takes the f of the chunk's last window
+                    for (int64_t x = 0; x + 1 < T; x++) pos_f[(size_t) (t0 + x)] = pos[(size_t) (t0 + x + 1)];
+                    pos_f[(size_t) (t0 + T - 1)] = spare;
+                    for (int k = cseg0[c]; k < cseg0[c + 1]; k++) ctx->h_segs[(size_t) k].spare_pos = spare;
+                }
+            });
+            n_pos = extra0[C];
+            cphase("plan: groups, row slots, positions");
+            if (planned) {
                 // negative_binomial count data: the row slots of every (region, min(x, 249)) bin, in plan order
                 {
                     std::vector<int32_t> boff((size_t) n_regions * 256 + 1, 0), blist;
@@ -851,8 +1006,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     DMALLOC(ctx->d_slot_h, rslots.size() * 4 * 8);
                     DMALLOC(ctx->d_H, (size_t) n_regions * 4 * 256 * 8);
                 }
-                ctx->n_groups = (int) grp_ar.size(); ctx->n_rowwaves = (int) (rslots.size() / 16);   // 16 slots per wavefront, 64 per region pad
-                while (grp_ar.size() % 4) { grp_ar.push_back(0); grp_n.push_back(0); }   // k_pair_sums: four groups per wavefront
+                ctx->n_rowwaves = (int) (rslots.size() / 16);   // 16 slots per wavefront, 64 per region pad
                 TRY(dev_upload(&ctx->d_grp_ar, grp_ar.data(), grp_ar.size()));
                 TRY(dev_upload(&ctx->d_grp_n, grp_n.data(), grp_n.size()));
                 TRY(dev_upload(&ctx->d_rowslots, rslots.data(), rslots.size()));
@@ -861,40 +1015,14 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 DMALLOC(ctx->d_grp_sums, (size_t) grp_ar.size() * 16 * 8);
                 DMALLOC(ctx->d_chunk_ll, C * 8);
                 DMALLOC(ctx->d_rw_stats, (size_t) ctx->n_rowwaves * (16 + 9 + 2 + 3 * 16 + 1) * 8);
-                n_pos = (int64_t) grp_ar.size() * HF_GRP_PAIRS;
                 ctx->rows_ready = true;
-            } else {
-                // no plan (sparse rows): the per-chunk statistics read the records by window; positions in slot order
-                for (size_t t = 0; t < N; t++) pos[t] = slot_of[t];
-                n_pos = ctx->n_slots;
             }
-            // windows without a pair of their own (x = 0, 1), and the f of every chunk's last window
-            for (size_t c = 0; c < C; c++) {
-                const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
-                if (T <= 0) continue;
-                if (ctx->rows_ready) for (int64_t x = 0; x < T && x < 2; x++) pos[(size_t) (t0 + x)] = (int32_t) n_pos++;
-                for (int64_t x = 0; x + 1 < T; x++) pos_f[(size_t) (t0 + x)] = pos[(size_t) (t0 + x + 1)];
-                pos_f[(size_t) (t0 + T - 1)] = (int32_t) n_pos++;   // == SegDesc.spare_pos of the chunk's last segment (below)
-            }
-            // the chunk's spare position goes into the descriptors of its segments
-            {
-                std::vector<SegDesc> segs((size_t) ctx->nseg);
-                if (hipMemcpy(segs.data(), ctx->d_seg, segs.size() * sizeof(SegDesc), hipMemcpyDeviceToHost) != hipSuccess) {
-                    hf_destroy(ctx); return set_err(HF_E_HIP, "segment descriptor download failed");
-                }
-                for (auto& d : segs) {
-                    const int64_t t_last = w->chunk_off[d.chunk + 1] - 1;
-                    d.spare_pos = pos_f[(size_t) t_last];
-                }
-                if (hipMemcpy(ctx->d_seg, segs.data(), segs.size() * sizeof(SegDesc), hipMemcpyHostToDevice) != hipSuccess) {
-                    hf_destroy(ctx); return set_err(HF_E_HIP, "segment descriptor upload failed");
-                }
-            }
+            TRY(dev_upload(&ctx->d_seg, ctx->h_segs.data(), ctx->h_segs.size()));
             ctx->n_pos = n_pos;
-            TRY(dev_upload(&ctx->d_pos, pos.data(), pos.size()));
+            TRY(dev_upload(&ctx->d_pos, pos, N));
+            TRY(dev_upload(&ctx->d_pos_f, pos_f, N));
             hipFree(ctx->d_recs); ctx->d_recs = nullptr;
             DMALLOC(ctx->d_recs, (size_t) n_pos * 64);
-            ctx->h_pos.swap(pos); ctx->h_pos_f.swap(pos_f);
             cphase("plan: uploads, allocations");
         }
     }
@@ -913,12 +1041,25 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         hipMemcpyToSymbol(HIP_SYMBOL(g_seg_trace), &ctx->d_seg_trace, sizeof(void*));
     }
 #endif
+    hrec_buf.reset();
+    {   // un-pinning 18 MB takes ~3 ms: on a thread of the context (joined by hf_destroy) while the caller goes on
+        char *pa = arena.a.pinned ? arena.a.p : nullptr, *pb = arena.b.pinned ? arena.b.p : nullptr;
+        if (pa) arena.a.p = nullptr;
+        if (pb) arena.b.p = nullptr;
+        if (pa || pb) ctx->unpin = std::thread([pa, pb, device] {
+            (void) hipSetDevice(device);
+            if (pa) (void) hipHostFree(pa);
+            if (pb) (void) hipHostFree(pb);
+        });
+    }
+    cphase("pinned buffers handed to the un-pinning thread");
     *out = ctx;
     return HF_OK;
 }
 
 void hf_destroy(hf_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->unpin.joinable()) ctx->unpin.join();
     hipSetDevice(ctx->device);
 #ifdef HF_SEG_TRACE
     if (ctx->d_seg_trace) {
@@ -1524,11 +1665,12 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
     if (!f_host && !b_host && !ctx->fb_recs) return HF_OK;
     if (ctx->fb_recs) {   // pair records (hf_seg.h): b_t is the second half of the record at pos[t], f_t the first half of the one at pos_f[t]
         // the positions of a range are scattered over the plan: gathered on the device, one copy back (maps uploaded on first use)
-        if (!ctx->d_pos_f) {
-            HIPCHK(hipMalloc((void**) &ctx->d_pos_f, (size_t) ctx->N * 4));
-            HIPCHK(hipMemcpy(ctx->d_pos_f, ctx->h_pos_f.data(), (size_t) ctx->N * 4, hipMemcpyHostToDevice));
+        if (!ctx->d_slot_of) {
             HIPCHK(hipMalloc((void**) &ctx->d_slot_of, (size_t) ctx->N * 4));
-            HIPCHK(hipMemcpy(ctx->d_slot_of, ctx->h_slot_of.data(), (size_t) ctx->N * 4, hipMemcpyHostToDevice));
+            std::vector<int32_t> so((size_t) ctx->N, 0);     // window -> slot (the scales are kept in slot order)
+            for (const SegDesc& d : ctx->h_segs)
+                for (int64_t x = 0; x < d.n; x++) so[(size_t) (d.t0 + x)] = seg_slot(d, x);
+            HIPCHK(hipMemcpy(ctx->d_slot_of, so.data(), (size_t) ctx->N * 4, hipMemcpyHostToDevice));
         }
         double* d_out = nullptr;
         HIPCHK(hipMalloc((void**) &d_out, (size_t) n * 9 * 8));

@@ -9,6 +9,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# hf_create computes every window's packed record on the host with the function k_setup runs on the device; under this switch it
+# also downloads the device's records and refuses to continue if a single bit differs (csrc/hf_estep.hip window_record)
+os.environ.setdefault("HF_CREATE_VERIFY", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
