@@ -76,6 +76,7 @@ def main():
                     help="BASELINE.json configs[n]: 2 = the headline workload (default); 4 = ONT-R10 preset, 7 bias regions, 8 kb windows; "
                          "5 = not a BASELINE config: configs[4] with coverage spread over 0..250 (worst case for the emission tables); "
                          "6 = not a BASELINE config: configs[2] with over-dispersed (negative-binomial, variance = 3 x mean) coverage")
+    ap.add_argument("--overdispersion", type=float, default=3.0, help="config 6 only: variance / mean of the negative-binomial coverage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--event-stride", type=int, default=4,
                     help="the dominant kernel is bracketed by a pair of HIP events in every n-th timed step (default 4; 1 = every step)")
@@ -148,7 +149,7 @@ def main():
         assert tdist.get_world_size() == args.gpus
 
     # ---- workload: BASELINE.json configs[2] (= configs[3] when sharded over 8 GPUs) ----
-    store = synth.config(args.config, scale=args.scale)
+    store = synth.config(args.config, scale=args.scale, overdispersion=args.overdispersion)
     base_store = store
     if args.scaling == "weak" and world > 1:      # one whole genome per rank: the chunk list of `world` genomes
         store = store.subset_chunks(list(range(store.n_chunks)) * world)
@@ -306,7 +307,7 @@ def main():
             other = {"error": repr(e)}
         try:
             sscale = min(args.scale, 0.05)
-            sstore = synth.config(args.config, scale=sscale)
+            sstore = synth.config(args.config, scale=sscale, overdispersion=args.overdispersion)
             smodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, sstore, alpha)
             ssh, _ = make_sharded(sstore, smodel, "chunks")
             ssh.force_collective = args.dist_path
@@ -387,7 +388,7 @@ def main():
                                     "(E-step+decode on GPU, M-step on host)" if args.config == 2 else
                                     "BASELINE.json configs[4]: synthetic 2x3.03 Gb diploid, ONT-R10 preset (8 kb windows), 7 bias "
                                     "regions with their own emission parameters, ONT-R10 v1.1.0 alpha, full EM step" if args.config == 4 else
-                                    "configs[2] with over-dispersed coverage (not a BASELINE config): negative binomial, variance = 3 x mean" if args.config == 6 else
+                                    "configs[2] with over-dispersed coverage (not a BASELINE config): negative binomial, variance = %g x mean" % args.overdispersion if args.config == 6 else
                                     "worst case for the emission tables (not a BASELINE config): configs[4] with coverage spread over "
                                     "0..250, ~1 window per (region, x, x_prev) key, K = 10")
                                    + ("" if args.scale == 1.0 else f" [scale {args.scale}]")

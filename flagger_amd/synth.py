@@ -291,8 +291,9 @@ def synthesize(contig_lengths: Sequence[int], window_len: int, chunk_len: int, r
         region_coverages=[int(x) for x in region_coverages], avg_alignment_len=avg_alignment_len)
 
 
-def config(n: int, scale: float = 1.0) -> WindowStore:
-    """BASELINE.json `configs[n]` (seed 1234+n).  `scale` < 1 shrinks contig lengths for tests."""
+def config(n: int, scale: float = 1.0, overdispersion: float = 3.0) -> WindowStore:
+    """BASELINE.json `configs[n]` (seed 1234+n).  `scale` < 1 shrinks contig lengths for tests; `overdispersion` = variance / mean of
+    config 6's coverage."""
     seed = 1234 + n
     if n == 1:   # 1 contig 10 Mb, 4 kb windows, fixed-parameter decode
         return synthesize([int(10_000_000 * scale)], 4000, 20_000_000, [20], seed)
@@ -315,5 +316,5 @@ def config(n: int, scale: float = 1.0) -> WindowStore:
     if n == 6:   # NOT a BASELINE config: configs[2] with over-dispersed coverage (negative binomial, variance = 3 x mean: what real
         # sequencing coverage looks like next to the Gaussian of SURVEY §8d), VERDICT r02 #5
         lens = [int(x * scale) for x in _HUMAN_CHROMS] * 2
-        return synthesize(lens, 4000, 20_000_000, [20], seed, contig_prefix="hap_ctg", overdispersion=3.0)
+        return synthesize(lens, 4000, 20_000_000, [20], seed, contig_prefix="hap_ctg", overdispersion=overdispersion)
     raise ValueError("configs[0] is generated by tests/golden/make_golden.py (simulated .cov)")
