@@ -184,6 +184,9 @@ struct hf_ctx {
     double* d_chunk_ll = nullptr;  // [C] log-likelihood per chunk (rows mode)
     double* d_recs = nullptr;      // [n_slots] pair records { f_{t-1}, b_t } of k_seg_fb, slot order; fb_recs: the last full pass wrote them
     bool fb_recs = false;
+    int32_t* d_grp_off = nullptr;     // compact plan: first position of every group (+ the end)
+    bool plan_compact = false;        // the groups' records back to back (sparse rows) instead of 64 positions per group
+    int rs_bpw = 1;                   // batches of 16 row slots per wavefront of k_row_stats
     int32_t* d_grp_ar = nullptr; int32_t* d_grp_n = nullptr; double* d_grp_sums = nullptr;   // per group: its row of A, its pairs
     int32_t* d_pos_f = nullptr;    // [N] position of the record that holds every window's f (getters)
     int32_t* d_slot_of = nullptr;  // window -> slot, built from h_segs and uploaded by the first getter call
@@ -378,6 +381,16 @@ static bool poll_ok(const hf_ctx* ctx, int last_kernel) {
 }
 static double next_stamp(hf_ctx* ctx) { ctx->poll_seq += 1.0; ctx->h_total[ctx->V + 1] = 0.0; return ctx->poll_seq; }
 
+// the groups' sums of f (x) b, times their row of A: padded plan (whole groups streamed) or compact plan (hf_create)
+static void launch_pair_sums(hf_ctx* ctx, hipStream_t st) {
+    if (ctx->plan_compact)
+        hipLaunchKernelGGL(k_pair_sums_compact, dim3((unsigned) ((ctx->n_groups + 63) / 64)), dim3(256), 0, st, ctx->n_groups, ctx->d_grp_ar, ctx->d_grp_off,
+                           ctx->d_lutA, ctx->d_recs, ctx->d_grp_sums);
+    else
+        hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) ((ctx->n_groups + 15) / 16)), dim3(256), 0, st, ctx->n_groups, ctx->d_grp_ar, ctx->d_grp_n,
+                           ctx->d_lutA, ctx->d_recs, ctx->d_grp_sums);
+}
+
 template <int KT>
 static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
     ctx->pass_rows = false;
@@ -385,14 +398,12 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         // statistics by emission row (hf_rows.h); hf_finish launches k_rows_total
         {
             KTimer t(ctx, st, HF_K_PAIR_SUMS);
-            hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) ((ctx->n_groups + 15) / 16)), dim3(256), 0, st, ctx->n_groups, ctx->d_grp_ar, ctx->d_grp_n,
-                               ctx->d_lutA, ctx->d_recs, ctx->d_grp_sums);
+            launch_pair_sums(ctx, st);
         }
         KTimer t(ctx, st, HF_K_ROW_STATS);
         constexpr size_t NA = 16 + 9 + 2 + 3 * KT + 1;
-        TileGeom g = tile_geom(ctx, k_row_stats<KT>, (size_t) (3 * ncol > 28 ? 3 * ncol : 28) * 65 * 8 + NA * 8, false);
+        TileGeom g = tile_geom(ctx, k_row_stats<KT>, NA * 8, false);   // the wavefronts' sums: four wavefronts per block, a block stays inside one region
         TILE_GEOM_OR_FAIL(g);
-        if (g.threads == 192) { g.threads = 128; g.lds = g.lds / 3 * 2; }   // 4, 2 or 1 wavefronts: a block stays inside one region
         const int wpb = (int) g.threads / 64;
         const int n_rw_blocks = (ctx->n_rowwaves + wpb - 1) / wpb, n_ll_blocks = (ctx->C + wpb - 1) / wpb;
         // the launch's last block also sums the partials (rows_total): into d_total and straight into the pinned host block
@@ -404,7 +415,7 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
                            ctx->n_rowwaves, n_rw_blocks, ctx->d_rw_region, ctx->d_rowslots, ctx->d_grp_sums, row_src(ctx), ctx->d_params,
                            ctx->d_rw_stats, ctx->C, ll_off(ctx), ll_part(ctx), ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll,
                            ctx->d_rw_off, ctx->K, bound ? ctx->d_rank_out : ctx->d_total, bound ? (double*) nullptr : ctx->d_total_host,
-                           bound ? ctx->d_rank_flag : (double*) nullptr, ctx->d_flags, seq, ctx->d_done, ctx->n_parts);
+                           bound ? ctx->d_rank_flag : (double*) nullptr, ctx->d_flags, seq, ctx->d_done, ctx->n_parts, ctx->rs_bpw);
         ctx->pass_wpb = wpb;
         ctx->pass_rows = true;
         ctx->pass_kc = ncol;
@@ -652,6 +663,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         ctx->h_total = reinterpret_cast<double*>(pin);
         ctx->h_flags = reinterpret_cast<unsigned*>(pin + tot_bytes);
         ctx->h_params = reinterpret_cast<DevParams*>(pin + tot_bytes + 64);
+        std::memset(ctx->h_params, 0, ctx->params_bytes);   // (pack_params fills the derived constants of the components in use only)
     }
     {
         void* dp = nullptr;
@@ -889,21 +901,31 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             for (auto& h : pcnt)
                 if (!h.empty())
                     for (size_t r = 0; r < n_ar; r++) { const int32_t here = h[r]; h[r] = cnt[r]; cnt[r] += here; }   // exclusive prefix over the parts
-            // a plan is padded to 64 positions per group: when most pairs sit in rows of their own (reads longer than the contigs:
-            // every window is a contig-end window) it would cost 64 positions per window — then the per-chunk statistics stay
+            // Two layouts of the groups' records.  PADDED: group g at positions g*64.. — k_pair_sums streams whole groups with a fixed
+            // geometry (the layout of inputs whose rows are popular: BASELINE configs[2], [4]).  When most pairs sit in rows of their
+            // own (coverage spread over the whole range, or reads longer than the contigs: every window a contig-end window) that
+            // would cost up to 64 positions per pair; then COMPACT: the groups back to back, group g at grp_off[g] —
+            // k_pair_sums_compact, four lanes per group.
             int64_t n_groups_all = 0;
             for (size_t r = 0; r < n_ar; r++) n_groups_all += (cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS;
             const bool dense = n_groups_all * HF_GRP_PAIRS <= 4 * (int64_t) np + (4 << 20);   // 32 MiB of slack
+            const bool compact = !dense;
+            // sparse plans have as many row slots as pairs, give or take: a wavefront of k_row_stats then takes `bpw` batches of 16
+            // slots before it reduces — a block's hand-off (partial vector, ticket) costs as much as a batch.  Measured on config 5
+            // (260 k slots, profiles/r03k_cfg5.txt): bpw 1 / 2 / 4 / 8 / 16 = 82 / 62 / 56 / 52 / 81 us: at least ~1000 wavefronts stay
+            int bpw = 1;
+            while (bpw < 8 && n_groups_all / 16 / (2 * bpw) >= 1000) bpw *= 2;
+            ctx->rs_bpw = bpw;
             cphase("plan: pairs");
             int32_t* const pos = P2;                      // record position of every window (b half) ...
             int32_t* const pos_f = reinterpret_cast<int32_t*>(P0);   // ... and of the record with its f (the packed records are no longer needed)
             if (w->chunk_off[0] != 0 || (size_t) w->chunk_off[C] != N) std::memset(pos, 0, N * 4);   // windows outside every chunk
             int64_t n_pos = 0;
             bool planned = false;
-            std::vector<int32_t> g_first;                         // first group of every row of A
-            std::vector<int32_t> grp_ar, grp_n;
+            std::vector<int32_t> g_pos0;                          // position of the first pair of every row of A
+            std::vector<int32_t> grp_ar, grp_n, grp_off;
             std::vector<RowSlot> rslots; std::vector<int32_t> rwreg, rwoff((size_t) n_regions + 1, 0);
-            if (np > 0 && dense && n_groups_all * HF_GRP_PAIRS + 3 * (int64_t) C < INT32_MAX && N < (size_t) INT32_MAX) {
+            if (np > 0 && (dense ? n_groups_all * HF_GRP_PAIRS : (int64_t) np) + 3 * (int64_t) C + 4 * HF_GRP_PAIRS < INT32_MAX && N < (size_t) INT32_MAX) {
                 // rows of A that occur, ordered by (region, row of A): combos are numbered by (emission key, class), keys are
                 // region-major; the contig-end windows' rows follow in window order
                 struct Occ { int32_t region, ar; };
@@ -918,16 +940,18 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     occ.push_back({reg, (int32_t) r});
                 }
                 std::stable_sort(occ.begin(), occ.end(), [](const Occ& a, const Occ& b) { return a.region < b.region; });
-                g_first.assign(n_ar, 0);
+                g_pos0.assign(n_ar, 0);
+                int64_t next_pos = 0;
+                const size_t unit = (size_t) 16 * (size_t) bpw;     // row slots per wavefront of k_row_stats
                 grp_ar.reserve((size_t) n_groups_all); grp_n.reserve((size_t) n_groups_all);
                 size_t oi = 0;
                 for (int reg = 0; reg < n_regions; reg++) {
-                    rwoff[(size_t) reg] = (int32_t) (rslots.size() / 16);
+                    rwoff[(size_t) reg] = (int32_t) (rslots.size() / unit);
                     int64_t open_row = -1;                         // emission row of the row slot being filled
                     for (; oi < occ.size() && occ[oi].region == reg; oi++) {
                         const size_t r = (size_t) occ[oi].ar;
                         const int64_t er = h_arow_src[r];
-                        g_first[r] = (int32_t) grp_ar.size();
+                        g_pos0[r] = (int32_t) (compact ? next_pos : (int64_t) grp_ar.size() * HF_GRP_PAIRS);
                         int32_t xpx;
                         if (er < ctx->n_lut) xpx = (int32_t) (((size_t) er / (size_t) ctx->M) % (size_t) ctx->M) | ((int32_t) ((size_t) er % (size_t) ctx->M) << 8);
                         else { const size_t t = (size_t) slow[(size_t) (er - ctx->n_lut)]; xpx = (int32_t) (w->cov[t] & 0xffu) | ((int32_t) (w->cov[t - 1] & 0xffu) << 8); }
@@ -935,20 +959,24 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                             const int32_t g = (int32_t) grp_ar.size();
                             grp_ar.push_back((int32_t) r);
                             grp_n.push_back((int32_t) (cnt[r] - b < HF_GRP_PAIRS ? cnt[r] - b : HF_GRP_PAIRS));
+                            grp_off.push_back((int32_t) next_pos);
+                            next_pos += grp_n.back();
                             // a row slot = up to 4 consecutive groups of one EMISSION row (its transition classes are adjacent)
                             if (open_row == er && rslots.back().ng < HF_ROWSLOT_GROUPS) rslots.back().ng++;
                             else { RowSlot sl; sl.row = (int32_t) er; sl.g0 = g; sl.ng = 1; sl.xpx = xpx; rslots.push_back(sl); open_row = er; }
                         }
                     }
-                    while (rslots.size() % 64) rslots.push_back({-1, 0, 0, 0});
-                    for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / 16; k++) rwreg.push_back(reg);
+                    while (rslots.size() % (4 * unit)) rslots.push_back({-1, 0, 0, 0});
+                    for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / unit; k++) rwreg.push_back(reg);
                 }
-                rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / 16);
+                rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / unit);
                 ctx->n_parts = 1;
                 for (int reg = 0; reg < n_regions; reg++) if (rwoff[(size_t) reg + 1] > rwoff[(size_t) reg]) ctx->n_parts++;
                 ctx->n_groups = (int) grp_ar.size();
                 while (grp_ar.size() % 4) { grp_ar.push_back(0); grp_n.push_back(0); }   // k_pair_sums: four groups per wavefront
-                n_pos = (int64_t) grp_ar.size() * HF_GRP_PAIRS;
+                grp_off.push_back((int32_t) next_pos);
+                n_pos = compact ? next_pos : (int64_t) grp_ar.size() * HF_GRP_PAIRS;
+                ctx->plan_compact = compact;
                 planned = true;
             } else n_pos = ctx->n_slots;    // no plan (sparse rows): the per-chunk statistics read the records by window; positions in slot order
             // third pass: the position of every window's record.  Pairs of a row of A in window order; the windows without a pair
@@ -968,7 +996,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         for (int64_t x = 2; x < T; x++) {
                             const size_t r = (size_t) (h_arow[(size_t) (t0 + x)] & 0x7fffffff);
                             const int64_t k = fill[r]++;
-                            pos[(size_t) (t0 + x)] = (int32_t) (((int64_t) g_first[r] + k / HF_GRP_PAIRS) * HF_GRP_PAIRS + k % HF_GRP_PAIRS);
+                            pos[(size_t) (t0 + x)] = g_pos0[r] + (int32_t) k;
                         }
                     } else {
                         for (int k = cseg0[c]; k < cseg0[c + 1]; k++) {
@@ -991,7 +1019,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     for (size_t k = 0; k < rslots.size(); k++)
                         if (rslots[k].row >= 0) {
                             const int x = rslots[k].xpx & 0xff;
-                            boff[(size_t) rwreg[k / 16] * 256 + (size_t) (x < HF_NB_MAX_COVERAGE ? x : HF_NB_MAX_COVERAGE - 1) + 1]++;
+                            boff[(size_t) rwreg[k / ((size_t) 16 * (size_t) ctx->rs_bpw)] * 256 + (size_t) (x < HF_NB_MAX_COVERAGE ? x : HF_NB_MAX_COVERAGE - 1) + 1]++;
                         }
                     for (size_t b = 0; b + 1 < boff.size(); b++) boff[b + 1] += boff[b];
                     blist.resize((size_t) boff.back());
@@ -999,16 +1027,17 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     for (size_t k = 0; k < rslots.size(); k++)
                         if (rslots[k].row >= 0) {
                             const int x = rslots[k].xpx & 0xff;
-                            blist[(size_t) fill[(size_t) rwreg[k / 16] * 256 + (size_t) (x < HF_NB_MAX_COVERAGE ? x : HF_NB_MAX_COVERAGE - 1)]++] = (int32_t) k;
+                            blist[(size_t) fill[(size_t) rwreg[k / ((size_t) 16 * (size_t) ctx->rs_bpw)] * 256 + (size_t) (x < HF_NB_MAX_COVERAGE ? x : HF_NB_MAX_COVERAGE - 1)]++] = (int32_t) k;
                         }
                     TRY(dev_upload(&ctx->d_bin_off, boff.data(), boff.size()));
                     TRY(dev_upload(&ctx->d_bin_list, blist.data(), blist.size()));
                     DMALLOC(ctx->d_slot_h, rslots.size() * 4 * 8);
                     DMALLOC(ctx->d_H, (size_t) n_regions * 4 * 256 * 8);
                 }
-                ctx->n_rowwaves = (int) (rslots.size() / 16);   // 16 slots per wavefront, 64 per region pad
+                ctx->n_rowwaves = (int) (rslots.size() / ((size_t) 16 * (size_t) ctx->rs_bpw));   // 16 * bpw slots per wavefront, four wavefronts per region pad
                 TRY(dev_upload(&ctx->d_grp_ar, grp_ar.data(), grp_ar.size()));
                 TRY(dev_upload(&ctx->d_grp_n, grp_n.data(), grp_n.size()));
+                if (compact) TRY(dev_upload(&ctx->d_grp_off, grp_off.data(), grp_off.size()));
                 TRY(dev_upload(&ctx->d_rowslots, rslots.data(), rslots.size()));
                 TRY(dev_upload(&ctx->d_rw_region, rwreg.data(), rwreg.size()));
                 TRY(dev_upload(&ctx->d_rw_off, rwoff.data(), rwoff.size()));
@@ -1023,6 +1052,9 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             TRY(dev_upload(&ctx->d_pos_f, pos_f, N));
             hipFree(ctx->d_recs); ctx->d_recs = nullptr;
             DMALLOC(ctx->d_recs, (size_t) n_pos * 64);
+            if (ctrace) std::fprintf(stderr, "[hf_create] statistics plan: %s, %d groups, %d row-slot wavefronts of %d x 16 slots, %lld positions for %lld pairs\n",
+                                     !planned ? "none (per-chunk statistics)" : ctx->plan_compact ? "compact" : "padded", ctx->n_groups, ctx->n_rowwaves,
+                                     ctx->rs_bpw, (long long) n_pos, (long long) np);
             cphase("plan: uploads, allocations");
         }
     }
@@ -1081,7 +1113,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
     hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0);
-    hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_grp_ar); hipFree(ctx->d_grp_n); hipFree(ctx->d_pos); hipFree(ctx->d_pos_f); hipFree(ctx->d_slot_of); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
+    hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_grp_ar); hipFree(ctx->d_grp_n); hipFree(ctx->d_grp_off); hipFree(ctx->d_pos); hipFree(ctx->d_pos_f); hipFree(ctx->d_slot_of); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
     hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_seg_ready); hipFree(ctx->d_scale_s);
     hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats);
@@ -1140,7 +1172,7 @@ static int pack_params(hf_ctx* ctx, const hf_params* p) {
         std::memcpy(g->weight, p->weight + (size_t) r * 4 * HF_MAXCOMP, sizeof(g->weight));
         const double bs = ctx->beta_star;
         for (int s = 0; s < 4; s++)
-            for (int c = 0; c < HF_MAXCOMP; c++) {
+            for (int c = 0; c < p->ncomp[s]; c++) {             // (per EM step and region: the components in use, not HF_MAXCOMP)
                 double var = g->var[s][c];
                 var *= bs;
                 g->gvar[s][c] = var;
@@ -1273,15 +1305,14 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         if (nbm && fl && rows_pass(ctx)) {   // statistics by emission row, negative_binomial (hf_nb_rows.h)
             {
                 KTimer t(ctx, st, HF_K_PAIR_SUMS);
-                hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) ((ctx->n_groups + 15) / 16)), dim3(256), 0, st, ctx->n_groups, ctx->d_grp_ar, ctx->d_grp_n,
-                                   ctx->d_lutA, ctx->d_recs, ctx->d_grp_sums);
+                launch_pair_sums(ctx, st);
             }
             {
                 KTimer t(ctx, st, HF_K_ROW_STATS);
                 const int n_rw_blocks = (ctx->n_rowwaves + 3) / 4, n_ll_blocks = (ctx->C + 3) / 4;
                 hipLaunchKernelGGL(k_row_stats_nb, dim3((unsigned) (n_rw_blocks + n_ll_blocks)), dim3(256), 0, st, ctx->n_rowwaves, n_rw_blocks,
                                    ctx->d_rowslots, ctx->d_grp_sums, ctx->d_slot_h, ctx->d_rw_stats, ctx->C, ll_off(ctx), ll_part(ctx),
-                                   ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll);
+                                   ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll, ctx->rs_bpw);
                 const int n_bins = ctx->R * 256;
                 hipLaunchKernelGGL(k_nb_hist, dim3((unsigned) ((n_bins + 3) / 4)), dim3(256), 0, st, n_bins, ctx->d_bin_off, ctx->d_bin_list,
                                    ctx->d_slot_h, ctx->d_H);

@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) k_row_stats_nb(int n_rowwaves, int n_rw_b
                                                       const double* __restrict__ grp_sums, double* __restrict__ slot_h,
                                                       double* __restrict__ blk_trans, int C, const int32_t* __restrict__ chunk_tile0,
                                                       const double* __restrict__ tile_ll, double* __restrict__ chunk_stats, int64_t V,
-                                                      double* __restrict__ chunk_ll) {
+                                                      double* __restrict__ chunk_ll, int bpw) {
     __shared__ double s_rows[4][16 * 65];
     __shared__ double s_blk[4][16];
     const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -40,10 +40,12 @@ __global__ void __launch_bounds__(256) k_row_stats_nb(int n_rowwaves, int n_rw_b
     }
     const int rw = (int) blockIdx.x * wpb + wave;
     const int p = lane & 3;
+    double tr[4] = {0.0, 0.0, 0.0, 0.0};          // the wavefront's transition counts: bpw batches of 16 slots in batch order
+    for (int bt = 0; bt < bpw; bt++) {
     RowSlot sl; sl.row = -1; sl.g0 = 0; sl.ng = 0; sl.xpx = 0;
-    const int64_t slot = (int64_t) rw * 16 + (lane >> 2);
+    const int64_t slot = ((int64_t) rw * bpw + bt) * 16 + (lane >> 2);
     if (rw < n_rowwaves) sl = slots[slot];
-    double tr[4] = {0.0, 0.0, 0.0, 0.0};
+    double ts[4] = {0.0, 0.0, 0.0, 0.0};          // this slot's
     if (sl.row >= 0) {
         const double* __restrict__ gs = grp_sums + (int64_t) sl.g0 * 16 + p;
         double gv[HF_ROWSLOT_GROUPS][4];
@@ -59,19 +61,20 @@ __global__ void __launch_bounds__(256) k_row_stats_nb(int n_rowwaves, int n_rw_b
                 for (int s4 = 0; s4 < 4; s4++) cnt[s4] += gv[g][s4];   // groups in plan order
             }
 #pragma unroll
-        for (int s = 0; s < 4; s++) tr[s] = cnt[s] / HF_TERMINATION_PROB;   // hmm.c:613-614
+        for (int s = 0; s < 4; s++) { ts[s] = cnt[s] / HF_TERMINATION_PROB; tr[s] += ts[s]; }   // hmm.c:613-614
     }
     {   // the slot's count data: previous states in index order (hmm.c:588-589), by the lane of previous state 0
         double h[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            const double a1 = __shfl(tr[s], (lane & ~3) | 1), a2 = __shfl(tr[s], (lane & ~3) | 2), a3 = __shfl(tr[s], (lane & ~3) | 3);
-            h[s] = ((tr[s] + a1) + a2) + a3;
+            const double a1 = __shfl(ts[s], (lane & ~3) | 1), a2 = __shfl(ts[s], (lane & ~3) | 2), a3 = __shfl(ts[s], (lane & ~3) | 3);
+            h[s] = ((ts[s] + a1) + a2) + a3;
         }
         if (p == 0 && sl.row >= 0) {
             double2* __restrict__ dst = reinterpret_cast<double2*>(slot_h) + slot * 2;
             dst[0] = make_double2(h[0], h[1]); dst[1] = make_double2(h[2], h[3]);
         }
+    }
     }
     double* __restrict__ s_row = s_rows[wave];
 #pragma unroll

@@ -17,6 +17,7 @@
 // of k_row_stats; row slots are padded to 64 per region (four wavefronts of 16 slots: the wavefronts of a block always
 // belong to one region).
 #pragma once
+#include <type_traits>
 #include "hf_scan.h"
 
 #define HF_GRP_PAIRS 64
@@ -83,6 +84,44 @@ __global__ void __launch_bounds__(256) k_pair_sums(int n_groups, const int32_t* 
                 const int kk = HF_PS(2 * pi + (u & 1), 2 * si + (u >> 1));
                 dst[kk] = acc[u] * A[kk];
             }
+        }
+    }
+}
+
+// k_pair_sums_compact: the same sums over a COMPACT plan (hf_create: most rows of A hold a handful of pairs; the groups'
+// records lie back to back, group g at grp_off[g]..grp_off[g+1]).  Four lanes per GROUP: the quad walks its group's records in
+// order — lane q holds piece q of the record as in k_pair_sums, the same 2x2 block of the count matrix — four records in flight;
+// 16 groups per wavefront, the wavefront runs as long as its largest group (<= 64 pairs).  The quad multiplies by its row of A
+// and writes its group's 128 bytes.
+__global__ void __launch_bounds__(256) k_pair_sums_compact(int n_groups, const int32_t* __restrict__ grp_ar, const int32_t* __restrict__ grp_off,
+                                                           const double* __restrict__ lutA, const double* __restrict__ recs,
+                                                           double* __restrict__ grp_sums) {
+    const int wave = (int) ((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    const int ql = lane & 3, g = wave * 16 + (lane >> 2);
+    const int pi = ql & 1, si = ql >> 1;
+    int base = 0, n = 0;
+    if (g < n_groups) { base = grp_off[g]; n = grp_off[g + 1] - base; }
+    const double2* __restrict__ R2 = reinterpret_cast<const double2*>(recs) + (int64_t) base * 4 + ql;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; __any(k0 < n); k0 += 4) {
+        double2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = k0 + j < n ? R2[(k0 + j) * 4] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const double f0 = quad_perm_f64<0x44>(v[j].x), f1 = quad_perm_f64<0x44>(v[j].y);
+            const double b0 = quad_perm_f64<0xFA>(v[j].x), b1 = quad_perm_f64<0xFA>(v[j].y);
+            acc[0] += f0 * b0; acc[1] += f1 * b0; acc[2] += f0 * b1; acc[3] += f1 * b1;
+        }
+    }
+    if (g < n_groups) {
+        const double* __restrict__ A = lutA + (int64_t) grp_ar[g] * 16;
+        double* __restrict__ dst = grp_sums + (int64_t) g * 16;
+#pragma unroll
+        for (int u = 0; u < 4; u += 2) {   // entries (2pi, s) and (2pi + 1, s) are adjacent (state-major): one 16-byte store
+            const int kk = HF_PS(2 * pi, 2 * si + (u >> 1));
+            const double2 a = *reinterpret_cast<const double2*>(A + kk);
+            *reinterpret_cast<double2*>(dst + kk) = make_double2(acc[u] * a.x, acc[u + 1] * a.y);
         }
     }
 }
@@ -225,17 +264,16 @@ __device__ double rows_total_ll(const int32_t* __restrict__ rw_off, int nreg, in
 // The last block of every part of the launch to finish then sums the part's partials: rows_total_region / rows_total_ll above.
 // ------------------------------------------------------------------------------------------
 template <int KT>
-__global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_blocks, const int32_t* __restrict__ rw_region,
+__global__ void __launch_bounds__(256) k_row_stats(int n_rowwaves, int n_rw_blocks, const int32_t* __restrict__ rw_region,
                                                       const RowSlot* __restrict__ slots, const double* __restrict__ grp_sums,
                                                       const RowSrc S, const DevParams* __restrict__ P, double* __restrict__ blk_stats,
                                                       int C, const int32_t* __restrict__ chunk_tile0,
                                                       const double* __restrict__ tile_ll, double* __restrict__ chunk_stats, int64_t V,
                                                       double* __restrict__ chunk_ll, const int32_t* __restrict__ rw_off, int Kctx,
                                                       double* __restrict__ out_dev, double* __restrict__ out_host, double* __restrict__ flag_row,
-                                                      const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done, int n_parts) {
+                                                      const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done, int n_parts, int bpw) {
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NS = 16 + 9 + 2;
-    constexpr int RS = 65;
     extern __shared__ __attribute__((aligned(16))) double s_rows[];
     const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __shared__ bool s_last;
@@ -252,106 +290,122 @@ __global__ void __launch_bounds__(256, 2) k_row_stats(int n_rowwaves, int n_rw_b
     const int rw = (int) blockIdx.x * wpb + wave;
     const int ncol = P->ncomp[3];
     const bool te = hf_err_is_truncexp(P);
-    const int nrows = 3 * ncol > NS + 1 ? 3 * ncol : NS + 1;
-    double* __restrict__ s_row = s_rows + wave * (nrows * RS);
-    double* __restrict__ s_acc = s_row + lane;
-    double* __restrict__ s_blk = s_rows + wpb * (nrows * RS);       // [wpb][NA] wave sums
-    const int p = lane & 3;
-    RowSlot sl; sl.row = -1; sl.g0 = 0; sl.ng = 0; sl.xpx = 0;
-    if (rw < n_rowwaves) sl = slots[(int64_t) rw * 16 + (lane >> 2)];
+    const int q = lane & 3;                               // the state (column of the counts) this lane of the quad works on
+    constexpr int KQ = (KT + 3) / 4;                      // components q, q + 4, .. of the collapsed state
     const DevRegion* __restrict__ R = &P->reg[rw < n_rowwaves ? rw_region[rw] : 0];
-    double tr[4] = {0.0, 0.0, 0.0, 0.0};                  // trans[p][s]
-    double g_mnum[3] = {0.0, 0.0, 0.0}, g_vnum[3] = {0.0, 0.0, 0.0}, g_den[3] = {0.0, 0.0, 0.0};
-    double te_num = 0.0, te_den = 0.0, c_wden = 0.0;
-    for (int i = 0; i < 3 * ncol; i++) s_acc[i * RS] = 0.0;
-    if (sl.row >= 0) {
-        // the slot's counts of this lane's previous state: entries (p, s) of every group sum (state-major: s*4 + p)
-        const double* __restrict__ gs = grp_sums + (int64_t) sl.g0 * 16 + p;
-        double gv[HF_ROWSLOT_GROUPS][4];
+    double aq[4];                                         // alpha[p][q], p = 0..3
 #pragma unroll
-        for (int g = 0; g < HF_ROWSLOT_GROUPS; g++)
+    for (int p = 0; p < 4; p++) aq[p] = P->alpha[p * 4 + q];
+    double om[4], o3[4];                                  // 1 - alpha[p][q], 1 - alpha[p][3]
 #pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) gv[g][s4] = gs[(int64_t) (g < sl.ng ? g : 0) * 16 + s4 * 4];
-        const double* __restrict__ er = S.lutE + (int64_t) sl.row * 16 + p;
-        double Ev[4];
+    for (int p = 0; p < 4; p++) { om[p] = 1.0 - aq[p]; o3[p] = 1.0 - P->alpha[p * 4 + 3]; }
+    double tr[4] = {0.0, 0.0, 0.0, 0.0};                  // trans[p][q]
+    double gm = 0.0, gv = 0.0, gd = 0.0, te_num = 0.0, te_den = 0.0, c_wden = 0.0;
+    double cm[KQ], cv[KQ], cd[KQ];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) Ev[s4] = er[s4 * 4];
-        const double* __restrict__ crow = S.lutC + ((int64_t) sl.row * 4) * S.K + p;   // [component][previous state]
-        double pcv[KT];
-#pragma unroll
-        for (int cc = 0; cc < KT; cc++) pcv[cc] = cc < ncol ? crow[cc * 4] : 0.0;
+    for (int j = 0; j < KQ; j++) { cm[j] = 0.0; cv[j] = 0.0; cd[j] = 0.0; }
+    // bpw batches of 16 row slots (hf_create: 1 unless the plan is sparse), accumulated in batch order before the one reduction
+    for (int bt = 0; bt < bpw; bt++) {
+        RowSlot sl; sl.row = -1; sl.g0 = 0; sl.ng = 0; sl.xpx = 0;
+        if (rw < n_rowwaves) sl = slots[((int64_t) rw * bpw + bt) * 16 + (lane >> 2)];
+        const bool have = sl.row >= 0;
+        // column q of the slot's summed counts (rows and tables are state-major: a column is 32 contiguous bytes), groups in plan order
         double cnt[4] = {0.0, 0.0, 0.0, 0.0};
+        {
+            const double2* __restrict__ gs = reinterpret_cast<const double2*>(grp_sums + (int64_t) sl.g0 * 16 + q * 4);
+            double2 g01[HF_ROWSLOT_GROUPS], g23[HF_ROWSLOT_GROUPS];
 #pragma unroll
-        for (int g = 0; g < HF_ROWSLOT_GROUPS; g++)
-            if (g < sl.ng) {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; s4++) cnt[s4] += gv[g][s4];   // groups in plan order
+            for (int g = 0; g < HF_ROWSLOT_GROUPS; g++) {
+                const bool on = have && g < sl.ng;
+                g01[g] = on ? gs[g * 8] : make_double2(0.0, 0.0);
+                g23[g] = on ? gs[g * 8 + 1] : make_double2(0.0, 0.0);
             }
+#pragma unroll
+            for (int g = 0; g < HF_ROWSLOT_GROUPS; g++)
+                if (g < sl.ng) { cnt[0] += g01[g].x; cnt[1] += g01[g].y; cnt[2] += g23[g].x; cnt[3] += g23[g].y; }
+        }
+        double Eq[4] = {1.0, 1.0, 1.0, 1.0};
+        if (have) {
+            const double2* __restrict__ er = reinterpret_cast<const double2*>(S.lutE + (int64_t) sl.row * 16 + q * 4);
+            const double2 e01 = er[0], e23 = er[1];
+            Eq[0] = e01.x; Eq[1] = e01.y; Eq[2] = e23.x; Eq[3] = e23.y;
+        }
         const double x = (double) (sl.xpx & 0xff), px = (double) ((sl.xpx >> 8) & 0xff);
-        double adj3 = 0.0;
+        double adj[4], xa[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const double adj = cnt[s] / HF_TERMINATION_PROB;          // hmm.c:613-614
-            tr[s] = adj;                                              // hmm_utils.c:2010-2015
-            if (s == 3) adj3 = adj;
-            else if (s == 0 && te) { te_num = adj * x; te_den = adj; }   // hmm_utils.c:1027-1034
-            else {                                                    // hmm_utils.c:812-839, one component
-                const double alpha = P->alpha[p * 4 + s];
-                const double x_adj = alpha == 0.0 ? x : (x - alpha * px) / (1.0 - alpha);
-                const double w = adj * Ev[s] / Ev[s];
-                g_mnum[s] = w * x_adj;
-                const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
-                g_vnum[s] = w * z * z;
-                g_den[s] = w;
+        for (int p = 0; p < 4; p++) {
+            adj[p] = cnt[p] / HF_TERMINATION_PROB;                          // hmm.c:613-614
+            xa[p] = aq[p] == 0.0 ? x : (x - aq[p] * px) / om[p];            // hmm_utils.c:812-839
+        }
+        if (have) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) tr[p] += adj[p];                    // hmm_utils.c:2010-2015
+            if (q == 0 && te) {                                             // hmm_utils.c:1027-1034
+#pragma unroll
+                for (int p = 0; p < 4; p++) { te_num += adj[p] * x; te_den += adj[p]; }
+            } else if (q < 3) {                                             // one component
+                const double mu = R->mean[q][0];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const double w = adj[p] * Eq[p] / Eq[p];
+                    gm += w * xa[p];
+                    const double z = (xa[p] - mu) * om[p];
+                    gv += w * z * z;
+                    gd += w;
+                }
             }
         }
-        const double alpha3 = P->alpha[p * 4 + 3];
-        const double xa = alpha3 == 0.0 ? x : (x - alpha3 * px) / (1.0 - alpha3), om = 1.0 - alpha3;
+        // the collapsed state: its counts, adjusted coverages and emission values are lane 3's; every lane of the quad takes
+        // components q, q + 4, ..: one 32-byte row of the component table [component][previous state] each
+        double a3[4], x3[4], E3[4];
 #pragma unroll
-        for (int cc = 0; cc < KT; cc++) {         // collapsed state
-            if (cc >= ncol) continue;
-            const double w = adj3 * pcv[cc] / Ev[3];
-            const double z = (xa - R->mean[3][cc]) * om;
-            s_acc[cc * RS] = w * xa; s_acc[(ncol + cc) * RS] = w * z * z; s_acc[(2 * ncol + cc) * RS] = w;
-            c_wden += w;
+        for (int p = 0; p < 4; p++) {
+            a3[p] = quad_perm_f64<0xFF>(adj[p]); x3[p] = quad_perm_f64<0xFF>(xa[p]); E3[p] = quad_perm_f64<0xFF>(Eq[p]);
+        }
+        if (have) {
+            const double2* __restrict__ crow = reinterpret_cast<const double2*>(S.lutC + ((int64_t) sl.row * 4) * S.K);
+#pragma unroll
+            for (int j = 0; j < KQ; j++) {
+                const int cc = q + 4 * j;
+                if (cc >= ncol) continue;
+                const double2 u01 = crow[cc * 2], u23 = crow[cc * 2 + 1];
+                const double pc[4] = {u01.x, u01.y, u23.x, u23.y};
+                const double mu = R->mean[3][cc];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const double w = a3[p] * pc[p] / E3[p];
+                    cm[j] += w * x3[p];
+                    const double z = (x3[p] - mu) * o3[p];
+                    cv[j] += w * z * z;
+                    cd[j] += w;
+                    c_wden += w;
+                }
+            }
         }
     }
-    // sums over the 64 lanes in lane order: accumulator i is summed by lane i out of its LDS row
+    // the 16 quads of the wavefront: a fixed butterfly (lanes 0..3 end up with the sums of their state / their components)
+    double* __restrict__ s_blk = s_rows;                  // [wpb][NA] wave sums, StatAcc<KT> order
     double* __restrict__ wsum = s_blk + wave * NA;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto quads = [](double v) { v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); return v; };
+#pragma unroll
+    for (int p = 0; p < 4; p++) tr[p] = quads(tr[p]);
+    gm = quads(gm); gv = quads(gv); gd = quads(gd); te_num = quads(te_num); te_den = quads(te_den); c_wden = quads(c_wden);
+#pragma unroll
+    for (int j = 0; j < KQ; j++) { cm[j] = quads(cm[j]); cv[j] = quads(cv[j]); cd[j] = quads(cd[j]); }
     {
-        double v = 0.0;
-        if (lane < 3 * ncol) {
-            const double* __restrict__ row = s_row + lane * RS;
-#pragma unroll 8
-            for (int l = 0; l < 64; l++) v += row[l];
-        }
-        for (int i = lane; i < 3 * KT; i += 64) wsum[NS + i] = 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 3 * ncol) wsum[NS + (lane / ncol) * KT + (lane % ncol)] = v;
+        const double w1 = __shfl(c_wden, 1), w2 = __shfl(c_wden, 2), w3 = __shfl(c_wden, 3);
+        if (lane == 0) wsum[NS + 3 * KT] = ((c_wden + w1) + w2) + w3;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // StatAccSmall order: trans[16] (row p*4 + s: only this lane's previous state), g_mnum[3], g_vnum[3], g_den[3], te_num, te_den
+    if (lane < 4) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) s_acc[i * RS] = (i >> 2) == p ? tr[i & 3] : 0.0;
+        for (int p = 0; p < 4; p++) wsum[p * 4 + q] = tr[p];
+        if (q < 3) { wsum[16 + q] = gm; wsum[19 + q] = gv; wsum[22 + q] = gd; }
+        if (q == 0) { wsum[25] = te_num; wsum[26] = te_den; }
 #pragma unroll
-    for (int s = 0; s < 3; s++) { s_acc[(16 + s) * RS] = g_mnum[s]; s_acc[(19 + s) * RS] = g_vnum[s]; s_acc[(22 + s) * RS] = g_den[s]; }
-    s_acc[25 * RS] = te_num; s_acc[26 * RS] = te_den;
-    s_acc[NS * RS] = c_wden;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane <= NS) {
-        const double* __restrict__ row = s_row + lane * RS;
-        double v = 0.0;
-#pragma unroll 8
-        for (int l = 0; l < 64; l++) v += row[l];
-        wsum[lane < NS ? lane : NS + 3 * KT] = v;
+        for (int j = 0; j < KQ; j++) {
+            const int cc = q + 4 * j;
+            if (cc < KT) { wsum[NS + cc] = cm[j]; wsum[NS + KT + cc] = cv[j]; wsum[NS + 2 * KT + cc] = cd[j]; }
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NA; i += blockDim.x) {   // the block's wavefronts in wave order

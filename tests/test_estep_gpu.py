@@ -127,8 +127,8 @@ def test_multi_region_ont(algo):
 
 @pytest.mark.parametrize("algo", ALGOS)
 def test_wide_coverage_support_worst_case_for_the_tables(algo):
-    """synth.config(5): coverage spread over 0..250 in 7 regions, K = 10 — nearly every window has its own emission row, the
-    statistics plan is refused as sparse (per-chunk statistics take over) and the row tables leave the L2."""
+    """synth.config(5): coverage spread over 0..250 in 7 regions, K = 10 — nearly every window has its own emission row: the
+    statistics plan is the compact one (groups back to back, several batches of row slots per wavefront) and the row tables leave the L2."""
     store = synth.config(5, scale=0.01)
     K = hmm.getBestNumberOfCollapsedComps(store)
     assert K == 10 and store.n_regions == 7 and int(store.cov.max()) == 250
@@ -469,19 +469,27 @@ def test_partial_range_getters_and_rank_total_in_both_statistics_modes():
         other.close()
 
 
-def test_sparse_statistics_plan_falls_back_to_per_chunk_statistics():
-    """Reads longer than the contigs: every window is a contig-end window with a private emission row, a plan padded to 64
-    slots per row would cost 64 slots per window — hf_create keeps the per-chunk statistics then; results as ever."""
+def test_sparse_statistics_plan_is_compact():
+    """Reads longer than the contigs: every window is a contig-end window with a private emission row and a row of A of its own.
+    A plan padded to 64 positions per group would cost 64 positions per pair; hf_create lays the groups out back to back instead
+    (rounds 1-2 fell back to the per-chunk statistics here).  Statistics by row == per-chunk statistics == the oracle."""
     store = synth.synthesize([350_000] * 240, 1000, 200_000, [20], seed=5, avg_alignment_len=400_000)   # 84 k windows, none interior
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, store, synth.HIFI_ALPHA)
     em = hmm.EMList(store, model)
     try:
-        assert em.stats_mode == N.HF_STATS_CHUNKS
-        em.set_stats_mode(N.HF_STATS_ROWS)            # asking for it does not help: there is no plan
-        assert em.stats_mode == N.HF_STATS_CHUNKS
+        assert em.stats_mode == N.HF_STATS_ROWS
+        em.launch(model); rows = np.array(em.finish())
+        em.set_stats_mode(N.HF_STATS_CHUNKS)
+        em.launch(model); chunks = np.array(em.finish())
+        scale = np.maximum(np.abs(chunks), 1e-9 * np.abs(chunks).max())
+        assert np.all(np.abs(rows - chunks) <= 1e-12 * scale), np.max(np.abs(rows - chunks) / scale)
+        em.set_stats_mode(N.HF_STATS_ROWS)
+        em.launch(model); again = np.array(em.finish())
+        assert np.array_equal(again, rows)                                 # fixed plan: reproducible bit for bit
     finally:
         em.close()
-    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, synth.HIFI_ALPHA, N.HF_ALGO_SCAN, n_iter=1)
+    for mt, alpha in ((hmm.MODEL_TRUNC_EXP_GAUSSIAN, synth.HIFI_ALPHA), (hmm.MODEL_NEGATIVE_BINOMIAL, np.zeros((4, 4)))):
+        _check_pass(store, mt, 4, alpha, N.HF_ALGO_SCAN, n_iter=1)
 
 
 @pytest.mark.parametrize("seed", range(8))
