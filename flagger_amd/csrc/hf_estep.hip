@@ -914,7 +914,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             // slots before it reduces — a block's hand-off (partial vector, ticket) costs as much as a batch.  Measured on config 5
             // (260 k slots, profiles/r03k_cfg5.txt): bpw 1 / 2 / 4 / 8 / 16 = 82 / 62 / 56 / 52 / 81 us: at least ~1000 wavefronts stay
             int bpw = 1;
-            while (bpw < 8 && n_groups_all / 16 / (2 * bpw) >= 1000) bpw *= 2;
+            while (bpw < 8 && n_groups_all / 16 / (2 * bpw) >= 1000) bpw *= 2;   // (below that a second batch per wavefront costs more than it saves: cfg-2 +4 us)
             ctx->rs_bpw = bpw;
             cphase("plan: pairs");
             int32_t* const pos = P2;                      // record position of every window (b half) ...

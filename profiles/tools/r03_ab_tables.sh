@@ -1,1 +1,1 @@
-for c in 5; do echo "== config $c"; BENCH_ARGS="--config $c" bash profiles/tools/r03_ab.sh "-DHF_TABLE_JOBS_LARGE=32" "-DHF_TABLE_JOBS_LARGE=16" "-DHF_TABLE_JOBS_LARGE=64" "-DHF_TABLE_JOBS_LARGE=8"; done
+for c in 2; do echo "== config $c"; BENCH_ARGS="--config $c" bash profiles/tools/r03_ab.sh "-DHF_DUMMY" "-DHF_PS_PIPE" "-DHF_DUMMY" "-DHF_PS_PIPE"; done
