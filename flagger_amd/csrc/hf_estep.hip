@@ -909,12 +909,16 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             int64_t n_groups_all = 0;
             for (size_t r = 0; r < n_ar; r++) n_groups_all += (cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS;
             const bool dense = n_groups_all * HF_GRP_PAIRS <= 4 * (int64_t) np + (4 << 20);   // 32 MiB of slack
-            const bool compact = !dense;
+            bool compact = !dense;
+            const char* const force = std::getenv("HF_STATS_PLAN");     // tests: "compact" / "padded" [",bpw=N"] on inputs of any size
+            if (force && std::strstr(force, "compact")) compact = true;
+            if (force && std::strstr(force, "padded") && n_groups_all * HF_GRP_PAIRS + 3 * (int64_t) C + 4 * HF_GRP_PAIRS < INT32_MAX) compact = false;
             // sparse plans have as many row slots as pairs, give or take: a wavefront of k_row_stats then takes `bpw` batches of 16
             // slots before it reduces — a block's hand-off (partial vector, ticket) costs as much as a batch.  Measured on config 5
             // (260 k slots, profiles/r03k_cfg5.txt): bpw 1 / 2 / 4 / 8 / 16 = 82 / 62 / 56 / 52 / 81 us: at least ~1000 wavefronts stay
             int bpw = 1;
             while (bpw < 8 && n_groups_all / 16 / (2 * bpw) >= 1000) bpw *= 2;   // (below that a second batch per wavefront costs more than it saves: cfg-2 +4 us)
+            if (force) { const char* b = std::strstr(force, "bpw="); if (b) { const int v = std::atoi(b + 4); if (v >= 1 && v <= 64) bpw = v; } }
             ctx->rs_bpw = bpw;
             cphase("plan: pairs");
             int32_t* const pos = P2;                      // record position of every window (b half) ...
@@ -925,7 +929,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             std::vector<int32_t> g_pos0;                          // position of the first pair of every row of A
             std::vector<int32_t> grp_ar, grp_n, grp_off;
             std::vector<RowSlot> rslots; std::vector<int32_t> rwreg, rwoff((size_t) n_regions + 1, 0);
-            if (np > 0 && (dense ? n_groups_all * HF_GRP_PAIRS : (int64_t) np) + 3 * (int64_t) C + 4 * HF_GRP_PAIRS < INT32_MAX && N < (size_t) INT32_MAX) {
+            if (np > 0 && (compact ? (int64_t) np : n_groups_all * HF_GRP_PAIRS) + 3 * (int64_t) C + 4 * HF_GRP_PAIRS < INT32_MAX && N < (size_t) INT32_MAX) {
                 // rows of A that occur, ordered by (region, row of A): combos are numbered by (emission key, class), keys are
                 // region-major; the contig-end windows' rows follow in window order
                 struct Occ { int32_t region, ar; };

@@ -11,9 +11,13 @@ from flagger_amd import hmm, synth, _native as N  # noqa: E402
 from oracle_py import Oracle  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
+PLANS = ["", "compact", "compact,bpw=3", "padded,bpw=2", "compact,bpw=8"]     # HF_STATS_PLAN of the seed (hf_create reads it)
 bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(5000 + seed)
+    plan = PLANS[seed % len(PLANS)]
+    if plan: os.environ["HF_STATS_PLAN"] = plan
+    else: os.environ.pop("HF_STATS_PLAN", None)
     window_len = int(rng.choice([500, 1000, 4000]))
     chunk_len = int(rng.choice([20, 77, 300])) * window_len
     lengths = [int(rng.integers(2, 3000)) * window_len + int(rng.integers(0, window_len)) for _ in range(int(rng.integers(1, 6)))]

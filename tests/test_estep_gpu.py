@@ -492,12 +492,17 @@ def test_sparse_statistics_plan_is_compact():
         _check_pass(store, mt, 4, alpha, N.HF_ALGO_SCAN, n_iter=1)
 
 
+@pytest.mark.parametrize("plan", ["", "compact", "compact,bpw=3", "padded,bpw=2"])
 @pytest.mark.parametrize("seed", range(8))
-def test_random_inputs_both_statistics_modes_against_each_other_and_the_oracle(seed):
+def test_random_inputs_both_statistics_modes_against_each_other_and_the_oracle(seed, plan, monkeypatch):
     """Seeded random shapes — contig lengths from a few windows to many tiles, window / chunk lengths, 1-5 regions with
     short region runs, clipped windows (End column), read lengths from shorter than a window to longer than a contig,
     K 2..9, the three alpha tables — one full pass: statistics by row == per-chunk statistics to rounding, and the
-    per-chunk vector, log-likelihood and labels against the oracle."""
+    per-chunk vector, log-likelihood and labels against the oracle.  `plan`: the layout hf_create chooses by itself, and both
+    layouts of the statistics plan forced (HF_STATS_PLAN: compact plans and several batches of row slots per wavefront are
+    otherwise chosen for large sparse inputs only)."""
+    if plan:
+        monkeypatch.setenv("HF_STATS_PLAN", plan)
     rng = np.random.default_rng(1000 + seed)
     window_len = int(rng.choice([500, 1000, 4000]))
     chunk_len = int(rng.choice([20, 77, 300])) * window_len
