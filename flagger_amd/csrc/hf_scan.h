@@ -208,10 +208,8 @@ __device__ __forceinline__ uint32_t load_recs(const uint32_t* __restrict__ rec, 
 // NaNs are stored, not reported: only a window that actually uses the row raises HF_E_NAN.
 // ------------------------------------------------------------------------------------------
 // rows per block: few when there are few rows (more blocks than CUs: the kernel is then latency-bound), many otherwise
-#define HF_TABLE_JOBS_SMALL 8
-#ifndef HF_TABLE_JOBS_LARGE
+#define HF_TABLE_JOBS_SMALL 8    // (measured again in round 3: 4 / 16 / 32 rows per block are within 1 us at 9 k and 25 k rows; 32 at 260 k rows: 8 / 16 / 64 are 20-45 % slower)
 #define HF_TABLE_JOBS_LARGE 32
-#endif
 // flags: 1 star (table key), 2 first, 4 active; bits 8..: transition class of the job's row of A (hf_seg.h); row: index of the row in lutE / lutC units
 struct TableJob { double x, px, bt; int64_t row; int32_t r; int32_t flags; };
 template <int HF_TABLE_JOBS_PER_BLOCK>
