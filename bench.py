@@ -308,46 +308,66 @@ def main():
         try:
             sscale = min(args.scale, 0.05)
             sstore = synth.config(args.config, scale=sscale, overdispersion=args.overdispersion)
-            smodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, sstore, alpha)
-            ssh, _ = make_sharded(sstore, smodel, "chunks")
-            ssh.force_collective = args.dist_path
-            iters, lls = 5, []
-            for _ in range(iters):
+            iters = 5
+
+            def sharded_run(exchange):
+                """`iters` EM iterations + the final inference pass (hmm_flagger.c:464) over all ranks: (log-likelihoods, labels of the
+                whole input on every rank)."""
+                import numpy as np
+                smodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, sstore, alpha)
+                ssh, _ = make_sharded(sstore, smodel, exchange)
+                ssh.force_collective = args.dist_path
+                lls = []
+                for _ in range(iters):
+                    hmm.EM_runOneIterationForList(ssh, smodel)
+                    lls.append(smodel.loglikelihood)
+                    hmm.HMM_estimateParameters(smodel, 1e-3)
+                    hmm.HMM_resetEstimators(smodel)
                 hmm.EM_runOneIterationForList(ssh, smodel)
                 lls.append(smodel.loglikelihood)
-                hmm.HMM_estimateParameters(smodel, 1e-3)
-                hmm.HMM_resetEstimators(smodel)
-            hmm.EM_runOneIterationForList(ssh, smodel)          # the final inference pass (hmm_flagger.c:464)
-            lls.append(smodel.loglikelihood)
-            mine = ssh.local_labels() if hasattr(ssh, "local_labels") else ssh.local.labels()
-            first = ssh.first_window if hasattr(ssh, "first_window") else int(sstore.chunk_off[ssh.bounds[rank]])
-            parts = [None] * world
-            tdist.all_gather_object(parts, (first, mine.tobytes()))
-            getattr(ssh, 'close', lambda: None)()
-            if rank == 0:
-                try:                                   # rank-0-only work: whatever happens here, every rank reaches the barrier below
-                    import numpy as np
-                    lab_n = np.full(sstore.n_windows, -1, dtype=np.int8)
-                    for f0, b in parts:
-                        a = np.frombuffer(b, dtype=np.int8)
-                        lab_n[f0:f0 + a.size] = a
-                    rmodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, sstore, alpha)
-                    rem = hmm.EMList(sstore, rmodel, True, 0.95, device=local_rank, algo=algo)
-                    rem.set_stats_mode(N.HF_STATS_CHUNKS)
-                    rlls = []
-                    for _ in range(iters):
-                        hmm.EM_runOneIterationForList(rem, rmodel)
-                        rlls.append(rmodel.loglikelihood)
-                        hmm.HMM_estimateParameters(rmodel, 1e-3)
-                        hmm.HMM_resetEstimators(rmodel)
+                mine = ssh.local_labels() if hasattr(ssh, "local_labels") else ssh.local.labels()
+                first = ssh.first_window if hasattr(ssh, "first_window") else int(sstore.chunk_off[ssh.bounds[rank]])
+                parts = [None] * world
+                tdist.all_gather_object(parts, (first, mine.tobytes()))
+                getattr(ssh, 'close', lambda: None)()
+                lab = np.full(sstore.n_windows, -1, dtype=np.int8)
+                for f0, b in parts:
+                    a = np.frombuffer(b, dtype=np.int8)
+                    lab[f0:f0 + a.size] = a
+                return lls, lab
+
+            def one_context_run(stats_mode):
+                rmodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, sstore, alpha)
+                rem = hmm.EMList(sstore, rmodel, True, 0.95, device=local_rank, algo=algo)
+                if stats_mode is not None:
+                    rem.set_stats_mode(stats_mode)
+                rlls = []
+                for _ in range(iters):
                     hmm.EM_runOneIterationForList(rem, rmodel)
                     rlls.append(rmodel.loglikelihood)
-                    lab_1 = rem.labels()
-                    rem.close()
+                    hmm.HMM_estimateParameters(rmodel, 1e-3)
+                    hmm.HMM_resetEstimators(rmodel)
+                hmm.EM_runOneIterationForList(rem, rmodel)
+                rlls.append(rmodel.loglikelihood)
+                lab = rem.labels()
+                rem.close()
+                return rlls, lab
+
+            lls, lab_n = sharded_run("chunks")
+            lls_r, lab_r = sharded_run("ranks")
+            if rank == 0:
+                try:                                   # rank-0-only work: whatever happens here, every rank reaches the barrier below
+                    rlls, lab_1 = one_context_run(N.HF_STATS_CHUNKS)
                     invariance = {"what": f"{iters} EM iterations + final pass, exchange chunks over {world} rank(s) vs one context (per-chunk statistics) on rank 0",
                                   "scale": sscale, "n_windows": sstore.n_windows, "loglikelihoods_bit_identical": lls == rlls,
                                   "labels_identical": bool((lab_n == lab_1).all()), "label_mismatches": int((lab_n != lab_1).sum()),
                                   "final_loglikelihood": lls[-1]}
+                    # the headline exchange (`ranks`: every rank sums its shard by emission row first) is equal to the one-GPU run up
+                    # to the rounding of a different order of additions: how far, and whether a single label moves
+                    qlls, lab_q = one_context_run(None)
+                    invariance["exchange_ranks_vs_one_context"] = {
+                        "label_mismatches": int((lab_r != lab_q).sum()),
+                        "loglikelihood_max_rel_diff": max(abs(a - b) / abs(b) for a, b in zip(lls_r, qlls))}
                 except Exception as e:
                     invariance = {"error": repr(e)}
             barrier()
