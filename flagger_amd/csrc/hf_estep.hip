@@ -5,10 +5,11 @@
 // One pass (per EM iteration), HF_ALGO_SCAN:
 //   hf_scan.h    k_tables      emission rows of this iteration (per occurring (region, x, x_prev) + per contig-end window)
 //                              and the rows of A_t = T_t∘e_t           (hmm_utils.c:753-793, 941-947, 2278-2292)
-//   hf_seg.h     k_seg_prod    one workgroup per chunk segment: lane products of A_t, product of the segment
-//                k_seg_fb      scans, scaled forward + log-likelihood, scaled backward + posterior argmax, pair records
+//   hf_seg.h     k_seg_fb      one workgroup per chunk segment, ONE launch: lane products of A_t, scans, the segments' products
+//                              handed over inside the launch, scaled forward + log-likelihood, scaled backward + posterior
+//                              argmax, pair records   (k_seg_prod + k_seg_fb<., false>: the two-launch fall-back)
 //                                                                        (hmm.c:333-434, 452-545, 671-692)
-//   hf_rows.h    k_pair_sums, k_row_stats, k_rows_total: xi sufficient statistics summed by emission row (default)
+//   hf_rows.h    k_pair_sums / k_pair_sums_compact, k_row_stats (its last blocks sum the pass's total): xi sufficient statistics summed by emission row (default)
 //                                                                        (hmm.c:563-650, hmm_utils.c:812-839, 1027-1034)
 //   hf_chunks.h  k_stats_tile, k_chunk_stats, k_reduce: the same statistics as one vector per chunk, summed in chunk-list
 //                order (hmm.c:759-763) — HF_STATS_CHUNKS, the per-chunk multi-GPU exchange, HF_ALGO_SEQ
@@ -175,9 +176,9 @@ struct hf_ctx {
     bool pass_bound = false;       // the last pass wrote them there
     bool stream_stamp_ok = true; uint32_t stream_stamp = 0;   // wait_total: completion through hipStreamWriteValue32 (HF_STREAM_STAMP=0: off)
     bool pass_polled = false;      // the last rows-mode pass carried a stamp (decided at launch: k_row_stats writes the total itself)
-    unsigned* d_done = nullptr;    // k_reduce / k_rows_total: blocks finished (the last one stamps the host block)
+    unsigned* d_done = nullptr;    // k_reduce / k_row_stats: blocks finished (the last one sums the parts and stamps the host block)
     unsigned long long* d_cks = nullptr;   // k_reduce: XOR of the words written (checksum of a polled pass)
-    int poll_kind = 0;             // what the last polled kernel was: 1 k_rows_total (a checksum per region), 2 k_reduce (one)
+    int poll_kind = 0;             // what the last polled kernel was: 1 k_row_stats' total (a checksum per region), 2 k_reduce (one)
     int n_groups = 0, n_rowwaves = 0, n_parts = 1;   // n_parts: regions that have a row, + 1 (the log-likelihood blocks): hf_rows.h hand-offs
     bool pass_nb = false;          // the last rows-mode pass ran the negative_binomial kernels (hf_nb_rows.h)
     int32_t* d_bin_off = nullptr; int32_t* d_bin_list = nullptr; double* d_slot_h = nullptr; double* d_H = nullptr;   // count-data plan
@@ -395,7 +396,7 @@ template <int KT>
 static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
     ctx->pass_rows = false;
     if (full && rows_pass(ctx)) {
-        // statistics by emission row (hf_rows.h); hf_finish launches k_rows_total
+        // statistics by emission row (hf_rows.h); the total of the pass comes out of k_row_stats' last blocks
         {
             KTimer t(ctx, st, HF_K_PAIR_SUMS);
             launch_pair_sums(ctx, st);

@@ -9,7 +9,7 @@
 //                    slot's contribution to the count data of its (region, x): the sum over previous states, per state
 //   k_nb_hist        one wavefront per (region, bin): the slots of the bin in plan order (a static list of hf_create)
 //   k_nb_total       one block per region: transition counts, the estimator increments of every (state, component) from
-//                    the region's count data, the log-likelihood; published like k_rows_total (checksum + stamp)
+//                    the region's count data, the log-likelihood; published like the total of k_row_stats (checksum + stamp)
 #pragma once
 #include "hf_rows.h"
 #include "hf_nb.h"
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) k_nb_hist(int n_bins, const int32_t* __re
 // estimator vector as k_chunk_stats_nb builds a chunk's: transition counts, then for every (state, component) the
 // theta / lambda / weight increments over the coverage values (hmm_utils.c:537-566; one wavefront per (state, component), lanes over x),
 // the weight denominators shared by the
-// components of a state (hmm_utils.c:66-74).  Published with the checksum and the stamp of k_rows_total.
+// components of a state (hmm_utils.c:66-74).  Published with the checksum and the stamp of k_row_stats' total (hf_rows.h).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_nb_total(const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_trans,
                                                   const double* __restrict__ H, const DevParams* __restrict__ P, const NbTables nb,
