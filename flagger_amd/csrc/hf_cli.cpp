@@ -448,10 +448,10 @@ int main(int argc, char* argv[]) {
     }
     fprintf(stderr, "[%s] EM+decode: %d passes over %ld windows in %.4f s = %.3e windows/s on GPU %d\n", ts(), passes, (long) N, emTime,
             (double) N * passes / emTime, device);
-    if (run.multi) hf_multi_destroy(run.multi);
-    hf_destroy(run.ctx);
-    hfm_destroy(model);
-    hfio_destroy(tab);
+    phase("final BED");
+    if (run.multi) hf_multi_destroy(run.multi);   // (joins the ranks' threads and communicators: RCCL wants an orderly end)
+    // the one-GPU context, the model and the window table are NOT destroyed: the process ends below without unwinding anything
+    // (freeing ~40 device allocations one by one was 5 ms of a 0.15 s run)
     fprintf(stderr, "[%s] Done! \n", ts());
     phase("outputs");
     const double realtime = real_time() - realtimeStart, cputime = cpu_time();
