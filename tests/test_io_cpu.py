@@ -146,8 +146,8 @@ def test_synthetic_store_written_as_cov_loads_back_identically(ext, tmp_path):
 
 
 def test_loader_number_shapes_line_endings_and_block_boundaries(tmp_path):
-    """The block reader (a second thread inflates 4 MiB blocks ahead of the parser) and the fast field parser against the
-    oracle's gzgets + atoi/atof: every number shape falls back to the library where the fast path does not apply; lines
+    """The block reader (one thread inflates line-aligned blocks of ~4 MiB, a few threads turn their lines into records, the
+    caller consumes them in file order) and the fast field parser against the oracle's gzgets + atoi/atof: every number shape falls back to the library where the fast path does not apply; lines
     that straddle block boundaries; a last line without newline; CRLF line endings."""
     header = ["#annotation:len:2", "#annotation:name:0:no_annotation", "#annotation:name:1:whole_genome", "#region:len:1",
               "#region:coverage:0:20", "#label:len:4", "#truth:true", "#avg_alignment_len:9000", "#start-only:false"]
@@ -173,6 +173,10 @@ def test_loader_number_shapes_line_endings_and_block_boundaries(tmp_path):
     with gzip.open(tmp_path / "z.cov.gz", "wt") as f:
         f.write(text)
     _same_store(fio.Table(str(tmp_path / "z.cov.gz"), 50_000, 100).store(), ref)
+    # a line longer than a block (a 5 MiB comment in the header): the block grows until it holds a line end
+    long_line = "#" + "x" * (5 << 20)
+    (tmp_path / "long.cov").write_text("\n".join(header[:3] + [long_line] + header[3:] + lines[len(header):]) + "\n")
+    _same_store(fio.Table(str(tmp_path / "long.cov"), 50_000, 100).store(), ref)
     (tmp_path / "empty.cov").write_text("")
     with pytest.raises(Exception):
         fio.Table(str(tmp_path / "empty.cov"), 50_000, 100)
