@@ -397,6 +397,18 @@ def main():
                               " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
             except Exception:
                 traffic = None
+        # what actually bounds the kernel (also from a committed counter pass of this command, not this run): the share of a SIMD's
+        # time in which its VALU issues, 3 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES with three resident wavefronts per SIMD
+        valu_busy, valu_src = None, None
+        sq = os.path.join(ROOT, "profiles", "r03l_pmc_sq_b.json")
+        if os.path.exists(sq) and world == 1 and args.scale == 1.0 and args.config == 2:
+            try:
+                for k, v in json.load(open(sq)).items():
+                    if k.split("<")[0] == dom and v.get("SQ_WAVE_CYCLES"):
+                        valu_busy = 3.0 * v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
+                valu_src = "profiles/r03l_pmc_sq_b.json (rocprofv3 --pmc SQ pass of this command, not this run)"
+            except Exception:
+                valu_busy = None
         out = {
             "metric": "coverage windows/sec through EM+decode; achieved HBM GB/s vs roofline",
             "value": n_windows * args.steps / dt, "unit": "windows/s",
@@ -427,7 +439,9 @@ def main():
                                                                      f"HIP event pair around {dom} in every {args.event_stride}. step of the timed region"),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_WINDOW * local_windows,
                          "kernel_ms_all": kavg, "algorithmic_bytes_per_window": ALGO_BYTES_PER_WINDOW,
-                         "windows_per_launch": local_windows},
+                         "windows_per_launch": local_windows,
+                         "valu_busy_frac_of_simd_time": valu_busy, "valu_busy_source": valu_src,
+                         "note": "the kernel is bound by dependent fp64 instruction chains at three wavefronts per SIMD, not by HBM bytes (DESIGN.md section 5)"},
             "loglikelihood_after_last_step": ll,
         }
         if weak is not None:
