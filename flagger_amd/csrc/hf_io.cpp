@@ -3,11 +3,18 @@
 #include "../../include/hmm_flagger_io.h"
 #include "../../include/hmm_flagger_summary.h"
 #include <zlib.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <algorithm>
+#include "hf_inflate.h"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -145,16 +152,28 @@ void parse_block(char* text, size_t len, std::vector<CovRec>& out);      // belo
 class BlockReader {
   public:
     struct Block {
-        std::vector<char> text;         // whole lines, '\n'-terminated except possibly the file's last one
-        size_t len = 0;
-        std::vector<CovRec> recs;
+        std::vector<char> text;         // [carry of the block before | this block's bytes]
+        size_t off = 0, len = 0;        // the lines to parse: text[off .. off + len), whole lines ('\n'-terminated except the file's last)
+        size_t data0 = 0, data_len = 0; // this block's own bytes (CRC-32 of a gzip member is over these)
+        std::vector<CovRec> recs;       // CovRec offsets are relative to base()
+        uint32_t crc = 0;               // crc32 of the block's own bytes (computed by the thread that parses it)
+        bool member_end = false;        // a gzip member ends with this block: its CRC-32 and ISIZE
+        uint32_t want_crc = 0, want_isize = 0;
         int state = 0;                  // 0 empty, 1 filled (text), 2 being parsed, 3 parsed, 4 being consumed
         bool last = false;              // no data: the end marker
+        char* base() { return text.data() + off; }
     };
-    explicit BlockReader(gzFile f) : f_(f) {
+    // own decoder over the mapped file (gzip members or plain text); zlib's gzread when the file cannot be mapped (or HF_IO_ZLIB=1)
+    explicit BlockReader(const char* path) {
+        const char* force = std::getenv("HF_IO_ZLIB");
+        if (!(force && force[0] == '1')) map_file(path);
+        if (!map_) {
+            gz_ = gzopen(path, "r");                                 // also reads uncompressed text
+            if (!gz_) { open_failed_ = true; return; }
+            gzbuffer(gz_, 1 << 20);
+        }
         unsigned hw = std::thread::hardware_concurrency();
         const int nw = hw >= 8 ? 4 : (hw >= 4 ? 2 : 1);
-        for (auto& b : blk_) b.text.resize(kCap + 1);
         prod_ = std::thread([this] { produce(); });
         for (int i = 0; i < nw; i++) work_.emplace_back([this] { parse_loop(); });
     }
@@ -163,7 +182,11 @@ class BlockReader {
         cv_.notify_all();
         if (prod_.joinable()) prod_.join();
         for (auto& t : work_) if (t.joinable()) t.join();
+        if (gz_) gzclose(gz_);
+        if (map_) munmap(const_cast<uint8_t*>(map_), map_len_ ? map_len_ : 1);
+        if (fd_ >= 0) close(fd_);
     }
+    bool open_failed() const { return open_failed_; }
     // the next block in file order, parsed; nullptr at the end of the file.  The block handed out before is recycled.
     Block* next() {
         std::unique_lock<std::mutex> g(m_);
@@ -171,17 +194,80 @@ class BlockReader {
         cv_.wait(g, [this] { return blk_[cons_].state == 3; });
         Block* b = &blk_[cons_];
         if (b->last) return nullptr;
+        // gzip members: CRC-32 and length of what was decoded, block by block (crc32_combine)
+        run_crc_ = run_len_ ? (uint32_t) crc32_combine(run_crc_, b->crc, (z_off_t) b->data_len) : b->crc;
+        run_len_ += b->data_len;
+        if (b->member_end) {
+            if (run_crc_ != b->want_crc || (uint32_t) run_len_ != b->want_isize) { failed_ = true; return nullptr; }
+            run_crc_ = 0; run_len_ = 0;
+        }
         b->state = 4; held_ = cons_; cons_ = (cons_ + 1) % kN;
         return b;
     }
-    // true when the stream ended on a zlib error (truncated or corrupt .cov.gz) instead of its end
+    // true when the stream ended on an error (truncated or corrupt .cov.gz, CRC mismatch) instead of its end
     bool failed() const { return failed_; }
 
   private:
     static constexpr size_t kCap = 4u << 20;
+    static constexpr size_t kHist = 32768;
     static constexpr int kN = 8;
+    void map_file(const char* path) {
+        fd_ = open(path, O_RDONLY);
+        if (fd_ < 0) return;
+        struct stat st;
+        if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd_); fd_ = -1; return; }
+        map_len_ = (size_t) st.st_size;
+        if (map_len_ == 0) { map_ = reinterpret_cast<const uint8_t*>(""); map_is_static_ = true; return; }
+        void* p = mmap(nullptr, map_len_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (p == MAP_FAILED) { close(fd_); fd_ = -1; map_len_ = 0; return; }
+        madvise(p, map_len_, MADV_SEQUENTIAL);
+        map_ = static_cast<const uint8_t*>(p);
+    }
+    // up to `want` more bytes of the file's text behind b.text[have): returns what was produced; sets eof / failed_ / member_end
+    size_t fetch(Block& b, size_t have, size_t hist, size_t want, bool& eof) {
+        if (gz_) {
+            size_t got = 0;
+            while (got < want) {                                    // gzread returns short counts only at the end of the stream
+                const int r = gzread(gz_, b.text.data() + have + got, (unsigned) (want - got));
+                if (r < 0) { failed_ = true; eof = true; break; }   // corrupt deflate data, I/O error
+                if (r == 0) {                                       // end of data: a stream cut before its trailer is an error, not EOF
+                    int errnum = Z_OK;
+                    (void) gzerror(gz_, &errnum);
+                    if (errnum != Z_OK && errnum != Z_STREAM_END) failed_ = true;
+                    eof = true; break;
+                }
+                got += (size_t) r;
+            }
+            return got;
+        }
+        if (!gzip_) {                                               // plain text
+            size_t n = map_len_ - inf_.pos;
+            if (n > want) n = want;
+            std::memcpy(b.text.data() + have, map_ + inf_.pos, n);
+            inf_.pos += n;
+            if (inf_.pos == map_len_) eof = true;
+            return n;
+        }
+        size_t got = 0;
+        const int rc = inf_.run(reinterpret_cast<uint8_t*>(b.text.data()) + have, want, hist, &got);
+        if (rc == hfz::END_OF_MEMBER) {
+            uint32_t crc = 0, isz = 0;
+            if (inf_.read_gzip_trailer(&crc, &isz) != hfz::OK) { failed_ = true; eof = true; return got; }
+            b.member_end = true; b.want_crc = crc; b.want_isize = isz;
+            // another member (concatenated gzip files), or the end; anything else after a member is ignored, as gzread does
+            if (inf_.pos >= map_len_ || inf_.read_gzip_header() != hfz::OK) eof = true;
+        } else if (rc != hfz::OK) { failed_ = true; eof = true; }
+        return got;
+    }
     void produce() {
-        std::vector<char> tail;                                     // the unfinished line of the block before
+        if (map_) {
+            inf_.in = map_; inf_.in_len = map_len_; inf_.pos = 0;
+            gzip_ = map_len_ >= 2 && map_[0] == 0x1f && map_[1] == 0x8b;
+            if (gzip_ && inf_.read_gzip_header() != hfz::OK) failed_ = true;
+        }
+        std::vector<char> carry;                                    // the end of the block before: >= the decoder's 32 KiB of history and
+        size_t tail = 0;                                            // ... the unfinished line (its last `tail` bytes)
+        bool eof = failed_;
         for (int i = 0;; i = (i + 1) % kN) {
             {
                 std::unique_lock<std::mutex> g(m_);
@@ -189,40 +275,43 @@ class BlockReader {
                 if (stop_) return;
             }
             Block& b = blk_[i];
-            size_t got = tail.size();
-            if (b.text.size() < got + kCap + 1) b.text.resize(got + kCap + 1);
-            if (got) std::memcpy(b.text.data(), tail.data(), got);
-            tail.clear();
-            bool eof = false;
-            for (;;) {                                              // until the block holds a line end (or the file ends)
-                const size_t want = b.text.size() - 1 - got;
-                size_t have = 0;
-                while (have < want) {                               // gzread returns short counts only at the end of the stream
-                    const int r = gzread(f_, b.text.data() + got + have, (unsigned) (want - have));
-                    if (r < 0) { failed_ = true; eof = true; break; }   // corrupt deflate data, I/O error
-                    if (r == 0) {                                   // end of data: a stream cut before its trailer is an error, not EOF
-                        int errnum = Z_OK;
-                        (void) gzerror(f_, &errnum);
-                        if (errnum != Z_OK && errnum != Z_STREAM_END) failed_ = true;
-                        eof = true; break;
-                    }
-                    have += (size_t) r;
-                }
-                got += have;
-                if (eof) break;
-                size_t k = got;
-                while (k > 0 && b.text[k - 1] != '\n') k--;
-                if (k > 0) { tail.assign(b.text.data() + k, b.text.data() + got); got = k; break; }
-                b.text.resize(b.text.size() * 2);                   // one line longer than the block: keep reading
+            const size_t c = carry.size();
+            if (b.text.size() < c + kCap + 1) b.text.resize(c + kCap + 1);
+            if (c) std::memcpy(b.text.data(), carry.data(), c);
+            b.member_end = false; b.data0 = c;
+            size_t have = c, end_of_lines = 0;
+            bool cut = false;
+            while (!eof && !cut) {                                  // until the block holds a line end (or the file / a member ends)
+                const size_t want = b.text.size() - 1 - have;
+                have += fetch(b, have, have, want, eof);
+                if (b.member_end || eof) break;
+                size_t k = have;
+                while (k > c - tail && b.text[k - 1] != '\n') k--;
+                if (k > c - tail) { end_of_lines = k; cut = true; break; }
+                if (b.text.size() - 1 - have < 4096) b.text.resize(b.text.size() * 2);   // one line longer than the block: keep reading
             }
-            if (failed_) got = 0;                                   // hand over the end marker; load_cov asks failed()
+            size_t new_tail = 0;
+            if (!cut) {                                             // the end of a member or of the file
+                if (eof) end_of_lines = have;                       // (a last line without '\n' is a line)
+                else {
+                    size_t k = have;
+                    while (k > c - tail && b.text[k - 1] != '\n') k--;
+                    end_of_lines = k;
+                }
+            }
+            new_tail = have - end_of_lines;
+            b.off = c - tail; b.len = end_of_lines - b.off; b.data_len = have - c;
+            const size_t keep = std::min(have, std::max(kHist, new_tail));
+            carry.assign(b.text.data() + have - keep, b.text.data() + have);
+            tail = new_tail;
+            const bool nothing = failed_ || (b.data_len == 0 && b.len == 0 && eof && !b.member_end);
             {
                 std::lock_guard<std::mutex> g(m_);
-                b.len = got; b.last = got == 0; b.recs.clear();
-                b.state = b.last ? 3 : 1;
+                b.last = nothing; b.recs.clear();
+                b.state = nothing ? 3 : 1;
             }
             cv_.notify_all();
-            if (got == 0) return;
+            if (nothing) return;
         }
     }
     void parse_loop() {
@@ -234,18 +323,27 @@ class BlockReader {
                 if (stop_ || blk_[parse_].last) { cv_.notify_all(); return; }
                 i = parse_; blk_[i].state = 2; parse_ = (parse_ + 1) % kN;
             }
-            parse_block(blk_[i].text.data(), blk_[i].len, blk_[i].recs);
-            { std::lock_guard<std::mutex> g(m_); blk_[i].state = 3; }
+            Block& b = blk_[i];
+            b.crc = gzip_ ? (uint32_t) crc32(0L, reinterpret_cast<const Bytef*>(b.text.data() + b.data0), (uInt) b.data_len) : 0u;
+            parse_block(b.base(), b.len, b.recs);
+            { std::lock_guard<std::mutex> g(m_); b.state = 3; }
             cv_.notify_all();
         }
     }
-    gzFile f_;
+    gzFile gz_ = nullptr;
+    int fd_ = -1;
+    const uint8_t* map_ = nullptr;
+    size_t map_len_ = 0;
+    bool map_is_static_ = false, gzip_ = false, open_failed_ = false;
+    hfz::Inflater inf_;
     Block blk_[kN];
     std::thread prod_;
     std::vector<std::thread> work_;
     std::mutex m_;
     std::condition_variable cv_;
     int parse_ = 0, cons_ = 0, held_ = -1;
+    uint32_t run_crc_ = 0;
+    uint64_t run_len_ = 0;
     bool stop_ = false;
     std::atomic<bool> failed_{false};
 };
@@ -329,12 +427,10 @@ void parse_block(char* text, size_t len, std::vector<CovRec>& out) {
 // ---- .cov / .cov.gz: header (track_reader.c:48-457), rows (:751-818), chunks (chunk.c:240-294), windows ----
 hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
     if (chunk_len <= 0 || window_len <= 0) { g_io_err = "chunkLen/windowLen must be > 0"; return nullptr; }
-    gzFile f = gzopen(path, "r");                                   // also reads uncompressed text
-    if (!f) { g_io_err = std::string("[Error] Unable to open ") + path; return nullptr; }
-    gzbuffer(f, 1 << 20);
+    BlockReader* reader = new BlockReader(path);                    // .cov.gz (gzip members) and uncompressed text
+    if (reader->open_failed()) { delete reader; g_io_err = std::string("[Error] Unable to open ") + path; return nullptr; }
     hfio_table* t = new hfio_table();
     t->chunk_len = chunk_len; t->window_len = window_len;
-    BlockReader* reader = new BlockReader(f);
     bool have_ann = false, have_reg = false, have_lab = false, have_avg = false;
     int n_ann = 0, n_reg = 0, parsed_cov = 0;
     std::string ctg;
@@ -343,7 +439,7 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
     ChunkMeta cur{};
     WindowAcc acc;
     int next_pos = 0;                                               // next base expected in the current contig
-    auto fail = [&](const std::string& m) { g_io_err = m; delete reader; gzclose(f); delete t; return (hfio_table*) nullptr; };
+    auto fail = [&](const std::string& m) { g_io_err = m; delete reader; delete t; return (hfio_table*) nullptr; };
     auto first_chunk = [&]() {
         cur.ctg = ctg; cur.ctg_len = ctg_len; cur.s = 0;
         cur.e = ctg_len < 2 * chunk_len ? ctg_len - 1 : chunk_len - 1;   // chunk.c:262
@@ -356,7 +452,7 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
     while (BlockReader::Block* blk = reader->next())
     for (const CovRec& r : blk->recs) {
         if (r.kind == CovRec::HEADER) {
-            const char* line = blk->text.data() + r.s;
+            const char* line = blk->base() + r.s;
             if (starts_with(line, "#annotation:len") && !have_ann) {
                 const char* p = field_after(line, 2); n_ann = p ? std::atoi(p) : 0; have_ann = true;
                 t->annotation_names.assign((size_t) (n_ann > 0 ? n_ann : 0), "NA");
@@ -388,7 +484,7 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
         if (!have_reg) return fail("Error: No '#region:len:' found in the header. region len should be at least 1.");
         if (n_reg <= 0 || n_reg > HF_MAXREGIONS) return fail("Error: The value of '#region:len:' in the header should be at least 1 (and at most 64).");
         if (r.kind == CovRec::CONTIG) {
-            char* line = blk->text.data() + r.s;
+            char* line = blk->base() + r.s;
             if (in_contig) { t->push_window(acc); t->close_chunk(cur); }
             char* sp = std::strchr(line, ' ');
             ctg_len = sp ? std::atoi(sp + 1) : 0;
@@ -420,9 +516,8 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
         }
         next_pos = e + 1;
     }
-    if (reader->failed()) return fail(std::string("Error: ") + path + " is truncated or corrupt (zlib reported an error before the end of the stream)");
+    if (reader->failed()) return fail(std::string("Error: ") + path + " is truncated or corrupt (the deflate stream ended on an error, or a gzip member's CRC-32 / length does not match)");
     delete reader;
-    gzclose(f);
     if (in_contig) { t->push_window(acc); t->close_chunk(cur); }
     if (!have_ann || !have_reg) { g_io_err = "Error: missing '#annotation:len:' / '#region:len:' header"; delete t; return nullptr; }
     if (parsed_cov != n_reg) { g_io_err = "Error: Number of parsed region coverages does not match '#region:len:' in the header line."; delete t; return nullptr; }
@@ -517,6 +612,43 @@ hfio_table* hfio_load(const char* path, int chunk_len, int window_len) {
 }
 
 void hfio_destroy(hfio_table* t) { delete t; }
+
+int hfio_gunzip(const char* path, unsigned char** out, size_t* n) {
+    if (!path || !out || !n) return -5;
+    *out = nullptr; *n = 0;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return -5;
+    std::vector<uint8_t> in;
+    {
+        uint8_t buf[1 << 16];
+        size_t r;
+        while ((r = std::fread(buf, 1, sizeof buf, f)) > 0) in.insert(in.end(), buf, buf + r);
+        std::fclose(f);
+    }
+    static thread_local hfz::Inflater z;
+    z.in = in.data(); z.in_len = in.size(); z.pos = 0;
+    int rc = z.read_gzip_header();
+    if (rc != hfz::OK) return rc == hfz::ERR_TRUNCATED ? -2 : -3;
+    size_t cap = 1 << 20, len = 0, member0 = 0;
+    uint8_t* o = (uint8_t*) std::malloc(cap);
+    if (!o) return -5;
+    for (;;) {
+        if (cap - len < (1 << 16)) { cap *= 2; uint8_t* p2 = (uint8_t*) std::realloc(o, cap); if (!p2) { std::free(o); return -5; } o = p2; }
+        size_t got = 0;
+        rc = z.run(o + len, cap - len, len - member0, &got);
+        len += got;
+        if (rc == hfz::OK) continue;
+        if (rc != hfz::END_OF_MEMBER) { std::free(o); return rc == hfz::ERR_TRUNCATED ? -2 : -1; }
+        uint32_t crc = 0, isz = 0;
+        if (z.read_gzip_trailer(&crc, &isz) != hfz::OK) { std::free(o); return -2; }
+        if ((uint32_t) crc32(0L, o + member0, (uInt) (len - member0)) != crc || (uint32_t) (len - member0) != isz) { std::free(o); return -4; }
+        member0 = len;
+        if (z.pos >= z.in_len || z.read_gzip_header() != hfz::OK) break;     // the next member, or the end (trailing bytes are ignored)
+    }
+    *out = o; *n = len;
+    return 0;
+}
+void hfio_free(void* p) { std::free(p); }
 int64_t hfio_n_windows(const hfio_table* t) { return (int64_t) t->cov.size(); }
 int32_t hfio_n_chunks(const hfio_table* t) { return (int32_t) t->chunks.size(); }
 int32_t hfio_n_regions(const hfio_table* t) { return (int32_t) t->region_coverages.size(); }

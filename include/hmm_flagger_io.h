@@ -14,6 +14,7 @@
 #define HMM_FLAGGER_IO_H
 
 #include <stdint.h>
+#include <stddef.h>
 #include "hmm_flagger_hip.h"
 
 #ifdef __cplusplus
@@ -67,6 +68,11 @@ int hfio_write_summary(hfio_table *t, const int8_t *labels, const char *output_p
 int32_t hfio_truth_available(const hfio_table *t);
 int32_t hfio_n_labels(const hfio_table *t);
 int hfio_write_posterior_bed(const hfio_table *t, const double *posterior, const int8_t *labels, const char *path);
+/* The loader's own DEFLATE / gzip decoder (csrc/hf_inflate.h) on a whole file, for tests and tools: every member of `path`
+ * decoded into one malloc'ed buffer (*out, *n; free with hfio_free), each member's CRC-32 and ISIZE verified.
+ * 0, or -1 data error / -2 truncated / -3 not a gzip file / -4 CRC-32 or length mismatch / -5 cannot read the file. */
+int hfio_gunzip(const char *path, unsigned char **out, size_t *n);
+void hfio_free(void *p);
 
 #ifdef __cplusplus
 }
