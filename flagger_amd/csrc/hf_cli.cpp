@@ -134,6 +134,7 @@ static const char* run_error() { return g_run ? g_run->error() : hf_last_error()
 // writeBenchmarkingStats, hmm_flagger.c:134-162
 static int write_summary(Run& run, const std::string& dir, const std::string& suffix, const std::vector<std::string>& labelNames,
                          const char* binArrayFilePath, double overlapRatioThreshold, int threads) {
+    const double t_begin = real_time();
     const int64_t N = hfio_n_windows(run.tab);
     std::vector<int8_t> labels((size_t) N);
     int rc = run.labels(labels.data());
@@ -147,6 +148,7 @@ static int write_summary(Run& run, const std::string& dir, const std::string& su
         exit(EXIT_FAILURE);
     }
     fprintf(stderr, "[%s] Writing tables to file %s is done.\n", ts(), path.c_str());
+    if (getenv("HF_CLI_TIMING")) fprintf(stderr, "[phase]   (summary tables %s: %.1f ms)\n", suffix.c_str(), (real_time() - t_begin) * 1e3);
     return HF_OK;
 }
 
