@@ -183,7 +183,7 @@ class BlockReader {
         if (prod_.joinable()) prod_.join();
         for (auto& t : work_) if (t.joinable()) t.join();
         if (gz_) gzclose(gz_);
-        if (map_) munmap(const_cast<uint8_t*>(map_), map_len_ ? map_len_ : 1);
+        if (map_ && !map_is_static_) munmap(const_cast<uint8_t*>(map_), map_len_);
         if (fd_ >= 0) close(fd_);
     }
     bool open_failed() const { return open_failed_; }
