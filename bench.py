@@ -68,8 +68,11 @@ def cpu_baseline(store_full, K, alpha, cores):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: a timed region of a quarter of a second behind a warm-up long enough for the GPU's clocks and the HIP runtime's
+    # one-off work (a ~30 ms stall some 80 ms into a process's first launches, profiles/tools/r03_step_drift.py): 20 steps behind
+    # 3 warm-up steps measure 0.127 ms per step, behind 1000 warm-up steps 0.121, 2000 steps behind 1000: 0.118 (same box)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=1000)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink contig lengths (testing only; 1.0 = BASELINE workload)")
     ap.add_argument("--algo", choices=["scan", "seq"], default="scan")
     ap.add_argument("--config", type=int, choices=[2, 4, 5, 6], default=2,
