@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
 #pragma unroll
         for (int s = 0; s < 4; s++) u[s] = Rl->trans[s][4];     // the end vector (hmm.c:452-467)
         M4 Q;
-        double xv[16];
+        double xv[16], xs[16];     // the products of the lanes before / after this one (exclusive prefix / suffix)
         if constexpr (FUSED) {
             // ---- A (one launch): the lane product is computed here (k_seg_prod's loop); the segment's product is what the prefix
             // scan leaves in lane 63: it is PUBLISHED for the chunk's other segments, theirs are awaited (seg_gather) ----
@@ -442,6 +442,15 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 for (int s = 0; s < 4; s++) v[s] /= sv;
             }
             if (BWD) v4_renorm(u);
+            if (BWD) {
+                // the second scan needs nothing from the other segments: it runs BEFORE their products are awaited, so that the
+                // skew between the segments of a chunk is spent here instead of in the polls below (k_seg_fb 60.5 -> 59 us)
+                m4_unpark(Q, lane, blk);
+                m4_scan_suffix(Q, lane);
+#pragma unroll
+                for (int k = 0; k < 16; k++) xs[k] = __shfl_down(Q.m[k], 1);   // exclusive suffix: lanes lane+1..63
+            }
+            TR_STAMP(3);
             if (d.nseg > 1) {
                 // lane l takes the product of segment base + l of the chunk (waits for its flag: bounded), a chain step reads it
                 // from that lane (v_readlane: wave-uniform index)
@@ -479,7 +488,6 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                         for (int q = (d.nseg - 1 < base + 63 ? d.nseg - 1 : base + 63); q >= lo; q--) { double M[16]; from_lane(q - base, M); v4_mul_left(u, M); v4_renorm(u); }
                     }
             }
-            TR_STAMP(3);
             TR_STAMP(4);
         } else {
         // ---- A (two launches): loads, in the order they are consumed (vmcnt counts in order): row indices, the products of the
@@ -540,14 +548,16 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
         if (chunk_first) { fin[0] = 1.0; fin[1] = 0.0; fin[2] = 0.0; fin[3] = 0.0; }   // (1,0,0,0)·A_first = start∘e
         TR_STAMP(5);
         if (BWD) {
-            m4_unpark(Q, lane, blk);
-            m4_scan_suffix(Q, lane);
+            if constexpr (!FUSED) {
+                m4_unpark(Q, lane, blk);
+                m4_scan_suffix(Q, lane);
 #pragma unroll
-            for (int k = 0; k < 16; k++) xv[k] = __shfl_down(Q.m[k], 1);   // exclusive suffix: lanes lane+1..63
+                for (int k = 0; k < 16; k++) xs[k] = __shfl_down(Q.m[k], 1);   // exclusive suffix: lanes lane+1..63
+            }
             // direction of b at the lane's last window: everything after it applied to the end vector
 #pragma unroll
             for (int s = 0; s < 4; s++) bdir[s] = u[s];
-            if (lane < 63) v4_mul_left(bdir, xv);
+            if (lane < 63) v4_mul_left(bdir, xs);
         }
     }
     TR_STAMP(6);

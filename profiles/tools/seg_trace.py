@@ -9,8 +9,8 @@ t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, N).astype(np.int64)
 t = t[t[:, 19] > 0]
 L = t[:, 19].astype(float)
 print("workgroups", len(t), " windows per lane: mean %.2f" % L.mean(), " windows per segment: mean %.0f" % t[:, 20].mean())
-names = ["row indices, offset table, lane product (8 row fetches)", "park, prefix scan, product published", "wait for the other segments + both chains",
-         "-", "carried-in f", "unpark + suffix scan + direction of b", "forward replay",
+names = ["row indices, offset table, lane product (8 row fetches)", "park, prefix scan, product published", "unpark + suffix scan (before the other segments are awaited)",
+         "wait for the other segments + both chains", "carried-in f", "direction of b", "forward replay",
          "log-likelihood", "b at the last window, label", "backward replay", "last record, labels out"]
 life = (t[:, 11] - t[:, 0]).astype(float)
 print("cycles per workgroup (mean), total %.0f:" % life.mean())
