@@ -31,3 +31,20 @@ print("first workgroup starts .. last ends: %.0f cycles (s_memtime)" % float(t[:
 print("workgroup end (s_memrealtime, us after the first end): p10 %.1f  p50 %.1f  p90 %.1f  max %.1f" %
       tuple((np.percentile(e, q) - e.min()) / 100.0 for q in (10, 50, 90, 100)))
 print("lifetime cycles: p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % tuple(np.percentile(life, q) for q in (10, 50, 90, 100)))
+# who is slow: the phases of the slowest and the fastest tenth of the workgroups, lifetimes by XCD, by SIMD slot, by windows per lane
+order = np.argsort(life)
+n10 = max(1, len(order) // 10)
+fast, slow = order[:n10], order[-n10:]
+print("phase means, fastest tenth | slowest tenth of the workgroups (by lifetime):")
+for k, nm in enumerate(names):
+    d = (t[:, k + 1] - t[:, k]).astype(float)
+    print("  %-58s %8.0f | %8.0f" % (nm, d[fast].mean(), d[slow].mean()))
+print("start (cycles after the first start): fastest tenth %.0f, slowest tenth %.0f" % ((t[fast, 0] - t[:, 0].min()).mean(), (t[slow, 0] - t[:, 0].min()).mean()))
+print("windows per lane: fastest tenth %.2f, slowest tenth %.2f" % (L[fast].mean(), L[slow].mean()))
+for x in sorted(set((xcc & 0xf).tolist())):
+    sel = (xcc & 0xf) == x
+    print("  XCD %d: %4d workgroups, lifetime mean %.0f  p90 %.0f" % (x, int(sel.sum()), life[sel].mean(), np.percentile(life[sel], 90)))
+simd = (hw >> 4) & 3
+for x in range(4):
+    sel = simd == x
+    if sel.any(): print("  SIMD %d: %4d workgroups, lifetime mean %.0f" % (x, int(sel.sum()), life[sel].mean()))
