@@ -452,10 +452,30 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             }
             TR_STAMP(3);
             if (d.nseg > 1) {
-                // lane l takes the product of segment base + l of the chunk (waits for its flag: bounded), a chain step reads it
-                // from that lane (v_readlane: wave-uniform index)
+                // lane l takes the product of segment base + l of the chunk (waits for its flag: bounded)
                 double Tm[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) Tm[k] = 0.0;
                 int have_base = -1;
+                // the gathered products go through the (idle) row block: lane l parks segment base + l's matrix, a chain step reads
+                // matrix q with one broadcast read per 16 bytes — LDS instructions instead of 32 v_readlane per step (-0.5 us)
+                auto stage = [&]() {
+                    M4 T;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) T.m[k] = Tm[k];
+                    __builtin_amdgcn_s_waitcnt(0xC07F);          // earlier reads of the block have returned
+                    __builtin_amdgcn_wave_barrier();
+                    m4_park(T, lane, blk);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                };
+                auto from_lane = [&](int src, double M[16]) {
+                    const double2* __restrict__ row = reinterpret_cast<const double2*>(blk) + src * 8;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { const double2 t2 = row[(k + (src >> 1)) & 7]; M[2 * k] = t2.x; M[2 * k + 1] = t2.y; }
+                };
+
                 auto gather = [&](int base) {
                     if (base == have_base) return;
                     have_base = base;
@@ -470,12 +490,9 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
 #pragma unroll
                         for (int k = 0; k < 16; k++) Tm[k] = seg_xcu_load(Pseg + (int64_t) (d.seg0 + q) * 16 + k);
                     }
+                    stage();
                 };
-                auto from_lane = [&](int src, double M[16]) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++)
-                        M[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(Tm[k]), src), __builtin_amdgcn_readlane(__double2loint(Tm[k]), src));
-                };
+
                 for (int base = 0; base < d.k; base += 64) {                  // through the chunk's earlier segments
                     gather(base);
                     const int hi = d.k < base + 64 ? d.k : base + 64;
