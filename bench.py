@@ -81,8 +81,8 @@ def main():
                          "6 = not a BASELINE config: configs[2] with over-dispersed (negative-binomial, variance = 3 x mean) coverage")
     ap.add_argument("--overdispersion", type=float, default=3.0, help="config 6 only: variance / mean of the negative-binomial coverage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--event-stride", type=int, default=4,
-                    help="the dominant kernel is bracketed by a pair of HIP events in every n-th timed step (default 4; 1 = every step)")
+    ap.add_argument("--event-stride", type=int, default=32,
+                    help="the dominant kernel is bracketed by a pair of HIP events in every n-th timed step (default 32: a pair costs ~15 us of host and device time, 1/32 of that per step; 1 = every step)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events inside the timed region; the dominant kernel's duration then comes from the untimed "
                          "passes that follow — for comparing launch paths, not the default")

@@ -3,6 +3,7 @@
 // operand order of the reference (programs/submodules/hmm_utils/hmm_utils.c) so that the only
 // differences from the CPU path are the last-ulp behaviour of exp()/log().
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/hmm_flagger_hip.h"
@@ -126,6 +127,25 @@ struct DevParams {
     uint8_t item_s[HF_TABLE_MAX_ITEMS], item_u[HF_TABLE_MAX_ITEMS], item_c[HF_TABLE_MAX_ITEMS];
     DevRegion reg[1];                   // n_regions entries
 };
+
+// ---- the parameter block of a one-region model through the KERNEL ARGUMENTS of the pass's first kernel ----
+// Per EM step the host used to enqueue a copy of the parameter block (a blit kernel: 2.5-3 us, a kernel boundary and one more
+// API call on the step's critical path) before k_tables.  For one region the bytes that are in use (the components in use, not
+// HF_MAXCOMP of them) fit the 4 KiB of kernel arguments: the host sends every 8-byte word in use with its place in the DevParams image,
+// every block of k_tables rebuilds the image in LDS, block 0 also in global memory for the kernels after it.
+#define HF_KP_MAX_WORDS 384
+struct KParams {
+    int32_t n_words, pad;
+    uint16_t idx[HF_KP_MAX_WORDS];     // where word i goes: 8-byte words of the DevParams image
+    double data[HF_KP_MAX_WORDS];
+};
+static_assert(sizeof(KParams) <= 3860, "k_tables' other arguments need the rest of the 4 KiB");
+static_assert(sizeof(DevParams) % 8 == 0 && offsetof(DevParams, reg) % 8 == 0, "the image is copied in 8-byte words");
+
+// all threads of a block: the image out of the kernel arguments (dst: LDS, or global memory)
+__device__ __forceinline__ void kparams_expand(const KParams& kp, double* __restrict__ dst, int tid, int nthreads) {
+    for (int i = tid; i < kp.n_words; i += nthreads) dst[kp.idx[i]] = kp.data[i];
+}
 
 __device__ __forceinline__ bool hf_err_is_truncexp(const DevParams* __restrict__ P) {
     return P->model_type == HF_MODEL_TRUNC_EXP_GAUSSIAN;

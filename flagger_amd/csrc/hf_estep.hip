@@ -152,6 +152,8 @@ struct hf_ctx {
     double* d_tile_stats = nullptr; // [ntiles][R][NA(16)]
     unsigned* d_flags = nullptr;
     DevParams* d_params = nullptr; DevParams* h_params = nullptr; size_t params_bytes = 0;
+    KParams kparams{};             // the parameter block as kernel arguments of k_tables (one region: pack_kparams)
+    bool kp_ok = true, kp_now = false;   // HF_PARAMS_COPY=1 switches the kernel-argument path off; this pass uses it
     unsigned* h_flags = nullptr;
     double* h_total = nullptr;     // pinned [V+1]: reduced vector + flag word, one copy per pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
@@ -657,6 +659,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     hipMemset(ctx->d_cks, 0, 8);
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
     DMALLOC(ctx->d_params, ctx->params_bytes);
+    hipMemset(ctx->d_params, 0, ctx->params_bytes);   // (the kernel-argument path writes the bytes in use only)
     {   // one pinned block: the result vector (+ flag word, stamp, checksums) | the flag word of hf_check | the parameter block
         const size_t tot_bytes = ((size_t) ctx->V + 2 + HF_MAXREGIONS) * 8;
         char* pin = nullptr;
@@ -1067,6 +1070,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     { const char* e = std::getenv("HF_SEG_LAUNCHES"); ctx->seg_fused = !(e && e[0] == '2'); }   // HF_SEG_LAUNCHES=2: k_seg_prod + k_seg_fb
     ctx->seg_test_timeout = std::getenv("HF_SEG_TEST_TIMEOUT") != nullptr;
     { const char* e = std::getenv("HF_STREAM_STAMP"); if (e && e[0] == '0') ctx->stream_stamp_ok = false; }
+    { const char* e = std::getenv("HF_PARAMS_COPY"); if (e && e[0] == '1') ctx->kp_ok = false; }   // the parameter block by a copy ahead of every pass
     {
         const char* e = std::getenv("HF_STATS");
         ctx->stats_mode = (e && std::strcmp(e, "chunks") == 0) ? HF_STATS_CHUNKS : HF_STATS_ROWS;
@@ -1199,9 +1203,44 @@ static int pack_params(hf_ctx* ctx, const hf_params* p) {
 }
 
 
+// the 8-byte words of the packed block that are in use, each with its place in the image (hf_device.h KParams); false: they do not fit
+static bool pack_kparams(hf_ctx* ctx, const hf_params* p) {
+    if (ctx->R != 1) return false;
+    const DevParams* h = ctx->h_params;
+    KParams& kp = ctx->kparams;
+    const char* const base = reinterpret_cast<const char*>(h);
+    int nw = 0;
+    bool fits = true;
+    auto add = [&](const void* first, size_t bytes) {
+        const size_t o = (size_t) (reinterpret_cast<const char*>(first) - base);
+        if (!fits || bytes == 0) return;
+        if (o % 8 || bytes % 8 || nw + (int) (bytes / 8) > HF_KP_MAX_WORDS) { fits = false; return; }
+        std::memcpy(kp.data + nw, first, bytes);
+        for (size_t i = 0; i < bytes / 8; i++) kp.idx[nw + (int) i] = (uint16_t) (o / 8 + i);
+        nw += (int) (bytes / 8);
+    };
+    const DevRegion* g = &h->reg[0];
+    add(h, offsetof(DevParams, reg));                                                    // the header, the item list
+    add(g->trans, sizeof g->trans + sizeof g->tcond + 2 * sizeof(double));               // trans, tcond, lambda, trunc_point: contiguous
+    static_assert(offsetof(DevRegion, tcond) == sizeof(double) * 25 && offsetof(DevRegion, lambda) == sizeof(double) * (25 + 128) &&
+                  offsetof(DevRegion, mean) == sizeof(double) * (25 + 128 + 2), "DevRegion starts with trans | tcond | lambda | trunc_point");
+    for (int s = 0; s < HF_NSTATES; s++) {
+        const size_t nc = (size_t) p->ncomp[s] * sizeof(double);
+        add(g->mean[s], nc); add(g->var[s], nc); add(g->weight[s], nc); add(g->gvar[s], nc); add(g->gnorm[s], nc);
+        for (int u = 0; u < 4; u++) add(g->m1[s][u], nc);
+    }
+    add(&g->te_lam, 2 * sizeof(double));
+    if (!fits) return false;
+    kp.n_words = nw; kp.pad = 0;
+    return true;
+}
+
 // everything one pass enqueues on `st` after the parameters were packed into the pinned block
 static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t st) {
-    HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
+    // the parameter block: through the kernel arguments of k_tables when it fits them (one region, HF_ALGO_SCAN, Gaussian models:
+    // hf_device.h KParams), a copy ahead of the pass otherwise
+    ctx->kp_now = ctx->kp_ok && ctx->C > 0 && ctx->algo == HF_ALGO_SCAN && p->model_type != HF_MODEL_NEGATIVE_BINOMIAL && pack_kparams(ctx, p);
+    if (!ctx->kp_now) HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
     for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
     ctx->prof_now = ctx->prof_stride <= 1 || (ctx->prof_pass++ % ctx->prof_stride) == 0;
     ctx->pass_rows = false; ctx->pass_bound = false;
@@ -1242,10 +1281,16 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                                    ctx->d_slow_w, ctx->d_rec, ctx->M, ctx->d_nbE, ctx->d_lutE, ctx->d_Es, ctx->d_flags);
             else
             {
-#define HF_LAUNCH_TABLES(J) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables<J>), dim3((unsigned) ((jobs + J - 1) / J + (jobs == 0))), dim3(256), 0, st, nk, \
+#define HF_LAUNCH_TABLES(J, KA, KP) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables<J, KA>), dim3((unsigned) ((jobs + J - 1) / J + (jobs == 0))), dim3(256), 0, st, nk, \
                                kl, ctx->n_slow, ctx->d_slow_w, ctx->d_rec, ctx->d_beta, ctx->M, ctx->K, ctx->d_params, ctx->d_lutE, ctx->d_lutC, \
-                               ctx->d_Es, ctx->d_Cs, ctx->d_flags, arows ? ctx->d_arow_cls : (const int32_t*) nullptr, arows ? ctx->d_lutA : (double*) nullptr)
-                if (jobs < 64 * 1024) HF_LAUNCH_TABLES(HF_TABLE_JOBS_SMALL); else HF_LAUNCH_TABLES(HF_TABLE_JOBS_LARGE);
+                               ctx->d_Es, ctx->d_Cs, ctx->d_flags, arows ? ctx->d_arow_cls : (const int32_t*) nullptr, arows ? ctx->d_lutA : (double*) nullptr, \
+                               KP, ctx->d_params)
+                if (ctx->kp_now) {     // the parameter block travels in the kernel arguments (pack_kparams): no copy was enqueued
+                    if (jobs < 64 * 1024) HF_LAUNCH_TABLES(HF_TABLE_JOBS_SMALL, true, ctx->kparams); else HF_LAUNCH_TABLES(HF_TABLE_JOBS_LARGE, true, ctx->kparams);
+                } else {
+                    const NoKParams none{0};
+                    if (jobs < 64 * 1024) HF_LAUNCH_TABLES(HF_TABLE_JOBS_SMALL, false, none); else HF_LAUNCH_TABLES(HF_TABLE_JOBS_LARGE, false, none);
+                }
 #undef HF_LAUNCH_TABLES
             }
         }

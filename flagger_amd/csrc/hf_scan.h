@@ -11,6 +11,7 @@
 // No emission value is ever written to HBM per window: a row is 128 B gathered from the tables (L2-resident) where
 // it is used.
 #pragma once
+#include <type_traits>
 #include "hf_device.h"
 
 struct M4 { double m[16]; };   // row-major: m[pre*4 + s]
@@ -212,14 +213,16 @@ __device__ __forceinline__ uint32_t load_recs(const uint32_t* __restrict__ rec, 
 #define HF_TABLE_JOBS_LARGE 32
 // flags: 1 star (table key), 2 first, 4 active; bits 8..: transition class of the job's row of A (hf_seg.h); row: index of the row in lutE / lutC units
 struct TableJob { double x, px, bt; int64_t row; int32_t r; int32_t flags; };
-template <int HF_TABLE_JOBS_PER_BLOCK>
+struct NoKParams { int32_t n_ranges; };
+template <int HF_TABLE_JOBS_PER_BLOCK, bool KARG>
 __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __restrict__ keys, int n_slow,
                                                 const int64_t* __restrict__ slow_w, const uint32_t* __restrict__ rec,
                                                 const double* __restrict__ beta, int M, int K,
-                                                const DevParams* __restrict__ P, double* __restrict__ lutE,
+                                                const DevParams* __restrict__ Pg, double* __restrict__ lutE,
                                                 double* __restrict__ lutC, double* __restrict__ Es,
                                                 double* __restrict__ Cs, unsigned* __restrict__ flags,
-                                                const int32_t* __restrict__ cls, double* __restrict__ lutA) {
+                                                const int32_t* __restrict__ cls, double* __restrict__ lutA,
+                                                const std::conditional_t<KARG, KParams, NoKParams> kp, DevParams* __restrict__ P_out) {
     // cls / lutA (statistics by emission row, hf_seg.h): job j also writes row j of A = (transition table of class cls[j]) ∘ E;
     // `keys` is then the list of the (key, class) pairs that occur — a key with two classes is evaluated twice (same values)
     __shared__ TableJob s_job[HF_TABLE_JOBS_PER_BLOCK];
@@ -228,6 +231,16 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
     __shared__ unsigned char s_item[3][HF_TABLE_MAX_ITEMS];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) *flags = 0u;   // first kernel of every pass
+    // the parameter block: in global memory (copied before the launch), or — one region, hf_device.h KParams — in the kernel
+    // arguments: rebuilt here in LDS, and by block 0 in global memory for the kernels that follow
+    __shared__ double s_params[KARG ? sizeof(DevParams) / 8 : 1];
+    const DevParams* __restrict__ P;
+    if constexpr (KARG) {
+        kparams_expand(kp, s_params, tid, 256);
+        if (blockIdx.x == 0) kparams_expand(kp, reinterpret_cast<double*>(P_out), tid, 256);
+        __syncthreads();
+        P = reinterpret_cast<const DevParams*>(s_params);
+    } else P = Pg;
     const int ncol = P->ncomp[3], n_items = P->n_items;
     const bool te = hf_err_is_truncexp(P);
     const int job0 = blockIdx.x * HF_TABLE_JOBS_PER_BLOCK;
