@@ -403,13 +403,13 @@ def main():
         # what actually bounds the kernel (also from a committed counter pass of this command, not this run): the share of a SIMD's
         # time in which its VALU issues, 3 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES with three resident wavefronts per SIMD
         valu_busy, valu_src = None, None
-        sq = os.path.join(ROOT, "profiles", "r03m_pmc_sq_b.json")
+        sq = os.path.join(ROOT, "profiles", "r03n_pmc_sq_b.json")
         if os.path.exists(sq) and world == 1 and args.scale == 1.0 and args.config == 2:
             try:
                 for k, v in json.load(open(sq)).items():
                     if k.split("<")[0] == dom and v.get("SQ_WAVE_CYCLES"):
                         valu_busy = 3.0 * v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
-                valu_src = "profiles/r03m_pmc_sq_b.json (rocprofv3 --pmc SQ pass of this command, not this run)"
+                valu_src = "profiles/r03n_pmc_sq_b.json (rocprofv3 --pmc SQ pass of this command, not this run)"
             except Exception:
                 valu_busy = None
         out = {
