@@ -616,6 +616,16 @@ def test_one_launch_segment_kernel_equals_two_launches(scale):
 
 
 @pytest.mark.parametrize("multi", [False, True], ids=["one context", "hf_multi"])
+def test_parameter_block_in_the_kernel_arguments_equals_the_copy(multi):
+    """One region: the words of the parameter block that are in use travel in k_tables' kernel arguments, every block rebuilds the
+    block in LDS and block 0 in global memory for the kernels after it (hf_device.h KParams).  HF_PARAMS_COPY=1 is the copy ahead
+    of every pass that other models still take: IDENTICAL log-likelihoods, statistics and labels."""
+    a = _pass_in_subprocess({}, 0.05, passes=3, multi=multi)
+    b = _pass_in_subprocess({"HF_PARAMS_COPY": "1"}, 0.05, passes=3, multi=multi)
+    assert a[0] == b[0] and a[2] == b[2] and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("multi", [False, True], ids=["one context", "hf_multi"])
 def test_hand_off_time_out_falls_back_to_two_launches(multi):
     """HF_SEG_TEST_TIMEOUT=1 makes the first one-launch pass wait for flags nobody writes: every wait is given up after its bounded
     number of polls, the flag word carries HF_FLAG_SYNC, the host re-runs the pass with two launches (hf_finish itself; hf_multi
