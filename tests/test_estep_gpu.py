@@ -615,6 +615,15 @@ def test_one_launch_segment_kernel_equals_two_launches(scale):
     assert a[0] == b[0] and a[2] == b[2] and np.array_equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("K", [12, 13, 16])
+def test_many_collapsed_components_with_and_without_the_kernel_argument_path(K):
+    """The words of a one-region parameter block fit k_tables' kernel arguments up to 12 collapsed components (hf_device.h
+    HF_KP_MAX_WORDS); 13 and more take the copy ahead of the pass — both against the oracle (the reference's command line clamps K to
+    2..10, the library accepts up to HF_MAXCOMP = 16)."""
+    store = synth.config(2, scale=0.01)
+    _check_pass(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, synth.HIFI_ALPHA, N.HF_ALGO_SCAN, n_iter=2)
+
+
 @pytest.mark.parametrize("multi", [False, True], ids=["one context", "hf_multi"])
 def test_parameter_block_in_the_kernel_arguments_equals_the_copy(multi):
     """One region: the words of the parameter block that are in use travel in k_tables' kernel arguments, every block rebuilds the
