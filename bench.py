@@ -25,6 +25,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 ALGO_BYTES_PER_WINDOW = 17.0   # 16-byte packed window record (chunk.c:669-697) + 1 label byte, SURVEY §8d
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector (VALU) peak: half of the 157.3 TF f32 vector peak of /opt/skills/guides/MI355X_MICROARCH.md
+                                # (256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz)
 
 
 def effective_cores() -> int:
@@ -81,8 +83,12 @@ def main():
                          "6 = not a BASELINE config: configs[2] with over-dispersed (negative-binomial, variance = 3 x mean) coverage")
     ap.add_argument("--overdispersion", type=float, default=3.0, help="config 6 only: variance / mean of the negative-binomial coverage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--event-stride", type=int, default=32,
-                    help="the dominant kernel is bracketed by a pair of HIP events in every n-th timed step (default 32: a pair costs ~15 us of host and device time, 1/32 of that per step; 1 = every step)")
+    ap.add_argument("--no-em-run", action="store_true", help="skip the `em_run` leg (a real EM to convergence in a fresh context, and the cold "
+                                                             "command line) that follows the timed region")
+    ap.add_argument("--event-stride", type=int, default=0,
+                    help="the dominant kernel is bracketed by a pair of HIP events in every n-th timed step; default 0 = max(1, min(32, steps // 8)): "
+                         "at least 8 samples however short the timed region is (the driver's --steps 20: every 2nd step, 10 samples; a pair "
+                         "costs a few microseconds of the step it is in); the line reports the MEDIAN of the samples and their number")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events inside the timed region; the dominant kernel's duration then comes from the untimed "
                          "passes that follow — for comparing launch paths, not the default")
@@ -215,18 +221,20 @@ def main():
         step()
         kt = em.kernel_times()
         dom = max(kt, key=kt.get)
+    stride = args.event_stride if args.event_stride > 0 else max(1, min(32, args.steps // 8))
     em.set_profiling([] if args.no_kernel_events else [dom])   # timed region: only the dominant kernel is bracketed by HIP events,
-    em.set_profiling_stride(args.event_stride)                 # and only in every n-th step (an event pair costs ~10 us of a 0.19 ms step)
-    dom_ms = 0.0
+    em.set_profiling_stride(stride)                            # and only in every n-th step
+    dom_ms, dom_samples = 0.0, []
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        if not args.no_kernel_events and i % stride == 0:      # this step carried the pair (hf_set_profiling_stride counts from 0): its duration
+            dom_samples.append(em.kernel_times()[dom])
     barrier()
     dt = time.perf_counter() - t0
-    if not args.no_kernel_events:          # the library summed the event pairs of the timed passes
-        tot, cnt = em.kernel_time_sums()[dom]
-        dom_ms = tot / max(cnt, 1)
+    if dom_samples:                        # median: the first sample follows the barrier's idle gap and runs at a lower clock
+        dom_ms = float(np.median(dom_samples))
     # per-kernel breakdown from a few extra passes outside the timed region (every kernel bracketed)
     em.set_profiling_stride(1)
     em.set_profiling(True)
@@ -241,6 +249,63 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
     ll = model.loglikelihood
+
+    # ---- a REAL EM run (SURVEY 8d defines the metric as N x (I + 1) / t_EM of one): fresh model, fresh context, EM to convergence
+    # (-n 100 -t 1e-3) + the final inference pass, wall-timed; no warm-up of its own.  Twice: in this (by now warm) process through the
+    # same native calls as the timed region, and as a COLD process — the hmm_flagger command line on the same windows (.bin), which
+    # times its own E-steps + M-steps (file reading, hf_create and output writing excluded, as the metric says) ----
+    em_run = None
+    if world == 1 and not dist_path and not args.no_em_run:
+        try:
+            rmodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
+            frac = 0.8 if args.config in (4, 5) else 0.95
+            c0 = time.perf_counter()
+            rem = hmm.EMList(store, rmodel, True, frac, device=local_rank, algo=algo)
+            create_ms = (time.perf_counter() - c0) * 1e3
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            passes, conv = 0, False
+            while passes < 100 and not conv:
+                conv = rem.em_iterate(rmodel, True, 1e-3)
+                passes += 1
+            rem.em_iterate(rmodel, False, 1e-3)                   # final inference, hmm_flagger.c:464
+            passes += 1
+            rdt = time.perf_counter() - r0
+            rem.close()
+            em_run = {"value": n_windows * passes / rdt, "unit": "windows/s", "passes": passes, "converged": bool(conv), "ms": rdt * 1e3,
+                      "ms_per_pass": rdt / passes * 1e3, "vs_steady_state_step": (rdt / passes) / (dt / args.steps),
+                      "hf_create_ms": create_ms, "final_loglikelihood": rmodel.loglikelihood,
+                      "what": "fresh context in this (warm) process: EM to convergence (100 iterations at most, tol 1e-3) + final pass, wall-timed, "
+                              "hf_create not included (reported beside it)"}
+            cli = os.path.join(ROOT, "flagger_amd", "csrc", "hmm_flagger")
+            if os.path.exists(cli) and args.config in (2, 4, 6):
+                import re
+                import subprocess
+                import tempfile
+                with tempfile.TemporaryDirectory() as td:
+                    store.write_bin(os.path.join(td, "w.bin"))
+                    os.mkdir(os.path.join(td, "o"))
+                    cmd = [cli, "-i", os.path.join(td, "w.bin"), "-n", "100", "-t", "1e-3", "-o", os.path.join(td, "o"), "--device", str(local_rank)]
+                    cmd += (["-x", "ont-r10", "-A", os.path.join(ROOT, "tests", "golden", "alpha_ont_r10.tsv")] if args.config == 4 else
+                            ["-W", str(store.window_len), "-A", os.path.join(ROOT, "tests", "golden", "alpha_hifi.tsv")])
+                    best = None
+                    for _ in range(3):                            # three cold processes: the median of their own EM+decode times
+                        w0 = time.perf_counter()
+                        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                        wall = time.perf_counter() - w0
+                        m = re.search(r"EM\+decode: (\d+) passes over (\d+) windows in ([0-9.]+) s", r.stderr)
+                        if r.returncode == 0 and m:
+                            best = (best or []) + [(float(m.group(3)), int(m.group(1)), wall)]
+                    if best:
+                        best.sort()
+                        t_em, p_cli, wall = best[len(best) // 2]
+                        em_run["cli_cold_process"] = {"value": n_windows * p_cli / t_em, "unit": "windows/s", "passes": p_cli, "ms": t_em * 1e3,
+                                                      "ms_per_pass": t_em / p_cli * 1e3, "vs_steady_state_step": (t_em / p_cli) / (dt / args.steps),
+                                                      "process_wall_ms": wall * 1e3, "runs": len(best),
+                                                      "what": "`hmm_flagger -n 100 -t 1e-3` on the same windows (.bin), a fresh process each: its own "
+                                                              "'EM+decode' line (E-steps + M-steps; loading, hf_create and output files excluded), median of the runs"}
+        except Exception as e:                  # the headline number above stays valid
+            em_run = {"error": repr(e)}
 
     # second leg at N > 1: the same exchange with one WHOLE genome per GPU (weak scaling), outside the timed region above
     weak = None
@@ -390,28 +455,55 @@ def main():
         # gfx950) and labelled with where it came from; null for any other workload
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and world == 1 and args.scale == 1.0 and args.config == 2:
+        pmc_tag = None
+        same_workload = world == 1 and args.scale == 1.0 and args.config == 2
+        if os.path.exists(pmc) and same_workload:
             try:
-                for k, v in json.load(open(pmc)).items():
-                    if k.split("<")[0] == dom:
+                doc = json.load(open(pmc))
+                pmc_tag = doc.get("_meta", {}).get("tag")
+                for k, v in doc.items():
+                    if not k.startswith("_") and k.split("<")[0] == dom:
                         traffic = v["hbm_bytes_per_launch"]
                 import hashlib
                 traffic_src = "profiles/pmc_traffic.json sha256:" + hashlib.sha256(open(pmc, "rb").read()).hexdigest()[:12] + \
+                              (f" = profiles/{pmc_tag}_pmc_traffic.json" if pmc_tag else "") + \
                               " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not this run)"
             except Exception:
                 traffic = None
-        # what actually bounds the kernel (also from a committed counter pass of this command, not this run): the share of a SIMD's
-        # time in which its VALU issues, 3 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES with three resident wavefronts per SIMD
-        valu_busy, valu_src = None, None
-        sq = os.path.join(ROOT, "profiles", "r03n_pmc_sq_b.json")
-        if os.path.exists(sq) and world == 1 and args.scale == 1.0 and args.config == 2:
+
+        def committed_counters(suffix):
+            """Per-launch counter averages of the dominant kernel from the committed SQ pass of the SAME snapshot as the traffic
+            figure (profiles/<tag>_<suffix>.json, the tag is in pmc_traffic.json's _meta): (values, source) or (None, None)."""
+            if not (pmc_tag and same_workload):
+                return None, None
+            f = os.path.join(ROOT, "profiles", f"{pmc_tag}_{suffix}.json")
             try:
-                for k, v in json.load(open(sq)).items():
-                    if k.split("<")[0] == dom and v.get("SQ_WAVE_CYCLES"):
-                        valu_busy = 3.0 * v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
-                valu_src = "profiles/r03n_pmc_sq_b.json (rocprofv3 --pmc SQ pass of this command, not this run)"
+                for k, v in json.load(open(f)).items():
+                    if k.split("<")[0] == dom:
+                        return v, f"profiles/{pmc_tag}_{suffix}.json (rocprofv3 --pmc SQ pass of this command, not this run)"
             except Exception:
-                valu_busy = None
+                pass
+            return None, None
+        # what actually bounds the kernel: (1) the share of a SIMD's time in which its VALU issues, waves-per-SIMD x SQ_ACTIVE_INST_VALU /
+        # SQ_WAVE_CYCLES; (2) the fp64 rate: flops from the SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 instruction counters (wavefront
+        # instructions x 64 lanes, FMA = 2 flops) / this run's kernel time, against the fp64 vector peak
+        valu_busy, valu_src = None, None
+        sqb, src_b = committed_counters("pmc_sq_b")
+        if sqb and sqb.get("SQ_WAVE_CYCLES"):
+            valu_busy, valu_src = 3.0 * sqb["SQ_ACTIVE_INST_VALU"] / sqb["SQ_WAVE_CYCLES"], src_b
+        fp64 = None
+        f64c, src_f = committed_counters("pmc_fp64")
+        if f64c and dom_ms > 0:
+            fma, mul, add, trans = (f64c.get("SQ_INSTS_VALU_" + n + "_F64", 0.0) for n in ("FMA", "MUL", "ADD", "TRANS"))
+            flops = 64.0 * (2.0 * fma + mul + add + trans)
+            ach = flops / (dom_ms * 1e-3) / 1e12
+            fp64 = {"bound": "fp64-valu", "achieved": ach, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_VECTOR_PEAK_TFLOPS,
+                    "kernel": dom, "flops_per_launch": flops,
+                    "wave_instructions_per_launch": {"fma_f64": fma, "mul_f64": mul, "add_f64": add, "trans_f64": trans},
+                    "flops_source": src_f + ": (2 x SQ_INSTS_VALU_FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) x 64 lanes per launch; "
+                                    "divided by THIS run's median kernel time",
+                    "note": "fp64 comparisons / max / ldexp / frexp / moves are VALU work too but no flops: the kernel's VALU issue share is "
+                            "valu_busy_frac_of_simd_time in `roofline`"}
         out = {
             "metric": "coverage windows/sec through EM+decode; achieved HBM GB/s vs roofline",
             "value": n_windows * args.steps / dt, "unit": "windows/s",
@@ -438,15 +530,24 @@ def main():
                                           if collective_used["name"] == "native" else ", exchange through torch.distributed: " + collective_used["name"]))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
-                         "kernel_ms_timed": dom_ms, "kernel_events": (0 if args.no_kernel_events else
-                                                                     f"HIP event pair around {dom} in every {args.event_stride}. step of the timed region"),
+                         "kernel_ms_timed": dom_ms, "n_samples": len(dom_samples),
+                         "kernel_ms_samples": {"median": dom_ms, "mean": float(np.mean(dom_samples)) if dom_samples else None,
+                                               "min": min(dom_samples) if dom_samples else None, "max": max(dom_samples) if dom_samples else None},
+                         "kernel_events": (0 if args.no_kernel_events else
+                                           f"HIP event pair around {dom} in every {stride}. step of the timed region; kernel_ms_timed = median of n_samples"),
+                         "limiter": "fp64 VALU issue and dependent fp64 chains at three wavefronts per SIMD (see roofline_fp64), not HBM bytes",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_WINDOW * local_windows,
                          "kernel_ms_all": kavg, "algorithmic_bytes_per_window": ALGO_BYTES_PER_WINDOW,
                          "windows_per_launch": local_windows,
                          "valu_busy_frac_of_simd_time": valu_busy, "valu_busy_source": valu_src,
-                         "note": "the kernel is bound by dependent fp64 instruction chains at three wavefronts per SIMD, not by HBM bytes (DESIGN.md section 5)"},
+                         "note": "`bound` names the ceiling this object is priced against (bytes: SURVEY 8d classifies the path as a streaming scan); "
+                                 "what limits the kernel is in `limiter` and `roofline_fp64` (DESIGN.md section 5)"},
             "loglikelihood_after_last_step": ll,
         }
+        if fp64 is not None:
+            out["roofline_fp64"] = fp64
+        if em_run is not None:
+            out["em_run"] = em_run
         if weak is not None:
             out["weak_scaling"] = weak
         if other is not None:

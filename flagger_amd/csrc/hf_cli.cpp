@@ -20,7 +20,7 @@
 #include <vector>
 
 static const char* ts() {                                   // common.c:116 get_timestamp
-    static char buf[64];
+    static thread_local char buf[64];
     time_t t = time(nullptr);
     struct tm tmv;
     localtime_r(&t, &tmv);
@@ -131,24 +131,43 @@ struct Run {
 static Run* g_run = nullptr;
 static const char* run_error() { return g_run ? g_run->error() : hf_last_error(); }
 
-// writeBenchmarkingStats, hmm_flagger.c:134-162
+// writeBenchmarkingStats, hmm_flagger.c:134-162.  The tables are OUTPUT: the labels of the pass come down (pinned buffer), and the
+// tables are computed and written by a worker thread while the EM goes on (the "initial" tables used to sit inside
+// the EM phase, ~10 ms of a 21 ms run).  One job at a time; summary_join() before anything that needs the files or the table.
+struct SummaryJob {
+    std::thread th;
+    std::vector<int8_t> labels;
+    int rc = 0;
+    std::string err, path;
+    double ms = 0.0;
+};
+static SummaryJob g_summary;
+static void summary_join() {
+    if (g_summary.th.joinable()) g_summary.th.join();
+    if (g_summary.rc != 0) { fprintf(stderr, "[%s] %s\n", ts(), g_summary.err.c_str()); exit(EXIT_FAILURE); }
+}
 static int write_summary(Run& run, const std::string& dir, const std::string& suffix, const std::vector<std::string>& labelNames,
-                         const char* binArrayFilePath, double overlapRatioThreshold, int threads) {
+                         const char* binArrayFilePath, double overlapRatioThreshold, int threads, bool wait) {
+    summary_join();
     const double t_begin = real_time();
     const int64_t N = hfio_n_windows(run.tab);
-    std::vector<int8_t> labels((size_t) N);
-    int rc = run.labels(labels.data());
+    g_summary.labels.resize((size_t) N);
+    int rc = run.labels(g_summary.labels.data());
     if (rc != HF_OK) return rc;
-    std::vector<const char*> names;
-    for (const auto& s : labelNames) names.push_back(s.c_str());
-    const std::string path = dir + "/prediction_summary_" + suffix + ".tsv";
-    if (hfio_write_summary(run.tab, labels.data(), path.c_str(), binArrayFilePath, names.empty() ? nullptr : names.data(),
-                           (int) names.size(), overlapRatioThreshold, threads) != 0) {
-        fprintf(stderr, "[%s] %s\n", ts(), hfio_last_error());
-        exit(EXIT_FAILURE);
-    }
-    fprintf(stderr, "[%s] Writing tables to file %s is done.\n", ts(), path.c_str());
-    if (getenv("HF_CLI_TIMING")) fprintf(stderr, "[phase]   (summary tables %s: %.1f ms)\n", suffix.c_str(), (real_time() - t_begin) * 1e3);
+    g_summary.path = dir + "/prediction_summary_" + suffix + ".tsv";
+    const bool timing = getenv("HF_CLI_TIMING") != nullptr;
+    g_summary.th = std::thread([&run, labelNames, binArrayFilePath, overlapRatioThreshold, threads, suffix, timing, t_begin] {
+        std::vector<const char*> names;
+        for (const auto& s : labelNames) names.push_back(s.c_str());
+        if (hfio_write_summary(run.tab, g_summary.labels.data(), g_summary.path.c_str(), binArrayFilePath, names.empty() ? nullptr : names.data(),
+                               (int) names.size(), overlapRatioThreshold, threads) != 0) {
+            g_summary.rc = -1; g_summary.err = hfio_last_error();
+            return;
+        }
+        fprintf(stderr, "[%s] Writing tables to file %s is done.\n", ts(), g_summary.path.c_str());
+        if (timing) fprintf(stderr, "[phase]   (summary tables %s: %.1f ms, beside the EM)\n", suffix.c_str(), (real_time() - t_begin) * 1e3);
+    });
+    if (wait) summary_join();
     return HF_OK;
 }
 
@@ -388,11 +407,23 @@ int main(int argc, char* argv[]) {
     int iter = 1;
     bool converged = false;
     const int nChunks = hfio_n_chunks(tab);
+    // EM+decode time (BASELINE metric): E-steps (decode included), M-steps and SQUAREM's algebra; writing the
+    // log-likelihood, parameter and summary files and the log lines is output and not counted (it is still part of `emWall`)
     const double emStart = real_time();
+    double emTime = 0.0;
+    std::vector<double> passMs;                             // HF_CLI_TIMING: every E-step of the loop
     int passes = 0;
+    auto timed_estep = [&](hfm_model* m, int mode, double* st) -> int {
+        const double t0 = real_time();
+        const int r = run.estep(m, mode, st);
+        const double dt = real_time() - t0;
+        emTime += dt;
+        if (phaseTiming) passMs.push_back(dt * 1e3);
+        return r;
+    };
     while (iter <= numberOfIterations && !converged) {
         fprintf(stderr, "[%s] [Iteration %s = %d] Running EM jobs for %d chunks (on GPU %d) ...\n", ts(), acceleration ? "accelerated" : "", iter, nChunks, device);
-        if ((rc = run.estep(model, HF_MODE_FULL)) != HF_OK) return die_estep(rc);
+        if ((rc = timed_estep(model, HF_MODE_FULL, run.stats.data())) != HF_OK) return die_estep(rc);
         passes++;
         fprintf(stderr, "[%s] [Iteration %s = %d] EM jobs are all finished.\n", ts(), acceleration ? "accelerated" : "", iter);
         fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, acceleration ? 3 * (iter - 1) : iter - 1, run.stats[0]);
@@ -400,18 +431,27 @@ int main(int argc, char* argv[]) {
             char suffix[64];
             if (iter == 1) snprintf(suffix, sizeof suffix, "initial");
             else snprintf(suffix, sizeof suffix, acceleration ? "iteration_accelerated_%d" : "iteration_%d", iter - 1);
-            if ((rc = write_summary(run, dir, suffix, labelNames, binArrayFilePath, overlapRatioThreshold, threads)) != HF_OK) return die_estep(rc);
+            if ((rc = write_summary(run, dir, suffix, labelNames, binArrayFilePath, overlapRatioThreshold, threads, false)) != HF_OK) return die_estep(rc);
         }
         if (acceleration) {                                  // hmm_flagger.c:382-416
             fprintf(stderr, "[%s] [Iteration accelerated = %d] Running SQUAREM acceleration.\n", ts(), iter);
-            auto estep_cb = [&](hfm_model* m, int mode, double* st) -> int {
-                return run.estep(m, mode, st);
+            auto estep_cb = [&](hfm_model* m, int mode, double* st) -> int {   // (the whole accelerated iteration is timed as one block)
+                const double t1 = real_time();
+                const int r = run.estep(m, mode, st);
+                if (phaseTiming) passMs.push_back((real_time() - t1) * 1e3);
+                return r;
             };
+            const double t0 = real_time();
             rc = squarem_iteration(&model, run.stats, convergenceTol, estep_cb, &passes);
+            emTime += real_time() - t0;
             if (rc != HF_OK) return die_estep(rc);
             fprintf(stderr, "[%s] [Iteration accelerated = %d] Finished SQUAREM acceleration.\n", ts(), iter);
         }
-        converged = hfm_estimate(model, run.stats.data(), convergenceTol) != 0;
+        {
+            const double t0 = real_time();
+            converged = hfm_estimate(model, run.stats.data(), convergenceTol) != 0;
+            emTime += real_time() - t0;
+        }
         fprintf(stderr, "[%s] [Iteration %s = %d] Parameters are estimated and updated.\n", ts(), acceleration ? "accelerated" : "", iter);
         if (writeParamsPerIter) {
             char suffix[64];
@@ -423,14 +463,14 @@ int main(int argc, char* argv[]) {
     if (converged) fprintf(stderr, "[%s] Parameters converged after %d iterations (tol=%.2e)\n", ts(), iter - 1, convergenceTol);
     else fprintf(stderr, "[%s] Parameter estimation stopped (not yet converged based on the given tolerance) after %d iterations (tol=%.2e)\n", ts(), iter - 1, convergenceTol);
     fprintf(stderr, "[%s] [Final Inference] Running EM jobs for %d chunks (on GPU %d) ...\n", ts(), nChunks, device);
-    if ((rc = run.estep(model, HF_MODE_FULL)) != HF_OK) return die_estep(rc);
+    if ((rc = timed_estep(model, HF_MODE_FULL, run.stats.data())) != HF_OK) return die_estep(rc);
     passes++;
-    const double emTime = real_time() - emStart;
+    const double emWall = real_time() - emStart;
     fprintf(stderr, "[%s] [Final Inference] EM jobs are all finished.\n", ts());
     fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, acceleration ? 3 * (iter - 1) : iter - 1, run.stats[0]);
     fclose(llf);
     write_params(model, dir, "final");
-    if ((rc = write_summary(run, dir, "final", labelNames, binArrayFilePath, overlapRatioThreshold, threads)) != HF_OK) return die_estep(rc);
+    if ((rc = write_summary(run, dir, "final", labelNames, binArrayFilePath, overlapRatioThreshold, threads, true)) != HF_OK) return die_estep(rc);
     std::vector<int8_t> labels((size_t) N);
     if ((rc = run.labels(labels.data())) != HF_OK) return die_estep(rc);
     memcpy(hfio_prediction(tab), labels.data(), (size_t) N);
@@ -441,6 +481,11 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "[%s] Writing posterior bed : %s\n", ts(), pp.c_str());
         hfio_write_posterior_bed(tab, post.data(), labels.data(), pp.c_str());
     }
+    if (phaseTiming && !passMs.empty()) {
+        fprintf(stderr, "[phase]   E-step passes (ms):");
+        for (size_t k = 0; k < passMs.size(); k++) fprintf(stderr, " %.3f", passMs[k]);
+        fprintf(stderr, "\n");
+    }
     phase("EM + final inference");
     // 6. final BED
     fprintf(stderr, "[%s] Writing final BED file. \n", ts());
@@ -448,8 +493,8 @@ int main(int argc, char* argv[]) {
         fprintf(stderr, "[%s] Error: %s/final_flagger_prediction.bed cannot be opened.\n", ts(), outputDir);
         return EXIT_FAILURE;
     }
-    fprintf(stderr, "[%s] EM+decode: %d passes over %ld windows in %.4f s = %.3e windows/s on GPU %d\n", ts(), passes, (long) N, emTime,
-            (double) N * passes / emTime, device);
+    fprintf(stderr, "[%s] EM+decode: %d passes over %ld windows in %.4f s = %.3e windows/s on GPU %d (E-steps, M-steps; the loop with its "
+            "log lines and output files took %.4f s)\n", ts(), passes, (long) N, emTime, (double) N * passes / emTime, device, emWall);
     phase("final BED");
     if (run.multi) hf_multi_destroy(run.multi);   // (joins the ranks' threads and communicators: RCCL wants an orderly end)
     // the one-GPU context, the model and the window table are NOT destroyed: the process ends below without unwinding anything

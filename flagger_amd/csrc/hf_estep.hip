@@ -1068,6 +1068,23 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     }
     { const char* e = std::getenv("HF_HOST_TRACE"); ctx->host_trace = e && e[0] == '1'; }
     { const char* e = std::getenv("HF_SEG_LAUNCHES"); ctx->seg_fused = !(e && e[0] == '2'); }   // HF_SEG_LAUNCHES=2: k_seg_prod + k_seg_fb
+    if (ctx->seg_fused && ctx->nseg > 0) {
+        // Static guard of the one-launch hand-off: the segments of a chunk wait for each other INSIDE the launch, so all
+        // of them have to be resident together.  A chunk with more segments than the device holds workgroups of k_seg_fb (small
+        // --windowLen with a large --chunkLen: > 1.57 M windows in one chunk on 256 CUs x 12) could only time out (65 536 polls per
+        // waiting lane) and re-run every first pass in two launches: such a context starts in two-launch mode.
+        int per_cu = 0, cus = 0, max_nseg = 0;
+        for (const SegDesc& d : ctx->h_segs) if (d.nseg > max_nseg) max_nseg = d.nseg;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_seg_fb<true, true>, 64, seg_lds_bytes()) != hipSuccess) { (void) hipGetLastError(); per_cu = 0; }
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) { (void) hipGetLastError(); cus = 0; }
+        int64_t resident = (int64_t) per_cu * cus;
+        if (const char* e = std::getenv("HF_SEG_RESIDENT")) resident = std::atoll(e);   // tests: pretend a smaller device
+        if (resident > 0 && max_nseg > resident) ctx->seg_fused = false;
+        if (ctrace || ctx->host_trace)
+            std::fprintf(stderr, "[hf_create] segment kernel: %d segments, longest chunk %d; %lld workgroups resident (%d per CU x %d CUs): %s\n",
+                         ctx->nseg, max_nseg, (long long) resident, per_cu, cus,
+                         ctx->seg_fused ? "one launch" : "TWO launches (a chunk has more segments than the device holds workgroups)");
+    }
     ctx->seg_test_timeout = std::getenv("HF_SEG_TEST_TIMEOUT") != nullptr;
     { const char* e = std::getenv("HF_STREAM_STAMP"); if (e && e[0] == '0') ctx->stream_stamp_ok = false; }
     { const char* e = std::getenv("HF_PARAMS_COPY"); if (e && e[0] == '1') ctx->kp_ok = false; }   // the parameter block by a copy ahead of every pass
@@ -1236,7 +1253,9 @@ static bool pack_kparams(hf_ctx* ctx, const hf_params* p) {
 }
 
 // everything one pass enqueues on `st` after the parameters were packed into the pinned block
-static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t st) {
+// retry: the pass again after HF_E_RETRY (hf_finish) — the caller's negative_binomial tables went up with the first attempt and
+// may have been freed or rewritten since (hf_estep and hf_finish are separate calls): they are NOT read again
+static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t st, bool retry = false) {
     // the parameter block: through the kernel arguments of k_tables when it fits them (one region, HF_ALGO_SCAN, Gaussian models:
     // hf_device.h KParams), a copy ahead of the pass otherwise
     ctx->kp_now = ctx->kp_ok && ctx->C > 0 && ctx->algo == HF_ALGO_SCAN && p->model_type != HF_MODEL_NEGATIVE_BINOMIAL && pack_kparams(ctx, p);
@@ -1251,7 +1270,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         const bool full = mode == HF_MODE_FULL;
         const bool nbm = p->model_type == HF_MODEL_NEGATIVE_BINOMIAL;
         if (nbm) {   // the caller's per-x tables go up with the parameters
-            if (!p->nb_E || !p->nb_P || !p->nb_dig || !p->nb_r || !p->nb_beta)
+            if (!retry && (!p->nb_E || !p->nb_P || !p->nb_dig || !p->nb_r || !p->nb_beta))
                 return set_err(HF_E_ARG, "hf_estep: negative_binomial needs hf_params.nb_E/nb_P/nb_dig/nb_r/nb_beta");
             if (p->nb_max_x > 0 && ctx->M - 1 > p->nb_max_x)
                 return set_err(HF_E_ARG, "hf_estep: the windows hold coverage values above hf_params.nb_max_x (hfm_set_max_coverage)");
@@ -1263,11 +1282,13 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 HIPCHK(hipMalloc((void**) &ctx->d_nbBeta, nR));
                 HIPCHK(hipMalloc((void**) &ctx->d_tile_hist, ((size_t) ctx->ntiles * ctx->R * HF_NB_TILE_VEC + 1) * 8));
             }
-            HIPCHK(hipMemcpyAsync(ctx->d_nbE, p->nb_E, nE, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(ctx->d_nbP, p->nb_P, nP, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(ctx->d_nbDig, p->nb_dig, nP, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(ctx->d_nbR, p->nb_r, nR, hipMemcpyHostToDevice, st));
-            HIPCHK(hipMemcpyAsync(ctx->d_nbBeta, p->nb_beta, nR, hipMemcpyHostToDevice, st));
+            if (!retry) {
+                HIPCHK(hipMemcpyAsync(ctx->d_nbE, p->nb_E, nE, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(ctx->d_nbP, p->nb_P, nP, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(ctx->d_nbDig, p->nb_dig, nP, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(ctx->d_nbR, p->nb_r, nR, hipMemcpyHostToDevice, st));
+                HIPCHK(hipMemcpyAsync(ctx->d_nbBeta, p->nb_beta, nR, hipMemcpyHostToDevice, st));
+            }
         }
         {   // also clears the flag word: first kernel of every pass
             KTimer t(ctx, st, HF_K_TABLES);
@@ -1424,6 +1445,8 @@ int hf_get_stats_mode(const hf_ctx* ctx) {
     return ctx && ctx->stats_mode == HF_STATS_ROWS && ctx->rows_ready && ctx->algo == HF_ALGO_SCAN ? HF_STATS_ROWS : HF_STATS_CHUNKS;
 }
 
+int hf_seg_launches(const hf_ctx* ctx) { return !ctx || !seg_pass(ctx) ? 0 : (ctx->seg_fused ? 1 : 2); }
+
 int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
     if (!ctx || !dst_dev) return set_err(HF_E_ARG, "hf_copy_chunk_stats: bad argument");
     if (ctx->pass_rows) return set_err(HF_E_ARG, "hf_copy_chunk_stats: the last pass ran in HF_STATS_ROWS mode (no per-chunk vectors)");
@@ -1500,6 +1523,11 @@ int hf_check(hf_ctx* ctx, void* stream) {
     HIPCHK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     accumulate_kernel_times(ctx);
+    if ((*ctx->h_flags & HF_FLAG_SYNC) && ctx->seg_fused) {   // as hf_finish: two launches from now on, the caller repeats the pass
+        ctx->seg_fused = false;
+        std::fprintf(stderr, "[hmm_flagger_hip] one-launch segment kernel: a hand-off timed out; this context falls back to k_seg_prod + k_seg_fb\n");
+        return set_err(HF_E_RETRY, "a hand-off of the one-launch segment kernel timed out: the context now runs two launches, repeat hf_estep");
+    }
     return flags_to_code(*ctx->h_flags);
 }
 
@@ -1581,7 +1609,16 @@ static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_ho
             return flags_to_code(fl2);
         }
     }
-    if (!seen) HIPCHK(hipStreamSynchronize(st));
+    if (!seen) {
+        HIPCHK(hipStreamSynchronize(st));
+        // the stream has drained and the stamp still is not there: hipStreamWriteValue32 returns success on this stack but the write
+        // does not land where the host polls — stop paying the 2 s bail-out in every later pass
+        if (ctx->stream_stamp_ok && ctx->stream_stamp != 0 &&
+            *(reinterpret_cast<volatile uint32_t*>(ctx->h_flags) + 1) != ctx->stream_stamp) {
+            ctx->stream_stamp_ok = false;
+            std::fprintf(stderr, "[hmm_flagger_hip] the stream's completion stamp did not arrive; passes complete through hipStreamSynchronize from now on\n");
+        }
+    }
     if (seen && poll_mode() == 2) {   // HF_POLL=debug: did anything still arrive after the block was accepted?
         std::vector<double> snap(ctx->h_total, ctx->h_total + ctx->V + 1);
         HIPCHK(hipStreamSynchronize(st));
@@ -1624,7 +1661,7 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
     rc = wait_total(ctx, st, polled, stats_host);
     if (rc == HF_E_RETRY) {   // the pass again, in two launches (the packed parameters are still in the pinned block)
         if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev0, st));
-        rc = enqueue_pass(ctx, &ctx->last_p, ctx->last_mode, st);
+        rc = enqueue_pass(ctx, &ctx->last_p, ctx->last_mode, st, true);
         if (rc) return rc;
         return hf_finish(ctx, stats_host, stream);
     }

@@ -153,6 +153,17 @@ struct Inflater {
         reset_member();
         return OK;
     }
+    // After a member's trailer: OK = the header of another member has been read; END_OF_MEMBER = the input ends here, or what follows
+    // does not start with the gzip magic (trailing garbage: ignored, as gzread does); ERR_TRUNCATED = the bytes that follow START
+    // a gzip member (1f 8b) but the file ends inside its header — a concatenated / bgzip file cut there must not load silently with
+    // its last rows missing.
+    int next_member() {
+        if (pos >= in_len) return END_OF_MEMBER;
+        const int rc = read_gzip_header();
+        if (rc == OK) return OK;
+        if (rc == ERR_TRUNCATED && in_len - pos >= 2 && in[pos] == 0x1f && in[pos + 1] == 0x8b) return ERR_TRUNCATED;
+        return END_OF_MEMBER;
+    }
     // after END_OF_MEMBER: CRC-32 and ISIZE of the trailer (the decoder has consumed whole bytes only up to the end of the last block)
     int read_gzip_trailer(uint32_t* crc, uint32_t* isize) {
         // give back the whole bytes still in the bit buffer

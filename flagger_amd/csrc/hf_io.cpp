@@ -255,7 +255,9 @@ class BlockReader {
             if (inf_.read_gzip_trailer(&crc, &isz) != hfz::OK) { failed_ = true; eof = true; return got; }
             b.member_end = true; b.want_crc = crc; b.want_isize = isz;
             // another member (concatenated gzip files), or the end; anything else after a member is ignored, as gzread does
-            if (inf_.pos >= map_len_ || inf_.read_gzip_header() != hfz::OK) eof = true;
+            const int nm = inf_.next_member();
+            if (nm == hfz::ERR_TRUNCATED) { failed_ = true; eof = true; }      // the file ends inside the next member's header
+            else if (nm != hfz::OK) eof = true;
         } else if (rc != hfz::OK) { failed_ = true; eof = true; }
         return got;
     }
@@ -643,7 +645,9 @@ int hfio_gunzip(const char* path, unsigned char** out, size_t* n) {
         if (z.read_gzip_trailer(&crc, &isz) != hfz::OK) { std::free(o); return -2; }
         if ((uint32_t) crc32(0L, o + member0, (uInt) (len - member0)) != crc || (uint32_t) (len - member0) != isz) { std::free(o); return -4; }
         member0 = len;
-        if (z.pos >= z.in_len || z.read_gzip_header() != hfz::OK) break;     // the next member, or the end (trailing bytes are ignored)
+        const int nm = z.next_member();                                      // the next member, or the end (trailing bytes that are no gzip member are ignored)
+        if (nm == hfz::ERR_TRUNCATED) { std::free(o); return -2; }           // cut inside the next member's header
+        if (nm != hfz::OK) break;
     }
     *out = o; *n = len;
     return 0;

@@ -1,6 +1,8 @@
 // hf_seg.h — HF_ALGO_SCAN: one WORKGROUP (one wavefront) per chunk segment, the whole forward / backward / decode of the
-// segment in two launches (BASELINE north_star: "one contig-chunk per workgroup ... wavefront prefix-scan for the
-// forward/backward recurrences").
+// segment in ONE launch (k_seg_fb<., true>: phases A-D below in one kernel, the segments of a chunk hand their products to
+// each other inside the launch) — or in two (k_seg_prod = phase A, then k_seg_fb<., false> = B-D: the fall-back after a hand-off
+// timed out, the choice of hf_create for chunks with more segments than the device holds workgroups, HF_SEG_LAUNCHES=2)
+// (BASELINE north_star: "one contig-chunk per workgroup ... wavefront prefix-scan for the forward/backward recurrences").
 //
 // A chunk of T windows (hmm.c:333-545 runs it strictly sequentially) is cut into n = ceil(T / HF_SEG_SPLIT) equal SEGMENTS of
 // at most 64*LMAX windows (one-wavefront workgroups: a CU is busy for the sum of its workgroups' steps, and they spread most
@@ -46,6 +48,12 @@
 
 // one-launch mode (k_seg_fb<., true>): hand-off of a segment's product to the chunk's other segments — write-through stores,
 // a drained queue, then the flag (= the launch's epoch); readers poll the flag and read past their caches
+// The hand-offs here and in hf_rows.h order "data stores, then flag / ticket" with relaxed atomics + s_waitcnt vmcnt(0): on GFX9 /
+// CDNA vmcnt counts stores as well as loads, so the wait drains them; gfx10+ tracks stores in vscnt and the same code would publish
+// a flag before its data.  This library is written for gfx950 only — refuse any other device target at compile time.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "hf_seg.h / hf_rows.h: the in-launch hand-offs rely on GFX9 (CDNA) vmcnt semantics; build with --offload-arch=gfx950"
+#endif
 #define HF_SEG_SPIN_MAX (1 << 16)            // polls of one flag before the wait is given up (HF_FLAG_SYNC: the host falls back to two launches)
 __device__ __forceinline__ void seg_xcu_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double seg_xcu_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }

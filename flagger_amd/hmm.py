@@ -347,6 +347,11 @@ class EMList:
     def stats_mode(self) -> int:
         return int(self._L.hf_get_stats_mode(self._h))
 
+    @property
+    def seg_launches(self) -> int:
+        """1: one-launch segment kernel, 2: k_seg_prod + k_seg_fb, 0: no segment kernels (hf_seg_launches)."""
+        return int(self._L.hf_seg_launches(self._h))
+
     # --- E-step pieces (used directly by the multi-GPU path in dist.py) ---
     def launch(self, model: HMM, mode: int = N.HF_MODE_FULL) -> None:
         p = model.params()

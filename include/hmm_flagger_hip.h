@@ -44,9 +44,10 @@ enum {
     HF_E_NAN = -4,        /* "[Error] prob is NAN"             hmm_utils.c:782-786 */
     HF_E_REGION = -5,     /* a window's region index >= n_regions */
     HF_E_NOGPU = -6,      /* no HIP device: there is no CPU fallback */
-    HF_E_RETRY = -7       /* hf_finish_exchange / hf_finish_gathered only: the context changed its launch mode (a hand-off inside the
-                           * one-launch segment kernel timed out on some rank) and the pass has to be run again: hf_estep, exchange,
-                           * finish — every rank gets this code together.  hf_finish and hf_em_iterate re-run the pass themselves. */
+    HF_E_RETRY = -7       /* hf_finish_exchange / hf_finish_gathered / hf_check only: the context changed its launch mode (a hand-off
+                           * inside the one-launch segment kernel timed out) and the pass has to be run again: hf_estep, exchange,
+                           * finish — with an exchange every rank gets this code together.  hf_finish and hf_em_iterate re-run the
+                           * pass themselves. */
 };
 
 typedef struct hf_ctx hf_ctx;
@@ -173,7 +174,8 @@ int hf_write_flag_row(hf_ctx *ctx, double *row_dev, void *stream);
 /* (hf_finish synchronises the stream.  Environment HF_POLL=1 opts into polling a checksummed completion stamp in the
  * pinned result block instead — a few microseconds less per pass, see hf_estep.hip — HF_POLL=debug verifies it.) */
 int hf_finish(hf_ctx *ctx, double *stats_host, void *stream);
-/* Only wait + error flags (multi-GPU callers reduce the gathered vectors themselves). */
+/* Only wait + error flags (multi-GPU callers reduce the gathered vectors themselves).  HF_E_RETRY: a hand-off of the one-launch
+ * segment kernel timed out; the context has switched to two launches and the caller repeats the pass from hf_estep. */
 int hf_check(hf_ctx *ctx, void *stream);
 
 /* How a HF_MODE_FULL pass of HF_ALGO_SCAN produces the statistics:
@@ -196,6 +198,10 @@ int hf_set_stats_mode(hf_ctx *ctx, int mode);
  * hf_finish_gathered(rows = the gathered vectors, row_index = NULL, n = world size) sums them in rank order. */
 int hf_rank_total(hf_ctx *ctx, double *out_dev, void *stream);
 int hf_get_stats_mode(const hf_ctx *ctx);          /* the mode the NEXT full pass will use */
+/* Launches of the segment forward-backward in the NEXT pass: 1 = k_seg_fb alone (its segments hand their products over inside the
+ * launch), 2 = k_seg_prod + k_seg_fb (hf_create's choice for a chunk with more segments than the device holds workgroups,
+ * environment HF_SEG_LAUNCHES=2, or after a hand-off timed out), 0 = the context does not run the segment kernels (HF_ALGO_SEQ, empty). */
+int hf_seg_launches(const hf_ctx *ctx);
 
 /* Results of the last HF_MODE_FULL pass (HF_E_ARG when the last pass was HF_MODE_FORWARD_ONLY: f and scales would be new,
  * b and the labels stale). */
@@ -212,8 +218,8 @@ int hf_last_kernel_ms(hf_ctx *ctx, float *ms);
  * the LAST pass in milliseconds (0 for kernels not selected or not run).  Call after hf_finish/hf_check.
  * Each selected kernel adds two event packets to the stream, so select only what is being measured. */
 #define HF_NKERNELS 16
-/* HF_K_PROD_TILE, HF_K_CARRY, HF_K_FB_TILE: round 1's tile kernels, retired (never run; the indices stay) */
-enum { HF_K_TABLES = 0, HF_K_PROD_TILE, HF_K_CARRY, HF_K_FB_TILE, HF_K_STATS_TILE, HF_K_CHUNK_STATS, HF_K_REDUCE,
+/* indices 1..3 are reserved (round 1's tile kernels, retired in round 2: no name, never run; the later indices keep their values) */
+enum { HF_K_TABLES = 0, HF_K_STATS_TILE = 4, HF_K_CHUNK_STATS, HF_K_REDUCE,
        HF_K_EMIT_ROWS, HF_K_FWD_SEQ, HF_K_BWD_SEQ, HF_K_PAIR_SUMS, HF_K_ROW_STATS, HF_K_ROWS_TOTAL, HF_K_SEG_PROD, HF_K_SEG_FB, HF_K_AROWS };
 #define HF_PROF_PASS 0x80000000u   /* in kernel_mask: also bracket the whole pass (hf_last_kernel_ms) */
 int hf_set_profiling(hf_ctx *ctx, unsigned kernel_mask);

@@ -320,3 +320,31 @@ def test_full_size_em_to_convergence_equals_the_oracle_command_line(extra, tmp_p
             assert (tmp_path / "gpu" / n).read_text() == (tmp_path / "cpu" / n).read_text(), n
     n_ll = len((tmp_path / "gpu" / "loglikelihood.tsv").read_text().splitlines())
     assert (5 < n_ll < 20) if extra else (20 < n_ll < 60), n_ll
+
+
+@pytest.mark.parametrize("extra", [[], ["--accelerate"]], ids=["em", "squarem"])
+def test_full_size_ont_r10_seven_regions_em_to_convergence_equals_the_oracle_command_line(extra, tmp_path):
+    """BASELINE configs[4] at full size: `hmm_flagger -x ont-r10` (8 kb windows, minReadFractionAtEnds 0.8,
+    hmm_flagger.c:36-58) on the 764 k-window track with 7 bias regions — per-region emission series (hmm_utils.c:1605-1652),
+    region changes inside chunks (hmm.c:398-400), K = 10 — from the `.cov.gz` (one run per window), EM to convergence
+    (-n 100 -t 1e-3), plain and with SQUAREM: every TSV / BED of the HIP command line equals the oracle command line's byte for
+    byte."""
+    store = synth.config(4)
+    assert store.n_regions == 7 and store.window_len == 8000 and 700_000 < store.n_windows < 850_000
+    cov = tmp_path / "cfg4.cov.gz"
+    store.write_cov(str(cov))
+    args = ["-i", str(cov), "-x", "ont-r10", "-n", "100", "-t", "1e-3", "-A", os.path.join(GOLD, "alpha_ont_r10.tsv"), "-w"] + extra
+    r = _run(CLI, args, tmp_path / "gpu")
+    assert "Parameters converged after" in r.stderr or "Parameter estimation stopped" in r.stderr
+    assert f"{store.n_chunks} chunks are parsed ({store.n_windows} windows of 8000 bases)" in r.stderr
+    binp = tmp_path / "cfg4.bin"                       # the oracle's per-base .cov reader needs minutes for 6 Gb: it reads the same windows as .bin
+    store.write_bin(str(binp))
+    _run(ORACLE, ["-i", str(binp)] + args[2:] + ["--threads", "16"], tmp_path / "cpu")
+    names = sorted(os.listdir(tmp_path / "cpu"))
+    assert len(names) > 8 and "final_flagger_prediction.bed" in names and "loglikelihood.tsv" in names
+    for n in names:
+        if n.endswith((".tsv", ".bed")):
+            assert (tmp_path / "gpu" / n).read_text() == (tmp_path / "cpu" / n).read_text(), n
+    # seven regions really were fitted: seven parameter series in the final emission table
+    emis = (tmp_path / "gpu" / "emission_final.tsv").read_text().splitlines()
+    assert len(emis[1].split("\t")) == 4 + 7, emis[1]

@@ -376,6 +376,61 @@ def test_full_size_cfg2_one_pass_and_invariants():
     orc.close()
 
 
+def test_full_size_cfg4_one_pass_and_invariants_per_region():
+    """BASELINE configs[4] at full size: ONT-R10 preset (hmm_flagger.c:36-58: 8 kb windows, minReadFractionAtEnds
+    0.8), 7 bias regions with their own emission series (hmm_utils.c:1605-1652), region changes inside chunks (hmm.c:398-400),
+    K = 10: one E-pass with non-trivial parameters against the oracle — labels identical, log-likelihood and every region's
+    statistics within 1e-9 — plus the estimator identities per region."""
+    store = synth.config(4)
+    assert 700_000 < store.n_windows < 850_000 and store.n_regions == 7 and 250 < store.n_chunks < 330
+    assert len(np.unique(store.regions())) == 7
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    assert K == 10
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.ONT_R10_ALPHA)
+    em = hmm.EMList(store, model, True, 0.8)
+    hmm.EM_runOneIterationForList(em, model)
+    hmm.HMM_estimateParameters(model, 1e-3)
+    hmm.EM_runOneIterationForList(em, model)
+    got = model.estimators.copy()
+    lab = em.labels()
+    orc = Oracle(store, 0, K, synth.ONT_R10_ALPHA, 0.25, 0.75, True, 0.8, threads=16)
+    try:
+        orc.set_param_vector(model.param_vector())
+        assert orc.run_iteration() == 0
+        ref = orc.stats_vector(K)
+        assert abs(got[0] - ref[0]) <= LL_RTOL * abs(ref[0]), (got[0], ref[0])
+        scale = np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+        assert np.all(np.abs(got - ref) <= STAT_RTOL * scale), np.max(np.abs(got - ref) / scale)
+        olab = orc.labels()
+        assert np.array_equal(lab, olab), f"{np.count_nonzero(lab != olab)} label mismatches of {lab.size}"
+        # pairs (i, i+1), i = 1..T-2, are counted in the region of window i+1 (hmm.c:576-590): total xi mass per region = its pairs
+        reg = store.regions()
+        pairs_r = np.zeros(7)
+        for c in range(store.n_chunks):
+            a, b = int(store.chunk_off[c]), int(store.chunk_off[c + 1])
+            if b - a > 2:
+                pairs_r += np.bincount(reg[a + 2:b], minlength=7)
+        st = N.region_stride(K)
+        for r in range(7):
+            base = 1 + r * st
+            trans = got[base + 24 * K: base + 24 * K + 16]
+            assert pairs_r[r] > 1000 and abs(trans.sum() - pairs_r[r]) <= 1e-7 * pairs_r[r], (r, trans.sum(), pairs_r[r])
+            for s_ in (1, 2, 3):
+                nc = K if s_ == 3 else 1
+                md = got[base + ((s_ * 3 + 0) * 2 + 1) * K: base + ((s_ * 3 + 0) * 2 + 1) * K + nc]
+                vd = got[base + ((s_ * 3 + 1) * 2 + 1) * K: base + ((s_ * 3 + 1) * 2 + 1) * K + nc]
+                wn = got[base + ((s_ * 3 + 2) * 2 + 0) * K: base + ((s_ * 3 + 2) * 2 + 0) * K + nc]
+                wd = got[base + ((s_ * 3 + 2) * 2 + 1) * K: base + ((s_ * 3 + 2) * 2 + 1) * K + nc]
+                assert np.array_equal(md, vd) and np.array_equal(md, wn) and np.all(wd == wd[0])
+                assert abs(wd[0] - md.sum()) <= 1e-9 * wd[0]
+                assert abs(md.sum() - trans.reshape(4, 4)[:, s_].sum()) <= 1e-9 * md.sum()
+        post = em.posterior(0, 100_000)
+        assert np.allclose(post.sum(axis=1), 1.0, atol=1e-12) and np.array_equal(post.argmax(axis=1), lab[:100_000])
+    finally:
+        em.close()
+        orc.close()
+
+
 def test_shared_denominator_division_is_bit_identical_where_the_guard_allows_it():
     """k_stats_tile divides many numerators by the same denominator through one refined reciprocal (hf_device.h
     prediv / divp).  Wherever its guard admits the operands the quotient must be the correctly rounded a / d,
@@ -643,3 +698,40 @@ def test_hand_off_time_out_falls_back_to_two_launches(multi):
     b = _pass_in_subprocess({"HF_SEG_LAUNCHES": "2"}, 0.05, multi=multi)
     assert "falls back to k_seg_prod + k_seg_fb" in a[3]
     assert a[0] == b[0] and a[2] == b[2] and np.array_equal(a[1], b[1])
+
+
+def test_static_guard_of_the_one_launch_hand_off(monkeypatch):
+    """a chunk with more segments than the device holds workgroups of k_seg_fb can never have all of them resident —
+    every wait of the one-launch kernel would run into its bound.  hf_create sees that and starts such a context in two-launch
+    mode (no time-out, no retry): one chunk of 2 M windows (3 907 segments against 12 x 256 resident workgroups), against the oracle;
+    and the same decision forced on a small input by pretending a device that holds five workgroups (HF_SEG_RESIDENT)."""
+    small = synth.config(2, scale=0.02)
+    K = hmm.getBestNumberOfCollapsedComps(small)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, small, synth.HIFI_ALPHA)
+    em = hmm.EMList(small, model, True, 0.95)
+    assert em.seg_launches == 1
+    em.close()
+    monkeypatch.setenv("HF_SEG_RESIDENT", "5")
+    em = hmm.EMList(small, model, True, 0.95)
+    assert em.seg_launches == 2
+    em.close()
+    monkeypatch.delenv("HF_SEG_RESIDENT")
+    W = 1000
+    big = synth.synthesize([2_000_000 * W], W, 2_000_000 * W, [20], seed=21)
+    assert big.n_chunks == 1 and big.n_windows == 2_000_000
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, big, synth.HIFI_ALPHA)
+    em = hmm.EMList(big, model, True, 0.95)
+    orc = Oracle(big, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 4, synth.HIFI_ALPHA, 0.25, 0.75, True, 0.95, threads=1)
+    try:
+        assert em.seg_launches == 2
+        hmm.EM_runOneIterationForList(em, model)
+        assert em.seg_launches == 2
+        assert orc.run_iteration() == 0
+        ref, got = orc.stats_vector(model.maxNumberOfComps), model.estimators
+        assert abs(got[0] - ref[0]) <= LL_RTOL * abs(ref[0])
+        scale = np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+        assert np.all(np.abs(got - ref) <= STAT_RTOL * scale)
+        assert np.array_equal(em.labels(), orc.labels())
+    finally:
+        em.close()
+        orc.close()

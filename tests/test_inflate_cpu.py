@@ -126,3 +126,30 @@ def test_loader_reads_concatenated_gzip_members_like_gzread(tmp_path):
     finally:
         del os.environ["HF_IO_ZLIB"]
     assert np.array_equal(a.cov, c.cov) and np.array_equal(a.chunk_off, c.chunk_off)
+
+
+def test_a_file_cut_inside_the_next_members_header_is_an_error(tmp_path):
+    """after a complete member, bytes that START a gzip member (1f 8b) but end inside its header were taken for the
+    end of the file — a concatenated / bgzip input cut there loaded silently without its last rows."""
+    from flagger_amd import io as fio, synth
+    a, b = b"first member\n" * 1000, b"second member\n" * 3000
+    za, zb = _gz(a), _gz(b)
+    p = tmp_path / "cut_header.gz"
+    for keep in (2, 3, 5, 9):                                               # magic (+ part of the fixed 10 bytes)
+        p.write_bytes(za + zb[:keep])
+        rc, got = _gunzip(p)
+        assert rc == -2 and got is None, (keep, rc)
+    hdr = b"\x1f\x8b\x08" + bytes([4]) + b"\0\0\0\0\0\x03" + struct.pack("<H", 50) + b"short"   # FEXTRA longer than the file
+    p.write_bytes(za + hdr)
+    assert _gunzip(p)[0] == -2
+    p.write_bytes(za + b"\x1f")                                             # one stray byte is no member: ignored
+    assert _gunzip(p) == (0, a)
+    # the loader itself (mapped file, threaded reader): an error, not a shorter table
+    st = synth.synthesize([400_000, 90_000], 1000, 100_000, [20], seed=4)
+    st.write_cov(str(tmp_path / "one.cov"))
+    text = (tmp_path / "one.cov").read_bytes()
+    cut = text.index(b"\n", len(text) // 2) + 1
+    z2 = _gz(text[cut:], 1)
+    (tmp_path / "cut.cov.gz").write_bytes(_gz(text[:cut]) + z2[:6])
+    with pytest.raises(Exception):
+        fio.Table(str(tmp_path / "cut.cov.gz"), 100_000, 1000)

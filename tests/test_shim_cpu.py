@@ -56,3 +56,14 @@ def test_the_documented_shim_compiles_links_and_has_no_cpu_fallback(tmp_path):
         assert r.returncode == 1 and "no HIP device" in r.stderr and not os.path.exists(str(tmp_path / "out.bin"))
     else:
         assert r.returncode == 0, r.stderr
+
+
+def test_integration_md_prints_the_compiled_shim():
+    """INTEGRATION.md section 1 is what a maintainer copies from: its listing must be the file the tests compile, byte for byte
+    (the document still showed the model-type cast that round 2 had fixed in the file)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shim = open(os.path.join(ROOT, "integration", "hmm_hip_shim.c")).read()
+    start = doc.index("```c\n/* hmm_hip_shim.c") + len("```c\n")
+    end = doc.index("\n```\n", start)
+    assert doc[start:end] == shim.rstrip("\n"), "INTEGRATION.md section 1 differs from integration/hmm_hip_shim.c: regenerate the listing"
+    assert "? HF_MODEL_GAUSSIAN : HF_MODEL_TRUNC_EXP_GAUSSIAN" not in doc
