@@ -96,8 +96,8 @@ def main():
                     help="multi-GPU exchange: one statistics vector per rank, all-gathered and summed in rank order (default: BASELINE "
                          "north_star's single collective over the EM sufficient statistics; statistics by emission row on every rank, "
                          "equal to a one-GPU run up to the rounding of the order), or the per-chunk vectors summed in chunk-list order "
-                         "(what `hmm_flagger --gpus N` defaults to: statistics, EM trajectory and BED labels identical for every N, "
-                         "bit for bit; slower per-chunk statistics kernels)")
+                         "(statistics, EM trajectory and BED labels identical for every N bit for bit by construction; slower per-chunk "
+                         "statistics kernels; `hmm_flagger --gpus N` defaults to `ranks` too since round 4)")
     ap.add_argument("--collective", choices=["native", "torch"], default="native",
                     help="multi-GPU path: native = pass + RCCL all-gather + ordered reduction in ONE library call per EM pass on the "
                          "pass's own stream (hf_multi_create_rank; torch.distributed only carries the RCCL id at start-up); "

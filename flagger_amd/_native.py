@@ -22,6 +22,10 @@ HF_PROF_PASS = 0x80000000
 HF_OK, HF_E_ARG, HF_E_HIP, HF_E_SCALE, HF_E_NAN, HF_E_REGION, HF_E_NOGPU, HF_E_RETRY = 0, -1, -2, -3, -4, -5, -6, -7
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libhmmflagger_hip.so")
+# profiling only (profiles/tools/build_variants.sh): HF_LIBRARY_VARIANT=<name> loads csrc/variants/libhmmflagger_hip.<name>.so — the same
+# sources built with other -DHF_... switches, for same-box A/B runs without rebuilding on the GPU box
+if os.environ.get("HF_LIBRARY_VARIANT"):
+    LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "variants", "libhmmflagger_hip.%s.so" % os.environ["HF_LIBRARY_VARIANT"])
 
 
 class hf_windows(C.Structure):
@@ -83,6 +87,7 @@ def lib() -> C.CDLL:
     sig("hf_last_error", C.c_char_p)
     sig("hf_device_count", C.c_int)
     sig("hf_warmup", C.c_int, C.c_int)
+    sig("hfm_warmup_pipeline", C.c_int, C.c_int)
     sig("hf_create", C.c_int, C.POINTER(hf_windows), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp))
     sig("hf_destroy", None, vp)
     sig("hf_estep", C.c_int, vp, C.POINTER(hf_params), C.c_int, vp)

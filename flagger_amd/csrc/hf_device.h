@@ -47,7 +47,7 @@ struct SegDesc {
     int reg_first, reg_last; // region of the chunk's first / last window
     int chunk;               // chunk index
     int spare_pos;           // record position whose f half takes f of the CHUNK's last window
-    int pad1;
+    int ident_row;           // the table's identity row (behind the rows of A): what a lane multiplies by past its last window
 };
 static_assert(sizeof(SegDesc) == 64, "SegDesc is one 64-byte load");
 // statistics by emission row (hf_rows.h): one pair (t-1, t) of the plan, one row slot

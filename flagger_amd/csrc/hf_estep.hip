@@ -18,6 +18,7 @@
 //                k_fwd_seq / k_bwd_seq (one wavefront per chunk, sequential recurrences)
 // There is no CPU fallback: without a HIP device hf_create fails with HF_E_NOGPU.
 #include "hf_device.h"
+#include <hip/hip_ext.h>
 #include "../../include/hmm_flagger_model.h"
 #ifndef HF_SCAN_L
 #define HF_SCAN_L 4   // consecutive windows per lane in the scan kernels
@@ -155,9 +156,11 @@ struct hf_ctx {
     KParams kparams{};             // the parameter block as kernel arguments of k_tables (one region: pack_kparams)
     bool kp_ok = true, kp_now = false;   // HF_PARAMS_COPY=1 switches the kernel-argument path off; this pass uses it
     unsigned* h_flags = nullptr;
+    int8_t* h_label = nullptr;     // pinned [N] (same block as h_total): staging of hf_get_labels
     double* h_total = nullptr;     // pinned [V+1]: reduced vector + flag word, one copy per pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
     double ksum[HF_NKERNELS] = {}; int64_t kcount[HF_NKERNELS] = {};   // accumulated by hf_finish while profiling is on
+    float klast[HF_NKERNELS] = {}; bool klast_ok[HF_NKERNELS] = {};      // the last pass's durations as hf_finish read them (hf_kernel_times returns these)
     unsigned prof_mask = 0;        // bit k: kernel k (HF_K_*) is bracketed by kev[2k], kev[2k+1]
     int prof_stride = 1; long prof_pass = 0; bool prof_now = true;   // events only in every prof_stride-th pass (hf_set_profiling_stride)
     hipEvent_t kev[2 * HF_NKERNELS] = {}; bool kran[HF_NKERNELS] = {};
@@ -663,10 +666,12 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     {   // one pinned block: the result vector (+ flag word, stamp, checksums) | the flag word of hf_check | the parameter block
         const size_t tot_bytes = ((size_t) ctx->V + 2 + HF_MAXREGIONS) * 8;
         char* pin = nullptr;
-        if (hipHostMalloc((void**) &pin, tot_bytes + 64 + ctx->params_bytes) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed"); }
+        const size_t par_bytes = (ctx->params_bytes + 63) / 64 * 64;
+        if (hipHostMalloc((void**) &pin, tot_bytes + 64 + par_bytes + N) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed"); }
         ctx->h_total = reinterpret_cast<double*>(pin);
         ctx->h_flags = reinterpret_cast<unsigned*>(pin + tot_bytes);
         ctx->h_params = reinterpret_cast<DevParams*>(pin + tot_bytes + 64);
+        ctx->h_label = reinterpret_cast<int8_t*>(pin + tot_bytes + 64 + par_bytes);   // hf_get_labels: the labels come down through pinned memory
         std::memset(ctx->h_params, 0, ctx->params_bytes);   // (pack_params fills the derived constants of the components in use only)
     }
     {
@@ -838,6 +843,11 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 TRY(dev_upload(&ctx->d_arow_src, a_src.data(), a_src.size()));
                 TRY(dev_upload(&ctx->d_arow_cls, a_cls.data(), a_cls.size()));
                 DMALLOC(ctx->d_lutA, (a_src.size() + 1) * 16 * 8);
+                {   // one row behind the rows of A: the IDENTITY (hf_seg.h: what a lane multiplies by past its last window); no kernel writes it
+                    double ident[16];
+                    for (int k = 0; k < 16; k++) ident[k] = (k % 5 == 0) ? 1.0 : 0.0;
+                    if (hipMemcpy(ctx->d_lutA + a_src.size() * 16, ident, sizeof ident, hipMemcpyHostToDevice) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: the identity row"); }
+                }
                 if (ctrace) std::fprintf(stderr, "[hf_create] %d emission keys, %d (key, transition class) rows, %d slow windows\n",
                                          ctx->n_keys, n_combo, ctx->n_slow);
             }
@@ -858,7 +868,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     d.slot0 = (int32_t) nslots; nslots += (int64_t) d.L * NL;
                     d.slow0 = (int32_t) (std::lower_bound(slow.begin(), slow.end(), (int64_t) d.t0) - slow.begin());
                     d.chunk_slow0 = ctx->n_combo + soff[c];               // the A row of the chunk's first window
-                    d.seg0 = first; d.k = (int) k; d.chunk = (int) c;
+                    d.seg0 = first; d.k = (int) k; d.chunk = (int) c; d.ident_row = ctx->n_arows;
                     d.reg_first = (int32_t) ((w->annot[t0] & 0xFC00000000000000ULL) >> 58);
                     d.reg_last = (int32_t) ((w->annot[t0 + T - 1] & 0xFC00000000000000ULL) >> 58);
                     segs.push_back(d);
@@ -1059,7 +1069,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             TRY(dev_upload(&ctx->d_pos, pos, N));
             TRY(dev_upload(&ctx->d_pos_f, pos_f, N));
             hipFree(ctx->d_recs); ctx->d_recs = nullptr;
-            DMALLOC(ctx->d_recs, (size_t) n_pos * 64);
+            if (n_pos + (int64_t) ctx->nseg >= INT32_MAX) { hf_destroy(ctx); return set_err(HF_E_ARG, "hf_create: more than 2^31 record positions (shard the chunk list: hmm_flagger_multi.h)"); }
+            DMALLOC(ctx->d_recs, ((size_t) n_pos + (size_t) ctx->nseg) * 64);   // + one spare record per segment (hf_seg.h: where lanes without a window write)
             if (ctrace) std::fprintf(stderr, "[hf_create] statistics plan: %s, %d groups, %d row-slot wavefronts of %d x 16 slots, %lld positions for %lld pairs\n",
                                      !planned ? "none (per-chunk statistics)" : ctx->plan_compact ? "compact" : "padded", ctx->n_groups, ctx->n_rowwaves,
                                      ctx->rs_bpw, (long long) n_pos, (long long) np);
@@ -1260,7 +1271,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
     // hf_device.h KParams), a copy ahead of the pass otherwise
     ctx->kp_now = ctx->kp_ok && ctx->C > 0 && ctx->algo == HF_ALGO_SCAN && p->model_type != HF_MODEL_NEGATIVE_BINOMIAL && pack_kparams(ctx, p);
     if (!ctx->kp_now) HIPCHK(hipMemcpyAsync(ctx->d_params, ctx->h_params, ctx->params_bytes, hipMemcpyHostToDevice, st));
-    for (int i = 0; i < HF_NKERNELS; i++) ctx->kran[i] = false;
+    for (int i = 0; i < HF_NKERNELS; i++) { ctx->kran[i] = false; ctx->klast_ok[i] = false; }
     ctx->prof_now = ctx->prof_stride <= 1 || (ctx->prof_pass++ % ctx->prof_stride) == 0;
     ctx->pass_rows = false; ctx->pass_bound = false;
     ctx->pass_seg = false;
@@ -1354,17 +1365,25 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                     KTimer t(ctx, st, HF_K_SEG_PROD);
                     hipLaunchKernelGGL(k_seg_prod, dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
                 }
-                KTimer t(ctx, st, HF_K_SEG_FB);
+                // the dominant kernel is timed by the dispatch's OWN start / stop timestamps (hipExtLaunchKernelGGL hands the two events to
+                // the launch): what rocprofv3 reports for the kernel, without the two marker packets of an event pair around it (those
+                // measured 3 us more than the kernel and cost the step ~15 us)
+                const bool tfb = ((ctx->prof_mask >> HF_K_SEG_FB) & 1u) && ctx->prof_now;
+                if (tfb) ctx->kran[HF_K_SEG_FB] = true;
                 const unsigned epoch = ++ctx->seg_epoch;
                 // HF_SEG_TEST_TIMEOUT=1 (tests/test_estep_gpu.py): the first one-launch pass waits for flags nobody writes, so that
                 // the time-out, HF_E_RETRY and the fall-back to two launches are exercised
                 const unsigned wait_epoch = (ctx->seg_test_timeout && epoch == 1) ? 0xffffffffu : epoch;
-#define HF_SEG_FB_LAUNCH(B, F) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow, \
-                        ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_seg_ready, epoch, wait_epoch, ctx->d_pos, ctx->d_recs, ctx->d_scale_s, ctx->d_label, \
-                        ctx->d_seg_ll, ctx->d_flags)
+#define HF_SEG_FB_ARGS ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_seg_ready, epoch, wait_epoch, ctx->d_pos, ctx->d_recs, \
+                        ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags, (int32_t) ctx->n_pos
+#define HF_SEG_FB_LAUNCH(B, F) do { \
+                    if (tfb) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) ctx->nseg), dim3(64), (uint32_t) lds, st, \
+                                                   ctx->kev[2 * HF_K_SEG_FB], ctx->kev[2 * HF_K_SEG_FB + 1], 0, HF_SEG_FB_ARGS); \
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) ctx->nseg), dim3(64), lds, st, HF_SEG_FB_ARGS); } while (0)
                 if (full) { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(true, true); else HF_SEG_FB_LAUNCH(true, false); }
                 else { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(false, true); else HF_SEG_FB_LAUNCH(false, false); }
 #undef HF_SEG_FB_LAUNCH
+#undef HF_SEG_FB_ARGS
                 ctx->pass_seg = true;
                 if (full) ctx->fb_recs = true;
             } else
@@ -1504,7 +1523,7 @@ static void accumulate_kernel_times(hf_ctx* ctx) {
     for (int i = 0; i < HF_NKERNELS; i++)
         if (ctx->kran[i]) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ctx->kev[2 * i], ctx->kev[2 * i + 1]) == hipSuccess) { ctx->ksum[i] += ms; ctx->kcount[i]++; }
+            if (hipEventElapsedTime(&ms, ctx->kev[2 * i], ctx->kev[2 * i + 1]) == hipSuccess) { ctx->ksum[i] += ms; ctx->kcount[i]++; ctx->klast[i] = ms; ctx->klast_ok[i] = true; }
         }
 }
 
@@ -1769,7 +1788,13 @@ int hf_get_labels(hf_ctx* ctx, int8_t* labels_host) {
     if (!ctx || !labels_host) return set_err(HF_E_ARG, "hf_get_labels: bad argument");
     if (!ctx->have_full) return set_err(HF_E_ARG, "hf_get_labels: the last pass was not HF_MODE_FULL (a forward-only pass decodes nothing)");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemcpy(labels_host, ctx->d_label, (size_t) ctx->N, hipMemcpyDeviceToHost));
+    // through the context's pinned block (a pageable destination costs a staging copy inside the runtime: the first 1.5 MB download of a
+    // process was measured at several milliseconds, in the middle of the command line's EM loop)
+    if (ctx->h_label && ctx->N > 0) {
+        HIPCHK(hipMemcpyAsync(ctx->h_label, ctx->d_label, (size_t) ctx->N, hipMemcpyDeviceToHost, nullptr));
+        HIPCHK(hipStreamSynchronize(nullptr));
+        std::memcpy(labels_host, ctx->h_label, (size_t) ctx->N);
+    } else HIPCHK(hipMemcpy(labels_host, ctx->d_label, (size_t) ctx->N, hipMemcpyDeviceToHost));
     return HF_OK;
 }
 
@@ -1850,7 +1875,11 @@ int hf_get_posterior(hf_ctx* ctx, int64_t first, int64_t n, double* post_host) {
 int hf_set_profiling(hf_ctx* ctx, unsigned kernel_mask) {
     if (!ctx) return set_err(HF_E_ARG, "hf_set_profiling: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
-    if (kernel_mask && !ctx->kev[0]) for (int i = 0; i < 2 * HF_NKERNELS; i++) HIPCHK(hipEventCreate(&ctx->kev[i]));
+    // timing-only events: no system-scope fence when they fire (the default event writes back and invalidates the caches — k_seg_fb's 130 MB
+    // of records would leave the L2 before k_pair_sums reads them: a sampled step was measured 15 us slower than an unsampled one)
+    if (kernel_mask && !ctx->kev[0])
+        for (int i = 0; i < 2 * HF_NKERNELS; i++)
+            if (hipEventCreateWithFlags(&ctx->kev[i], hipEventDisableSystemFence) != hipSuccess) { (void) hipGetLastError(); HIPCHK(hipEventCreate(&ctx->kev[i])); }
     ctx->prof_mask = kernel_mask & (((1u << HF_NKERNELS) - 1u) | HF_PROF_PASS);
     for (int i = 0; i < HF_NKERNELS; i++) { ctx->kran[i] = false; ctx->ksum[i] = 0.0; ctx->kcount[i] = 0; }
     return HF_OK;
@@ -1872,7 +1901,10 @@ int hf_kernel_times(hf_ctx* ctx, float ms[HF_NKERNELS]) {
     if (!ctx || !ms || !ctx->prof_mask) return set_err(HF_E_ARG, "hf_kernel_times: profiling is off");
     for (int i = 0; i < HF_NKERNELS; i++) {
         ms[i] = 0.f;
-        if (ctx->kran[i]) HIPCHK(hipEventElapsedTime(&ms[i], ctx->kev[2 * i], ctx->kev[2 * i + 1]));
+        if (ctx->kran[i]) {
+            if (ctx->klast_ok[i]) ms[i] = ctx->klast[i];       // hf_finish has read this pair already
+            else HIPCHK(hipEventElapsedTime(&ms[i], ctx->kev[2 * i], ctx->kev[2 * i + 1]));
+        }
     }
     return HF_OK;
 }

@@ -425,6 +425,56 @@ int hfm_is_feasible(const hfm_model* mc) {
     return ok ? 1 : 0;
 }
 
+// hf_warmup + one miniature EM per kernel family: every kernel of the default pass (the emission tables with the parameter block in
+// the kernel arguments and by copy, the one-launch segment kernel in both modes, pair sums, the row statistics of every component-count
+// template) is launched once on a synthetic track of 2 x 1 100 windows, so that the caller's first real pass does not pay the
+// runtime's first-launch work (the command line's first E-step took 0.3-0.4 ms against 0.114 ms for the third:
+// profiles/r04a_cli_wall.txt).  A few milliseconds, meant for the thread that brings the runtime up while the input is read.
+int hfm_warmup_pipeline(int device) {
+    int rc = hf_warmup(device);
+    if (rc != HF_OK) return rc;
+    const int C = 2, T = 1100, W = 4000;
+    std::vector<int64_t> off = {0, T, 2 * T};
+    std::vector<uint16_t> cov((size_t) C * T), mapq((size_t) C * T), clip((size_t) C * T, 0);
+    std::vector<uint64_t> ann((size_t) C * T, 0);
+    std::vector<int32_t> cs = {0, T * W}, ce = {T * W - 1, 2 * T * W - 1}, cl = {2 * T * W, 2 * T * W};
+    struct Cfg { int K, R; };
+    const Cfg cfgs[] = {{3, 1}, {6, 1}, {10, 1}, {6, 2}};
+    for (const Cfg& cf : cfgs) {
+        for (size_t t = 0; t < cov.size(); t++) {
+            cov[t] = (uint16_t) (14 + (t * 7) % 13 + ((t / 97) % 5 == 0 ? 20 : 0));
+            mapq[t] = cov[t];
+            ann[t] = cf.R > 1 ? (uint64_t) ((t / 300) % (size_t) cf.R) << 58 : 0;
+        }
+        hf_windows w;
+        std::memset(&w, 0, sizeof w);
+        w.n_windows = (int64_t) cov.size(); w.n_chunks = C; w.chunk_off = off.data();
+        w.cov = cov.data(); w.mapq = mapq.data(); w.clip = clip.data(); w.annot = ann.data();
+        w.chunk_s = cs.data(); w.chunk_e = ce.data(); w.chunk_ctg_len = cl.data();
+        w.window_len = W; w.mean_read_len = 15000; w.adjust_contig_ends = 1; w.min_read_frac = 0.95;
+        w.max_high_mapq_ratio = 0.25; w.min_high_mapq_ratio = 0.75;
+        const int32_t regcov[2] = {20, 24};
+        hfm_model* m = hfm_create(HF_MODEL_TRUNC_EXP_GAUSSIAN, cf.K, regcov, cf.R, 0, 15000, W, nullptr, 0.25, 0.75);
+        if (!m) return HF_E_ARG;
+        w.min_highly_clipped_ratio = hfm_min_highly_clipped_ratio(m);
+        hf_ctx* ctx = nullptr;
+        rc = hf_create(&w, cf.R, hfm_max_comps(m), device, HF_ALGO_SCAN, &ctx);
+        if (rc == HF_OK) {
+            std::vector<double> st((size_t) hf_chunk_stats_len(ctx));
+            int cv = 0;
+            rc = hf_em_iterate(ctx, m, HF_MODE_FULL, 1, 1e-3, st.data(), &cv, nullptr);
+            if (rc == HF_OK) rc = hf_em_iterate(ctx, m, HF_MODE_FORWARD_ONLY, 0, 1e-3, st.data(), &cv, nullptr);
+            if (rc == HF_OK) rc = hf_em_iterate(ctx, m, HF_MODE_FULL, 0, 1e-3, st.data(), &cv, nullptr);
+            std::vector<int8_t> lab(cov.size());
+            if (rc == HF_OK) rc = hf_get_labels(ctx, lab.data());
+            hf_destroy(ctx);
+        }
+        hfm_destroy(m);
+        if (rc != HF_OK) return rc;
+    }
+    return HF_OK;
+}
+
 // hmm_flagger.c:105-111 + 1012-1013
 int hfm_best_collapsed_comps(const uint16_t* cov, int64_t n, const int32_t* region_coverages, int n_regions) {
     int maxc = 0;

@@ -46,6 +46,37 @@
 
 // SegDesc: hf_device.h
 
+// ---- round 4: the segment kernel on an arithmetic diet.  Of the 5 840 VALU instructions a wavefront issued, 2 420 were
+// fp64 FMA / MUL / ADD / RCP (profiles/r04a_pmc_fp64.json); the rest moved, compared, rescaled.  Every piece has its own switch (1 = on,
+// the default) so that a same-box A/B can price it: -DHF_SEG_INTMAX=0 ...
+#ifndef HF_SEG_INTMAX
+#define HF_SEG_INTMAX 1     // renormalisation: the largest entry's exponent from an integer maximum of the high words (entries are >= 0)
+#endif
+#ifndef HF_SEG_RENORM2
+#define HF_SEG_RENORM2 1    // one power-of-two renormalisation per TWO products (lane products, scan levels): exact either way
+#endif
+#ifndef HF_SEG_IDROW
+#define HF_SEG_IDROW 1      // lanes past their last window multiply by an identity row of the table: no branches, no copies in the product loop
+#endif
+#ifndef HF_SEG_IDLANE
+#define HF_SEG_IDLANE 1     // scan levels inside a row of 16 lanes: lanes without a source multiply by the identity (no branch, no copy)
+#endif
+#ifndef HF_SEG_VECSUF
+#define HF_SEG_VECSUF 1     // suffix scan: the two cross-row levels on 4-vectors (what is consumed is suffix·u, not the suffix).; -0.2 us alone, +0.6 us once the rest of the kernel is straight-line (profiles/r04b_ab_variants.txt, r04c_ab_variants.txt)
+#endif
+#ifndef HF_SEG_IDBCAST
+#define HF_SEG_IDBCAST 1    // the prefix scan's two cross-row levels (row_bcast) straight-line too: rows without a source keep an identity matrix
+#endif
+#ifndef HF_SEG_TRASH
+#define HF_SEG_TRASH 1      // record / scale stores of lanes without a window go to a per-segment spare record instead of being branched around
+#endif
+#ifndef HF_SEG_WAVESHR
+#define HF_SEG_WAVESHR 1    // the neighbour lane's prefix by DPP wave_shr:1 (GFX9) instead of 32 ds_bpermute
+#endif
+#ifndef HF_SEG_RCP
+#define HF_SEG_RCP 1        // replays: one division (the reciprocal of the scale) and four multiplications per window instead of four divisions
+#endif
+
 // one-launch mode (k_seg_fb<., true>): hand-off of a segment's product to the chunk's other segments — write-through stores,
 // a drained queue, then the flag (= the launch's epoch); readers poll the flag and read past their caches
 // The hand-offs here and in hf_rows.h order "data stores, then flag / ticket" with relaxed atomics + s_waitcnt vmcnt(0): on GFX9 /
@@ -107,8 +138,20 @@ __device__ __forceinline__ void v4_mul_left(double v[4], const double* __restric
     for (int i = 0; i < 4; i++) v[i] = u[i];
 }
 
-// power-of-two renormalisation with a tree maximum (the chain of m4_renorm is 15 dependent operations)
+// power-of-two renormalisation: the largest entry into [0.5, 1).  Entries are probabilities (>= 0, finite, or NaN), so the order of
+// the doubles is the order of their high words: an integer maximum (v_max3_u32) gives the exponent without 15 v_max_f64 and a frexp.
+// A largest entry that is zero or denormal leaves the matrix as it is; a NaN entry stays a NaN (and reaches the scale of its window).
 __device__ __forceinline__ void m4_renorm_tree(M4& a) {
+#if HF_SEG_INTMAX
+    unsigned h = (unsigned) __double2hiint(a.m[0]);
+#pragma unroll
+    for (int i = 1; i < 16; i++) { const unsigned g = (unsigned) __double2hiint(a.m[i]); h = g > h ? g : h; }
+    const int be = (int) ((h >> 20) & 0x7ffu);
+    int ne = be ? 1022 - be : 0;                 // minus frexp's exponent of a normal number
+    asm volatile("" : "+v"(ne));                 // (ONE select, on the exponent: hipcc otherwise selects between x and ldexp(x) sixteen times)
+#pragma unroll
+    for (int i = 0; i < 16; i++) a.m[i] = ldexp(a.m[i], ne);
+#else
     double t[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) t[i] = fmax(a.m[i], a.m[i + 8]);
@@ -121,6 +164,7 @@ __device__ __forceinline__ void m4_renorm_tree(M4& a) {
 #pragma unroll
         for (int i = 0; i < 16; i++) a.m[i] = ldexp(a.m[i], -e);
     }
+#endif
 }
 
 // ---- DPP moves of a 4x4 matrix (gfx9 row_shr / row_shl / row_bcast): lanes without a source keep their own value ----
@@ -137,6 +181,13 @@ __device__ __forceinline__ double dpp0_f64(double v) {
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// the same move with `oldv` for the lanes the move does not write
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_old_f64(double oldv, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(oldv), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(oldv), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ void m4_dpp(M4& dst, const M4& src) {
 #pragma unroll
@@ -147,33 +198,82 @@ __device__ __forceinline__ void m4_dpp(M4& dst, const M4& src) {
 #define HF_DPP_ROW_BCAST15 0x142
 #define HF_DPP_ROW_BCAST31 0x143
 
+#define HF_DPP_WAVE_SHR1 0x138
+#define HF_DPP_WAVE_SHL1 0x130
+// a level inside a row of 16 lanes.  HF_SEG_IDLANE: the neighbour's matrix arrives with zeros where there is no neighbour (bound_ctrl),
+// the diagonal is set to one there, and EVERY lane multiplies — by the identity where the level does not apply: exact, no branch, no
+// copy of the product back into place.
+__device__ __forceinline__ void m4_dpp_or_identity_fix(M4& X, bool has_source) {
+#pragma unroll
+    for (int d = 0; d < 16; d += 5) X.m[d] = __hiloint2double(has_source ? __double2hiint(X.m[d]) : 0x3ff00000, __double2loint(X.m[d]));   // (the low word is 0 already)
+}
+template <int CTRL>
+__device__ __forceinline__ void m4_dpp0(M4& dst, const M4& src) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) dst.m[i] = dpp0_f64<CTRL, 0xf>(src.m[i]);
+}
 // inclusive prefix product over the 64 lanes: lane l ends with Q_0 ... Q_l (power-of-two renormalised: exact)
 __device__ __forceinline__ void m4_scan_prefix(M4& Pq, int lane) {
     M4 Lft, R;
-#define HF_STEP_SHR(n)                                                                                  \
+#if HF_SEG_IDLANE
+#define HF_STEP_SHR(n, RN)                                                                              \
+    m4_dpp0<HF_DPP_ROW_SHR(n)>(Lft, Pq);                                                                 \
+    m4_dpp_or_identity_fix(Lft, (lane & 15) >= (n));                                                    \
+    m4_mul(R, Lft, Pq); Pq = R;                                                                         \
+    if (RN) m4_renorm_tree(Pq);
+#else
+#define HF_STEP_SHR(n, RN)                                                                              \
     m4_dpp<HF_DPP_ROW_SHR(n)>(Lft, Pq);                                                                  \
-    if ((lane & 15) >= (n)) { m4_mul(R, Lft, Pq); Pq = R; m4_renorm_tree(Pq); }
-    HF_STEP_SHR(1) HF_STEP_SHR(2) HF_STEP_SHR(4) HF_STEP_SHR(8)
+    if ((lane & 15) >= (n)) { m4_mul(R, Lft, Pq); Pq = R; if (RN) m4_renorm_tree(Pq); }
+#endif
+    HF_STEP_SHR(1, !HF_SEG_RENORM2) HF_STEP_SHR(2, 1) HF_STEP_SHR(4, !HF_SEG_RENORM2) HF_STEP_SHR(8, 1)
 #undef HF_STEP_SHR
+#if HF_SEG_IDBCAST
+    // the rows the broadcast does not write keep the `old` operand: the identity — every lane multiplies, no branch, no copy
+#pragma unroll
+    for (int i = 0; i < 16; i++) Lft.m[i] = dpp_old_f64<HF_DPP_ROW_BCAST15, 0xa>((i % 5 == 0) ? 1.0 : 0.0, Pq.m[i]);   // rows 1, 3 <- lane 15 of rows 0, 2
+    m4_mul(R, Lft, Pq); Pq = R;
+    if (!HF_SEG_RENORM2) m4_renorm_tree(Pq);
+#pragma unroll
+    for (int i = 0; i < 16; i++) Lft.m[i] = dpp_old_f64<HF_DPP_ROW_BCAST31, 0xc>((i % 5 == 0) ? 1.0 : 0.0, Pq.m[i]);   // rows 2, 3 <- lane 31
+    m4_mul(R, Lft, Pq); Pq = R;
+    m4_renorm_tree(Pq);
+#else
     m4_dpp<HF_DPP_ROW_BCAST15, 0xa>(Lft, Pq);                 // rows 1, 3 <- lane 15 of rows 0, 2
-    if (lane & 16) { m4_mul(R, Lft, Pq); Pq = R; m4_renorm_tree(Pq); }
+    if (lane & 16) { m4_mul(R, Lft, Pq); Pq = R; if (!HF_SEG_RENORM2) m4_renorm_tree(Pq); }
     m4_dpp<HF_DPP_ROW_BCAST31, 0xc>(Lft, Pq);                 // rows 2, 3 <- lane 31
-    if (lane >= 32) { m4_mul(R, Lft, Pq); Pq = R; m4_renorm_tree(Pq); }
+    if (lane >= 32) { m4_mul(R, Lft, Pq); Pq = R; if (!HF_SEG_RENORM2) m4_renorm_tree(Pq); }
+    if (HF_SEG_RENORM2) m4_renorm_tree(Pq);
+#endif
 }
-// inclusive suffix product: lane l ends with Q_l ... Q_63
+// the four levels of the suffix scan inside a row of 16 lanes: lane l ends with Q_l ... Q_(last lane of its row)
+__device__ __forceinline__ void m4_scan_suffix_rows(M4& Sq, int lane) {
+    M4 Rgt, R;
+#if HF_SEG_IDLANE
+#define HF_STEP_SHL(n, RN)                                                                              \
+    m4_dpp0<HF_DPP_ROW_SHL(n)>(Rgt, Sq);                                                                 \
+    m4_dpp_or_identity_fix(Rgt, (lane & 15) + (n) < 16);                                                \
+    m4_mul(R, Sq, Rgt); Sq = R;                                                                         \
+    if (RN) m4_renorm_tree(Sq);
+#else
+#define HF_STEP_SHL(n, RN)                                                                              \
+    m4_dpp<HF_DPP_ROW_SHL(n)>(Rgt, Sq);                                                                  \
+    if ((lane & 15) + (n) < 16) { m4_mul(R, Sq, Rgt); Sq = R; if (RN) m4_renorm_tree(Sq); }
+#endif
+    HF_STEP_SHL(1, !HF_SEG_RENORM2) HF_STEP_SHL(2, 1) HF_STEP_SHL(4, !HF_SEG_RENORM2) HF_STEP_SHL(8, 1)
+#undef HF_STEP_SHL
+}
+// inclusive suffix product over the 64 lanes: lane l ends with Q_l ... Q_63 (without HF_SEG_VECSUF)
 __device__ __forceinline__ void m4_scan_suffix(M4& Sq, int lane) {
     M4 Rgt, R;
-#define HF_STEP_SHL(n)                                                                                  \
-    m4_dpp<HF_DPP_ROW_SHL(n)>(Rgt, Sq);                                                                  \
-    if ((lane & 15) + (n) < 16) { m4_mul(R, Sq, Rgt); Sq = R; m4_renorm_tree(Sq); }
-    HF_STEP_SHL(1) HF_STEP_SHL(2) HF_STEP_SHL(4) HF_STEP_SHL(8)
-#undef HF_STEP_SHL
+    m4_scan_suffix_rows(Sq, lane);
 #pragma unroll
     for (int i = 0; i < 16; i++) Rgt.m[i] = __shfl(Sq.m[i], (lane | 15) + 1);   // first lane of the next row
-    if (!(lane & 16)) { m4_mul(R, Sq, Rgt); Sq = R; m4_renorm_tree(Sq); }       // rows 0, 2
+    if (!(lane & 16)) { m4_mul(R, Sq, Rgt); Sq = R; if (!HF_SEG_RENORM2) m4_renorm_tree(Sq); }       // rows 0, 2
 #pragma unroll
     for (int i = 0; i < 16; i++) Rgt.m[i] = __shfl(Sq.m[i], 32);
-    if (lane < 32) { m4_mul(R, Sq, Rgt); Sq = R; m4_renorm_tree(Sq); }
+    if (lane < 32) { m4_mul(R, Sq, Rgt); Sq = R; if (!HF_SEG_RENORM2) m4_renorm_tree(Sq); }
+    if (HF_SEG_RENORM2) m4_renorm_tree(Sq);
 }
 
 // ---- LDS of a segment workgroup: the 8 KiB row block | the offset table [LMAX][8][8] u32 | the labels [64*LMAX] ----
@@ -181,14 +281,16 @@ __device__ __forceinline__ void m4_scan_suffix(M4& Sq, int lane) {
 // eleven.  k_seg_fb's prologue stages the chunk's segment products in the row block, which is idle until the scans.
 __host__ __device__ constexpr size_t seg_lds_bytes() { return 8192 + (size_t) 64 * HF_SEG_LMAX * 5; }
 static_assert((size_t) HF_SEG_PSTAGE * 128 <= 8192, "the staged segment products fit the row block");
+static_assert(64 * HF_SEG_LMAX >= 3 * 128, "the label area holds three parked matrices (seg_suffix_side)");
 
 // the segment's row indices, read coalesced (lane l takes windows l, 64 + l, ...)
-__device__ __forceinline__ void seg_load_arows(const int32_t* __restrict__ arow_seg, int n, int L, int lane, int32_t rr[HF_SEG_LMAX]) {
+// (windows past the segment's end get `ident`, the table's identity row: hf_create writes it once behind the rows of A)
+__device__ __forceinline__ void seg_load_arows(const int32_t* __restrict__ arow_seg, int n, int L, int lane, int32_t ident, int32_t rr[HF_SEG_LMAX]) {
 #pragma unroll
-    for (int c = 0; c < HF_SEG_LMAX; c++) { const int w = c * 64 + lane; rr[c] = (c < L && w < n) ? arow_seg[w] : 0; }
+    for (int c = 0; c < HF_SEG_LMAX; c++) { const int w = c * 64 + lane; rr[c] = (c < L && w < n) ? arow_seg[w] : ident; }
 }
 // ... and filed as BYTE OFFSETS of the rows (index << 7; hf_create keeps n_arows < 2^25) where the cooperative fetch reads
-// them: window w = j*L + i (lane j's i-th) at [i][j & 7][j >> 3]; windows past the segment's end point at row 0
+// them: window w = j*L + i (lane j's i-th) at [i][j & 7][j >> 3]; windows past the segment's end point at the identity row
 __device__ __forceinline__ void seg_offsets_store(const int32_t rr[HF_SEG_LMAX], int L, int lane, uint32_t* __restrict__ s_off) {
     const uint32_t inv = (65536u + (uint32_t) L - 1u) / (uint32_t) L;   // w / L for w < 512, L <= 8: (w * inv) >> 16, exact
 #pragma unroll
@@ -313,6 +415,119 @@ __global__ void __launch_bounds__(256) k_arows(int n_rows, const int32_t* __rest
     lutA[(int64_t) id * 16 + o] = t * lutE[(int64_t) src[id] * 16 + o];
 }
 
+// Suffix side of phase B.  Without HF_SEG_VECSUF: the inclusive suffix scan over the 64 lanes, xs = the product of the lanes after
+// this one.  With it: only the four levels inside the rows of 16 lanes; xs = the product of the lanes after this one IN ITS ROW (the
+// identity for a row's last lane), and the products of rows 1..3 (the inclusive suffix of their first lanes) parked in LDS (s_T, 3 x 16
+// doubles in the label area, idle until phase D): the end vector is later carried across the rows as a VECTOR (seg_suffix_apply),
+// 3 x 16 multiply-adds instead of two levels of 64 (+ 64 ds_bpermute + renormalisations) — what is consumed is suffix·u, never the suffix.
+__device__ __forceinline__ void seg_suffix_side(M4& Q, int lane, double xs[16], double* s_T) {
+#if HF_SEG_VECSUF
+    m4_scan_suffix_rows(Q, lane);
+    if ((lane & 15) == 0 && lane > 0) {
+        double2* dst = reinterpret_cast<double2*>(s_T) + ((lane >> 4) - 1) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[k] = make_double2(Q.m[2 * k], Q.m[2 * k + 1]);
+    }
+    M4 X;
+    m4_dpp0<HF_DPP_ROW_SHL(1)>(X, Q);
+    m4_dpp_or_identity_fix(X, (lane & 15) != 15);
+#pragma unroll
+    for (int k = 0; k < 16; k++) xs[k] = X.m[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#else
+    m4_scan_suffix(Q, lane);
+#pragma unroll
+    for (int k = 0; k < 16; k++) xs[k] = __shfl_down(Q.m[k], 1);   // exclusive suffix: lanes lane+1..63
+    (void) s_T;
+#endif
+}
+// direction of b at the lane's last window: everything after it (in the segment: xs and the later rows; then u, the end vector carried
+// in through the chunk's later segments) applied to u
+__device__ __forceinline__ void seg_suffix_apply(const double u[4], const double xs[16], int lane, const double* s_T, double bdir[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) bdir[s] = u[s];
+#if HF_SEG_VECSUF
+    const int row = lane >> 4;
+#pragma unroll
+    for (int k = 3; k >= 1; k--) {                               // z_(k-1) = T_k · z_k for the lanes of rows < k
+        double M[16], z[4] = {bdir[0], bdir[1], bdir[2], bdir[3]};
+        const double2* src = reinterpret_cast<const double2*>(s_T) + (k - 1) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const double2 t2 = src[q]; M[2 * q] = t2.x; M[2 * q + 1] = t2.y; }
+        v4_mul_left(z, M);
+#pragma unroll
+        for (int s = 0; s < 4; s++) bdir[s] = row < k ? z[s] : bdir[s];
+    }
+    v4_renorm(bdir);
+    v4_mul_left(bdir, xs);                                       // (a row's last lane: the identity)
+#else
+    if (lane < 63) v4_mul_left(bdir, xs);
+    (void) s_T;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
+// The lane product Q_j = A_{jL} ... A_{jL+L-1} (phase A; k_seg_prod and the one-launch k_seg_fb run the same code, so their results are
+// the same bits).  A chunk-first window is left out of its lane's product: it belongs to the start vector.  All 64 lanes run all L
+// steps (the row fetch is cooperative).  HF_SEG_IDROW: the steps past a lane's last window fetch the table's IDENTITY row and are
+// multiplied like any other (exact), the first factor is taken as it is, and the loop runs two products per trip with the roles of Q
+// and R swapped — no branch, no copy of a product back into place, one renormalisation per trip (HF_SEG_RENORM2).
+// On entry the fetch of step 0 has NOT been issued; on return nothing is in flight.
+// ------------------------------------------------------------------------------------------
+// (`blk` must NOT be declared __restrict__ here: the rows arrive in it through the LDS-DMA of rows_issue — inline assembly — and a noalias
+// ARGUMENT lets the compiler assume that nothing but this function's own stores changes the block: it hoisted the row reads out of the loop)
+__device__ __forceinline__ void seg_lane_product(const RowFetch& F, const double* blk, int lane, int L, int m, bool chunk_first, M4& Q) {
+    double E[16];
+    M4 A, R;
+#define HF_ROW_TO_M4(dst) _Pragma("unroll") for (int k_ = 0; k_ < 16; k_++) (dst).m[k_] = E[HF_PS(k_ >> 2, k_ & 3)]
+    rows_issue(F, 0);
+#if HF_SEG_IDROW
+    rows_read(blk, lane, E);
+    if (1 < L) rows_issue(F, 1);
+    HF_ROW_TO_M4(Q);                                             // the first factor: no product with the identity
+    if (chunk_first) m4_identity(Q);                             // (lane 0 of a chunk's first segment)
+    int i = 1;
+#pragma unroll 1
+    for (; i + 1 < L; i += 2) {
+        rows_read(blk, lane, E);
+        rows_issue(F, i + 1);
+        HF_ROW_TO_M4(A);
+        m4_mul(R, Q, A);
+        if (!HF_SEG_RENORM2) m4_renorm_tree(R);
+        rows_read(blk, lane, E);
+        if (i + 2 < L) rows_issue(F, i + 2);
+        HF_ROW_TO_M4(A);
+        m4_mul(Q, R, A);
+        m4_renorm_tree(Q);
+    }
+    if (i < L) {                                                 // L even: one more factor
+        rows_read(blk, lane, E);
+        HF_ROW_TO_M4(A);
+        m4_mul(R, Q, A);
+        Q = R;
+        m4_renorm_tree(Q);
+    }                                                            // (L == 1: the row as it is; the scans renormalise)
+    (void) m;
+#else
+    const int i0 = chunk_first ? 1 : 0;
+    m4_identity(Q);
+#pragma unroll 1
+    for (int i = 0; i < L; i++) {
+        rows_read(blk, lane, E);
+        if (i + 1 < L) rows_issue(F, i + 1);                     // in flight during this step
+        if (i < m && i >= i0) {
+            HF_ROW_TO_M4(A);
+            if (i == i0) Q = A;                                  // the first factor: no product with the identity
+            else { m4_mul(R, Q, A); Q = R; }
+            if (!HF_SEG_RENORM2 || ((i - i0) & 1) || i + 1 >= m) m4_renorm_tree(Q);
+        }
+    }
+#endif
+#undef HF_ROW_TO_M4
+}
+
 // ------------------------------------------------------------------------------------------
 // k_seg_prod: phase A for every segment: the lane products (lane-minor: 1 KiB per store instruction; k_seg_fb's scans start
 // from them) and the product of the whole segment (used by the chunk's OTHER segments only).  A chunk-first window is left
@@ -330,28 +545,12 @@ __global__ void __launch_bounds__(64, 4) k_seg_prod(const SegDesc* __restrict__ 
     const int m = d.n - a < L ? (d.n - a > 0 ? d.n - a : 0) : L;
     {
         int32_t rr[HF_SEG_LMAX];
-        seg_load_arows(arow + d.t0, d.n, L, lane, rr);
+        seg_load_arows(arow + d.t0, d.n, L, lane, d.ident_row, rr);
         seg_offsets_store(rr, L, lane, s_off);
     }
     const RowFetch F = rowfetch_init(lutA, s_off, blk, lane);
-    const int i0 = (a == 0 && d.k == 0) ? 1 : 0;               // the chunk's first window starts the chain (hmm.c:333-364)
     M4 Q;
-    m4_identity(Q);
-    rows_issue(F, 0);
-#pragma unroll 1
-    for (int i = 0; i < L; i++) {
-        double E[16];
-        rows_read(blk, lane, E);
-        if (i + 1 < L) rows_issue(F, i + 1);                     // in flight during this step
-        if (i < m && i >= i0) {
-            M4 A, R;
-#pragma unroll
-            for (int k = 0; k < 16; k++) A.m[k] = E[HF_PS(k >> 2, k & 3)];
-            if (i == i0) Q = A;                                  // the first factor: no product with the identity
-            else { m4_mul(R, Q, A); Q = R; }
-            m4_renorm_tree(Q);
-        }
-    }
+    seg_lane_product(F, blk, lane, L, m, a == 0 && d.k == 0, Q);   // the chunk's first window starts the chain (hmm.c:333-364)
     {
         double2* __restrict__ dst = reinterpret_cast<double2*>(Qs) + (int64_t) g * 8 * 64 + lane;
 #pragma unroll
@@ -376,13 +575,14 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                                                            const double* __restrict__ Qs, double* Pseg, unsigned* ready, unsigned epoch, unsigned wait_epoch,
                                                            const int32_t* __restrict__ pos, double* __restrict__ recs, double* __restrict__ scale_s,
                                                            int8_t* __restrict__ label, double* __restrict__ seg_ll,
-                                                           unsigned* __restrict__ flags) {
+                                                           unsigned* __restrict__ flags, int32_t trash0) {
     constexpr int LM = HF_SEG_LMAX;
     extern __shared__ __attribute__((aligned(16))) double s_W[];
     double* __restrict__ blk = s_W;                                           // the 8 KiB row block
     uint32_t* __restrict__ s_off = reinterpret_cast<uint32_t*>(s_W + 1024);   // the row offsets of the replay
     int8_t* __restrict__ s_lab = reinterpret_cast<int8_t*>(s_W + 1024) + 64 * LM * 4;   // [64 * LM] labels of the segment
     double* __restrict__ s_P = s_W;                                           // prologue: the chunk's segment products, in the (still idle) row block
+    double* __restrict__ s_T = reinterpret_cast<double*>(s_lab);             // phase B: the suffix products of rows 1..3 (384 of the label area's 512 bytes, idle until phase D)
     const int g = blockIdx.x, lane = threadIdx.x;
     const SegDesc d = sd[g];
     const int L = d.L, n = d.n;
@@ -396,7 +596,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     const RowFetch F = rowfetch_init(lutA, s_off, blk, lane);
     {
         int32_t rr[LM];
-        seg_load_arows(arow + d.t0, n, L, lane, rr);
+        seg_load_arows(arow + d.t0, n, L, lane, d.ident_row, rr);
         // forward vector entering the chunk: start∘e of its first window = row (0, s) of that window's row of A
         double v[4], u[4];
         {
@@ -413,23 +613,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             // ---- A (one launch): the lane product is computed here (k_seg_prod's loop); the segment's product is what the prefix
             // scan leaves in lane 63: it is PUBLISHED for the chunk's other segments, theirs are awaited (seg_gather) ----
             seg_offsets_store(rr, L, lane, s_off);
-            const int i0 = chunk_first ? 1 : 0;
-            m4_identity(Q);
-            rows_issue(F, 0);
-#pragma unroll 1
-            for (int i = 0; i < L; i++) {
-                double E[16];
-                rows_read(blk, lane, E);
-                if (i + 1 < L) rows_issue(F, i + 1);
-                if (i < m && i >= i0) {
-                    M4 A2, R2;
-#pragma unroll
-                    for (int k = 0; k < 16; k++) A2.m[k] = E[HF_PS(k >> 2, k & 3)];
-                    if (i == i0) Q = A2;                         // the first factor: no product with the identity
-                    else { m4_mul(R2, Q, A2); Q = R2; }
-                    m4_renorm_tree(Q);
-                }
-            }
+            seg_lane_product(F, blk, lane, L, m, chunk_first, Q);
             TR_STAMP(1);
             if (BWD) m4_park(Q, lane, blk);
             m4_scan_prefix(Q, lane);
@@ -442,8 +626,14 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 if (lane == 63) __hip_atomic_store(ready + g, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             TR_STAMP(2);
+#if HF_SEG_WAVESHR
+            { M4 X_; m4_dpp0<HF_DPP_WAVE_SHR1>(X_, Q); m4_dpp_or_identity_fix(X_, lane > 0);   // one DPP move per word instead of a ds_bpermute; lane 0: the identity
+#pragma unroll
+              for (int k = 0; k < 16; k++) xv[k] = X_.m[k]; }
+#else
 #pragma unroll
             for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);   // exclusive prefix: the product of lanes 0..lane-1
+#endif
             {
                 const double sv = ((v[0] + v[1]) + v[2]) + v[3];
 #pragma unroll
@@ -454,9 +644,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 // the second scan needs nothing from the other segments: it runs BEFORE their products are awaited, so that the
                 // skew between the segments of a chunk is spent here instead of in the polls below (k_seg_fb 60.5 -> 59 us)
                 m4_unpark(Q, lane, blk);
-                m4_scan_suffix(Q, lane);
-#pragma unroll
-                for (int k = 0; k < 16; k++) xs[k] = __shfl_down(Q.m[k], 1);   // exclusive suffix: lanes lane+1..63
+                seg_suffix_side(Q, lane, xs, s_T);
             }
             TR_STAMP(3);
             if (d.nseg > 1) {
@@ -561,10 +749,16 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
         if (BWD) m4_park(Q, lane, blk);
         TR_STAMP(4);
         m4_scan_prefix(Q, lane);
+#if HF_SEG_WAVESHR
+        { M4 X_; m4_dpp0<HF_DPP_WAVE_SHR1>(X_, Q); m4_dpp_or_identity_fix(X_, lane > 0);
+#pragma unroll
+          for (int k = 0; k < 16; k++) xv[k] = X_.m[k]; }
+#else
 #pragma unroll
         for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);   // exclusive prefix: the product of lanes 0..lane-1
+#endif
         }
-        if (lane > 0) v4_mul_right(v, xv);
+        if (HF_SEG_WAVESHR || lane > 0) v4_mul_right(v, xv);
         {
             const double su = ((v[0] + v[1]) + v[2]) + v[3];
 #pragma unroll
@@ -575,14 +769,13 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
         if (BWD) {
             if constexpr (!FUSED) {
                 m4_unpark(Q, lane, blk);
-                m4_scan_suffix(Q, lane);
-#pragma unroll
-                for (int k = 0; k < 16; k++) xs[k] = __shfl_down(Q.m[k], 1);   // exclusive suffix: lanes lane+1..63
+                seg_suffix_side(Q, lane, xs, s_T);
             }
-            // direction of b at the lane's last window: everything after it applied to the end vector
+            seg_suffix_apply(u, xs, lane, s_T, bdir);
+            // (keep the four values HERE: left to itself the compiler sinks this arithmetic into the branch of phase D that uses it and
+            // carries xs — 32 registers — across the replays, spilling the forward state instead: 195 spilled registers against 48)
 #pragma unroll
-            for (int s = 0; s < 4; s++) bdir[s] = u[s];
-            if (lane < 63) v4_mul_left(bdir, xs);
+            for (int s = 0; s < 4; s++) asm volatile("" : "+v"(bdir[s]));
         }
     }
     TR_STAMP(6);
@@ -615,8 +808,14 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 const double sc = ((nf[0] + nf[1]) + nf[2]) + nf[3];
                 if (!(chunk_first && i == 0) && sc < 1e-50) bad |= HF_FLAG_SCALE;   // hmm.c:412-415 (not at the chunk's first window)
                 if (!(sc == sc)) bad |= HF_FLAG_NAN;                      // a NaN emission value (hmm_utils.c:783-786)
+#if HF_SEG_RCP
+                const double rsc = 1.0 / sc;                              // (f differs from nf / sc in the last bit at most)
+#pragma unroll
+                for (int s = 0; s < 4; s++) { f[s] = nf[s] * rsc; fs[i][s] = f[s]; }
+#else
 #pragma unroll
                 for (int s = 0; s < 4; s++) { f[s] = nf[s] / sc; fs[i][s] = f[s]; }
+#endif
                 { int e2; lm *= frexp(sc, &e2); le += e2; }                // hmm.c:428, see above
                 scl = sc; ss[i] = sc;
             }
@@ -677,14 +876,26 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + lane;
             const double2 v0 = img[0], v1 = img[64], v2 = img[128], v3 = img[192];
-            const int32_t pact = act ? pk : -1;             // the record of lane r goes to position pact(r): lanes 4r .. 4r+3 of instruction r >> 4
             double2* __restrict__ R2 = reinterpret_cast<double2*>(recs) + (lane & 3);
+#if HF_SEG_TRASH
+            // lanes without a window k write THE SEGMENT'S SPARE RECORD (position trash0 + g, behind the plan's positions) and a padding slot
+            // of the scales (a segment owns 64 L slots): straight-line stores instead of five regions of masked execution per step
+            const int32_t pact = act ? pk : trash0 + g;     // the record of lane r goes to position pact(r): lanes 4r .. 4r+3 of instruction r >> 4
+            const int32_t p0 = __shfl(pact, lane >> 2), p1 = __shfl(pact, 16 + (lane >> 2)), p2 = __shfl(pact, 32 + (lane >> 2)), p3 = __shfl(pact, 48 + (lane >> 2));
+            R2[(int64_t) p0 * 4] = v0;
+            R2[(int64_t) p1 * 4] = v1;
+            R2[(int64_t) p2 * 4] = v2;
+            R2[(int64_t) p3 * 4] = v3;
+            scale_s[slot_ij + (int64_t) k * 64] = sck;
+#else
+            const int32_t pact = act ? pk : -1;             // the record of lane r goes to position pact(r): lanes 4r .. 4r+3 of instruction r >> 4
             const int32_t p0 = __shfl(pact, lane >> 2), p1 = __shfl(pact, 16 + (lane >> 2)), p2 = __shfl(pact, 32 + (lane >> 2)), p3 = __shfl(pact, 48 + (lane >> 2));
             if (p0 >= 0) R2[(int64_t) p0 * 4] = v0;
             if (p1 >= 0) R2[(int64_t) p1 * 4] = v1;
             if (p2 >= 0) R2[(int64_t) p2 * 4] = v2;
             if (p3 >= 0) R2[(int64_t) p3 * 4] = v3;
             if (act) scale_s[slot_ij + (int64_t) k * 64] = sck;
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                    // the block has been read out: the next row fetch may land
         };
@@ -714,8 +925,14 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                     }
                     const double sc = ss[k - 1];
                     if (sc < 1e-50) bad |= HF_FLAG_SCALE;                     // hmm.c:521-524
+#if HF_SEG_RCP
+                    const double rsc = 1.0 / sc;
+#pragma unroll
+                    for (int s = 0; s < 4; s++) b[s] = nb[s] * rsc;
+#else
 #pragma unroll
                     for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
+#endif
                     s_lab[a + k - 1] = (int8_t) posterior_label_fast(fs[k - 1], b, sc);
                 }
                 TR_LAP(6);

@@ -82,6 +82,10 @@ void hfm_set_loglikelihood(hfm_model *m, double ll);
 int hf_em_iterate(hf_ctx *ctx, hfm_model *model, int mode, int do_mstep, double tol, double *stats_host, int *converged,
                   void *stream);
 
+/* hf_warmup(device) and then one miniature synthetic EM per kernel family of the default pass (a few milliseconds): the first real pass
+ * then finds every kernel launched once.  Optional; for the thread that brings the runtime up while the input is read. */
+int hfm_warmup_pipeline(int device);
+
 int hfm_best_collapsed_comps(const uint16_t *cov, int64_t n_windows, const int32_t *region_coverages, int n_regions);
 int hfm_read_alpha_tsv(const char *path, double *alpha16);
 

@@ -704,14 +704,14 @@ def test_static_guard_of_the_one_launch_hand_off(monkeypatch):
     """a chunk with more segments than the device holds workgroups of k_seg_fb can never have all of them resident —
     every wait of the one-launch kernel would run into its bound.  hf_create sees that and starts such a context in two-launch
     mode (no time-out, no retry): one chunk of 2 M windows (3 907 segments against 12 x 256 resident workgroups), against the oracle;
-    and the same decision forced on a small input by pretending a device that holds five workgroups (HF_SEG_RESIDENT)."""
+    and the same decision forced on a small input by pretending a device that holds two workgroups (HF_SEG_RESIDENT)."""
     small = synth.config(2, scale=0.02)
     K = hmm.getBestNumberOfCollapsedComps(small)
     model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, small, synth.HIFI_ALPHA)
     em = hmm.EMList(small, model, True, 0.95)
     assert em.seg_launches == 1
     em.close()
-    monkeypatch.setenv("HF_SEG_RESIDENT", "5")
+    monkeypatch.setenv("HF_SEG_RESIDENT", "2")              # (this input's longest chunk has three segments)
     em = hmm.EMList(small, model, True, 0.95)
     assert em.seg_launches == 2
     em.close()
