@@ -167,6 +167,7 @@ static int write_summary(Run& run, const std::string& dir, const std::string& su
         fprintf(stderr, "[%s] Writing tables to file %s is done.\n", ts(), g_summary.path.c_str());
         if (timing) fprintf(stderr, "[phase]   (summary tables %s: %.1f ms, beside the EM)\n", suffix.c_str(), (real_time() - t_begin) * 1e3);
     });
+    if (timing) fprintf(stderr, "[phase]   (summary tables %s: labels down + worker started in %.2f ms)\n", suffix.c_str(), (real_time() - t_begin) * 1e3);
     if (wait) summary_join();
     return HF_OK;
 }
