@@ -157,6 +157,7 @@ struct hf_ctx {
     bool kp_ok = true, kp_now = false;   // HF_PARAMS_COPY=1 switches the kernel-argument path off; this pass uses it
     unsigned* h_flags = nullptr;
     int8_t* h_label = nullptr;     // pinned [N] (same block as h_total): staging of hf_get_labels
+    int8_t* d_label_host = nullptr; // its device address (a kernel writes the labels there)
     double* h_total = nullptr;     // pinned [V+1]: reduced vector + flag word, one copy per pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
     double ksum[HF_NKERNELS] = {}; int64_t kcount[HF_NKERNELS] = {};   // accumulated by hf_finish while profiling is on
@@ -454,6 +455,11 @@ static int launch_nb_total(hf_ctx* ctx, hipStream_t st, double* out, bool with_f
     return 0;
 }
 
+__global__ void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 // host getters (hf_get_forward_backward): f, b and the scale of windows first .. first + n, gathered from the pair records
 __global__ void k_gather_fb(int64_t first, int64_t n, const int32_t* __restrict__ pos, const int32_t* __restrict__ pos_f,
                             const int32_t* __restrict__ slot_of, const double* __restrict__ recs, const double* __restrict__ scale_s,
@@ -653,7 +659,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
 
     if (algo == HF_ALGO_SEQ) DMALLOC(ctx->d_E, N * 16 * 8);
     if (algo == HF_ALGO_SEQ) DMALLOC(ctx->d_scale, N * 8);   // window-order scales: the sequential cross-check only (hf_seg.h keeps them by slot)
-    DMALLOC(ctx->d_label, N);
+    DMALLOC(ctx->d_label, N + 16);
     DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, ((size_t) ctx->V + 1) * 8);
     DMALLOC(ctx->d_flags, 4);
     DMALLOC(ctx->d_done, HF_DONE_BYTES);         // tickets and scratch of the in-launch hand-offs (hf_rows.h)
@@ -664,10 +670,10 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     DMALLOC(ctx->d_params, ctx->params_bytes);
     hipMemset(ctx->d_params, 0, ctx->params_bytes);   // (the kernel-argument path writes the bytes in use only)
     {   // one pinned block: the result vector (+ flag word, stamp, checksums) | the flag word of hf_check | the parameter block
-        const size_t tot_bytes = ((size_t) ctx->V + 2 + HF_MAXREGIONS) * 8;
+        const size_t tot_bytes = (((size_t) ctx->V + 2 + HF_MAXREGIONS) * 8 + 63) / 64 * 64;   // (what follows stays 64-byte aligned)
         char* pin = nullptr;
         const size_t par_bytes = (ctx->params_bytes + 63) / 64 * 64;
-        if (hipHostMalloc((void**) &pin, tot_bytes + 64 + par_bytes + N) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed"); }
+        if (hipHostMalloc((void**) &pin, tot_bytes + 64 + par_bytes + N + 16) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed"); }
         ctx->h_total = reinterpret_cast<double*>(pin);
         ctx->h_flags = reinterpret_cast<unsigned*>(pin + tot_bytes);
         ctx->h_params = reinterpret_cast<DevParams*>(pin + tot_bytes + 64);
@@ -676,8 +682,10 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     }
     {
         void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, ctx->h_total, 0) == hipSuccess) ctx->d_total_host = (double*) dp;
-        else (void) hipGetLastError();
+        if (hipHostGetDevicePointer(&dp, ctx->h_total, 0) == hipSuccess) {
+            ctx->d_total_host = (double*) dp;
+            ctx->d_label_host = reinterpret_cast<int8_t*>(dp) + (reinterpret_cast<char*>(ctx->h_label) - reinterpret_cast<char*>(ctx->h_total));
+        } else (void) hipGetLastError();
     }
     cphase("device + pinned allocations");
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
@@ -1790,8 +1798,14 @@ int hf_get_labels(hf_ctx* ctx, int8_t* labels_host) {
     HIPCHK(hipSetDevice(ctx->device));
     // through the context's pinned block (a pageable destination costs a staging copy inside the runtime: the first 1.5 MB download of a
     // process was measured at several milliseconds, in the middle of the command line's EM loop)
-    if (ctx->h_label && ctx->N > 0) {
-        HIPCHK(hipMemcpyAsync(ctx->h_label, ctx->d_label, (size_t) ctx->N, hipMemcpyDeviceToHost, nullptr));
+    // A KERNEL writes them into the context's pinned block (as the passes write their totals), the host copies them on: a process's first
+    // device-to-host COPY into a fresh pinned block was measured at 8.9 ms (the second at 0.15 ms: profiles/r04e_cli_wall.txt) — in the
+    // middle of the command line's EM loop, for the "initial" summary tables; the kernel takes ~0.1 ms the first time too.
+    if (ctx->d_label_host && ctx->N > 0) {
+        const int64_t n16 = (ctx->N + 15) / 16;      // (d_label and the pinned block are padded to 16 bytes)
+        hipLaunchKernelGGL(k_copy16, dim3((unsigned) ((n16 + 255) / 256)), dim3(256), 0, nullptr, reinterpret_cast<const uint4*>(ctx->d_label),
+                           reinterpret_cast<uint4*>(ctx->d_label_host), n16);
+        HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(nullptr));
         std::memcpy(labels_host, ctx->h_label, (size_t) ctx->N);
     } else HIPCHK(hipMemcpy(labels_host, ctx->d_label, (size_t) ctx->N, hipMemcpyDeviceToHost));

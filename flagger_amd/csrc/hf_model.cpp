@@ -9,6 +9,12 @@
 #include <cstring>
 #include <vector>
 #include <string>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <algorithm>
 
 namespace {
 constexpr int S = HF_NSTATES;
@@ -82,6 +88,57 @@ struct hfm_model {
     double& T(int r, int i, int j) { return trans[(size_t) r * 25 + i * 5 + j]; }
     bool gaussian_state(int s) const { return !(s == 0 && model_type == HF_MODEL_TRUNC_EXP_GAUSSIAN); }
 };
+
+// a few host threads for the negative-binomial tables of hfm_params (started on first use; the caller works too)
+namespace {
+struct NbPool {
+    std::mutex m, run_m;
+    std::condition_variable cv, cv_done;
+    std::vector<std::thread> th;
+    const std::function<void(size_t)>* job = nullptr;
+    size_t n = 0, gen = 0;
+    std::atomic<size_t> next{0}, done{0};
+    int busy = 0;
+    bool stop = false;
+    void worker() {
+        size_t seen = 0;
+        for (;;) {
+            const std::function<void(size_t)>* f; size_t N;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen; f = job; N = n;
+                if (!f) continue;
+                busy++;
+            }
+            for (size_t k; (k = next.fetch_add(1)) < N;) { (*f)(k); done.fetch_add(1); }
+            { std::lock_guard<std::mutex> g(m); busy--; }
+            cv_done.notify_all();
+        }
+    }
+    void run(size_t N, const std::function<void(size_t)>& f) {
+        std::unique_lock<std::mutex> only(run_m, std::try_to_lock);      // (two models filling their tables at once: the second one by itself)
+        if (N < 4 || !only.owns_lock()) { for (size_t k = 0; k < N; k++) f(k); return; }
+        {
+            std::lock_guard<std::mutex> g(m);
+            if (th.empty()) {
+                const unsigned hw = std::thread::hardware_concurrency();
+                const size_t T = std::min<size_t>(7, hw > 1 ? hw - 1 : 0);
+                for (size_t t = 0; t < T; t++) th.emplace_back([this] { worker(); });
+            }
+            next.store(0); done.store(0); job = &f; n = N; gen++;
+        }
+        cv.notify_all();
+        for (size_t k; (k = next.fetch_add(1)) < N;) { f(k); done.fetch_add(1); }
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return done.load() >= N && busy == 0; });
+        job = nullptr; n = 0;
+    }
+    ~NbPool() { { std::lock_guard<std::mutex> g(m); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
+};
+NbPool& nb_pool() { static NbPool p; return p; }
+}
 
 extern "C" {
 
@@ -169,9 +226,15 @@ void hfm_params(const hfm_model* m, hf_params* out) {
     m->nb_dig.assign((size_t) m->R * S * K * NX, 0.0);
     m->nb_r.assign((size_t) m->R * S * K, 0.0);
     m->nb_beta.assign((size_t) m->R * S * K, 0.0);
+    // one job per (region, state, component): ~250 lgamma + exp each (25 us) — on a small pool of host threads (the tables cost 0.1 ms
+    // per EM iteration on one thread, a quarter of the negative-binomial step; each job writes its own rows: same values in any order)
+    struct Job { int r, s, c; };
+    std::vector<Job> jobs;
     for (int r = 0; r < m->R; r++)
         for (int s = 0; s < S; s++)
-            for (int c = 0; c < m->ncomp[s]; c++) {
+            for (int c = 0; c < m->ncomp[s]; c++) jobs.push_back({r, s, c});
+    nb_pool().run(jobs.size(), [&](size_t j) {
+                const int r = jobs[j].r, s = jobs[j].s, c = jobs[j].c;
                 const double theta = mm->M(r, s, c), lambda = mm->Vr(r, s, c), w = mm->W(r, s, c);
                 const double rr = -1 * lambda / std::log(theta);
                 const size_t pc = ((size_t) r * S + s) * K + c;
@@ -180,15 +243,16 @@ void hfm_params(const hfm_model* m, hf_params* out) {
                 double* P = &m->nb_P[pc * NX];
                 double* D = &m->nb_dig[pc * NX];
                 // the x-independent terms once per component (pure functions of the same arguments: same doubles)
-                const double lg_r = lgamma(rr), r_log_theta = rr * std::log(theta), log_1m_theta = std::log(1 - theta);
+                int sg = 0;                                       // (lgamma_r: lgamma's value without the global signgam)
+                const double lg_r = lgamma_r(rr, &sg), r_log_theta = rr * std::log(theta), log_1m_theta = std::log(1 - theta);
                 for (int x = 0; x < NXF; x++) {
-                    double p = w * std::exp(lgamma(rr + x) - lg_r - lgx1[x] + r_log_theta + (double) x * log_1m_theta);
+                    double p = w * std::exp(lgamma_r(rr + x, &sg) - lg_r - lgx1[x] + r_log_theta + (double) x * log_1m_theta);
                     if (!(p != p) && p < 1e-40) p = 1e-40;       // NaN is kept: the E-step reports it if the value is used
                     P[x] = p;
                 }
                 D[0] = (double) digammal_(rr);
                 for (int x = 1; x < NXF; x++) D[x] = D[x - 1] + 1.0 / (rr + x - 1);
-            }
+            });
     for (int r = 0; r < m->R; r++)
         for (int s = 0; s < S; s++)
             for (int x = 0; x < NXF; x++) {

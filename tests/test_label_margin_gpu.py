@@ -6,7 +6,7 @@ Here the question is asked of the inputs a user has: BASELINE configs[2] at full
 100 000-observation tracks, each AFTER the EM has converged (the pass that writes the BED, hmm_flagger.c:464).  Both sides
 decode with the SAME converged parameters; for every window the relative gap between the two largest ORACLE posteriors
 is binned (< 1e-12, < 1e-10, < 1e-8) and the HIP <-> oracle label mismatches are counted per bin.  Asserted: no mismatch
-outside the 1e-12 band.  The counts go to gpurun_out/r03_label_margin.json (DESIGN.md §2 quotes the committed copy)."""
+outside the 1e-12 band.  The counts go to gpurun_out/label_margin.json (DESIGN.md §2 quotes the committed copy)."""
 import json
 import os
 
@@ -65,7 +65,7 @@ def test_margin_of_the_final_labels(name, cov, model_type, tol):
             rec["gap<%g" % band] = {"windows": int(inside.sum()), "mismatches": int((mism & inside).sum())}
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
-        path = os.path.join(out, "r03_label_margin.json")
+        path = os.path.join(out, "label_margin.json")
         allrec = json.load(open(path)) if os.path.exists(path) else {}
         allrec[name] = rec
         json.dump(allrec, open(path, "w"), indent=1)
