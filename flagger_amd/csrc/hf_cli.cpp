@@ -100,7 +100,9 @@ static double random_factor(double dev) {                  // hmm_flagger.c:113-
 
 struct Run;
 static const char* run_error();
+static void summary_wait_quietly();
 static int die_estep(int rc) {
+    summary_wait_quietly();                                                         // (a worker still writing tables: let it finish before the process unwinds)
     if (rc == HF_E_SCALE) fprintf(stderr, "scale is very low!\n");                 // hmm.c:413
     else if (rc == HF_E_NAN) fprintf(stderr, "[Error] prob is NAN\n");             // hmm_utils.c:784
     else fprintf(stderr, "[%s] Error: %s\n", ts(), run_error());
@@ -142,6 +144,7 @@ struct SummaryJob {
     double ms = 0.0;
 };
 static SummaryJob g_summary;
+static void summary_wait_quietly() { if (g_summary.th.joinable()) g_summary.th.join(); }
 static void summary_join() {
     if (g_summary.th.joinable()) g_summary.th.join();
     if (g_summary.rc != 0) { fprintf(stderr, "[%s] %s\n", ts(), g_summary.err.c_str()); exit(EXIT_FAILURE); }

@@ -152,6 +152,9 @@ __device__ __forceinline__ double xcu_load(const double* p) { return __hip_atomi
 __device__ __forceinline__ double* done_scratch(unsigned* done) { return reinterpret_cast<double*>(done + ((HF_DONE_WORDS + 1) & ~1)); }
 #define HF_DONE_BYTES ((((HF_DONE_WORDS + 1) & ~1) * 4) + (HF_MAXREGIONS + 1) * 8)
 
+#ifndef HF_ROWS_TOTAL_INFLIGHT
+#define HF_ROWS_TOTAL_INFLIGHT 32   // loads a thread of the totalling block keeps in flight (a wavefront counts at most 63 outstanding)
+#endif
 // one region; returns (thread 0) the checksum sum of what was written
 template <int KT>
 __device__ unsigned long long rows_total_region(int r, const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_stats,
@@ -174,12 +177,13 @@ __device__ unsigned long long rows_total_region(int r, const int32_t* __restrict
     for (int w = tid; w < nq * NA; w += nt) {
         const int q = w / NA, i = w - q * NA;
         double v = 0.0;
-        for (int k = w0 + q; k < w1; k += nq * 32) {   // 32 loads in flight (the partials come from other CUs: every load is a miss), adds in plan order
-            double xk[32];
+        constexpr int NF = HF_ROWS_TOTAL_INFLIGHT;
+        for (int k = w0 + q; k < w1; k += nq * NF) {   // NF loads in flight (the partials come from other CUs: every load is a miss), adds in plan order
+            double xk[NF];
 #pragma unroll
-            for (int u = 0; u < 32; u++) xk[u] = k + nq * u < w1 ? xcu_load(blk_stats + (int64_t) (k + nq * u) * NA + i) : 0.0;
+            for (int u = 0; u < NF; u++) xk[u] = k + nq * u < w1 ? xcu_load(blk_stats + (int64_t) (k + nq * u) * NA + i) : 0.0;
 #pragma unroll
-            for (int u = 0; u < 32; u++) if (k + nq * u < w1) v += xk[u];
+            for (int u = 0; u < NF; u++) if (k + nq * u < w1) v += xk[u];
         }
         part[q][i] = v;
     }

@@ -231,24 +231,14 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
     __shared__ unsigned char s_item[3][HF_TABLE_MAX_ITEMS];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) *flags = 0u;   // first kernel of every pass
-    // the parameter block: in global memory (copied before the launch), or — one region, hf_device.h KParams — in the kernel
-    // arguments: rebuilt here in LDS, and by block 0 in global memory for the kernels that follow
-    __shared__ double s_params[KARG ? sizeof(DevParams) / 8 : 1];
-    const DevParams* __restrict__ P;
-    if constexpr (KARG) {
-        kparams_expand(kp, s_params, tid, 256);
-        if (blockIdx.x == 0) kparams_expand(kp, reinterpret_cast<double*>(P_out), tid, 256);
-        __syncthreads();
-        P = reinterpret_cast<const DevParams*>(s_params);
-    } else P = Pg;
-    const int ncol = P->ncomp[3], n_items = P->n_items;
-    const bool te = hf_err_is_truncexp(P);
+    // the jobs of the block first: their loads (key / window record / beta: global memory) are in flight while the parameter block is
+    // rebuilt below — two dependent rounds of global latency were the larger part of this launch-bound kernel's critical path
     const int job0 = blockIdx.x * HF_TABLE_JOBS_PER_BLOCK;
     const int n_lut_rows = (int) ((Es - lutE) / 16);   // Es / Cs are the rows n_lut.. of the same buffers
+    TableJob J;
+    J.x = 0.0; J.px = 0.0; J.bt = 0.0; J.row = 0; J.r = 0; J.flags = 0;
     if (tid < HF_TABLE_JOBS_PER_BLOCK) {
         const int job = job0 + tid;
-        TableJob J;
-        J.x = 0.0; J.px = 0.0; J.bt = P->beta_star; J.row = 0; J.r = 0; J.flags = 0;
         if (job < n_keys) {
             const int64_t key = keys[job];
             const int64_t MM = (int64_t) M * M;
@@ -264,6 +254,21 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
             J.bt = beta[t]; J.row = (int64_t) n_lut_rows + k; J.flags = (first ? 2 : 0) | 4;
             if (cls) J.flags |= (cls[job] & 0xff) << 8;
         }
+    }
+    // the parameter block: in global memory (copied before the launch), or — one region, hf_device.h KParams — in the kernel
+    // arguments: rebuilt here in LDS, and by block 0 in global memory for the kernels that follow
+    __shared__ double s_params[KARG ? sizeof(DevParams) / 8 : 1];
+    const DevParams* __restrict__ P;
+    if constexpr (KARG) {
+        kparams_expand(kp, s_params, tid, 256);
+        if (blockIdx.x == 0) kparams_expand(kp, reinterpret_cast<double*>(P_out), tid, 256);
+        __syncthreads();
+        P = reinterpret_cast<const DevParams*>(s_params);
+    } else P = Pg;
+    const int ncol = P->ncomp[3], n_items = P->n_items;
+    const bool te = hf_err_is_truncexp(P);
+    if (tid < HF_TABLE_JOBS_PER_BLOCK) {
+        if ((J.flags & 5) != 4) J.bt = P->beta_star;   // table keys (and idle jobs): the interior windows' beta; a slow window keeps its own
         s_job[tid] = J;
     }
     if (tid < 16) s_base[tid] = P->item_base[tid];
