@@ -340,10 +340,10 @@ struct KTimer {
 // default 64 KiB is requested explicitly.
 struct TileGeom { unsigned blocks = 0, threads = 256; size_t lds = 0; bool ok = false; };
 template <class Kern>
-static TileGeom tile_geom(const hf_ctx* ctx, Kern kernel, size_t per_wave_bytes, bool with_tab = true) {
+static TileGeom tile_geom(const hf_ctx* ctx, Kern kernel, size_t per_wave_bytes, bool with_tab = true, int wmax = 4) {
     TileGeom g;
     const size_t tab = with_tab ? (size_t) ctx->R * HF_TAB_STRIDE * 8 : 0;
-    int w = 4;
+    int w = wmax;
     while (w >= 1 && tab + (size_t) w * per_wave_bytes > ctx->lds_max) w--;
     if (w < 1) return g;
     g.threads = 64u * (unsigned) w;
@@ -409,8 +409,9 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         }
         KTimer t(ctx, st, HF_K_ROW_STATS);
         constexpr size_t NA = 16 + 9 + 2 + 3 * KT + 1;
-        TileGeom g = tile_geom(ctx, k_row_stats<KT>, NA * 8, false);   // the wavefronts' sums: four wavefronts per block, a block stays inside one region
+        TileGeom g = tile_geom(ctx, k_row_stats<KT>, NA * 8, false, HF_RS_WPB);   // the wavefronts' sums: HF_RS_WPB wavefronts per block, a block stays inside one region
         TILE_GEOM_OR_FAIL(g);
+        if ((int) g.threads != 64 * HF_RS_WPB) { set_err(HF_E_ARG, "k_row_stats: the block's partial sums do not fit the LDS"); ctx->launch_failed = true; return; }
         const int wpb = (int) g.threads / 64;
         const int n_rw_blocks = (ctx->n_rowwaves + wpb - 1) / wpb, n_ll_blocks = (ctx->C + wpb - 1) / wpb;
         // the launch's last block also sums the partials (rows_total): into d_total and straight into the pinned host block
@@ -992,7 +993,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                             else { RowSlot sl; sl.row = (int32_t) er; sl.g0 = g; sl.ng = 1; sl.xpx = xpx; rslots.push_back(sl); open_row = er; }
                         }
                     }
-                    while (rslots.size() % (4 * unit)) rslots.push_back({-1, 0, 0, 0});
+                    while (rslots.size() % (HF_RS_WPB * unit)) rslots.push_back({-1, 0, 0, 0});   // whole blocks of k_row_stats per region
                     for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / unit; k++) rwreg.push_back(reg);
                 }
                 rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / unit);

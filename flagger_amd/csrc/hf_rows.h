@@ -152,6 +152,10 @@ __device__ __forceinline__ double xcu_load(const double* p) { return __hip_atomi
 __device__ __forceinline__ double* done_scratch(unsigned* done) { return reinterpret_cast<double*>(done + ((HF_DONE_WORDS + 1) & ~1)); }
 #define HF_DONE_BYTES ((((HF_DONE_WORDS + 1) & ~1) * 4) + (HF_MAXREGIONS + 1) * 8)
 
+#ifndef HF_RS_WPB
+#define HF_RS_WPB 8    // wavefronts per block of k_row_stats (a multiple of 4: k_row_stats_nb keeps 4): the block that totals a region then reads
+#endif                 // 144 partial vectors instead of 288 — one batch of loads per thread instead of three
+static_assert(HF_RS_WPB % 4 == 0 && HF_RS_WPB <= 16, "regions are padded to whole blocks of HF_RS_WPB wavefronts; the negative-binomial kernels use 4");
 #ifndef HF_ROWS_TOTAL_INFLIGHT
 #define HF_ROWS_TOTAL_INFLIGHT 32   // loads a thread of the totalling block keeps in flight (a wavefront counts at most 63 outstanding)
 #endif
@@ -172,7 +176,7 @@ __device__ unsigned long long rows_total_region(int r, const int32_t* __restrict
     const int rstride = 24 * Kctx + 16;
     int nq = nt / NA;                              // interleaved accumulators per element: one (element, accumulator) item per thread
     nq = nq < 1 ? 1 : (nq > NQMAX ? NQMAX : nq);
-    const int w0 = rw_off[r] / wpb, w1 = rw_off[r + 1] / wpb;   // rw_off counts wavefronts, a multiple of 4 per region
+    const int w0 = rw_off[r] / wpb, w1 = rw_off[r + 1] / wpb;   // rw_off counts wavefronts, a multiple of HF_RS_WPB per region
     for (int v = tid; v < rstride; v += nt) blockv[v] = 0.0;
     for (int w = tid; w < nq * NA; w += nt) {
         const int q = w / NA, i = w - q * NA;
@@ -268,7 +272,7 @@ __device__ double rows_total_ll(const int32_t* __restrict__ rw_off, int nreg, in
 // The last block of every part of the launch to finish then sums the part's partials: rows_total_region / rows_total_ll above.
 // ------------------------------------------------------------------------------------------
 template <int KT>
-__global__ void __launch_bounds__(256) k_row_stats(int n_rowwaves, int n_rw_blocks, const int32_t* __restrict__ rw_region,
+__global__ void __launch_bounds__(64 * HF_RS_WPB) k_row_stats(int n_rowwaves, int n_rw_blocks, const int32_t* __restrict__ rw_region,
                                                       const RowSlot* __restrict__ slots, const double* __restrict__ grp_sums,
                                                       const RowSrc S, const DevParams* __restrict__ P, double* __restrict__ blk_stats,
                                                       int C, const int32_t* __restrict__ chunk_tile0,
