@@ -70,9 +70,6 @@
 #ifndef HF_SEG_TRASH
 #define HF_SEG_TRASH 1      // record / scale stores of lanes without a window go to a per-segment spare record instead of being branched around
 #endif
-#ifndef HF_SEG_RECSWZ
-#define HF_SEG_RECSWZ 0     // the record transposition through LDS with rotated pieces (bank-conflict-free writes): measured 0.3 us SLOWER (profiles/r04e_ab_variants.txt): off
-#endif
 #ifndef HF_SEG_WAVESHR
 #define HF_SEG_WAVESHR 1    // the neighbour lane's prefix by DPP wave_shr:1 (GFX9) instead of 32 ds_bpermute
 #endif
@@ -872,25 +869,14 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
         const int32_t* __restrict__ pos_seg = pos + d.t0;
         auto store_rec = [&](int k, bool act, int32_t pk, const double* __restrict__ fk, double sck) {
             double2* __restrict__ mine = reinterpret_cast<double2*>(blk) + lane * 4;
-#if HF_SEG_RECSWZ
-            // piece j of lane l's record sits in slot (j + (l >> 2)) & 3 of the record: the sixteen lanes a 128-bit LDS write serves at a
-            // time then cover all 64 banks once (lane by lane at a 64-byte stride they hit four: 3.1 M conflict cycles per launch,
-            // a third of the kernel's LDS time, profiles/r04d_pmc_sq_b.json); the reads below undo the rotation
-            const int rot = lane >> 2;
-            mine[rot & 3] = make_double2(fk[0], fk[1]); mine[(rot + 1) & 3] = make_double2(fk[2], fk[3]);
-            mine[(rot + 2) & 3] = make_double2(b[0], b[1]); mine[(rot + 3) & 3] = make_double2(b[2], b[3]);
-#else
+            // (rotating the pieces so that these writes are free of bank conflicts — lane by lane at a 64-byte stride they hit four banks of
+            // 64 — was measured 0.3 us SLOWER, profiles/r04e_ab_variants.txt: the conflicts are not on the kernel's critical path)
             mine[0] = make_double2(fk[0], fk[1]); mine[1] = make_double2(fk[2], fk[3]);
             mine[2] = make_double2(b[0], b[1]); mine[3] = make_double2(b[2], b[3]);
-#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#if HF_SEG_RECSWZ
-            const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + ((lane & ~3) + (((lane & 3) + (lane >> 4)) & 3));
-#else
             const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + lane;
-#endif
             const double2 v0 = img[0], v1 = img[64], v2 = img[128], v3 = img[192];
             double2* __restrict__ R2 = reinterpret_cast<double2*>(recs) + (lane & 3);
 #if HF_SEG_TRASH

@@ -376,6 +376,39 @@ def test_full_size_cfg2_one_pass_and_invariants():
     orc.close()
 
 
+@pytest.mark.parametrize("model_type,cfg", [(hmm.MODEL_GAUSSIAN, 2), (hmm.MODEL_NEGATIVE_BINOMIAL, 2), (hmm.MODEL_TRUNC_EXP_GAUSSIAN, 6)],
+                         ids=["gaussian", "negative_binomial", "over-dispersed coverage"])
+def test_full_size_other_models_one_pass(model_type, cfg):
+    """BASELINE configs[2]'s geometry at FULL size (1.5 M windows, 286 chunks) for the model types that are not the headline — `gaussian`,
+    `negative_binomial` (hmm_utils.c:335-639: count data, digamma table) — and the headline model on over-dispersed coverage
+    (synth.config(6): negative-binomial coverage, variance = 3 x mean, K = 9): one pass with non-trivial parameters against the
+    oracle: labels identical, log-likelihood and statistics 1e-9."""
+    store = synth.config(cfg)
+    assert store.n_windows > 1_400_000
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    alpha = np.zeros((4, 4)) if model_type == hmm.MODEL_NEGATIVE_BINOMIAL else synth.HIFI_ALPHA
+    model = hmm.createModel(model_type, K, store, alpha)
+    em = hmm.EMList(store, model)
+    orc = Oracle(store, model_type, K, alpha, threads=16)
+    try:
+        hmm.EM_runOneIterationForList(em, model)
+        hmm.HMM_estimateParameters(model, 1e-3)
+        hmm.HMM_resetEstimators(model)
+        hmm.EM_runOneIterationForList(em, model)
+        got, lab = model.estimators.copy(), em.labels()
+        orc.set_param_vector(model.param_vector())
+        assert orc.run_iteration() == 0
+        ref = orc.stats_vector(K)
+        assert abs(got[0] - ref[0]) <= LL_RTOL * abs(ref[0]), (got[0], ref[0])
+        scale = np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+        assert np.all(np.abs(got - ref) <= STAT_RTOL * scale), np.max(np.abs(got - ref) / scale)
+        olab = orc.labels()
+        assert np.array_equal(lab, olab), f"{np.count_nonzero(lab != olab)} label mismatches of {lab.size}"
+    finally:
+        em.close()
+        orc.close()
+
+
 def test_full_size_cfg4_one_pass_and_invariants_per_region():
     """BASELINE configs[4] at full size: ONT-R10 preset (hmm_flagger.c:36-58: 8 kb windows, minReadFractionAtEnds
     0.8), 7 bias regions with their own emission series (hmm_utils.c:1605-1652), region changes inside chunks (hmm.c:398-400),
