@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) k_pair_sums(int n_groups, const int32_t* 
 #pragma unroll
         for (int j = 0; j < 4; j++) {                    // records j*16 + qd of group g: four 1 KiB loads in flight (all sixteen of the
             const bool have = j * 16 + qd < ng[g];       // wavefront at once was measured 25 % slower, the next group's four issued ahead 15 % slower, same box)
-            v[j] = have ? R2[(g * 4 + j) * 64] : make_double2(0.0, 0.0);
+            v[j] = have ? R2[(g * 4 + j) * 64] : make_double2(0.0, 0.0);   // (non-temporal loads: +1.5 .. 2 us, the records come out of the caches k_seg_fb left them in; profiles/r04i_ab_variants.txt)
         }
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll

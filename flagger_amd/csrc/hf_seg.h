@@ -888,7 +888,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             R2[(int64_t) p1 * 4] = v1;
             R2[(int64_t) p2 * 4] = v2;
             R2[(int64_t) p3 * 4] = v3;
-            scale_s[slot_ij + (int64_t) k * 64] = sck;
+            scale_s[slot_ij + (int64_t) k * 64] = sck;   // (non-temporal stores: k_pair_sums +3.5 us, it reads these records out of the cache; profiles/r04i_ab_variants.txt)
 #else
             const int32_t pact = act ? pk : -1;             // the record of lane r goes to position pact(r): lanes 4r .. 4r+3 of instruction r >> 4
             const int32_t p0 = __shfl(pact, lane >> 2), p1 = __shfl(pact, 16 + (lane >> 2)), p2 = __shfl(pact, 32 + (lane >> 2)), p3 = __shfl(pact, 48 + (lane >> 2));
