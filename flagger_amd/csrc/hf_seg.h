@@ -30,10 +30,16 @@
 // [step][lane & 7][lane >> 3]: two ds_read_b128 per step (round 2 moved them with eight dependent ds_bpermute per step).
 //
 // Output = the PAIR RECORDS the statistics read (hf_rows.h by emission row, hf_chunks.h per chunk): record(t) = { f_{t-1}[4],
-// b_t[4] }, 64 bytes, and the scales — both in SLOT order: window w of a segment (w = j*L + i) lives in slot
-// slot0 + i*64 + j, so that at every step the lanes of a wavefront write 64 consecutive records (the statistics address
-// records by slot; the host getters apply the same map).  f_{t-1} of a lane's first window is the previous lane's last
-// forward vector (one DPP-free shuffle), of a segment's first window the carried-in vector.  Labels leave through LDS.
+// b_t[4] }, 64 bytes, at the POSITION hf_create planned for window t (plan order: the statistics stream the records of a row of
+// A; without a plan positions = slots), and the scales in SLOT order: window w of a segment (w = j*L + i) lives in slot
+// slot0 + i*64 + j (512 contiguous bytes per store instruction; the host getters apply the same map).  f_{t-1} of a lane's
+// first window is the previous lane's last forward vector (one shuffle), of a segment's first window the carried-in vector.
+// Labels leave through LDS.
+//
+// Round 4: the kernel is STRAIGHT-LINE wherever a lane used to be branched around work that is the identity
+// for it — scan levels multiply by an identity matrix where there is no neighbour, lanes past their last window multiply by an
+// identity row of the table, lanes without a window store to the segment's spare record — and renormalises once per two products
+// from an integer maximum; every piece has a -DHF_SEG_... switch below for same-box A/B runs (profiles/tools/build_variants.sh).
 #pragma once
 #include "hf_scan.h"
 
