@@ -174,7 +174,8 @@ struct hf_ctx {
     int M = 1; double* d_lutE = nullptr; double* d_lutC = nullptr; int64_t n_lut = 0;
     int n_keys = 0; int32_t* d_keys = nullptr;
     // negative_binomial model: device copies of hf_params.nb_* and the per-tile count data (allocated on first use)
-    double *d_nbE = nullptr, *d_nbP = nullptr, *d_nbDig = nullptr, *d_nbR = nullptr, *d_nbBeta = nullptr, *d_tile_hist = nullptr;
+    double *d_nbE = nullptr, *d_nbP = nullptr, *d_nbDig = nullptr, *d_nbR = nullptr, *d_nbBeta = nullptr, *d_tile_hist = nullptr;   // d_nbE owns ONE buffer: E | P | dig | r | beta
+    char* h_nb[2] = {nullptr, nullptr}; hipEvent_t nb_ev[2] = {nullptr, nullptr}; bool nb_ev_used[2] = {false, false}; unsigned nb_turn = 0;   // pinned staging of those tables
     // statistics by emission row (hf_rows.h): the static plan and its work arrays
     int stats_mode = HF_STATS_CHUNKS; bool rows_ready = false, pass_rows = false; int pass_kc = 0, pass_wpb = 4;
     double poll_seq = 0.0;         // completion stamp of the last polled pass (hf_finish)
@@ -1151,13 +1152,14 @@ void hf_destroy(hf_ctx* ctx) {
     }
 #endif
     if (ctx->host_trace && ctx->ht_n)
-        std::fprintf(stderr, "[hf host trace] %ld EM steps: enqueue %.1f us, wait %.1f us, m-step %.1f us, gpu span (first launch .. reduction) %.1f us\n",
-                     ctx->ht_n, ctx->ht[0] / ctx->ht_n, ctx->ht[1] / ctx->ht_n, ctx->ht[2] / ctx->ht_n, ctx->ht[3] / ctx->ht_n);
+        std::fprintf(stderr, "[hf host trace] %ld EM steps: parameter view (hfm_params: the negative-binomial tables) %.1f us, enqueue %.1f us, wait %.1f us, m-step %.1f us, gpu span (first launch .. reduction) %.1f us\n",
+                     ctx->ht_n, ctx->ht[4] / ctx->ht_n, ctx->ht[0] / ctx->ht_n, ctx->ht[1] / ctx->ht_n, ctx->ht[2] / ctx->ht_n, ctx->ht[3] / ctx->ht_n);
     hipFree(ctx->d_off); hipFree(ctx->d_rec); hipFree(ctx->d_beta); hipFree(ctx->d_regmask); hipFree(ctx->d_E);
     hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); if (ctx->own_chunk_stats) hipFree(ctx->d_chunk_stats);
     hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
     hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
-    hipFree(ctx->d_nbE); hipFree(ctx->d_nbP); hipFree(ctx->d_nbDig); hipFree(ctx->d_nbR); hipFree(ctx->d_nbBeta); hipFree(ctx->d_tile_hist);
+    hipFree(ctx->d_nbE); hipFree(ctx->d_tile_hist);   // (d_nbP .. d_nbBeta point into d_nbE's buffer)
+    for (int b = 0; b < 2; b++) { if (ctx->h_nb[b]) hipHostFree(ctx->h_nb[b]); if (ctx->nb_ev[b]) hipEventDestroy(ctx->nb_ev[b]); }
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0);
     hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_grp_ar); hipFree(ctx->d_grp_n); hipFree(ctx->d_grp_off); hipFree(ctx->d_pos); hipFree(ctx->d_pos_f); hipFree(ctx->d_slot_of); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
     hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_seg_ready); hipFree(ctx->d_scale_s);
@@ -1296,18 +1298,30 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 return set_err(HF_E_ARG, "hf_estep: the windows hold coverage values above hf_params.nb_max_x (hfm_set_max_coverage)");
             const size_t nE = (size_t) ctx->R * 4 * HF_NB_NX * 8, nP = (size_t) ctx->R * 4 * ctx->K * HF_NB_NX * 8,
                          nR = (size_t) ctx->R * 4 * ctx->K * 8;
+            // ONE device buffer and ONE copy per pass for the five tables (round 4; five copies out of pageable memory were ~50 us of a
+            // 0.24 ms step): E | P | dig | r | beta, gathered into one of two pinned staging buffers (an event per buffer says when its
+            // last copy has left it: a caller may enqueue the next pass before this one has run)
+            const size_t nAll = nE + 2 * nP + 2 * nR;
             if (!ctx->d_nbE) {
-                HIPCHK(hipMalloc((void**) &ctx->d_nbE, nE)); HIPCHK(hipMalloc((void**) &ctx->d_nbP, nP));
-                HIPCHK(hipMalloc((void**) &ctx->d_nbDig, nP)); HIPCHK(hipMalloc((void**) &ctx->d_nbR, nR));
-                HIPCHK(hipMalloc((void**) &ctx->d_nbBeta, nR));
+                HIPCHK(hipMalloc((void**) &ctx->d_nbE, nAll));
+                char* base = reinterpret_cast<char*>(ctx->d_nbE);
+                ctx->d_nbP = reinterpret_cast<double*>(base + nE); ctx->d_nbDig = reinterpret_cast<double*>(base + nE + nP);
+                ctx->d_nbR = reinterpret_cast<double*>(base + nE + 2 * nP); ctx->d_nbBeta = reinterpret_cast<double*>(base + nE + 2 * nP + nR);
                 HIPCHK(hipMalloc((void**) &ctx->d_tile_hist, ((size_t) ctx->ntiles * ctx->R * HF_NB_TILE_VEC + 1) * 8));
+                for (int b = 0; b < 2; b++) {
+                    HIPCHK(hipHostMalloc((void**) &ctx->h_nb[b], nAll));
+                    HIPCHK(hipEventCreateWithFlags(&ctx->nb_ev[b], hipEventDisableTiming));
+                }
             }
             if (!retry) {
-                HIPCHK(hipMemcpyAsync(ctx->d_nbE, p->nb_E, nE, hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(ctx->d_nbP, p->nb_P, nP, hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(ctx->d_nbDig, p->nb_dig, nP, hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(ctx->d_nbR, p->nb_r, nR, hipMemcpyHostToDevice, st));
-                HIPCHK(hipMemcpyAsync(ctx->d_nbBeta, p->nb_beta, nR, hipMemcpyHostToDevice, st));
+                const int b = (int) (ctx->nb_turn++ & 1u);
+                if (ctx->nb_ev_used[b]) HIPCHK(hipEventSynchronize(ctx->nb_ev[b]));
+                char* h = ctx->h_nb[b];
+                std::memcpy(h, p->nb_E, nE); std::memcpy(h + nE, p->nb_P, nP); std::memcpy(h + nE + nP, p->nb_dig, nP);
+                std::memcpy(h + nE + 2 * nP, p->nb_r, nR); std::memcpy(h + nE + 2 * nP + nR, p->nb_beta, nR);
+                HIPCHK(hipMemcpyAsync(ctx->d_nbE, h, nAll, hipMemcpyHostToDevice, st));
+                HIPCHK(hipEventRecord(ctx->nb_ev[b], st));
+                ctx->nb_ev_used[b] = true;
             }
         }
         {   // also clears the flag word: first kernel of every pass
@@ -1767,10 +1781,11 @@ int hf_em_iterate(hf_ctx* ctx, hfm_model* model, int mode, int do_mstep, double 
                   void* stream) {
     if (!ctx || !model || !stats_host || (mode != HF_MODE_FULL && mode != HF_MODE_FORWARD_ONLY))
         return set_err(HF_E_ARG, "hf_em_iterate: bad argument");
+    using clk = std::chrono::steady_clock;
+    const auto tp = clk::now();
     hf_params p;
     hfm_params(model, &p);
     int rc = HF_OK;
-    using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     auto t1 = t0, t2 = t0;
     rc = hf_estep(ctx, &p, mode, stream);
@@ -1788,7 +1803,7 @@ int hf_em_iterate(hf_ctx* ctx, hfm_model* model, int mode, int do_mstep, double 
         float gpu_ms = 0.f;
         (void) hipEventElapsedTime(&gpu_ms, ctx->ev0, ctx->ev1);
         auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        ctx->ht[0] += us(t0, t1); ctx->ht[1] += us(t1, t2); ctx->ht[2] += us(t2, t3); ctx->ht[3] += gpu_ms * 1e3; ctx->ht_n++;
+        ctx->ht[0] += us(t0, t1); ctx->ht[1] += us(t1, t2); ctx->ht[2] += us(t2, t3); ctx->ht[3] += gpu_ms * 1e3; ctx->ht[4] += us(tp, t0); ctx->ht_n++;
     }
     return HF_OK;
 }

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <thread>
 #include <algorithm>
+#include <chrono>
 
 namespace {
 constexpr int S = HF_NSTATES;
@@ -97,7 +98,7 @@ struct NbPool {
     std::vector<std::thread> th;
     const std::function<void(size_t)>* job = nullptr;
     size_t n = 0, gen = 0;
-    std::atomic<size_t> next{0}, done{0};
+    std::atomic<size_t> next{0}, done{0}, gen_hint{0};
     int busy = 0;
     bool stop = false;
     void worker() {
@@ -105,6 +106,9 @@ struct NbPool {
         for (;;) {
             const std::function<void(size_t)>* f; size_t N;
             {
+                // (an EM loop asks again within ~0.2 ms: poll for that long before sleeping — a condition variable's wake-up costs 10-30 us)
+                const auto t_spin = std::chrono::steady_clock::now();
+                while (gen_hint.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() - t_spin < std::chrono::microseconds(400)) __builtin_ia32_pause();
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return stop || gen != seen; });
                 if (stop) return;
@@ -127,13 +131,15 @@ struct NbPool {
                 const size_t T = std::min<size_t>(7, hw > 1 ? hw - 1 : 0);
                 for (size_t t = 0; t < T; t++) th.emplace_back([this] { worker(); });
             }
-            next.store(0); done.store(0); job = &f; n = N; gen++;
+            next.store(0); done.store(0); job = &f; n = N; gen++; gen_hint.store(gen, std::memory_order_release);
         }
         cv.notify_all();
         for (size_t k; (k = next.fetch_add(1)) < N;) { f(k); done.fetch_add(1); }
-        std::unique_lock<std::mutex> lk(m);
-        cv_done.wait(lk, [&] { return done.load() >= N && busy == 0; });
-        job = nullptr; n = 0;
+        while (done.load(std::memory_order_acquire) < N) __builtin_ia32_pause();      // (microseconds: polled, not slept on)
+        for (;;) {                                                                   // ... and no worker still holds the job
+            std::lock_guard<std::mutex> g(m);
+            if (busy == 0) { job = nullptr; n = 0; break; }
+        }
     }
     ~NbPool() { { std::lock_guard<std::mutex> g(m); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); }
 };
@@ -228,30 +234,38 @@ void hfm_params(const hfm_model* m, hf_params* out) {
     m->nb_beta.assign((size_t) m->R * S * K, 0.0);
     // one job per (region, state, component): ~250 lgamma + exp each (25 us) — on a small pool of host threads (the tables cost 0.1 ms
     // per EM iteration on one thread, a quarter of the negative-binomial step; each job writes its own rows: same values in any order)
-    struct Job { int r, s, c; };
+    // (a component's x range in NB_SPLIT pieces: 9 jobs of 25 us on 8 threads would leave most of them idle half the time)
+    constexpr int NB_SPLIT = 4;
+    struct Job { int r, s, c, part; };
     std::vector<Job> jobs;
     for (int r = 0; r < m->R; r++)
         for (int s = 0; s < S; s++)
-            for (int c = 0; c < m->ncomp[s]; c++) jobs.push_back({r, s, c});
+            for (int c = 0; c < m->ncomp[s]; c++)
+                for (int part = 0; part < NB_SPLIT; part++) jobs.push_back({r, s, c, part});
     nb_pool().run(jobs.size(), [&](size_t j) {
-                const int r = jobs[j].r, s = jobs[j].s, c = jobs[j].c;
+                const int r = jobs[j].r, s = jobs[j].s, c = jobs[j].c, part = jobs[j].part;
+                const int x_lo = (int) ((int64_t) NXF * part / NB_SPLIT), x_hi = (int) ((int64_t) NXF * (part + 1) / NB_SPLIT);
                 const double theta = mm->M(r, s, c), lambda = mm->Vr(r, s, c), w = mm->W(r, s, c);
                 const double rr = -1 * lambda / std::log(theta);
                 const size_t pc = ((size_t) r * S + s) * K + c;
-                m->nb_r[pc] = rr;
-                m->nb_beta[pc] = -1 * theta / (1 - theta) - 1 / std::log(theta);
+                if (part == 0) {
+                    m->nb_r[pc] = rr;
+                    m->nb_beta[pc] = -1 * theta / (1 - theta) - 1 / std::log(theta);
+                }
                 double* P = &m->nb_P[pc * NX];
                 double* D = &m->nb_dig[pc * NX];
                 // the x-independent terms once per component (pure functions of the same arguments: same doubles)
                 int sg = 0;                                       // (lgamma_r: lgamma's value without the global signgam)
                 const double lg_r = lgamma_r(rr, &sg), r_log_theta = rr * std::log(theta), log_1m_theta = std::log(1 - theta);
-                for (int x = 0; x < NXF; x++) {
+                for (int x = x_lo; x < x_hi; x++) {
                     double p = w * std::exp(lgamma_r(rr + x, &sg) - lg_r - lgx1[x] + r_log_theta + (double) x * log_1m_theta);
                     if (!(p != p) && p < 1e-40) p = 1e-40;       // NaN is kept: the E-step reports it if the value is used
                     P[x] = p;
                 }
-                D[0] = (double) digammal_(rr);
-                for (int x = 1; x < NXF; x++) D[x] = D[x - 1] + 1.0 / (rr + x - 1);
+                if (part == 0) {                                  // the recurrence of the digamma table is sequential (and cheap): one piece does it
+                    D[0] = (double) digammal_(rr);
+                    for (int x = 1; x < NXF; x++) D[x] = D[x - 1] + 1.0 / (rr + x - 1);
+                }
             });
     for (int r = 0; r < m->R; r++)
         for (int s = 0; s < S; s++)
