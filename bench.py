@@ -233,6 +233,8 @@ def main():
             dom_samples.append(em.kernel_times()[dom])
     barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("BENCH_DUMP_SAMPLES") and rank == 0:   # the sequence of samples on stderr (how the kernel settles after a cold start)
+        print("[bench] %s samples (us): " % dom + " ".join("%.1f" % (v * 1e3) for v in dom_samples), file=sys.stderr)
     if dom_samples:                        # median: the first sample follows the barrier's idle gap and runs at a lower clock
         dom_ms = float(np.median(dom_samples))
     # per-kernel breakdown from a few extra passes outside the timed region (every kernel bracketed)
