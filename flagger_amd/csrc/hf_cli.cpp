@@ -141,7 +141,6 @@ struct SummaryJob {
     std::vector<int8_t> labels;
     int rc = 0;
     std::string err, path;
-    double ms = 0.0;
 };
 static SummaryJob g_summary;
 static void summary_wait_quietly() { if (g_summary.th.joinable()) g_summary.th.join(); }
