@@ -410,9 +410,12 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         }
         KTimer t(ctx, st, HF_K_ROW_STATS);
         constexpr size_t NA = 16 + 9 + 2 + 3 * KT + 1;
-        TileGeom g = tile_geom(ctx, k_row_stats<KT>, NA * 8, false, HF_RS_WPB);   // the wavefronts' sums: HF_RS_WPB wavefronts per block, a block stays inside one region
+        // the wavefronts' sums: HF_RS_WPB wavefronts per block (a block stays inside one region: hf_create pads the regions to that multiple) — four
+        // for a sparse plan, whose wavefronts take several batches of slots each: eight of those per block ran config 5 in 83 us instead of 51
+        const int want_wpb = ctx->rs_bpw > 1 ? 4 : HF_RS_WPB;
+        TileGeom g = tile_geom(ctx, k_row_stats<KT>, NA * 8, false, want_wpb);
         TILE_GEOM_OR_FAIL(g);
-        if ((int) g.threads != 64 * HF_RS_WPB) { set_err(HF_E_ARG, "k_row_stats: the block's partial sums do not fit the LDS"); ctx->launch_failed = true; return; }
+        if ((int) g.threads != 64 * want_wpb) { set_err(HF_E_ARG, "k_row_stats: the block's partial sums do not fit the LDS"); ctx->launch_failed = true; return; }
         const int wpb = (int) g.threads / 64;
         const int n_rw_blocks = (ctx->n_rowwaves + wpb - 1) / wpb, n_ll_blocks = (ctx->C + wpb - 1) / wpb;
         // the launch's last block also sums the partials (rows_total): into d_total and straight into the pinned host block
