@@ -29,6 +29,19 @@ def _same_files(a, b, names):
         assert (a / n).read_text() == (b / n).read_text(), n
 
 
+def _numbers_close(a, b, name, rtol=1e-6, atol=1e-8):
+    """Two TSV texts: the same tokens, numbers equal to rtol relative or atol absolute (what an --accelerate run is held to where it is not
+    byte-identical: profiles/r04_squarem_residue.txt)."""
+    ta, tb = a.split(), b.split()
+    assert len(ta) == len(tb), name
+    for x, y in zip(ta, tb):
+        if x == y:
+            continue
+        for u, w in zip(x.split(","), y.split(",")):
+            fu, fw = float(u), float(w)
+            assert abs(fu - fw) <= rtol * max(abs(fu), abs(fw)) + atol, (name, u, w)
+
+
 OUTPUTS = ["final_flagger_prediction.bed", "loglikelihood.tsv", "emission_initial.tsv", "emission_final.tsv",
            "transition_initial.tsv", "transition_final.tsv"]
 
@@ -353,14 +366,34 @@ def test_full_size_ont_r10_seven_regions_em_to_convergence_equals_the_oracle_com
                 # secondary parameters (here component weights of 1e-13 .. 1e-17: 7.87869e-17 | 7.87888e-17) — profiles/
                 # r04_squarem_residue.txt.  Labels and summary tables must be identical, the numbers equal to 1e-6 relative or 1e-8 absolute
                 # (weights and transition probabilities are fractions of one: a weight of 5.11626e-05 | 5.11631e-05 after ten accelerated iterations).
-                ta, tb = a.split(), b.split()
-                assert len(ta) == len(tb), n
-                for x, y in zip(ta, tb):
-                    if x == y:
-                        continue
-                    for u, w in zip(x.split(","), y.split(",")):
-                        fu, fw = float(u), float(w)
-                        assert abs(fu - fw) <= 1e-6 * max(abs(fu), abs(fw)) + 1e-8, (n, u, w)
+                _numbers_close(a, b, n)
     # seven regions really were fitted: seven parameter series in the final emission table
     emis = (tmp_path / "gpu" / "emission_final.tsv").read_text().splitlines()
     assert len(emis[1].split("\t")) == 4 + 7, emis[1]
+
+
+@pytest.mark.parametrize("seed", [8010, 8955])
+def test_accelerated_runs_of_the_residue_study_stay_within_tolerance(seed, tmp_path):
+    """VERDICT r03 #5.  Two of the twelve `--accelerate` runs of profiles/r03_fuzz.txt whose outputs differ from the oracle command line
+    in a last printed digit (8010: three log-likelihoods and both tables; 8955: one log-likelihood; the negative-binomial ones are worse
+    conditioned — 8870's component weights agree to four digits only, 3.95876e-01 | 3.95891e-01 — and are left to the study) — no
+    operation order closes them (profiles/r04_squarem_residue.txt: the device's exp / log are 1 ulp from glibc's for 6 % / 2 % of
+    arguments and SQUAREM amplifies that).  What must hold: identical BED, identical posterior BED / summary tables where written,
+    every number of the other files equal to 1e-5 relative / 1e-6 absolute — these are the WORST of 2 300 fuzzed command-line runs, on
+    inputs of 2-7 k windows after up to 15 accelerated iterations: one unit of a %.5e mantissa is up to 1e-5 relative; the full-size runs
+    hold 1e-6 / 1e-8."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "profiles", "tools"))
+    import fuzz_cli as F
+    d, store, model, extra, args = F.make_case(seed, True)
+    assert "--accelerate" in extra
+    outs = F.run_pair(d, args)
+    assert outs[0][0] == 0 and outs[1][0] == 0
+    for n in sorted(os.listdir(outs[1][1])):
+        if not n.endswith((".tsv", ".bed")):
+            continue
+        a, b = open(os.path.join(outs[0][1], n)).read(), open(os.path.join(outs[1][1], n)).read()
+        if n.endswith(".bed") or n.startswith("prediction_summary"):
+            assert a == b, n
+        else:
+            _numbers_close(a, b, n, rtol=1e-5, atol=1e-6)
