@@ -55,7 +55,7 @@ static struct option long_options[] = {                    // hmm_flagger.c:578-
     {"device", required_argument, nullptr, 1001},
     {"hipAlgo", required_argument, nullptr, 1002},         // scan (default) | seq (the on-device sequential cross-check)
     {"gpus", required_argument, nullptr, 1003},            // chunks sharded over GPUs device..device+N-1, one RCCL all-gather per pass
-    {"exchange", required_argument, nullptr, 1004},        // ranks (default) | chunks (bit-identical for every N)
+    {"exchange", required_argument, nullptr, 1004},        // chunks (default: bit-identical for every N) | ranks (one vector per GPU: faster)
     {nullptr, 0, nullptr, 0}};
 
 static void usage(const char* program) {
@@ -85,8 +85,10 @@ static void usage(const char* program) {
             "         --device                     (first) GPU index [0]        --hipAlgo scan|seq [scan]\n"
             "         --gpus N                     shard the chunks over GPUs device..device+N-1 (one process, one thread + one RCCL\n"
             "                                      rank per GPU, one all-gather of statistics per EM pass)\n"
-            "         --exchange ranks|chunks      what the GPUs exchange: one statistics vector per GPU summed in rank order (default) |\n"
-            "                                      per-chunk vectors summed in chunk-list order (bit-identical results for every N, slower)\n");
+            "         --exchange chunks|ranks      what the GPUs exchange: per-chunk vectors summed in chunk-list order (default: results are\n"
+            "                                      bit-identical for every N) | one statistics vector per GPU summed in rank order (faster per\n"
+            "                                      pass; equal across N only up to the rounding of the order of additions, which --accelerate\n"
+            "                                      can carry into the last printed digits)\n");
 }
 
 static bool dir_exists(const char* p) { struct stat sb; return stat(p, &sb) == 0 && S_ISDIR(sb.st_mode); }
@@ -379,9 +381,11 @@ int main(int argc, char* argv[]) {
     w.max_high_mapq_ratio = maxHighMapqRatio; w.min_high_mapq_ratio = minHighMapqRatio;
     w.min_highly_clipped_ratio = hfm_min_highly_clipped_ratio(model);
     // one GPU: one context (statistics by emission row).  --gpus N (or an explicit --exchange): the sharded list — by default with the
-    // rank-order exchange (every GPU sums its shard by emission row, one vector per GPU gathered: the fast statistics kernels; the printed
-    // files are the same for every N at full size, tests/test_multi_gpu.py); --exchange chunks: per-chunk vectors summed in chunk-list
-    // order, a result that is independent of N bit for bit by construction, 47 % slower per pass
+    // chunk-order exchange (per-chunk vectors summed in chunk-list order, the reference's own merge order hmm.c:759-763: a result that
+    // is independent of N bit for bit by construction; ADVICE r04: SQUAREM amplifies last-bit differences, so the command line's default
+    // must not depend on N).  --exchange ranks: every GPU sums its shard by emission row and one vector per GPU is gathered — the
+    // north-star's single collective and the fast statistics kernels, equal across N up to rounding (plain EM prints the same files for
+    // every N at full size, configs[2] and [4]: tests/test_multi_gpu.py); what bench.py --gpus N measures
     const bool sharded = nGpus > 1 || loopbackRanks > 0 || (nGpus == 1 && exchange >= 0);
     int rc;
     if (sharded) {
@@ -389,7 +393,7 @@ int main(int argc, char* argv[]) {
         std::vector<int> devs((size_t) world);
         for (int i = 0; i < world; i++) devs[(size_t) i] = loopbackRanks > 0 ? device : device + i;
         rc = hf_multi_create(&w, hfio_n_regions(tab), numberOfCollapsedComps, world, devs.data(), algo,
-                             exchange < 0 ? HF_EXCHANGE_RANKS : exchange, loopbackRanks > 0 ? HF_TRANSPORT_LOOPBACK : HF_TRANSPORT_RCCL,
+                             exchange < 0 ? HF_EXCHANGE_CHUNKS : exchange, loopbackRanks > 0 ? HF_TRANSPORT_LOOPBACK : HF_TRANSPORT_RCCL,
                              &run.multi);
         if (rc != HF_OK) { fprintf(stderr, "[%s] Error: %s\n", ts(), hf_multi_last_error()); return EXIT_FAILURE; }
         for (int r = 0; r < world; r++)

@@ -395,5 +395,9 @@ def test_accelerated_runs_of_the_residue_study_stay_within_tolerance(seed, tmp_p
         a, b = open(os.path.join(outs[0][1], n)).read(), open(os.path.join(outs[1][1], n)).read()
         if n.endswith(".bed") or n.startswith("prediction_summary"):
             assert a == b, n
+        elif n == "loglikelihood.tsv":
+            # the north-star's own bar for the EM log-likelihood: 1e-6 RELATIVE, nothing absolute (the observed difference of
+            # this seed is 6e-9; a 10x regression must not pass under the looser tolerance of the parameter tables)
+            _numbers_close(a, b, n, rtol=1e-6, atol=0.0)
         else:
             _numbers_close(a, b, n, rtol=1e-5, atol=1e-6)

@@ -2,7 +2,7 @@
 multiply-adds where the reference computes (f·T)·e, hmm.c:407, so a label can differ from the reference's where the two
 largest posteriors are equal to the last few ulps — tests/test_neartie_gpu.py constructs such inputs.)
 
-Here the question is asked of the inputs a user has: BASELINE configs[2] at full size and the reference simulator's three
+Here the question is asked of the inputs a user has: BASELINE configs[2] and configs[4] at full size and the reference simulator's three
 100 000-observation tracks, each AFTER the EM has converged (the pass that writes the BED, hmm_flagger.c:464).  Both sides
 decode with the SAME converged parameters; for every window the relative gap between the two largest ORACLE posteriors
 is binned (< 1e-12, < 1e-10, < 1e-8) and the HIP <-> oracle label mismatches are counted per bin.  Asserted: no mismatch
@@ -23,6 +23,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 CASES = [("configs[2], full size", None, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 1e-3),
+         # the 7-region ONT-R10 workload (region-change windows with the uniform T = 0.2 of hmm.c:398-400, K = 10) had not been studied
+         ("configs[4], full size", "cfg4", hmm.MODEL_TRUNC_EXP_GAUSSIAN, 1e-3),
          ("sim100k_exp_gaussian", "sim100k_exp_gaussian.cov.gz", hmm.MODEL_TRUNC_EXP_GAUSSIAN, 1e-4),
          ("sim100k_gaussian", "sim100k_gaussian.cov.gz", hmm.MODEL_GAUSSIAN, 1e-4),
          ("sim100k_negative_binomial", "sim100k_negative_binomial.cov.gz", hmm.MODEL_NEGATIVE_BINOMIAL, 1e-4)]
@@ -30,16 +32,20 @@ CASES = [("configs[2], full size", None, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 1e-3),
 
 @pytest.mark.parametrize("name,cov,model_type,tol", CASES, ids=[c[0].split(",")[0] for c in CASES])
 def test_margin_of_the_final_labels(name, cov, model_type, tol):
+    frac = 0.95
     if cov is None:
         store, alpha, K, adjust = synth.config(2), synth.HIFI_ALPHA, None, True
+        max_mapq, min_mapq = 0.25, 0.75
+    elif cov == "cfg4":   # -x ont-r10: minReadFractionAtEnds 0.8 (hmm_flagger.c:36-58)
+        store, alpha, K, adjust, frac = synth.config(4), synth.ONT_R10_ALPHA, None, True, 0.8
         max_mapq, min_mapq = 0.25, 0.75
     else:   # the docs/hmm_test recipe (tests/test_cli_gpu.py): --chunkLen 1000 --windowLen 1 --collapsedComps 4 --minHighMapqRatio 0 -e
         store, alpha, K, adjust = Table(os.path.join(GOLD, cov), 1000, 1).store(), np.zeros((4, 4)), 4, False
         max_mapq, min_mapq = 0.25, 0.0
     K = hmm.getBestNumberOfCollapsedComps(store) if K is None else K
     model = hmm.createModel(model_type, K, store, alpha, max_mapq, min_mapq)
-    em = hmm.EMList(store, model, adjust, 0.95)
-    orc = Oracle(store, model_type, K, alpha, max_mapq=max_mapq, min_mapq=min_mapq, adjust=adjust, threads=16)
+    em = hmm.EMList(store, model, adjust, frac)
+    orc = Oracle(store, model_type, K, alpha, max_mapq=max_mapq, min_mapq=min_mapq, adjust=adjust, min_read_frac=frac, threads=16)
     try:
         iters = 0
         for iters in range(1, 41 if model_type == hmm.MODEL_NEGATIVE_BINOMIAL else 101):     # hmm_flagger.c:337-445
