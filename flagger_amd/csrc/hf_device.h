@@ -50,6 +50,17 @@ struct SegDesc {
     int ident_row;           // the table's identity row (behind the rows of A): what a lane multiplies by past its last window
 };
 static_assert(sizeof(SegDesc) == 64, "SegDesc is one 64-byte load");
+// One row of the per-pass emission tables (hf_scan.h): static per context, built once by k_build_jobs.
+// flags: 1 star (table key: the per-iteration constants of beta_star apply), 2 first (chunk-first window), 4 active; bits 8..: transition class of
+// the job's row of A (hf_seg.h); row: index of the row in lutE / lutC units; bt: the window's own beta (beta_star for a table key)
+struct TableJob { double x, px, bt; int64_t row; int32_t r; int32_t flags; };
+// what the table work reads and writes: static per context (k_tables takes it by value)
+struct TabWork {
+    int32_t n_jobs, K;
+    const TableJob* jobs;
+    double *lutE, *lutC;
+    double* lutA;                          // statistics by emission row / segment kernels: job j also writes row j of A (null: no rows of A)
+};
 // statistics by emission row (hf_rows.h): one pair (t-1, t) of the plan, one row slot
 struct RowSlot { int32_t row, g0, ng, xpx; };                    // row < 0: padding; xpx = x | x_prev << 8
 

@@ -152,6 +152,7 @@ struct hf_ctx {
     double* d_tile_ll = nullptr;
     double* d_tile_stats = nullptr; // [ntiles][R][NA(16)]
     unsigned* d_flags = nullptr;
+    TableJob* d_jobs = nullptr; TabWork tabwork{};   // the job list of the per-pass tables (hf_scan.h k_build_jobs), built once
     DevParams* d_params = nullptr; DevParams* h_params = nullptr; size_t params_bytes = 0;
     KParams kparams{};             // the parameter block as kernel arguments of k_tables (one region: pack_kparams)
     bool kp_ok = true, kp_now = false;   // HF_PARAMS_COPY=1 switches the kernel-argument path off; this pass uses it
@@ -1109,6 +1110,21 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                          ctx->nseg, max_nseg, (long long) resident, per_cu, cus,
                          ctx->seg_fused ? "one launch" : "TWO launches (a chunk has more segments than the device holds workgroups)");
     }
+    {   // the job list of the per-pass tables (hf_scan.h), built once: the (key, class) list of the rows of A when the segment kernels run,
+        // the emission keys otherwise (HF_ALGO_SEQ); then the slow windows
+        const bool arows = ctx->nseg > 0 && ctx->d_lutA && algo == HF_ALGO_SCAN;
+        const int nk = arows ? ctx->n_combo : ctx->n_keys;
+        const int jobs = nk + ctx->n_slow;
+        DMALLOC(ctx->d_jobs, (size_t) (jobs + 1) * sizeof(TableJob));
+        if (jobs > 0) {
+            hipLaunchKernelGGL(k_build_jobs, dim3((unsigned) ((jobs + 255) / 256)), dim3(256), 0, 0, nk, arows ? ctx->d_arow_src : ctx->d_keys,
+                               arows ? ctx->d_arow_cls : (const int32_t*) nullptr, ctx->n_slow, ctx->d_slow_w, ctx->d_rec, ctx->d_beta, ctx->M,
+                               ctx->n_lut, ctx->beta_star, ctx->d_jobs);
+            if (hipGetLastError() != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: k_build_jobs"); }
+        }
+        TabWork& tw = ctx->tabwork;
+        tw.n_jobs = jobs; tw.K = ctx->K; tw.jobs = ctx->d_jobs; tw.lutE = ctx->d_lutE; tw.lutC = ctx->d_lutC; tw.lutA = arows ? ctx->d_lutA : nullptr;
+    }
     ctx->seg_test_timeout = std::getenv("HF_SEG_TEST_TIMEOUT") != nullptr;
     { const char* e = std::getenv("HF_STREAM_STAMP"); if (e && e[0] == '0') ctx->stream_stamp_ok = false; }
     { const char* e = std::getenv("HF_PARAMS_COPY"); if (e && e[0] == '1') ctx->kp_ok = false; }   // the parameter block by a copy ahead of every pass
@@ -1166,7 +1182,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0);
     hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_grp_ar); hipFree(ctx->d_grp_n); hipFree(ctx->d_grp_off); hipFree(ctx->d_pos); hipFree(ctx->d_pos_f); hipFree(ctx->d_slot_of); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
     hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_seg_ready); hipFree(ctx->d_scale_s);
-    hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
+    hipFree(ctx->d_jobs); hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats);
     hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats);
     if (ctx->h_total) hipHostFree(ctx->h_total);   // one pinned block: h_flags and h_params live in it
@@ -1332,17 +1348,14 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
             // statistics by emission row: the job list of the Gaussian tables is the (key, class) list of the rows of A (hf_seg.h)
             const bool arows = !nbm && seg_pass(ctx);
             const int nk = arows ? ctx->n_combo : ctx->n_keys;
-            const int32_t* kl = arows ? ctx->d_arow_src : ctx->d_keys;
             const int jobs = nk + ctx->n_slow;
             if (nbm)
                 hipLaunchKernelGGL(k_tables_nb, dim3((unsigned) (jobs / 256 + 1)), dim3(256), 0, st, ctx->n_keys, ctx->d_keys, ctx->n_slow,
                                    ctx->d_slow_w, ctx->d_rec, ctx->M, ctx->d_nbE, ctx->d_lutE, ctx->d_Es, ctx->d_flags);
             else
             {
-#define HF_LAUNCH_TABLES(J, KA, KP) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables<J, KA>), dim3((unsigned) ((jobs + J - 1) / J + (jobs == 0))), dim3(256), 0, st, nk, \
-                               kl, ctx->n_slow, ctx->d_slow_w, ctx->d_rec, ctx->d_beta, ctx->M, ctx->K, ctx->d_params, ctx->d_lutE, ctx->d_lutC, \
-                               ctx->d_Es, ctx->d_Cs, ctx->d_flags, arows ? ctx->d_arow_cls : (const int32_t*) nullptr, arows ? ctx->d_lutA : (double*) nullptr, \
-                               KP, ctx->d_params)
+#define HF_LAUNCH_TABLES(J, KA, KP) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tables<J, KA>), dim3((unsigned) ((jobs + J - 1) / J + (jobs == 0))), dim3(256), 0, st, \
+                               ctx->tabwork, ctx->d_params, ctx->d_flags, KP, ctx->d_params)
                 if (ctx->kp_now) {     // the parameter block travels in the kernel arguments (pack_kparams): no copy was enqueued
                     if (jobs < 64 * 1024) HF_LAUNCH_TABLES(HF_TABLE_JOBS_SMALL, true, ctx->kparams); else HF_LAUNCH_TABLES(HF_TABLE_JOBS_LARGE, true, ctx->kparams);
                 } else {

@@ -439,9 +439,21 @@ __global__ void __launch_bounds__(64 * HF_RS_WPB) k_row_stats(int n_rowwaves, in
     if (!s_last) return;
     if (part_id < nreg) {
         const unsigned long long x = rows_total_region<KT>(part_id, rw_off, wpb, blk_stats, P, Kctx, out_dev, out_host);
+        if (seq == 0.0) return;
         if (threadIdx.x == 0) xcu_store(scratch + part_id, __longlong_as_double((long long) x));
     } else {
         const double ll = rows_total_ll(rw_off, nreg, Kctx, chunk_ll, (int64_t) C, out_dev, out_host, scratch);
+        if (seq == 0.0) {
+            // No host polls the block (the default: completion is the stream's own stamp, hf_estep.hip wait_total): the parts need no common
+            // finish.  The flag word is final before this launch starts (k_seg_fb raised it), so this part writes it — one ticket round trip, one
+            // load and one store less on the launch's critical path than the round-3/4 "last part" stage (k_row_stats 13.3 -> ~11 us).
+            if (threadIdx.x == 0 && flags) {
+                const unsigned fl = *flags;
+                if (flag_row) flag_row[0] = (double) fl; else out_dev[V] = (double) fl;
+                if (out_host) out_host[V] = (double) fl;
+            }
+            return;
+        }
         if (threadIdx.x == 0) xcu_store(scratch + HF_MAXREGIONS, ll);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -211,50 +211,149 @@ __device__ __forceinline__ uint32_t load_recs(const uint32_t* __restrict__ rec, 
 // rows per block: few when there are few rows (more blocks than CUs: the kernel is then latency-bound), many otherwise
 #define HF_TABLE_JOBS_SMALL 8    // (measured again in round 3: 4 / 16 / 32 rows per block are within 1 us at 9 k and 25 k rows; 32 at 260 k rows: 8 / 16 / 64 are 20-45 % slower)
 #define HF_TABLE_JOBS_LARGE 32
-// flags: 1 star (table key), 2 first, 4 active; bits 8..: transition class of the job's row of A (hf_seg.h); row: index of the row in lutE / lutC units
-struct TableJob { double x, px, bt; int64_t row; int32_t r; int32_t flags; };
+// TableJob: hf_device.h
 struct NoKParams { int32_t n_ranges; };
+// TabWork (what the table work reads and writes): hf_device.h
+// the item list of a row as the evaluation reads it: LDS copies (k_tables) or the parameter block's own arrays
+struct TabItems { const int32_t* base; const uint8_t *s, *u, *c; };
+
+__device__ __forceinline__ void tab_store2(double* p, double a, double b) { *reinterpret_cast<double2*>(p) = make_double2(a, b); }   // two adjacent doubles, one 16-byte store
+template <int NT>
+__device__ __forceinline__ void tab_sync() {
+    if constexpr (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    else __syncthreads();
+}
+
+// the job list of a context, once (hf_create): job < n_keys is the (emission key [, transition class]) pair keys[job] / cls[job] of an interior
+// window, job - n_keys < n_slow the slow window slow_w[k] with its own beta (round 5: a pass used to rebuild this from keys / records /
+// betas every time — three dependent global loads at the head of a latency-bound kernel)
+__global__ void __launch_bounds__(256) k_build_jobs(int n_keys, const int32_t* __restrict__ keys, const int32_t* __restrict__ cls, int n_slow,
+                                                    const int64_t* __restrict__ slow_w, const uint32_t* __restrict__ rec, const double* __restrict__ beta,
+                                                    int M, int64_t n_lut_rows, double beta_star, TableJob* __restrict__ jobs) {
+    const int job = blockIdx.x * 256 + threadIdx.x;
+    if (job >= n_keys + n_slow) return;
+    TableJob J;
+    J.x = 0.0; J.px = 0.0; J.bt = beta_star; J.row = 0; J.r = 0; J.flags = 0;
+    if (job < n_keys) {
+        const int64_t key = keys[job];
+        const int64_t MM = (int64_t) M * M;
+        const int64_t idx = key % MM;
+        J.r = (int) (key / MM); J.x = (double) (idx / M); J.px = (double) (idx % M); J.row = key; J.flags = 1 | 4;
+    } else {
+        const int k = job - n_keys;
+        const int64_t t = slow_w[k];
+        const uint32_t rw = rec[t];
+        const bool first = REC_FIRST(rw) != 0;
+        J.r = (int) REC_REGION(rw); J.x = (double) REC_X(rw); J.px = first ? 0.0 : (double) REC_X(rec[t - 1]);
+        J.bt = beta[t]; J.row = n_lut_rows + k; J.flags = (first ? 2 : 0) | 4;
+    }
+    if (cls) J.flags |= (cls[job] & 0xff) << 8;
+    jobs[job] = J;
+}
+
+// the job of thread tid (< JOBS) of the unit whose first job is job0 (one 48-byte load; idle past the list's end)
+template <int JOBS>
+__device__ __forceinline__ TableJob tables_load_job(const TabWork& W, int job0, int tid) {
+    TableJob J;
+    J.x = 0.0; J.px = 0.0; J.bt = 0.0; J.row = 0; J.r = 0; J.flags = 0;
+    if (tid < JOBS && job0 + tid < W.n_jobs) J = W.jobs[job0 + tid];
+    return J;
+}
+
+// one unit of JOBS rows by NT threads: the rows x items grid flat (one exp each) into s_val, then the rows x outputs grid — E[pre][s],
+// the row of A = (transition table of the job's class)∘E and the component table, two adjacent values (previous states 2h, 2h + 1 of
+// one state / component: the tables are state-major) per thread and store.  (Round 5 also ran this function inside k_seg_fb — the tables
+// by the first workgroups of the segment kernel's own launch, one launch less per pass: 1.5 .. 10 us SLOWER per pass at every input size,
+// the in-launch wait for the tables is a chain of ~8 dependent global round trips where a kernel boundary costs ~2 us;
+// profiles/r05_ab_tab_*.txt, profiles/r05_tab_fused_experiment.patch.)
+template <int JOBS, int NT>
+__device__ __forceinline__ void tables_eval(const TabWork& W, const DevParams* __restrict__ P, const TabItems It, int job0, int tid, TableJob J,
+                                            TableJob* __restrict__ s_job, double (*__restrict__ s_val)[HF_TABLE_MAX_ITEMS]) {
+    const int ncol = P->ncomp[3], n_items = P->n_items;
+    const bool te = hf_err_is_truncexp(P);
+    if (tid < JOBS) s_job[tid] = J;
+    tab_sync<NT>();
+    // ---- the items ----
+    unsigned nan = 0;
+    for (int w = tid; w < JOBS * n_items; w += NT) {
+        const int jl = w / n_items, it = w - jl * n_items;
+        const TableJob Jw = s_job[jl];
+        if (!(Jw.flags & 4)) continue;
+        const int s = It.s[it], u = It.u[it], c = It.c[it];
+        const bool star = (Jw.flags & 1) != 0, first = (Jw.flags & 2) != 0;
+        const DevRegion* __restrict__ R = &P->reg[Jw.r];
+        double v;
+        if (s == 0 && te) v = star ? hf_trunc_exp_star(R, Jw.x) : hf_trunc_exp(R->lambda, R->trunc_point, Jw.x, Jw.bt);
+        else {
+            const double alpha = first ? 0.0 : P->ualpha[s][u];
+            v = star ? hf_gauss_comp_star(R->m1[s][u][c], R->gvar[s][c], R->gnorm[s][c], Jw.x, Jw.px, alpha, Jw.bt, &nan)
+                     : hf_gauss_comp(R->mean[s][c], R->var[s][c], R->weight[s][c], Jw.x, Jw.px, alpha, Jw.bt, &nan);
+        }
+        s_val[jl][it] = v;
+    }
+    tab_sync<NT>();
+    // ---- the outputs: 8 pairs of E (and of the row of A) and 2*ncol pairs of the component table per row ----
+    const int n_out = 8 + 2 * ncol;
+    for (int w = tid; w < JOBS * n_out; w += NT) {
+        const int jl = w / n_out, o = w - jl * n_out;
+        const TableJob Jw = s_job[jl];
+        if (!(Jw.flags & 4)) continue;
+        const bool first = (Jw.flags & 2) != 0;
+        if (o < 8) {
+            const int s = o >> 1, p0 = (o & 1) * 2;            // entries (p0, s), (p0 + 1, s): positions HF_PS(p0, s), + 1
+            double e[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int pre = p0 + h;
+                const int u = (first || (s == 0 && te)) ? 0 : P->umap[pre * 4 + s];
+                const int b0 = It.base[s * 4 + u];
+                double v;
+                if (s < 3) v = s_val[jl][b0];
+                else {
+                    v = 0.0;
+                    for (int c = 0; c < ncol; c++) v += s_val[jl][b0 + c];
+                }
+                if (first && pre != 0) v = 0.0;
+                e[h] = v;
+            }
+            tab_store2(W.lutE + Jw.row * 16 + HF_PS(p0, s), e[0], e[1]);
+            if (W.lutA) {
+                const int k = Jw.flags >> 8;
+                const DevRegion* __restrict__ R = &P->reg[Jw.r];
+                double t[2];
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                    t[h] = k == 9 ? R->trans[4][s] : (k == 8 ? 1.0 / (HF_NSTATES + 1) : R->tcond[k][(p0 + h) * 4 + s]);
+                tab_store2(W.lutA + (int64_t) (job0 + jl) * 16 + HF_PS(p0, s), t[0] * e[0], t[1] * e[1]);
+            }
+        } else {   // component probabilities per PREVIOUS STATE (the value of its alpha): no select in the consumer
+            const int q = o - 8, c = q >> 1, p0 = (q & 1) * 2;
+            double v[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int u = first ? 0 : P->umap[(p0 + h) * 4 + 3];
+                v[h] = first ? 0.0 : s_val[jl][It.base[3 * 4 + u] + c];
+            }
+            tab_store2(W.lutC + (Jw.row * 4) * W.K + c * 4 + p0, v[0], v[1]);
+        }
+    }
+}
+
 template <int HF_TABLE_JOBS_PER_BLOCK, bool KARG>
-__global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __restrict__ keys, int n_slow,
-                                                const int64_t* __restrict__ slow_w, const uint32_t* __restrict__ rec,
-                                                const double* __restrict__ beta, int M, int K,
-                                                const DevParams* __restrict__ Pg, double* __restrict__ lutE,
-                                                double* __restrict__ lutC, double* __restrict__ Es,
-                                                double* __restrict__ Cs, unsigned* __restrict__ flags,
-                                                const int32_t* __restrict__ cls, double* __restrict__ lutA,
+__global__ void __launch_bounds__(256) k_tables(const TabWork W, const DevParams* __restrict__ Pg, unsigned* __restrict__ flags,
                                                 const std::conditional_t<KARG, KParams, NoKParams> kp, DevParams* __restrict__ P_out) {
-    // cls / lutA (statistics by emission row, hf_seg.h): job j also writes row j of A = (transition table of class cls[j]) ∘ E;
+    // W.cls / W.lutA (statistics by emission row, hf_seg.h): job j also writes row j of A = (transition table of class cls[j]) ∘ E;
     // `keys` is then the list of the (key, class) pairs that occur — a key with two classes is evaluated twice (same values)
     __shared__ TableJob s_job[HF_TABLE_JOBS_PER_BLOCK];
     __shared__ double s_val[HF_TABLE_JOBS_PER_BLOCK][HF_TABLE_MAX_ITEMS];
-    __shared__ int s_base[16];
-    __shared__ unsigned char s_item[3][HF_TABLE_MAX_ITEMS];
+    __shared__ int32_t s_base[16];
+    __shared__ uint8_t s_item[3][HF_TABLE_MAX_ITEMS];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) *flags = 0u;   // first kernel of every pass
-    // the jobs of the block first: their loads (key / window record / beta: global memory) are in flight while the parameter block is
-    // rebuilt below — two dependent rounds of global latency were the larger part of this launch-bound kernel's critical path
+    // the jobs of the block first: their loads are in flight while the parameter block is rebuilt below — two dependent rounds of
+    // global latency were the larger part of this launch-bound kernel's critical path
     const int job0 = blockIdx.x * HF_TABLE_JOBS_PER_BLOCK;
-    const int n_lut_rows = (int) ((Es - lutE) / 16);   // Es / Cs are the rows n_lut.. of the same buffers
-    TableJob J;
-    J.x = 0.0; J.px = 0.0; J.bt = 0.0; J.row = 0; J.r = 0; J.flags = 0;
-    if (tid < HF_TABLE_JOBS_PER_BLOCK) {
-        const int job = job0 + tid;
-        if (job < n_keys) {
-            const int64_t key = keys[job];
-            const int64_t MM = (int64_t) M * M;
-            const int64_t idx = key % MM;
-            J.r = (int) (key / MM); J.x = (double) (idx / M); J.px = (double) (idx % M); J.row = key; J.flags = 1 | 4;
-            if (cls) J.flags |= (cls[job] & 0xff) << 8;
-        } else if (job - n_keys < n_slow) {
-            const int k = job - n_keys;
-            const int64_t t = slow_w[k];
-            const uint32_t rw = rec[t];
-            const bool first = REC_FIRST(rw) != 0;
-            J.r = (int) REC_REGION(rw); J.x = (double) REC_X(rw); J.px = first ? 0.0 : (double) REC_X(rec[t - 1]);
-            J.bt = beta[t]; J.row = (int64_t) n_lut_rows + k; J.flags = (first ? 2 : 0) | 4;
-            if (cls) J.flags |= (cls[job] & 0xff) << 8;
-        }
-    }
+    const TableJob J = tables_load_job<HF_TABLE_JOBS_PER_BLOCK>(W, job0, tid);
     // the parameter block: in global memory (copied before the launch), or — one region, hf_device.h KParams — in the kernel
     // arguments: rebuilt here in LDS, and by block 0 in global memory for the kernels that follow
     __shared__ double s_params[KARG ? sizeof(DevParams) / 8 : 1];
@@ -265,63 +364,8 @@ __global__ void __launch_bounds__(256) k_tables(int n_keys, const int32_t* __res
         __syncthreads();
         P = reinterpret_cast<const DevParams*>(s_params);
     } else P = Pg;
-    const int ncol = P->ncomp[3], n_items = P->n_items;
-    const bool te = hf_err_is_truncexp(P);
-    if (tid < HF_TABLE_JOBS_PER_BLOCK) {
-        if ((J.flags & 5) != 4) J.bt = P->beta_star;   // table keys (and idle jobs): the interior windows' beta; a slow window keeps its own
-        s_job[tid] = J;
-    }
     if (tid < 16) s_base[tid] = P->item_base[tid];
-    if (tid < n_items) { s_item[0][tid] = P->item_s[tid]; s_item[1][tid] = P->item_u[tid]; s_item[2][tid] = P->item_c[tid]; }
-    __syncthreads();
-    // ---- the items ----
-    unsigned nan = 0;
-    for (int w = tid; w < HF_TABLE_JOBS_PER_BLOCK * n_items; w += 256) {
-        const int jl = w / n_items, it = w - jl * n_items;
-        const TableJob J = s_job[jl];
-        if (!(J.flags & 4)) continue;
-        const int s = s_item[0][it], u = s_item[1][it], c = s_item[2][it];
-        const bool star = (J.flags & 1) != 0, first = (J.flags & 2) != 0;
-        const DevRegion* __restrict__ R = &P->reg[J.r];
-        double v;
-        if (s == 0 && te) v = star ? hf_trunc_exp_star(R, J.x) : hf_trunc_exp(R->lambda, R->trunc_point, J.x, J.bt);
-        else {
-            const double alpha = first ? 0.0 : P->ualpha[s][u];
-            v = star ? hf_gauss_comp_star(R->m1[s][u][c], R->gvar[s][c], R->gnorm[s][c], J.x, J.px, alpha, J.bt, &nan)
-                     : hf_gauss_comp(R->mean[s][c], R->var[s][c], R->weight[s][c], J.x, J.px, alpha, J.bt, &nan);
-        }
-        s_val[jl][it] = v;
-    }
-    __syncthreads();
-    // ---- the outputs: 16 values of E and 4*ncol of the component table per row ----
-    const int n_out = 16 + 4 * ncol;
-    for (int w = tid; w < HF_TABLE_JOBS_PER_BLOCK * n_out; w += 256) {
-        const int jl = w / n_out, o = w - jl * n_out;
-        const TableJob J = s_job[jl];
-        if (!(J.flags & 4)) continue;
-        const bool first = (J.flags & 2) != 0;
-        if (o < 16) {
-            const int pre = o >> 2, s = o & 3;
-            const int u = (first || (s == 0 && te)) ? 0 : P->umap[pre * 4 + s];
-            const int b0 = s_base[s * 4 + u];
-            double e;
-            if (s < 3) e = s_val[jl][b0];
-            else {
-                e = 0.0;
-                for (int c = 0; c < ncol; c++) e += s_val[jl][b0 + c];
-            }
-            if (first && pre != 0) e = 0.0;
-            lutE[J.row * 16 + HF_PS(pre, s)] = e;
-            if (lutA) {
-                const int k = J.flags >> 8;
-                const DevRegion* __restrict__ R = &P->reg[J.r];
-                const double t = k == 9 ? R->trans[4][s] : (k == 8 ? 1.0 / (HF_NSTATES + 1) : R->tcond[k][pre * 4 + s]);
-                lutA[(int64_t) (job0 + jl) * 16 + HF_PS(pre, s)] = t * e;
-            }
-        } else {   // component probabilities per PREVIOUS STATE (the value of its alpha): no select in the consumer
-            const int q = o - 16, c = q >> 2, pre = q & 3;
-            const int u = first ? 0 : P->umap[pre * 4 + 3];
-            lutC[(J.row * 4) * K + c * 4 + pre] = first ? 0.0 : s_val[jl][s_base[3 * 4 + u] + c];
-        }
-    }
+    if (tid < P->n_items) { s_item[0][tid] = P->item_s[tid]; s_item[1][tid] = P->item_u[tid]; s_item[2][tid] = P->item_c[tid]; }
+    TabItems It; It.base = s_base; It.s = s_item[0]; It.u = s_item[1]; It.c = s_item[2];
+    tables_eval<HF_TABLE_JOBS_PER_BLOCK, 256>(W, P, It, job0, tid, J, s_job, s_val);   // (its first barrier also covers s_base / s_item)
 }

@@ -52,37 +52,6 @@
 
 // SegDesc: hf_device.h
 
-// ---- round 4: the segment kernel on an arithmetic diet.  Of the 5 840 VALU instructions a wavefront issued, 2 420 were
-// fp64 FMA / MUL / ADD / RCP (profiles/r04a_pmc_fp64.json); the rest moved, compared, rescaled.  Every piece has its own switch (1 = on,
-// the default) so that a same-box A/B can price it: -DHF_SEG_INTMAX=0 ...
-#ifndef HF_SEG_INTMAX
-#define HF_SEG_INTMAX 1     // renormalisation: the largest entry's exponent from an integer maximum of the high words (entries are >= 0)
-#endif
-#ifndef HF_SEG_RENORM2
-#define HF_SEG_RENORM2 1    // one power-of-two renormalisation per TWO products (lane products, scan levels): exact either way
-#endif
-#ifndef HF_SEG_IDROW
-#define HF_SEG_IDROW 1      // lanes past their last window multiply by an identity row of the table: no branches, no copies in the product loop
-#endif
-#ifndef HF_SEG_IDLANE
-#define HF_SEG_IDLANE 1     // scan levels inside a row of 16 lanes: lanes without a source multiply by the identity (no branch, no copy)
-#endif
-#ifndef HF_SEG_VECSUF
-#define HF_SEG_VECSUF 1     // suffix scan: the two cross-row levels on 4-vectors (what is consumed is suffix·u, not the suffix).; -0.2 us alone, +0.6 us once the rest of the kernel is straight-line (profiles/r04b_ab_variants.txt, r04c_ab_variants.txt)
-#endif
-#ifndef HF_SEG_IDBCAST
-#define HF_SEG_IDBCAST 1    // the prefix scan's two cross-row levels (row_bcast) straight-line too: rows without a source keep an identity matrix
-#endif
-#ifndef HF_SEG_TRASH
-#define HF_SEG_TRASH 1      // record / scale stores of lanes without a window go to a per-segment spare record instead of being branched around
-#endif
-#ifndef HF_SEG_WAVESHR
-#define HF_SEG_WAVESHR 1    // the neighbour lane's prefix by DPP wave_shr:1 (GFX9) instead of 32 ds_bpermute
-#endif
-#ifndef HF_SEG_RCP
-#define HF_SEG_RCP 1        // replays: one division (the reciprocal of the scale) and four multiplications per window instead of four divisions
-#endif
-
 // one-launch mode (k_seg_fb<., true>): hand-off of a segment's product to the chunk's other segments — write-through stores,
 // a drained queue, then the flag (= the launch's epoch); readers poll the flag and read past their caches
 // The hand-offs here and in hf_rows.h order "data stores, then flag / ticket" with relaxed atomics + s_waitcnt vmcnt(0): on GFX9 /
@@ -148,7 +117,6 @@ __device__ __forceinline__ void v4_mul_left(double v[4], const double* __restric
 // the doubles is the order of their high words: an integer maximum (v_max3_u32) gives the exponent without 15 v_max_f64 and a frexp.
 // A largest entry that is zero or denormal leaves the matrix as it is; a NaN entry stays a NaN (and reaches the scale of its window).
 __device__ __forceinline__ void m4_renorm_tree(M4& a) {
-#if HF_SEG_INTMAX
     unsigned h = (unsigned) __double2hiint(a.m[0]);
 #pragma unroll
     for (int i = 1; i < 16; i++) { const unsigned g = (unsigned) __double2hiint(a.m[i]); h = g > h ? g : h; }
@@ -157,20 +125,6 @@ __device__ __forceinline__ void m4_renorm_tree(M4& a) {
     asm volatile("" : "+v"(ne));                 // (ONE select, on the exponent: hipcc otherwise selects between x and ldexp(x) sixteen times)
 #pragma unroll
     for (int i = 0; i < 16; i++) a.m[i] = ldexp(a.m[i], ne);
-#else
-    double t[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) t[i] = fmax(a.m[i], a.m[i + 8]);
-#pragma unroll
-    for (int i = 0; i < 4; i++) t[i] = fmax(t[i], t[i + 4]);
-    const double mx = fmax(fmax(t[0], t[1]), fmax(t[2], t[3]));
-    int e;
-    (void) frexp(mx, &e);
-    if (mx > 0.0) {
-#pragma unroll
-        for (int i = 0; i < 16; i++) a.m[i] = ldexp(a.m[i], -e);
-    }
-#endif
 }
 
 // ---- DPP moves of a 4x4 matrix (gfx9 row_shr / row_shl / row_bcast): lanes without a source keep their own value ----
@@ -221,52 +175,32 @@ __device__ __forceinline__ void m4_dpp0(M4& dst, const M4& src) {
 // inclusive prefix product over the 64 lanes: lane l ends with Q_0 ... Q_l (power-of-two renormalised: exact)
 __device__ __forceinline__ void m4_scan_prefix(M4& Pq, int lane) {
     M4 Lft, R;
-#if HF_SEG_IDLANE
 #define HF_STEP_SHR(n, RN)                                                                              \
     m4_dpp0<HF_DPP_ROW_SHR(n)>(Lft, Pq);                                                                 \
     m4_dpp_or_identity_fix(Lft, (lane & 15) >= (n));                                                    \
     m4_mul(R, Lft, Pq); Pq = R;                                                                         \
     if (RN) m4_renorm_tree(Pq);
-#else
-#define HF_STEP_SHR(n, RN)                                                                              \
-    m4_dpp<HF_DPP_ROW_SHR(n)>(Lft, Pq);                                                                  \
-    if ((lane & 15) >= (n)) { m4_mul(R, Lft, Pq); Pq = R; if (RN) m4_renorm_tree(Pq); }
-#endif
-    HF_STEP_SHR(1, !HF_SEG_RENORM2) HF_STEP_SHR(2, 1) HF_STEP_SHR(4, !HF_SEG_RENORM2) HF_STEP_SHR(8, 1)
+    HF_STEP_SHR(1, false) HF_STEP_SHR(2, 1) HF_STEP_SHR(4, false) HF_STEP_SHR(8, 1)
 #undef HF_STEP_SHR
-#if HF_SEG_IDBCAST
     // the rows the broadcast does not write keep the `old` operand: the identity — every lane multiplies, no branch, no copy
 #pragma unroll
     for (int i = 0; i < 16; i++) Lft.m[i] = dpp_old_f64<HF_DPP_ROW_BCAST15, 0xa>((i % 5 == 0) ? 1.0 : 0.0, Pq.m[i]);   // rows 1, 3 <- lane 15 of rows 0, 2
     m4_mul(R, Lft, Pq); Pq = R;
-    if (!HF_SEG_RENORM2) m4_renorm_tree(Pq);
+    if (false) m4_renorm_tree(Pq);
 #pragma unroll
     for (int i = 0; i < 16; i++) Lft.m[i] = dpp_old_f64<HF_DPP_ROW_BCAST31, 0xc>((i % 5 == 0) ? 1.0 : 0.0, Pq.m[i]);   // rows 2, 3 <- lane 31
     m4_mul(R, Lft, Pq); Pq = R;
     m4_renorm_tree(Pq);
-#else
-    m4_dpp<HF_DPP_ROW_BCAST15, 0xa>(Lft, Pq);                 // rows 1, 3 <- lane 15 of rows 0, 2
-    if (lane & 16) { m4_mul(R, Lft, Pq); Pq = R; if (!HF_SEG_RENORM2) m4_renorm_tree(Pq); }
-    m4_dpp<HF_DPP_ROW_BCAST31, 0xc>(Lft, Pq);                 // rows 2, 3 <- lane 31
-    if (lane >= 32) { m4_mul(R, Lft, Pq); Pq = R; if (!HF_SEG_RENORM2) m4_renorm_tree(Pq); }
-    if (HF_SEG_RENORM2) m4_renorm_tree(Pq);
-#endif
 }
 // the four levels of the suffix scan inside a row of 16 lanes: lane l ends with Q_l ... Q_(last lane of its row)
 __device__ __forceinline__ void m4_scan_suffix_rows(M4& Sq, int lane) {
     M4 Rgt, R;
-#if HF_SEG_IDLANE
 #define HF_STEP_SHL(n, RN)                                                                              \
     m4_dpp0<HF_DPP_ROW_SHL(n)>(Rgt, Sq);                                                                 \
     m4_dpp_or_identity_fix(Rgt, (lane & 15) + (n) < 16);                                                \
     m4_mul(R, Sq, Rgt); Sq = R;                                                                         \
     if (RN) m4_renorm_tree(Sq);
-#else
-#define HF_STEP_SHL(n, RN)                                                                              \
-    m4_dpp<HF_DPP_ROW_SHL(n)>(Rgt, Sq);                                                                  \
-    if ((lane & 15) + (n) < 16) { m4_mul(R, Sq, Rgt); Sq = R; if (RN) m4_renorm_tree(Sq); }
-#endif
-    HF_STEP_SHL(1, !HF_SEG_RENORM2) HF_STEP_SHL(2, 1) HF_STEP_SHL(4, !HF_SEG_RENORM2) HF_STEP_SHL(8, 1)
+    HF_STEP_SHL(1, false) HF_STEP_SHL(2, 1) HF_STEP_SHL(4, false) HF_STEP_SHL(8, 1)
 #undef HF_STEP_SHL
 }
 // inclusive suffix product over the 64 lanes: lane l ends with Q_l ... Q_63 (without HF_SEG_VECSUF)
@@ -275,11 +209,11 @@ __device__ __forceinline__ void m4_scan_suffix(M4& Sq, int lane) {
     m4_scan_suffix_rows(Sq, lane);
 #pragma unroll
     for (int i = 0; i < 16; i++) Rgt.m[i] = __shfl(Sq.m[i], (lane | 15) + 1);   // first lane of the next row
-    if (!(lane & 16)) { m4_mul(R, Sq, Rgt); Sq = R; if (!HF_SEG_RENORM2) m4_renorm_tree(Sq); }       // rows 0, 2
+    if (!(lane & 16)) { m4_mul(R, Sq, Rgt); Sq = R; if (false) m4_renorm_tree(Sq); }       // rows 0, 2
 #pragma unroll
     for (int i = 0; i < 16; i++) Rgt.m[i] = __shfl(Sq.m[i], 32);
-    if (lane < 32) { m4_mul(R, Sq, Rgt); Sq = R; if (!HF_SEG_RENORM2) m4_renorm_tree(Sq); }
-    if (HF_SEG_RENORM2) m4_renorm_tree(Sq);
+    if (lane < 32) { m4_mul(R, Sq, Rgt); Sq = R; if (false) m4_renorm_tree(Sq); }
+    if (true) m4_renorm_tree(Sq);
 }
 
 // ---- LDS of a segment workgroup: the 8 KiB row block | the offset table [LMAX][8][8] u32 | the labels [64*LMAX] ----
@@ -427,7 +361,6 @@ __global__ void __launch_bounds__(256) k_arows(int n_rows, const int32_t* __rest
 // doubles in the label area, idle until phase D): the end vector is later carried across the rows as a VECTOR (seg_suffix_apply),
 // 3 x 16 multiply-adds instead of two levels of 64 (+ 64 ds_bpermute + renormalisations) — what is consumed is suffix·u, never the suffix.
 __device__ __forceinline__ void seg_suffix_side(M4& Q, int lane, double xs[16], double* s_T) {
-#if HF_SEG_VECSUF
     m4_scan_suffix_rows(Q, lane);
     if ((lane & 15) == 0 && lane > 0) {
         double2* dst = reinterpret_cast<double2*>(s_T) + ((lane >> 4) - 1) * 8;
@@ -442,19 +375,12 @@ __device__ __forceinline__ void seg_suffix_side(M4& Q, int lane, double xs[16], 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
-    m4_scan_suffix(Q, lane);
-#pragma unroll
-    for (int k = 0; k < 16; k++) xs[k] = __shfl_down(Q.m[k], 1);   // exclusive suffix: lanes lane+1..63
-    (void) s_T;
-#endif
 }
 // direction of b at the lane's last window: everything after it (in the segment: xs and the later rows; then u, the end vector carried
 // in through the chunk's later segments) applied to u
 __device__ __forceinline__ void seg_suffix_apply(const double u[4], const double xs[16], int lane, const double* s_T, double bdir[4]) {
 #pragma unroll
     for (int s = 0; s < 4; s++) bdir[s] = u[s];
-#if HF_SEG_VECSUF
     const int row = lane >> 4;
 #pragma unroll
     for (int k = 3; k >= 1; k--) {                               // z_(k-1) = T_k · z_k for the lanes of rows < k
@@ -468,10 +394,6 @@ __device__ __forceinline__ void seg_suffix_apply(const double u[4], const double
     }
     v4_renorm(bdir);
     v4_mul_left(bdir, xs);                                       // (a row's last lane: the identity)
-#else
-    if (lane < 63) v4_mul_left(bdir, xs);
-    (void) s_T;
-#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -479,7 +401,7 @@ __device__ __forceinline__ void seg_suffix_apply(const double u[4], const double
 // the same bits).  A chunk-first window is left out of its lane's product: it belongs to the start vector.  All 64 lanes run all L
 // steps (the row fetch is cooperative).  HF_SEG_IDROW: the steps past a lane's last window fetch the table's IDENTITY row and are
 // multiplied like any other (exact), the first factor is taken as it is, and the loop runs two products per trip with the roles of Q
-// and R swapped — no branch, no copy of a product back into place, one renormalisation per trip (HF_SEG_RENORM2).
+// and R swapped — no branch, no copy of a product back into place, one renormalisation per trip (true).
 // On entry the fetch of step 0 has NOT been issued; on return nothing is in flight.
 // ------------------------------------------------------------------------------------------
 // (`blk` must NOT be declared __restrict__ here: the rows arrive in it through the LDS-DMA of rows_issue — inline assembly — and a noalias
@@ -489,7 +411,6 @@ __device__ __forceinline__ void seg_lane_product(const RowFetch& F, const double
     M4 A, R;
 #define HF_ROW_TO_M4(dst) _Pragma("unroll") for (int k_ = 0; k_ < 16; k_++) (dst).m[k_] = E[HF_PS(k_ >> 2, k_ & 3)]
     rows_issue(F, 0);
-#if HF_SEG_IDROW
     rows_read(blk, lane, E);
     if (1 < L) rows_issue(F, 1);
     HF_ROW_TO_M4(Q);                                             // the first factor: no product with the identity
@@ -501,7 +422,7 @@ __device__ __forceinline__ void seg_lane_product(const RowFetch& F, const double
         rows_issue(F, i + 1);
         HF_ROW_TO_M4(A);
         m4_mul(R, Q, A);
-        if (!HF_SEG_RENORM2) m4_renorm_tree(R);
+        if (false) m4_renorm_tree(R);
         rows_read(blk, lane, E);
         if (i + 2 < L) rows_issue(F, i + 2);
         HF_ROW_TO_M4(A);
@@ -516,21 +437,6 @@ __device__ __forceinline__ void seg_lane_product(const RowFetch& F, const double
         m4_renorm_tree(Q);
     }                                                            // (L == 1: the row as it is; the scans renormalise)
     (void) m;
-#else
-    const int i0 = chunk_first ? 1 : 0;
-    m4_identity(Q);
-#pragma unroll 1
-    for (int i = 0; i < L; i++) {
-        rows_read(blk, lane, E);
-        if (i + 1 < L) rows_issue(F, i + 1);                     // in flight during this step
-        if (i < m && i >= i0) {
-            HF_ROW_TO_M4(A);
-            if (i == i0) Q = A;                                  // the first factor: no product with the identity
-            else { m4_mul(R, Q, A); Q = R; }
-            if (!HF_SEG_RENORM2 || ((i - i0) & 1) || i + 1 >= m) m4_renorm_tree(Q);
-        }
-    }
-#endif
 #undef HF_ROW_TO_M4
 }
 
@@ -632,14 +538,9 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 if (lane == 63) __hip_atomic_store(ready + g, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             TR_STAMP(2);
-#if HF_SEG_WAVESHR
             { M4 X_; m4_dpp0<HF_DPP_WAVE_SHR1>(X_, Q); m4_dpp_or_identity_fix(X_, lane > 0);   // one DPP move per word instead of a ds_bpermute; lane 0: the identity
 #pragma unroll
               for (int k = 0; k < 16; k++) xv[k] = X_.m[k]; }
-#else
-#pragma unroll
-            for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);   // exclusive prefix: the product of lanes 0..lane-1
-#endif
             {
                 const double sv = ((v[0] + v[1]) + v[2]) + v[3];
 #pragma unroll
@@ -698,13 +599,13 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 for (int base = 0; base < d.k; base += 64) {                  // through the chunk's earlier segments
                     gather(base);
                     const int hi = d.k < base + 64 ? d.k : base + 64;
-                    for (int q = base; q < hi; q++) { double M[16]; from_lane(q - base, M); v4_mul_right(v, M); if (!HF_SEG_RENORM2 || ((q - base) & 1) || q + 1 == hi) v4_renorm(v); }
+                    for (int q = base; q < hi; q++) { double M[16]; from_lane(q - base, M); v4_mul_right(v, M); if (false || ((q - base) & 1) || q + 1 == hi) v4_renorm(v); }
                 }
                 if (BWD)                                                      // ... and back through the later ones
                     for (int base = ((d.nseg - 1) >> 6) << 6; base >= 0 && base + 64 > d.k + 1; base -= 64) {
                         gather(base);
                         const int lo = d.k + 1 > base ? d.k + 1 : base;
-                        for (int q = (d.nseg - 1 < base + 63 ? d.nseg - 1 : base + 63); q >= lo; q--) { double M[16]; from_lane(q - base, M); v4_mul_left(u, M); if (!HF_SEG_RENORM2 || ((q - base) & 1) || q == lo) v4_renorm(u); }
+                        for (int q = (d.nseg - 1 < base + 63 ? d.nseg - 1 : base + 63); q >= lo; q--) { double M[16]; from_lane(q - base, M); v4_mul_left(u, M); if (false || ((q - base) & 1) || q == lo) v4_renorm(u); }
                     }
             }
             TR_STAMP(4);
@@ -755,16 +656,11 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
         if (BWD) m4_park(Q, lane, blk);
         TR_STAMP(4);
         m4_scan_prefix(Q, lane);
-#if HF_SEG_WAVESHR
         { M4 X_; m4_dpp0<HF_DPP_WAVE_SHR1>(X_, Q); m4_dpp_or_identity_fix(X_, lane > 0);
 #pragma unroll
           for (int k = 0; k < 16; k++) xv[k] = X_.m[k]; }
-#else
-#pragma unroll
-        for (int k = 0; k < 16; k++) xv[k] = __shfl_up(Q.m[k], 1);   // exclusive prefix: the product of lanes 0..lane-1
-#endif
         }
-        if (HF_SEG_WAVESHR || lane > 0) v4_mul_right(v, xv);
+        if (true) v4_mul_right(v, xv);
         {
             const double su = ((v[0] + v[1]) + v[2]) + v[3];
 #pragma unroll
@@ -814,14 +710,9 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 const double sc = ((nf[0] + nf[1]) + nf[2]) + nf[3];
                 if (!(chunk_first && i == 0) && sc < 1e-50) bad |= HF_FLAG_SCALE;   // hmm.c:412-415 (not at the chunk's first window)
                 if (!(sc == sc)) bad |= HF_FLAG_NAN;                      // a NaN emission value (hmm_utils.c:783-786)
-#if HF_SEG_RCP
                 const double rsc = 1.0 / sc;                              // (f differs from nf / sc in the last bit at most)
 #pragma unroll
                 for (int s = 0; s < 4; s++) { f[s] = nf[s] * rsc; fs[i][s] = f[s]; }
-#else
-#pragma unroll
-                for (int s = 0; s < 4; s++) { f[s] = nf[s] / sc; fs[i][s] = f[s]; }
-#endif
                 { int e2; lm *= frexp(sc, &e2); le += e2; }                // hmm.c:428, see above
                 scl = sc; ss[i] = sc;
             }
@@ -885,7 +776,6 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + lane;
             const double2 v0 = img[0], v1 = img[64], v2 = img[128], v3 = img[192];
             double2* __restrict__ R2 = reinterpret_cast<double2*>(recs) + (lane & 3);
-#if HF_SEG_TRASH
             // lanes without a window k write THE SEGMENT'S SPARE RECORD (position trash0 + g, behind the plan's positions) and a padding slot
             // of the scales (a segment owns 64 L slots): straight-line stores instead of five regions of masked execution per step
             const int32_t pact = act ? pk : trash0 + g;     // the record of lane r goes to position pact(r): lanes 4r .. 4r+3 of instruction r >> 4
@@ -895,15 +785,6 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             R2[(int64_t) p2 * 4] = v2;
             R2[(int64_t) p3 * 4] = v3;
             scale_s[slot_ij + (int64_t) k * 64] = sck;   // (non-temporal stores: k_pair_sums +3.5 us, it reads these records out of the cache; profiles/r04i_ab_variants.txt)
-#else
-            const int32_t pact = act ? pk : -1;             // the record of lane r goes to position pact(r): lanes 4r .. 4r+3 of instruction r >> 4
-            const int32_t p0 = __shfl(pact, lane >> 2), p1 = __shfl(pact, 16 + (lane >> 2)), p2 = __shfl(pact, 32 + (lane >> 2)), p3 = __shfl(pact, 48 + (lane >> 2));
-            if (p0 >= 0) R2[(int64_t) p0 * 4] = v0;
-            if (p1 >= 0) R2[(int64_t) p1 * 4] = v1;
-            if (p2 >= 0) R2[(int64_t) p2 * 4] = v2;
-            if (p3 >= 0) R2[(int64_t) p3 * 4] = v3;
-            if (act) scale_s[slot_ij + (int64_t) k * 64] = sck;
-#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                    // the block has been read out: the next row fetch may land
         };
@@ -933,14 +814,9 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                     }
                     const double sc = ss[k - 1];
                     if (sc < 1e-50) bad |= HF_FLAG_SCALE;                     // hmm.c:521-524
-#if HF_SEG_RCP
                     const double rsc = 1.0 / sc;
 #pragma unroll
                     for (int s = 0; s < 4; s++) b[s] = nb[s] * rsc;
-#else
-#pragma unroll
-                    for (int s = 0; s < 4; s++) b[s] = nb[s] / sc;
-#endif
                     s_lab[a + k - 1] = (int8_t) posterior_label_fast(fs[k - 1], b, sc);
                 }
                 TR_LAP(6);
