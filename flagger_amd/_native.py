@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
     sig("hf_rank_total", C.c_int, vp, vp, vp)
     sig("hf_get_stats_mode", C.c_int, vp)
     sig("hf_seg_launches", C.c_int, vp)
+    sig("hf_seg_cached_steps", C.c_int, vp)
     sig("hf_finish_exchange", C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, pd, vp)
     sig("hf_bind_chunk_stats", C.c_int, vp, vp)
     sig("hf_write_flag_row", C.c_int, vp, vp, vp)

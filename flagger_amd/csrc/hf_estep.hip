@@ -207,6 +207,7 @@ struct hf_ctx {
     // one-launch mode (hf_seg.h): k_seg_fb computes the lane products itself and the segments of a chunk hand their products to
     // each other inside the launch (flags stamped with the launch's epoch); a timed-out wait switches the context to two launches
     unsigned* d_seg_ready = nullptr; unsigned seg_epoch = 0; bool seg_fused = true, seg_test_timeout = false;
+    int seg_nc = 0;                    // row blocks a segment workgroup keeps in LDS across its three walks (hf_seg.h: chosen so that all segments stay resident)
     hf_params last_p{}; int last_mode = HF_MODE_FULL;   // what the last hf_estep was given (the fallback re-runs the pass)
     // rows of A_t = T_t∘e_t (hf_seg.h): one per (emission key, transition class) that occurs at an interior window, then one
     // per slow window; d_arow[t] = the row of window t (bit 31: chunk-first), d_arow_src / d_arow_cls = where a row comes from
@@ -1105,10 +1106,40 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         int64_t resident = (int64_t) per_cu * cus;
         if (const char* e = std::getenv("HF_SEG_RESIDENT")) resident = std::atoll(e);   // tests: pretend a smaller device
         if (resident > 0 && max_nseg > resident) ctx->seg_fused = false;
+        // Cached row blocks (hf_seg.h, round 5): the LDS that a device with FEWER segments than it could hold leaves idle goes to the
+        // workgroups — the largest nc at which every segment is still resident at once.  Decided from the occupancy the runtime reports for
+        // that much dynamic LDS; HF_SEG_CACHED_STEPS forces a value (tests, A/B runs).
+        int nc = 0;
+        if (ctx->seg_fused && cus > 0) {
+            for (int c = HF_SEG_LMAX; c >= 1; c--) {
+                const size_t lds = seg_lds_bytes(c);
+                if (lds > ctx->lds_max && lds > 64 * 1024) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess ||
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) { (void) hipGetLastError(); continue; }
+                }
+                int pc = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_seg_fb<true, true>, 64, lds) != hipSuccess) { (void) hipGetLastError(); continue; }
+                int64_t res_c = (int64_t) pc * cus;
+                if (std::getenv("HF_SEG_RESIDENT") && per_cu > 0) res_c = resident * pc / per_cu;     // the pretended device, scaled alike
+                // 15 % of room to spare: where the segments filled the device to the last workgroup the API allows (1 531 segments at six
+                // per CU) k_seg_fb took 59 us instead of 41 — one workgroup per CU fewer was actually resident, and the segments of a chunk
+                // wait for each other (profiles/r05_scale_nc.txt)
+                if (res_c * 85 / 100 >= ctx->nseg) { nc = c; break; }
+            }
+            if (const char* e = std::getenv("HF_SEG_CACHED_STEPS")) {
+                const int v = std::atoi(e);
+                if (v >= 0 && v <= HF_SEG_LMAX) nc = v;
+                const size_t lds = seg_lds_bytes(nc);
+                if (lds > 64 * 1024 &&
+                    (hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess ||
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess)) { (void) hipGetLastError(); nc = 0; }
+            }
+        }
+        ctx->seg_nc = nc;
         if (ctrace || ctx->host_trace)
-            std::fprintf(stderr, "[hf_create] segment kernel: %d segments, longest chunk %d; %lld workgroups resident (%d per CU x %d CUs): %s\n",
+            std::fprintf(stderr, "[hf_create] segment kernel: %d segments, longest chunk %d; %lld workgroups resident (%d per CU x %d CUs): %s; %d of %d row blocks cached in LDS (%zu B per workgroup)\n",
                          ctx->nseg, max_nseg, (long long) resident, per_cu, cus,
-                         ctx->seg_fused ? "one launch" : "TWO launches (a chunk has more segments than the device holds workgroups)");
+                         ctx->seg_fused ? "one launch" : "TWO launches (a chunk has more segments than the device holds workgroups)", nc, HF_SEG_LMAX, seg_lds_bytes(nc));
     }
     {   // the job list of the per-pass tables (hf_scan.h), built once: the (key, class) list of the rows of A when the segment kernels run,
         // the emission keys otherwise (HF_ALGO_SEQ); then the slow windows
@@ -1385,10 +1416,11 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 }
             } else if (seg_pass(ctx)) {
                 // one workgroup per chunk segment does the whole forward-backward (hf_seg.h)
-                const size_t lds = seg_lds_bytes();
+                const int nc = ctx->seg_fused ? ctx->seg_nc : 0;     // cached row blocks: one-launch mode only (the lane products are computed in the same kernel)
+                const size_t lds = seg_lds_bytes(nc);
                 if (ctx->host_trace && !ctx->ht_n) {
                     int o1 = 0, o2 = 0;
-                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_seg_prod, 64, lds);
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&o1, k_seg_prod, 64, seg_lds_bytes());
                     if (ctx->seg_fused) hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_seg_fb<true, true>, 64, lds);
                     else hipOccupancyMaxActiveBlocksPerMultiprocessor(&o2, k_seg_fb<true, false>, 64, lds);
                     std::fprintf(stderr, "[hf host trace] segment kernels (%s): %d workgroups of 64 threads, %zu B of LDS; resident per CU: k_seg_prod %d, k_seg_fb %d\n",
@@ -1402,7 +1434,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 if (!ctx->seg_fused) {
                     if (!ctx->d_segQ) HIPCHK(hipMalloc((void**) &ctx->d_segQ, (size_t) ctx->nseg * 64 * 16 * 8));   // lane products: two-launch mode only
                     KTimer t(ctx, st, HF_K_SEG_PROD);
-                    hipLaunchKernelGGL(k_seg_prod, dim3((unsigned) ctx->nseg), dim3(64), lds, st, ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
+                    hipLaunchKernelGGL(k_seg_prod, dim3((unsigned) ctx->nseg), dim3(64), seg_lds_bytes(), st, ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
                 }
                 // the dominant kernel is timed by the dispatch's OWN start / stop timestamps (hipExtLaunchKernelGGL hands the two events to
                 // the launch): what rocprofv3 reports for the kernel, without the two marker packets of an event pair around it (those
@@ -1414,7 +1446,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 // the time-out, HF_E_RETRY and the fall-back to two launches are exercised
                 const unsigned wait_epoch = (ctx->seg_test_timeout && epoch == 1) ? 0xffffffffu : epoch;
 #define HF_SEG_FB_ARGS ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_seg_ready, epoch, wait_epoch, ctx->d_pos, ctx->d_recs, \
-                        ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags, (int32_t) ctx->n_pos
+                        ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags, (int32_t) ctx->n_pos, nc
 #define HF_SEG_FB_LAUNCH(B, F) do { \
                     if (tfb) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) ctx->nseg), dim3(64), (uint32_t) lds, st, \
                                                    ctx->kev[2 * HF_K_SEG_FB], ctx->kev[2 * HF_K_SEG_FB + 1], 0, HF_SEG_FB_ARGS); \
@@ -1504,6 +1536,7 @@ int hf_get_stats_mode(const hf_ctx* ctx) {
 }
 
 int hf_seg_launches(const hf_ctx* ctx) { return !ctx || !seg_pass(ctx) ? 0 : (ctx->seg_fused ? 1 : 2); }
+int hf_seg_cached_steps(const hf_ctx* ctx) { return !ctx || !seg_pass(ctx) || !ctx->seg_fused ? 0 : ctx->seg_nc; }
 
 int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
     if (!ctx || !dst_dev) return set_err(HF_E_ARG, "hf_copy_chunk_stats: bad argument");

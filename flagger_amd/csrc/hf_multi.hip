@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 #include <immintrin.h>
 
@@ -212,6 +213,7 @@ struct RankState {
     int rc = HF_OK; std::string err;
     std::thread th;
     hipEvent_t xe0 = nullptr, xe1 = nullptr; double x_us = 0.0; long x_n = 0;   // HF_HOST_TRACE=1: the all-gather, bracketed by events
+    double h_us[4] = {0, 0, 0, 0};   // HF_HOST_TRACE=2: host time in hf_estep / flag row + all-gather enqueue / hf_finish_exchange / the whole pass
 };
 }  // namespace
 
@@ -291,6 +293,7 @@ void rank_release(RankState& R) {
     hipSetDevice(R.device);
     if (R.xe0) {
         if (R.x_n) std::fprintf(stderr, "[hf_multi] rank %d: %ld passes, all-gather %.1f us per pass (events on the pass's stream)\n", R.r, R.x_n, R.x_us / R.x_n);
+        if (R.h_us[3] > 0.0) std::fprintf(stderr, "[hf_multi] rank %d host time (sums, ms): hf_estep %.2f, collective enqueue %.2f, hf_finish_exchange %.2f, pass %.2f\n", R.r, R.h_us[0] / 1e3, R.h_us[1] / 1e3, R.h_us[2] / 1e3, R.h_us[3] / 1e3);
         hipEventDestroy(R.xe0); hipEventDestroy(R.xe1); R.xe0 = R.xe1 = nullptr;
     }
     if (R.ctx) { hf_bind_chunk_stats(R.ctx, nullptr); hf_destroy(R.ctx); R.ctx = nullptr; }
@@ -309,7 +312,13 @@ int rank_estep(hf_multi* M, RankState& R) {
 int rank_estep_once(hf_multi* M, RankState& R) {
     const size_t slot = (size_t) M->rows_per_rank * (size_t) M->V;
     double* mine = R.xbuf + (size_t) R.r * slot;
+    static const bool htrace = [] { const char* e = std::getenv("HF_HOST_TRACE"); return e && e[0] == '2'; }();
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    auto lap = [&](int k, clk::time_point a) { if (htrace) R.h_us[k] += std::chrono::duration<double, std::micro>(clk::now() - a).count(); };
     int rc = hf_estep(R.ctx, M->p, M->mode, R.st);
+    lap(0, t0);
+    const auto t1 = clk::now();
     // a rank whose launch failed must still take part in the collective, or the others hang: it sends what it has
     // and reports its own error afterwards
     std::string first_err;
@@ -323,12 +332,15 @@ int rank_estep_once(hf_multi* M, RankState& R) {
     if (R.xe0) hipEventRecord(R.xe0, R.st);
     const int rc3 = hf_comm_allgather(R.comm, mine, R.xbuf, (int64_t) slot, R.st);   // whatever happened above: the peers are waiting in it
     if (R.xe0) hipEventRecord(R.xe1, R.st);
+    lap(1, t1);
+    const auto t2 = clk::now();
     if (rc3 != HF_OK && first_err.empty()) first_err = hf_comm_last_error();
     if (rc == HF_OK) rc = rc2 != HF_OK ? rc2 : rc3;
     if (rc != HF_OK) { R.err = first_err; hipStreamSynchronize(R.st); return rc; }
     const int64_t n_rows = M->exchange == HF_EXCHANGE_CHUNKS ? (int64_t) M->C : (int64_t) M->world;
     rc = hf_finish_exchange(R.ctx, R.xbuf, R.d_row_index, n_rows, M->world, M->rows_per_rank, M->flag_row, R.stats.data(), R.st);
     if (rc != HF_OK) R.err = hf_last_error();
+    lap(2, t2); lap(3, t0);
     if (R.xe0 && rc == HF_OK) { float ms = 0.f; if (hipEventElapsedTime(&ms, R.xe0, R.xe1) == hipSuccess) { R.x_us += ms * 1e3; R.x_n++; } }
     return rc;
 }

@@ -216,10 +216,16 @@ __device__ __forceinline__ void m4_scan_suffix(M4& Sq, int lane) {
     if (true) m4_renorm_tree(Sq);
 }
 
-// ---- LDS of a segment workgroup: the 8 KiB row block | the offset table [LMAX][8][8] u32 | the labels [64*LMAX] ----
-// 10.5 KiB: at least twelve workgroups per CU (3 per SIMD, what k_seg_fb's registers allow); 13 KiB was measured to admit only
-// eleven.  k_seg_fb's prologue stages the chunk's segment products in the row block, which is idle until the scans.
-__host__ __device__ constexpr size_t seg_lds_bytes() { return 8192 + (size_t) 64 * HF_SEG_LMAX * 5; }
+// ---- LDS of a segment workgroup: nc CACHED row blocks | the streaming row block | the offset table [LMAX][8][8] u32 | the labels [64*LMAX] ----
+// nc = 0 (a device full of segments: twelve workgroups per CU = 3 per SIMD, what k_seg_fb's registers allow): 10.5 KiB — 13 KiB was measured
+// to admit only eleven.  Round 5: a context with FEWER segments than the device holds at that rate gives every workgroup the LDS that
+// would otherwise lie idle (hf_create: the largest nc at which all segments are still resident together): the rows of the lane's first nc
+// steps stay in LDS blocks of their own from the first walk (the lane products) on, and the two replays read them there instead of
+// fetching them again — 24 dependent fetch -> compute steps per workgroup become 8 + 2 (8 - nc), and the first walk's fetches of the cached
+// steps are all in flight together.  That is the regime of the reference's own default (16 kb windows: ~380 k windows for a human diploid
+// assembly) and of every rank's share at 8 GPUs.  The streaming block doubles as the workgroup's scratch (parked matrices, the chunk's
+// segment products, the record transposition): cached blocks are never written after the first walk.
+__host__ __device__ constexpr size_t seg_lds_bytes(int nc = 0) { return (size_t) (nc + 1) * 8192 + (size_t) 64 * HF_SEG_LMAX * 5; }
 static_assert((size_t) HF_SEG_PSTAGE * 128 <= 8192, "the staged segment products fit the row block");
 static_assert(64 * HF_SEG_LMAX >= 3 * 128, "the label area holds three parked matrices (seg_suffix_side)");
 
@@ -244,23 +250,27 @@ __device__ __forceinline__ void seg_offsets_store(const int32_t rr[HF_SEG_LMAX],
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ---- cooperative row fetch through the wavefront's 8 KiB LDS block (see the header) ----
-// Row r of the step (the row lane r needs) occupies bytes r*128 .. r*128+127 of the block; piece p of the row sits in slot
+// ---- cooperative row fetch through the wavefront's 8 KiB LDS blocks (see the header) ----
+// Row r of the step (the row lane r needs) occupies bytes r*128 .. r*128+127 of the step's block; piece p of the row sits in slot
 // (p + (r >> 1)) & 7: the eight ds_read_b128 of a lane group then cover all 64 banks exactly once.
+// Step i lives in block i when i < nc (cached: fetched once per pass), in block nc (the streaming block) otherwise.
 struct RowFetch {
     const char* __restrict__ base;          // the table of rows of A (wave-uniform)
     const uint32_t* __restrict__ my_off;    // this lane's eight offsets of step 0: s_off + (lane >> 3) * 8; step i: + i * 64
-    uint32_t lds_blk;                       // LDS byte address of the row block (wave-uniform)
+    uint32_t lds0;                          // LDS byte address of block 0 (wave-uniform)
+    int nc;                                 // cached steps
     uint32_t off_even, off_odd;             // the 16-byte piece this lane moves, for even / odd instructions
 };
-__device__ __forceinline__ RowFetch rowfetch_init(const double* __restrict__ rows, const uint32_t* __restrict__ s_off, double* __restrict__ blk, int lane) {
+__device__ __forceinline__ int rows_block(const RowFetch& F, int step) { return step < F.nc ? step : F.nc; }
+__device__ __forceinline__ RowFetch rowfetch_init(const double* rows, const uint32_t* __restrict__ s_off, double* s_rows, int nc, int lane) {
     // lane (sub, part) of instruction q moves 16 bytes of row r = 8q + sub: piece (part - (r >> 1)) & 7 = (c0 - 4q) & 7, i.e.
     // one of two values; 32-bit byte offsets from the (wave-uniform) table base
     const int part = lane & 7, sub = lane >> 3;
     const uint32_t c0 = (uint32_t) (part - (sub >> 1));
     RowFetch F;
     F.base = reinterpret_cast<const char*>(rows); F.my_off = s_off + sub * 8;
-    F.lds_blk = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) (__attribute__((address_space(3))) char*) blk);
+    F.lds0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (uintptr_t) (__attribute__((address_space(3))) char*) s_rows);
+    F.nc = nc;
     F.off_even = (c0 & 7u) << 4; F.off_odd = ((c0 + 4u) & 7u) << 4;
     return F;
 }
@@ -268,26 +278,35 @@ __device__ __forceinline__ void rows_issue(const RowFetch& F, int step) {
     const uint4* __restrict__ t = reinterpret_cast<const uint4*>(F.my_off + step * 64);
     const uint4 o0 = t[0], o1 = t[1];
     const uint32_t o[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+    const uint32_t lb = F.lds0 + (uint32_t) rows_block(F, step) * 8192u;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
         const uint32_t off = o[q] | ((q & 1) ? F.off_odd : F.off_even);
         // The DMA is inline assembly on purpose: with the builtin, hipcc (ROCm 7.2) keeps a pending LDS write on its vmcnt
         // scoreboard and turns every wait before a later ds_read into vmcnt(0) — which would also wait for the backward
-        // replay's record stores (rows_read<NEWER>).  M0 = LDS address of the instruction's 1 KiB; nothing else in these
-        // kernels uses M0.  Unknown to the scoreboard, the DMA can only make the compiler's own counted waits longer.
-        const uint32_t la = F.lds_blk + (uint32_t) q * 1024u;
+        // replay's record stores.  M0 = LDS address of the instruction's 1 KiB; nothing else in these kernels uses M0.
+        // Unknown to the scoreboard, the DMA can only make the compiler's own counted waits longer.
+        const uint32_t la = lb + (uint32_t) q * 1024u;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(la), "v"(off), "s"(F.base) : "memory");
     }
 }
-// NEWER = vector-memory instructions issued AFTER the row fetch that may stay in flight (the backward replay's record stores:
-// vmcnt counts loads and stores in issue order, so "at most NEWER outstanding" means the older DMA has landed)
-template <int NEWER = 0>
-__device__ __forceinline__ void rows_read(const double* __restrict__ blk, int lane, double E[16]) {
-    static_assert(NEWER >= 0 && NEWER < 16, "vmcnt immediate");
-    __builtin_amdgcn_s_waitcnt(NEWER | (7 << 4));   // vmcnt(NEWER) lgkmcnt(0): the wavefront's own LDS-DMA has landed — nothing else orders it
+// wait until at most `newer_steps` row fetches (8 DMA instructions each) issued AFTER the one that is needed are still in flight
+// (vmcnt counts vector-memory instructions in issue order; the immediate is a constant: a wave-uniform switch)
+__device__ __forceinline__ void rows_wait(int newer_steps) {
+#define HF_VMCNT(n) __builtin_amdgcn_s_waitcnt((((n) & 15) | (((n) >> 4) << 14)) | (7 << 4) | (15 << 8))
+    switch (newer_steps) {
+        case 0: HF_VMCNT(0); break;  case 1: HF_VMCNT(8); break;  case 2: HF_VMCNT(16); break; case 3: HF_VMCNT(24); break;
+        case 4: HF_VMCNT(32); break; case 5: HF_VMCNT(40); break; case 6: HF_VMCNT(48); break; default: HF_VMCNT(56); break;
+    }
+#undef HF_VMCNT
+}
+// the lane's row of `step` out of its block (the caller has waited for the fetch: rows_wait; a cached step needs no wait after the first walk)
+// (`s_rows` must NOT be declared __restrict__: the rows arrive through the LDS-DMA of rows_issue — inline assembly)
+__device__ __forceinline__ void rows_read(const RowFetch& F, const double* s_rows, int step, int lane, double E[16]) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);     // lgkmcnt(0)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const double2* __restrict__ row = reinterpret_cast<const double2*>(blk) + lane * 8;
+    const double2* row = reinterpret_cast<const double2*>(s_rows + rows_block(F, step) * 1024) + lane * 8;
 #pragma unroll
     for (int k = 0; k < 8; k++) { const double2 d = row[(k + (lane >> 1)) & 7]; E[2 * k] = d.x; E[2 * k + 1] = d.y; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -399,44 +418,48 @@ __device__ __forceinline__ void seg_suffix_apply(const double u[4], const double
 // ------------------------------------------------------------------------------------------
 // The lane product Q_j = A_{jL} ... A_{jL+L-1} (phase A; k_seg_prod and the one-launch k_seg_fb run the same code, so their results are
 // the same bits).  A chunk-first window is left out of its lane's product: it belongs to the start vector.  All 64 lanes run all L
-// steps (the row fetch is cooperative).  HF_SEG_IDROW: the steps past a lane's last window fetch the table's IDENTITY row and are
-// multiplied like any other (exact), the first factor is taken as it is, and the loop runs two products per trip with the roles of Q
-// and R swapped — no branch, no copy of a product back into place, one renormalisation per trip (true).
-// On entry the fetch of step 0 has NOT been issued; on return nothing is in flight.
+// steps (the row fetch is cooperative).  The steps past a lane's last window fetch the table's IDENTITY row and are multiplied like any
+// other (exact), the first factor is taken as it is, and the loop runs two products per trip with the roles of Q and R swapped — no
+// branch, no copy of a product back into place, one power-of-two renormalisation per trip.
+// Fetch schedule: the steps that have a block of their own (the cached ones, and the first step of the streaming block) are issued
+// together, at most seven steps = 56 DMA instructions in flight (vmcnt counts 63); a further step is issued as soon as its block is free.
+// On entry nothing has been issued; on return nothing is in flight and blocks 0 .. nc-1 hold the rows of steps 0 .. nc-1.
 // ------------------------------------------------------------------------------------------
-// (`blk` must NOT be declared __restrict__ here: the rows arrive in it through the LDS-DMA of rows_issue — inline assembly — and a noalias
-// ARGUMENT lets the compiler assume that nothing but this function's own stores changes the block: it hoisted the row reads out of the loop)
-__device__ __forceinline__ void seg_lane_product(const RowFetch& F, const double* blk, int lane, int L, int m, bool chunk_first, M4& Q) {
+__device__ __forceinline__ void seg_lane_product(const RowFetch& F, const double* s_rows, int lane, int L, bool chunk_first, M4& Q) {
     double E[16];
     M4 A, R;
 #define HF_ROW_TO_M4(dst) _Pragma("unroll") for (int k_ = 0; k_ < 16; k_++) (dst).m[k_] = E[HF_PS(k_ >> 2, k_ & 3)]
-    rows_issue(F, 0);
-    rows_read(blk, lane, E);
-    if (1 < L) rows_issue(F, 1);
+    int issued = F.nc + 1 < L ? F.nc + 1 : L;
+    if (issued > 7) issued = 7;
+    for (int st = 0; st < issued; st++) rows_issue(F, st);
+    // step i: wait for its rows, read them, issue the next step whose block is free (a block of its own, or the streaming block once
+    // the step before it has been read out)
+    auto step_rows = [&](int i) {
+        rows_wait(issued - i - 1);
+        rows_read(F, s_rows, i, lane, E);
+        if (issued < L && (issued <= F.nc || issued - 1 <= i)) { rows_issue(F, issued); issued++; }
+    };
+    step_rows(0);
     HF_ROW_TO_M4(Q);                                             // the first factor: no product with the identity
     if (chunk_first) m4_identity(Q);                             // (lane 0 of a chunk's first segment)
     int i = 1;
 #pragma unroll 1
     for (; i + 1 < L; i += 2) {
-        rows_read(blk, lane, E);
-        rows_issue(F, i + 1);
+        step_rows(i);
         HF_ROW_TO_M4(A);
         m4_mul(R, Q, A);
-        if (false) m4_renorm_tree(R);
-        rows_read(blk, lane, E);
-        if (i + 2 < L) rows_issue(F, i + 2);
+        step_rows(i + 1);
         HF_ROW_TO_M4(A);
         m4_mul(Q, R, A);
         m4_renorm_tree(Q);
     }
     if (i < L) {                                                 // L even: one more factor
-        rows_read(blk, lane, E);
+        step_rows(i);
         HF_ROW_TO_M4(A);
         m4_mul(R, Q, A);
         Q = R;
         m4_renorm_tree(Q);
     }                                                            // (L == 1: the row as it is; the scans renormalise)
-    (void) m;
 #undef HF_ROW_TO_M4
 }
 
@@ -454,15 +477,14 @@ __global__ void __launch_bounds__(64, 4) k_seg_prod(const SegDesc* __restrict__ 
     const int g = blockIdx.x, lane = threadIdx.x;
     const SegDesc d = sd[g];
     const int L = d.L, a = lane * L;
-    const int m = d.n - a < L ? (d.n - a > 0 ? d.n - a : 0) : L;
     {
         int32_t rr[HF_SEG_LMAX];
         seg_load_arows(arow + d.t0, d.n, L, lane, d.ident_row, rr);
         seg_offsets_store(rr, L, lane, s_off);
     }
-    const RowFetch F = rowfetch_init(lutA, s_off, blk, lane);
+    const RowFetch F = rowfetch_init(lutA, s_off, blk, 0, lane);
     M4 Q;
-    seg_lane_product(F, blk, lane, L, m, a == 0 && d.k == 0, Q);   // the chunk's first window starts the chain (hmm.c:333-364)
+    seg_lane_product(F, blk, lane, L, a == 0 && d.k == 0, Q);      // the chunk's first window starts the chain (hmm.c:333-364)
     {
         double2* __restrict__ dst = reinterpret_cast<double2*>(Qs) + (int64_t) g * 8 * 64 + lane;
 #pragma unroll
@@ -487,13 +509,16 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                                                            const double* __restrict__ Qs, double* Pseg, unsigned* ready, unsigned epoch, unsigned wait_epoch,
                                                            const int32_t* __restrict__ pos, double* __restrict__ recs, double* __restrict__ scale_s,
                                                            int8_t* __restrict__ label, double* __restrict__ seg_ll,
-                                                           unsigned* __restrict__ flags, int32_t trash0) {
+                                                           unsigned* __restrict__ flags, int32_t trash0, int nc) {
     constexpr int LM = HF_SEG_LMAX;
     extern __shared__ __attribute__((aligned(16))) double s_W[];
-    double* __restrict__ blk = s_W;                                           // the 8 KiB row block
-    uint32_t* __restrict__ s_off = reinterpret_cast<uint32_t*>(s_W + 1024);   // the row offsets of the replay
-    int8_t* __restrict__ s_lab = reinterpret_cast<int8_t*>(s_W + 1024) + 64 * LM * 4;   // [64 * LM] labels of the segment
-    double* __restrict__ s_P = s_W;                                           // prologue: the chunk's segment products, in the (still idle) row block
+    // nc (wave-uniform, hf_create): the rows of the lane's steps 0 .. nc-1 stay in LDS blocks 0 .. nc-1 after the first walk (one-launch mode
+    // only: the host passes 0 otherwise); block nc streams the other steps and is the workgroup's scratch
+    double* s_rows = s_W;                                                     // block 0
+    double* blk = s_W + nc * 1024;                                            // the streaming / scratch block
+    uint32_t* __restrict__ s_off = reinterpret_cast<uint32_t*>(s_W + (nc + 1) * 1024);   // the row offsets of the replay
+    int8_t* __restrict__ s_lab = reinterpret_cast<int8_t*>(s_W + (nc + 1) * 1024) + 64 * LM * 4;   // [64 * LM] labels of the segment
+    double* s_P = blk;                                                        // prologue (two launches): the chunk's segment products, in the (still idle) row block
     double* __restrict__ s_T = reinterpret_cast<double*>(s_lab);             // phase B: the suffix products of rows 1..3 (384 of the label area's 512 bytes, idle until phase D)
     const int g = blockIdx.x, lane = threadIdx.x;
     const SegDesc d = sd[g];
@@ -505,7 +530,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     double fin[4], bdir[4];
     TR_DECL;
     TR_STAMP(0);
-    const RowFetch F = rowfetch_init(lutA, s_off, blk, lane);
+    const RowFetch F = rowfetch_init(lutA, s_off, s_rows, nc, lane);
     {
         int32_t rr[LM];
         seg_load_arows(arow + d.t0, n, L, lane, d.ident_row, rr);
@@ -525,7 +550,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             // ---- A (one launch): the lane product is computed here (k_seg_prod's loop); the segment's product is what the prefix
             // scan leaves in lane 63: it is PUBLISHED for the chunk's other segments, theirs are awaited (seg_gather) ----
             seg_offsets_store(rr, L, lane, s_off);
-            seg_lane_product(F, blk, lane, L, m, chunk_first, Q);
+            seg_lane_product(F, s_rows, lane, L, chunk_first, Q);
             TR_STAMP(1);
             if (BWD) m4_park(Q, lane, blk);
             m4_scan_prefix(Q, lane);
@@ -684,19 +709,22 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     // ---- C: forward replay (hmm.c:333-434).  fs[i], ss[i]: forward vector and scale of the lane's i-th window (registers) ----
     double f[4] = {fin[0], fin[1], fin[2], fin[3]};
     double fs[LM][4], ss[LM];
+#pragma unroll
+    for (int i = 0; i < LM; i++) { ss[i] = 0.0; fs[i][0] = fs[i][1] = fs[i][2] = fs[i][3] = 0.0; }   // (lanes without a window i store these to the spare record: defined values)
     double A[16];
     // log-likelihood of the lane's windows: sum of log(scale) (hmm.c:428) as log(product of the mantissas) + (sum of the
     // exponents)·ln 2 — one log per lane instead of one (~95 instructions) per window; <= HF_SEG_LMAX mantissas in [0.5, 1)
     double lm = 1.0, scl = 1.0;
     int le = 0;
-    rows_issue(F, 0);
+    if (nc < L) rows_issue(F, nc);                              // the first step that is not cached (nc == 0: every step is fetched again, as before round 5)
     TR_RESET();
 #pragma unroll
     for (int i = 0; i < LM; i++) {
         if (i < L) {                                            // wave-uniform
-            rows_read(blk, lane, A);
+            if (i >= nc) rows_wait(0);
+            rows_read(F, s_rows, i, lane, A);
             TR_LAP(0);
-            if (i + 1 < L) rows_issue(F, i + 1);                // in flight during this step
+            if (i >= nc && i + 1 < L) rows_issue(F, i + 1);     // in flight during this step
             TR_LAP(1);
             if (i < m) {
                 double nf[4];
@@ -710,9 +738,16 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 const double sc = ((nf[0] + nf[1]) + nf[2]) + nf[3];
                 if (!(chunk_first && i == 0) && sc < 1e-50) bad |= HF_FLAG_SCALE;   // hmm.c:412-415 (not at the chunk's first window)
                 if (!(sc == sc)) bad |= HF_FLAG_NAN;                      // a NaN emission value (hmm_utils.c:783-786)
-                const double rsc = 1.0 / sc;                              // (f differs from nf / sc in the last bit at most)
+                // one division per window: f = nf * (1 / sc) differs from nf / sc in the last bit at most.  A subnormal scale (possible only at a
+                // chunk's first window, which is exempt from the 1e-50 test) has no finite reciprocal: that window divides
+                const double rsc = 1.0 / sc;
+                if (__builtin_expect(sc < 0x1p-1021, 0)) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) { f[s] = nf[s] * rsc; fs[i][s] = f[s]; }
+                    for (int s = 0; s < 4; s++) { f[s] = nf[s] / sc; fs[i][s] = f[s]; }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) { f[s] = nf[s] * rsc; fs[i][s] = f[s]; }
+                }
                 { int e2; lm *= frexp(sc, &e2); le += e2; }                // hmm.c:428, see above
                 scl = sc; ss[i] = sc;
             }
@@ -794,14 +829,17 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
 #pragma unroll
         for (int k = LM - 1; k >= 1; k--) {
             if (k < L) {                                        // wave-uniform
-                if (k < L - 1) rows_read(blk, lane, A);
+                if (k < L - 1) {
+                    if (k >= nc) rows_wait(0);                  // (vmcnt(0): the record stores too, as before; a cached step waits for nothing)
+                    rows_read(F, s_rows, k, lane, A);
+                }
                 TR_LAP(3);
                 const bool act = k <= jl;                       // this lane has a window k
                 const int32_t pk = pk_next;
                 pk_next = (k - 1 <= jl && k - 1 >= 0) ? pos_seg[a + k - 1] : 0;   // in flight during this step
                 store_rec(k, act, pk, fs[k - 1], ss[k]);
                 TR_LAP(4);
-                if (k >= 2) rows_issue(F, k - 1);
+                if (k >= 2 && k - 1 >= nc) rows_issue(F, k - 1);
                 TR_LAP(5);
                 if (act) {
                     double nb[4];

@@ -352,6 +352,11 @@ class EMList:
         """1: one-launch segment kernel, 2: k_seg_prod + k_seg_fb, 0: no segment kernels (hf_seg_launches)."""
         return int(self._L.hf_seg_launches(self._h))
 
+    @property
+    def seg_cached_steps(self) -> int:
+        """Row blocks a segment workgroup keeps in LDS across its three walks (hf_seg_cached_steps; 0 on a device full of segments)."""
+        return int(self._L.hf_seg_cached_steps(self._h))
+
     # --- E-step pieces (used directly by the multi-GPU path in dist.py) ---
     def launch(self, model: HMM, mode: int = N.HF_MODE_FULL) -> None:
         p = model.params()

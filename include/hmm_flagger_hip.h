@@ -202,6 +202,10 @@ int hf_get_stats_mode(const hf_ctx *ctx);          /* the mode the NEXT full pas
  * launch), 2 = k_seg_prod + k_seg_fb (hf_create's choice for a chunk with more segments than the device holds workgroups,
  * environment HF_SEG_LAUNCHES=2, or after a hand-off timed out), 0 = the context does not run the segment kernels (HF_ALGO_SEQ, empty). */
 int hf_seg_launches(const hf_ctx *ctx);
+/* Row blocks (of at most 8 = windows per lane) that a segment workgroup of the NEXT one-launch pass keeps in LDS across its three walks
+ * instead of fetching them again: hf_create's choice — the largest number at which all segments are still resident together, 0 on a
+ * device full of segments, 8 for the reference's default window length or a 1/8 shard (environment HF_SEG_CACHED_STEPS forces it). */
+int hf_seg_cached_steps(const hf_ctx *ctx);
 
 /* Results of the last HF_MODE_FULL pass (HF_E_ARG when the last pass was HF_MODE_FORWARD_ONLY: f and scales would be new,
  * b and the labels stale). */

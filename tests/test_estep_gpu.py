@@ -768,3 +768,61 @@ def test_static_guard_of_the_one_launch_hand_off(monkeypatch):
     finally:
         em.close()
         orc.close()
+
+
+def test_cached_row_blocks_same_bits_and_chosen_by_residency(monkeypatch):
+    """VERDICT r04 #4 (the small-shard form of k_seg_fb).  A context with fewer segments than the device holds at twelve workgroups per CU
+    keeps the rows of the lane's first nc steps in LDS blocks of their own across the three walks (hf_seg.h) — the same rows, the same
+    arithmetic: statistics, labels, forward / backward vectors and a forward-only log-likelihood must be the SAME BITS for every nc, ragged
+    segments and several regions included.  hf_create chooses nc from what stays resident: all eight blocks when the device is nearly
+    empty, none when the (pretended) device holds just this context's segments at 10.5 KiB each, something in between in between."""
+    store = synth.config(4, scale=0.03)                 # 7 regions, ragged chunks, L from 1 to 8
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.ONT_R10_ALPHA)
+    ref = None
+    for nc in (0, 1, 3, 5, 8):
+        monkeypatch.setenv("HF_SEG_CACHED_STEPS", str(nc))
+        em = hmm.EMList(store, model, True, 0.8)
+        try:
+            assert em.seg_launches == 1 and em.seg_cached_steps == nc
+            em.launch(model); st = em.finish().copy()
+            lab = em.labels().copy()
+            f, b, sc = em.forward_backward()
+            em.launch(model, N.HF_MODE_FORWARD_ONLY); fwd = em.finish().copy()
+            got = (st, lab, f, b, sc, fwd[0])
+            if ref is None:
+                ref = got
+            else:
+                for x, y in zip(ref, got):
+                    assert np.array_equal(x, y), nc
+        finally:
+            em.close()
+    monkeypatch.delenv("HF_SEG_CACHED_STEPS")
+    em = hmm.EMList(store, model, True, 0.8)
+    nseg_small = None
+    try:
+        assert em.seg_cached_steps == 8                    # a few dozen segments on 256 CUs
+    finally:
+        em.close()
+    # a pretended device (HF_SEG_RESIDENT = workgroups resident at nc = 0; scaled by the real occupancy at every nc)
+    chosen = []
+    for resident in (1 << 20, 4000, 1200, 600, 300, 100, 12):
+        monkeypatch.setenv("HF_SEG_RESIDENT", str(resident))
+        em = hmm.EMList(store, model, True, 0.8)
+        try:
+            chosen.append(em.seg_cached_steps if em.seg_launches == 1 else -1)
+        finally:
+            em.close()
+    monkeypatch.delenv("HF_SEG_RESIDENT")
+    assert chosen[0] == 8 and chosen[-1] <= 0, chosen
+    assert all(a >= b for a, b in zip(chosen, chosen[1:])), chosen          # less room, fewer cached blocks
+    assert len(set(chosen)) >= 3, chosen
+    # two launches (the lane products come from k_seg_prod): nothing is cached
+    monkeypatch.setenv("HF_SEG_LAUNCHES", "2")
+    em = hmm.EMList(store, model, True, 0.8)
+    try:
+        assert em.seg_launches == 2 and em.seg_cached_steps == 0
+        em.launch(model); st2 = em.finish().copy()
+        assert np.array_equal(st2, ref[0]) and np.array_equal(em.labels(), ref[1])
+    finally:
+        em.close()
