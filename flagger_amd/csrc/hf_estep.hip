@@ -96,6 +96,71 @@ struct HostPool {
     }
 };
 HostPool& host_pool() { static HostPool p; return p; }
+
+// Pinned staging buffers of hf_create, kept for the life of the process (round 5): pinning costs ~0.2 ms per MB (1.2-1.3 ms of a 7 ms
+// hf_create on BASELINE configs[2]) and un-pinning as much again on a helper thread.  A context takes the smallest free buffer that
+// is large enough, or a new one (a free smaller one is given back first); hf_warmup pins a first set while the input loads.
+struct PinCache {
+    struct Slot { char* p = nullptr; size_t cap = 0; bool busy = false, pinned = false; };
+    std::mutex m;
+    std::vector<Slot> slots;
+    char* try_acquire(size_t bytes) {                     // a cached buffer, or nullptr
+        std::lock_guard<std::mutex> g(m);
+        int best = -1;
+        for (size_t i = 0; i < slots.size(); i++)
+            if (!slots[i].busy && slots[i].cap >= bytes && (best < 0 || slots[i].cap < slots[(size_t) best].cap)) best = (int) i;
+        if (best < 0) return nullptr;
+        slots[(size_t) best].busy = true;
+        return slots[(size_t) best].p;
+    }
+    char* acquire(size_t bytes) {                         // ... or a new one (pinned when possible; nullptr: out of host memory)
+        if (char* p = try_acquire(bytes)) return p;
+        Slot s;
+        s.cap = bytes + bytes / 8 + 4096;
+        {   // make room: one free buffer that was too small goes back
+            std::lock_guard<std::mutex> g(m);
+            for (size_t i = 0; i < slots.size(); i++)
+                if (!slots[i].busy) { if (slots[i].pinned) (void) hipHostFree(slots[i].p); else std::free(slots[i].p); slots.erase(slots.begin() + (long) i); break; }
+        }
+        if (hipHostMalloc((void**) &s.p, s.cap, hipHostMallocPortable) == hipSuccess) s.pinned = true;
+        else { (void) hipGetLastError(); s.p = (char*) std::malloc(s.cap); }
+        if (!s.p) return nullptr;
+        s.busy = true;
+        std::lock_guard<std::mutex> g(m);
+        slots.push_back(s);
+        return s.p;
+    }
+    void release(char* p) {
+        if (!p) return;
+        std::lock_guard<std::mutex> g(m);
+        for (auto& s : slots) if (s.p == p) s.busy = false;
+    }
+};
+PinCache& pin_cache() { static PinCache* c = new PinCache(); return *c; }   // (never destroyed: the process leaves without unwinding HIP)
+
+// Validity masks of hmm_utils.c:2229-2254 by table: bits 0, 1 from (coverage, high-mapq coverage), bit 2 from (coverage, clipped coverage), every
+// value below 256 — the reference's own divisions and comparisons, evaluated once per (thresholds) instead of twice per window.
+struct ValidityLut {
+    double max_mapq = -1.0, min_mapq = -1.0, min_clip = -1.0;
+    std::vector<uint8_t> m, c;      // [cv << 8 | mq] -> bits 0, 1;  [cv << 8 | cp] -> bit 2
+};
+std::shared_ptr<const ValidityLut> validity_lut(double max_mapq, double min_mapq, double min_clip) {
+    static std::mutex mu;
+    static std::shared_ptr<const ValidityLut> cached;
+    std::lock_guard<std::mutex> g(mu);
+    if (cached && cached->max_mapq == max_mapq && cached->min_mapq == min_mapq && cached->min_clip == min_clip) return cached;
+    auto L = std::make_shared<ValidityLut>();
+    L->max_mapq = max_mapq; L->min_mapq = min_mapq; L->min_clip = min_clip;
+    L->m.resize(65536); L->c.resize(65536);
+    for (unsigned cv = 0; cv < 256; cv++)
+        for (unsigned v = 0; v < 256; v++) {
+            const double ratio = (double) v / (0.1 + cv);                 // window_record's own expressions
+            L->m[(cv << 8) | v] = (uint8_t) ((!(ratio > max_mapq) ? 1u : 0u) | (!(ratio < min_mapq) ? 2u : 0u));
+            L->c[(cv << 8) | v] = (uint8_t) (!(ratio < min_clip) ? 4u : 0u);
+        }
+    cached = L;
+    return cached;
+}
 }
 template <class Fn>
 static void par_chunks(const int64_t* chunk_off, size_t C, Fn fn) {
@@ -214,7 +279,6 @@ struct hf_ctx {
     int32_t* d_arow = nullptr; int32_t* d_arow_src = nullptr; int32_t* d_arow_cls = nullptr; double* d_lutA = nullptr;
     int n_arows = 0, n_combo = 0;
     double* d_scale_s = nullptr; int64_t n_slots = 0;
-    std::thread unpin;                          // frees hf_create's pinned staging buffers
     std::vector<SegDesc> h_segs;                // the segment descriptors (the getters derive a window's slot from them)
     bool pass_seg = false;             // the last pass ran the segment kernels (log-likelihood partials per segment)
     unsigned long long* d_seg_trace = nullptr;   // -DHF_SEG_TRACE builds only
@@ -303,6 +367,16 @@ __global__ void k_regmask(const int64_t* __restrict__ off, const uint32_t* __res
         for (int w = 0; w < (int) (blockDim.x >> 6); w++) a |= sm[w];
         regmask[c] = a;
     }
+}
+
+// position of the record that holds every window's forward vector (the getters): the record of the NEXT window of its chunk, the chunk's
+// spare record for the last one
+__global__ void k_pos_f(const int64_t* __restrict__ off, const int32_t* __restrict__ pos, const int32_t* __restrict__ spare, int32_t* __restrict__ pos_f) {
+    const int c = blockIdx.y;
+    const int64_t t0 = off[c], T = off[c + 1] - t0;
+    const int64_t col = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= T) return;
+    pos_f[t0 + col] = col + 1 < T ? pos[t0 + col + 1] : spare[c];
 }
 
 #include "hf_scan.h"
@@ -518,6 +592,12 @@ int hf_warmup(int device) {
         if (d) hipFree(d);
         (void) hipGetLastError();
     }
+    {   // hf_create's pinned staging buffers (PinCache), for up to 2 M windows: pinning 32 MB takes ~6 ms — here, while the caller reads its input
+        PinCache& pc = pin_cache();
+        char* a = pc.acquire((size_t) 4 * (2u << 20));
+        char* b = pc.acquire((size_t) 12 * (2u << 20));
+        pc.release(a); pc.release(b);
+    }
     return HF_OK;
 }
 
@@ -561,7 +641,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     }
     const size_t N = (size_t) ctx->N, C = (size_t) ctx->C;
     uint16_t *d_cov = nullptr, *d_mapq = nullptr, *d_clip = nullptr; uint64_t* d_annot = nullptr;
-    int32_t *d_cs = nullptr, *d_ce = nullptr, *d_cl = nullptr;
+    int32_t *d_cs = nullptr, *d_ce = nullptr, *d_cl = nullptr, *d_spare = nullptr;
     int rc = 0;
 #define TRY(x) do { rc = (x); if (rc) { hf_destroy(ctx); return rc; } } while (0)
     TRY(dev_upload(&ctx->d_off, w->chunk_off, C + 1));
@@ -571,38 +651,44 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     // Pinned buffers of 4 bytes per window for everything this function moves between host and device (pageable copies were
     // measured at ~1 GB/s): P0 packed windows up, then the f-positions up; P1 the rows of A up; P2 the record positions up.  Pinning
     // costs ~0.2 ms per MB: P0 here, P1 and P2 on a helper thread while the first pass over the windows runs.
-    struct Pinned {
-        char* p = nullptr; bool pinned = false;
-        void get(size_t bytes) {
-            if (hipHostMalloc((void**) &p, bytes) == hipSuccess) pinned = true;
-            else { (void) hipGetLastError(); p = (char*) std::malloc(bytes); }
-        }
-        void release() { if (p) { if (pinned) hipHostFree(p); else std::free(p); } p = nullptr; }
-        ~Pinned() { release(); }
-    };
-    struct Arena { Pinned a, b; std::thread th; ~Arena() { if (th.joinable()) th.join(); } } arena;
+    // Pinned staging buffers of 4 bytes per window for everything this function moves between host and device (pageable copies were
+    // measured at ~1 GB/s): P0 packed windows up; P1 the rows of A up; P2 the record positions up; P3 (never uploaded) the packed records as the host computes them.  They come from the process-wide cache
+    // (PinCache: pinning costs ~0.2 ms per MB, 1.2 ms of this function until round 5); a first-time P1 | P2 is pinned on a helper thread while
+    // the first pass over the windows runs.  Back to the cache when the function leaves (its uploads are complete by then).
+    struct Staging {
+        char *a = nullptr, *b = nullptr; std::thread th;
+        ~Staging() { if (th.joinable()) th.join(); pin_cache().release(a); pin_cache().release(b); }
+    } arena;
     if (N > 0) {
-        arena.a.get(N * 4);
-        if (!arena.a.p) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of host memory"); }
-        arena.th = std::thread([&arena, device, N] { if (hipSetDevice(device) == hipSuccess) arena.b.get(2 * N * 4); });
+        arena.a = pin_cache().acquire(N * 4);
+        if (!arena.a) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of host memory"); }
+        arena.b = pin_cache().try_acquire(3 * N * 4);
+        if (!arena.b) arena.th = std::thread([&arena, device, N] { if (hipSetDevice(device) == hipSuccess) arena.b = pin_cache().acquire(3 * N * 4); });
     }
     cphase("pinned staging buffer");
-    uint32_t* const P0 = reinterpret_cast<uint32_t*>(arena.a.p);
+    uint32_t* const P0 = reinterpret_cast<uint32_t*>(arena.a);
     int32_t *P1 = nullptr, *P2 = nullptr;                                   // (set when the helper thread is joined)
-    std::unique_ptr<uint32_t[]> hrec_buf(N ? new uint32_t[N] : nullptr);     // the packed records as the host computes them
+    std::unique_ptr<uint32_t[]> hrec_own;                                    // the packed records as the host computes them: in P3, or (first context of a process: P1 | P2 | P3 are still being pinned) on the heap
     uint32_t* d_packed = nullptr;
+    hipEvent_t ev_packed = nullptr;
+    uint32_t* hrec_w0 = nullptr;
     std::vector<std::vector<int64_t>> part_slow(HF_PARTS);
     std::vector<int32_t> nslow(C, 0);
     std::vector<uint8_t> seen256((size_t) n_regions << 16, 0), mark256(((size_t) n_regions << 16) * HF_AROW_CLASSES, 0);
     std::atomic<int> wide{0}, bad_region{0};
     {
         uint32_t* stage = P0;
-        uint32_t* hrec_w = hrec_buf.get();                      // the packed records, computed here as k_setup computes them
+        if (arena.b) hrec_w0 = reinterpret_cast<uint32_t*>(arena.b + 2 * N * 4);
+        else { hrec_own.reset(N ? new uint32_t[N] : nullptr); hrec_w0 = hrec_own.get(); }
+        uint32_t* hrec_w = hrec_w0;                             // the packed records, computed here as k_setup computes them
         std::atomic<unsigned> maxx_all{0};
         if (N > 0) {
             // ONE pass over the windows: the packed upload word, the packed record, the largest coverage, the contig-end ("slow")
             // windows, and which (region, x, x_prev) emission keys and (key, transition class) rows of A occur (tables at a stride
             // of 256 per coverage value: the largest coverage is only known afterwards)
+            const std::shared_ptr<const ValidityLut> vlut = validity_lut(w->max_high_mapq_ratio, w->min_high_mapq_ratio, w->min_highly_clipped_ratio);
+            const uint8_t* const lut_m = vlut->m.data();
+            const uint8_t* const lut_c = vlut->c.data();
             par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
                 bool big = false, badr = false;
                 unsigned mx = 0;
@@ -613,18 +699,42 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     const size_t before = mine.size();
                     const size_t t0 = (size_t) w->chunk_off[c], te = (size_t) w->chunk_off[c + 1];
                     const int cs_ = w->chunk_s[c], ce_ = w->chunk_e[c], cl_ = w->chunk_ctg_len[c];
+                    // INTERIOR columns [ia, ib): beta_t is beta_star by construction (hmm.c:301-316: l = mid - L + 1 and u = mid, so u - l = L - 1)
+                    // — mid is non-decreasing in the column, so the two conditions cut a prefix and a suffix of the chunk.  Those windows take
+                    // their record from the validity tables (no division, no beta arithmetic); the others — and any window with a value above
+                    // 255 — go through window_record, the function k_setup runs.  The result is the same bits either way (HF_CREATE_VERIFY).
+                    int64_t ia = 1, ib = (int64_t) (te - t0);
+                    if (w->adjust_contig_ends) {
+                        const int Lr = w->mean_read_len;
+                        const int l2 = (int) (-(1 - w->min_read_frac) * Lr), u2 = (int) (cl_ - w->min_read_frac * Lr);
+                        auto mid_of = [&](int64_t col) {
+                            const int icol = (int) col;
+                            const int a1 = (int) (cs_ + (double) w->window_len * (icol + 0.5));
+                            const int a2 = (int) ((cs_ + (double) w->window_len * icol + ce_) / 2);
+                            return a1 < a2 ? a1 : a2;
+                        };
+                        while (ia < ib && !(mid_of(ia) - Lr + 1 >= l2)) ia++;
+                        while (ib > ia && !(mid_of(ib - 1) <= u2)) ib--;
+                    }
                     unsigned pre_region = 0, xp = 0;
                     for (size_t t = t0; t < te; t++) {
                         const unsigned cv = w->cov[t], mq = w->mapq[t], cp = w->clip[t];
                         const unsigned region = (unsigned) (w->annot[t] >> 58);
                         const unsigned x = cv & 0xffu;
-                        big |= (cv | mq | cp) > 0xffu;
+                        const bool wide_v = (cv | mq | cp) > 0xffu;
+                        big |= wide_v;
                         if (x > mx) mx = x;
                         stage[t] = cv | (mq << 8) | (cp << 16) | (region << 24);
-                        double bt;
-                        const uint32_t r = window_record(cv, mq, cp, region, pre_region, (int64_t) (t - t0), cs_, ce_, cl_, w->window_len,
-                                                         w->mean_read_len, w->adjust_contig_ends, w->min_read_frac, w->max_high_mapq_ratio,
-                                                         w->min_high_mapq_ratio, w->min_highly_clipped_ratio, ctx->beta_star, &bt);
+                        const int64_t col = (int64_t) (t - t0);
+                        uint32_t r;
+                        if (col >= ia && col < ib && !wide_v) {
+                            r = cv | (region << 8) | ((uint32_t) (lut_m[(cv << 8) | mq] | lut_c[(cv << 8) | cp]) << 16) | (pre_region != region ? 1u << 20 : 0u);
+                        } else {
+                            double bt;
+                            r = window_record(cv, mq, cp, region, pre_region, col, cs_, ce_, cl_, w->window_len,
+                                              w->mean_read_len, w->adjust_contig_ends, w->min_read_frac, w->max_high_mapq_ratio,
+                                              w->min_high_mapq_ratio, w->min_highly_clipped_ratio, ctx->beta_star, &bt);
+                        }
                         hrec_w[t] = r;
                         if (region >= (unsigned) n_regions) badr = true;
                         else if (REC_SLOW(r)) mine.push_back((int64_t) t);
@@ -649,7 +759,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             if (w->chunk_off[0] != 0 || (size_t) w->chunk_off[C] != N) wide.store(1);   // (a window outside every chunk: take the plain path)
             if (!wide.load()) {
                 hipError_t e1 = hipMalloc((void**) &d_packed, N * 4);
-                if (e1 == hipSuccess) e1 = hipMemcpy(d_packed, stage, N * 4, hipMemcpyHostToDevice);
+                if (e1 == hipSuccess) e1 = hipMemcpyAsync(d_packed, stage, N * 4, hipMemcpyHostToDevice, nullptr);   // (k_setup follows on the same stream; P0 is written again only by the third pass, behind ev_packed)
+                if (e1 == hipSuccess && hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming) == hipSuccess) (void) hipEventRecord(ev_packed, nullptr);
                 if (e1 != hipSuccess) { (void) hipGetLastError(); if (d_packed) hipFree(d_packed); d_packed = nullptr; }
             }
         }
@@ -707,20 +818,15 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         hipLaunchKernelGGL(k_regmask, dim3((unsigned) C), dim3(256), 0, 0, ctx->d_off, ctx->d_rec, ctx->d_regmask);
     }
     cphase("events, memsets, k_setup enqueued");
-    hipError_t e = hipDeviceSynchronize();
-    hipFree(d_packed); hipFree(d_cov); hipFree(d_mapq); hipFree(d_clip); hipFree(d_annot); hipFree(d_cs); hipFree(d_ce); hipFree(d_cl);
-    if (e != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("setup: ") + hipGetErrorString(e)); }
-    cphase("k_setup done, temporaries freed");
-    unsigned fl = 0;
-    hipMemcpy(&fl, ctx->d_flags, 4, hipMemcpyDeviceToHost);
-    if (fl & HF_FLAG_REGION) { hf_destroy(ctx); return set_err(HF_E_REGION, "a window's region index is >= n_regions"); }
+    // (round 5: no wait for k_setup here — the host computed every record itself, and a region index out of range has been refused already;
+    // the upload temporaries are freed, and the device's own flag word is read, behind the ONE synchronisation at the end of this function)
     {
         if (N == 0) ctx->M = 1;
         const size_t MM = (size_t) ctx->M * ctx->M;
         // slow windows (chunk-first, or beta differs from beta_star) and the transition classes: bits of the packed records, which the
         // packing loop above computed with k_setup's own function -- nothing comes back from the device (a first 6 MB device-to-host
         // copy into a fresh pinned block was measured at 7.8 ms, the second at 0.13 ms)
-        const uint32_t* const hrec = hrec_buf.get();
+        const uint32_t* const hrec = hrec_w0;
         if (N && std::getenv("HF_CREATE_VERIFY")) {
             std::vector<uint32_t> dev(N);
             bool same = hipMemcpy(dev.data(), ctx->d_rec, N * 4, hipMemcpyDeviceToHost) == hipSuccess;
@@ -784,8 +890,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         // ---- segments of the workgroup-per-segment forward-backward (hf_seg.h) and the record slot of every window ----
         std::vector<std::vector<int32_t>> pcnt(HF_PARTS);   // pairs per row of A, per part of the chunk list
         if (arena.th.joinable()) arena.th.join();
-        if (N > 0 && !arena.b.p) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of host memory"); }
-        P1 = reinterpret_cast<int32_t*>(arena.b.p); P2 = reinterpret_cast<int32_t*>(arena.b.p + N * 4);
+        if (N > 0 && !arena.b) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of host memory"); }
+        P1 = reinterpret_cast<int32_t*>(arena.b); P2 = reinterpret_cast<int32_t*>(arena.b + N * 4);
         int32_t* const h_arow = P1;                     // window -> row of A (also on the device)
         std::vector<int32_t> h_arow_src;                // row of A -> emission row (also on the device)
         std::vector<int32_t> cseg0;                     // first segment of every chunk
@@ -802,7 +908,11 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 auto cls_of = [](uint32_t r) { return REC_REGCHG(r) ? 8 : (int) REC_VMASK(r); };
                 std::vector<int32_t> combo_id((size_t) ctx->n_lut * NC, 0);
                 int32_t* cid = combo_id.data();
+                // (region and coverage from the packed upload words of the first pass when there are any — 4 bytes per window instead of the
+                // 10 of annot + cov: these passes run at the speed of the host's memory)
+                const uint32_t* const pk = d_packed ? P0 : nullptr;
                 auto key_of = [&](size_t t) {
+                    if (pk) return ((size_t) (pk[t] >> 24) * ctx->M + (pk[t] & 0xffu)) * ctx->M + (pk[t - 1] & 0xffu);
                     const size_t reg = (size_t) ((w->annot[t] & 0xFC00000000000000ULL) >> 58);
                     return (reg * ctx->M + (w->cov[t] & 0xffu)) * ctx->M + (w->cov[t - 1] & 0xffu);
                 };
@@ -826,6 +936,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 a_src.resize((size_t) n_combo + slow.size()); a_cls.resize((size_t) n_combo + slow.size());
                 const size_t n_ar_all = a_src.size();
                 int32_t* const arow = h_arow;
+                cphase("(key, class) list");
                 // second pass: every window's row of A, and the pairs per row of A (x >= 2: hmm.c:638-642) as one histogram per part
                 // of the chunk list (popular rows: no contended atomics)
                 par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
@@ -849,12 +960,14 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         }
                     }
                 });
+                cphase("rows of A (second pass)");
                 ctx->n_combo = n_combo; ctx->n_arows = (int) a_src.size();
                 if (a_src.size() >= ((size_t) 1 << 25)) {   // the segment kernels address a row by a 32-bit BYTE offset (index << 7)
                     hf_destroy(ctx);
                     return set_err(HF_E_ARG, "hf_create: more than 2^25 distinct rows of A (contig-end windows included): shard the chunk list (hmm_flagger_multi.h)");
                 }
-                TRY(dev_upload(&ctx->d_arow, arow, N));
+                DMALLOC(ctx->d_arow, N * 4);
+                if (hipMemcpyAsync(ctx->d_arow, arow, N * 4, hipMemcpyHostToDevice, nullptr) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: rows of A up"); }   // (P1: pinned, not written again)
                 TRY(dev_upload(&ctx->d_arow_src, a_src.data(), a_src.size()));
                 TRY(dev_upload(&ctx->d_arow_cls, a_cls.data(), a_cls.size()));
                 DMALLOC(ctx->d_lutA, (a_src.size() + 1) * 16 * 8);
@@ -950,8 +1063,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             if (force) { const char* b = std::strstr(force, "bpw="); if (b) { const int v = std::atoi(b + 4); if (v >= 1 && v <= 64) bpw = v; } }
             ctx->rs_bpw = bpw;
             cphase("plan: pairs");
-            int32_t* const pos = P2;                      // record position of every window (b half) ...
-            int32_t* const pos_f = reinterpret_cast<int32_t*>(P0);   // ... and of the record with its f (the packed records are no longer needed)
+            int32_t* const pos = P2;                      // record position of every window (b half); the position of the record with its f: k_pos_f
             if (w->chunk_off[0] != 0 || (size_t) w->chunk_off[C] != N) std::memset(pos, 0, N * 4);   // windows outside every chunk
             int64_t n_pos = 0;
             bool planned = false;
@@ -972,49 +1084,73 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     else reg = (int32_t) ((w->annot[(size_t) slow[(size_t) (er - ctx->n_lut)]] & 0xFC00000000000000ULL) >> 58);
                     occ.push_back({reg, (int32_t) r});
                 }
-                std::stable_sort(occ.begin(), occ.end(), [](const Occ& a, const Occ& b) { return a.region < b.region; });
+                cphase("plan: occ list");
+                if (n_regions > 1) std::stable_sort(occ.begin(), occ.end(), [](const Occ& a, const Occ& b) { return a.region < b.region; });
+                cphase("plan: occ sort");
                 g_pos0.assign(n_ar, 0);
                 int64_t next_pos = 0;
                 const size_t unit = (size_t) 16 * (size_t) bpw;     // row slots per wavefront of k_row_stats
-                grp_ar.reserve((size_t) n_groups_all); grp_n.reserve((size_t) n_groups_all);
-                size_t oi = 0;
-                for (int reg = 0; reg < n_regions; reg++) {
-                    rwoff[(size_t) reg] = (int32_t) (rslots.size() / unit);
-                    int64_t open_row = -1;                         // emission row of the row slot being filled
-                    for (; oi < occ.size() && occ[oi].region == reg; oi++) {
-                        const size_t r = (size_t) occ[oi].ar;
-                        const int64_t er = h_arow_src[r];
-                        g_pos0[r] = (int32_t) (compact ? next_pos : (int64_t) grp_ar.size() * HF_GRP_PAIRS);
-                        int32_t xpx;
-                        if (er < ctx->n_lut) xpx = (int32_t) (((size_t) er / (size_t) ctx->M) % (size_t) ctx->M) | ((int32_t) ((size_t) er % (size_t) ctx->M) << 8);
-                        else { const size_t t = (size_t) slow[(size_t) (er - ctx->n_lut)]; xpx = (int32_t) (w->cov[t] & 0xffu) | ((int32_t) (w->cov[t - 1] & 0xffu) << 8); }
-                        for (int64_t b = 0; b < cnt[r]; b += HF_GRP_PAIRS) {
-                            const int32_t g = (int32_t) grp_ar.size();
-                            grp_ar.push_back((int32_t) r);
-                            grp_n.push_back((int32_t) (cnt[r] - b < HF_GRP_PAIRS ? cnt[r] - b : HF_GRP_PAIRS));
-                            grp_off.push_back((int32_t) next_pos);
-                            next_pos += grp_n.back();
-                            // a row slot = up to 4 consecutive groups of one EMISSION row (its transition classes are adjacent)
-                            if (open_row == er && rslots.back().ng < HF_ROWSLOT_GROUPS) rslots.back().ng++;
-                            else { RowSlot sl; sl.row = (int32_t) er; sl.g0 = g; sl.ng = 1; sl.xpx = xpx; rslots.push_back(sl); open_row = er; }
+                // Groups and row slots by INDEX (round 5; a push_back per group cost 0.5 ms of this function): first the rows' bases — groups,
+                // positions, and the row slots of every run of rows of one EMISSION row (its transition classes are adjacent: a slot takes up to
+                // HF_ROWSLOT_GROUPS consecutive groups of the run) — then the arrays are sized once and filled by plain stores.
+                struct RowBase { int32_t g0, slot0, go; int64_t p0; };   // first group, first slot of the row's run, groups of the run before this row, first position
+                std::vector<RowBase> rb(occ.size());
+                size_t n_grp = 0, n_slot = 0;
+                {
+                    size_t oi = 0;
+                    for (int reg = 0; reg < n_regions; reg++) {
+                        rwoff[(size_t) reg] = (int32_t) (n_slot / unit);
+                        int64_t open_row = -1; size_t run_slot0 = n_slot; int32_t run_groups = 0;
+                        for (; oi < occ.size() && occ[oi].region == reg; oi++) {
+                            const size_t r = (size_t) occ[oi].ar;
+                            const int64_t er = h_arow_src[r];
+                            const int32_t ng = (int32_t) ((cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS);
+                            if (er != open_row) { n_slot = run_slot0 + (size_t) ((run_groups + HF_ROWSLOT_GROUPS - 1) / HF_ROWSLOT_GROUPS); run_slot0 = n_slot; run_groups = 0; open_row = er; }
+                            rb[oi].g0 = (int32_t) n_grp; rb[oi].slot0 = (int32_t) run_slot0; rb[oi].go = run_groups; rb[oi].p0 = next_pos;
+                            n_grp += (size_t) ng; run_groups += ng; next_pos += cnt[r];
                         }
+                        n_slot = run_slot0 + (size_t) ((run_groups + HF_ROWSLOT_GROUPS - 1) / HF_ROWSLOT_GROUPS);
+                        n_slot = (n_slot + HF_RS_WPB * unit - 1) / (HF_RS_WPB * unit) * (HF_RS_WPB * unit);   // whole blocks of k_row_stats per region
+                        for (size_t k = (size_t) rwoff[(size_t) reg]; k < n_slot / unit; k++) rwreg.push_back(reg);
                     }
-                    while (rslots.size() % (HF_RS_WPB * unit)) rslots.push_back({-1, 0, 0, 0});   // whole blocks of k_row_stats per region
-                    for (size_t k = (size_t) rwoff[(size_t) reg]; k < rslots.size() / unit; k++) rwreg.push_back(reg);
+                }
+                grp_ar.assign((n_grp + 3) / 4 * 4, 0); grp_n.assign((n_grp + 3) / 4 * 4, 0);   // (k_pair_sums: four groups per wavefront)
+                grp_off.assign(n_grp + 1, 0);
+                rslots.assign(n_slot, RowSlot{-1, 0, 0, 0});
+                for (size_t oi = 0; oi < occ.size(); oi++) {
+                    const size_t r = (size_t) occ[oi].ar;
+                    const int64_t er = h_arow_src[r];
+                    const RowBase B = rb[oi];
+                    g_pos0[r] = (int32_t) (compact ? B.p0 : (int64_t) B.g0 * HF_GRP_PAIRS);
+                    int32_t xpx;
+                    if (er < ctx->n_lut) xpx = (int32_t) (((size_t) er / (size_t) ctx->M) % (size_t) ctx->M) | ((int32_t) ((size_t) er % (size_t) ctx->M) << 8);
+                    else { const size_t t = (size_t) slow[(size_t) (er - ctx->n_lut)]; xpx = (int32_t) (w->cov[t] & 0xffu) | ((int32_t) (w->cov[t - 1] & 0xffu) << 8); }
+                    int64_t p = B.p0;
+                    for (int32_t j = 0, left = cnt[r]; left > 0; j++, left -= HF_GRP_PAIRS) {
+                        const size_t g = (size_t) (B.g0 + j);
+                        const int32_t here = left < HF_GRP_PAIRS ? left : HF_GRP_PAIRS;
+                        grp_ar[g] = (int32_t) r; grp_n[g] = here; grp_off[g] = (int32_t) p;
+                        p += here;
+                        RowSlot& sl = rslots[(size_t) B.slot0 + (size_t) ((B.go + j) / HF_ROWSLOT_GROUPS)];
+                        if ((B.go + j) % HF_ROWSLOT_GROUPS == 0) { sl.row = (int32_t) er; sl.g0 = (int32_t) g; sl.ng = 1; sl.xpx = xpx; }
+                        else sl.ng++;
+                    }
                 }
                 rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / unit);
                 ctx->n_parts = 1;
                 for (int reg = 0; reg < n_regions; reg++) if (rwoff[(size_t) reg + 1] > rwoff[(size_t) reg]) ctx->n_parts++;
-                ctx->n_groups = (int) grp_ar.size();
-                while (grp_ar.size() % 4) { grp_ar.push_back(0); grp_n.push_back(0); }   // k_pair_sums: four groups per wavefront
-                grp_off.push_back((int32_t) next_pos);
+                ctx->n_groups = (int) n_grp;
+                grp_off[n_grp] = (int32_t) next_pos;
                 n_pos = compact ? next_pos : (int64_t) grp_ar.size() * HF_GRP_PAIRS;
                 ctx->plan_compact = compact;
                 planned = true;
+                cphase("plan: group loop");
             } else n_pos = ctx->n_slots;    // no plan (sparse rows): the per-chunk statistics read the records by window; positions in slot order
             // third pass: the position of every window's record.  Pairs of a row of A in window order; the windows without a pair
             // of their own (x = 0, 1) and the f of every chunk's last window after the groups, chunk by chunk
+            cphase("plan: groups, row slots");
             std::vector<int64_t> extra0(C + 1, n_pos);
+            std::vector<int32_t> h_spare(C, 0);
             for (size_t c = 0; c < C; c++) {
                 const int64_t T = w->chunk_off[c + 1] - w->chunk_off[c];
                 extra0[c + 1] = extra0[c] + (T <= 0 ? 0 : (planned ? (T < 2 ? T : 2) : 0) + 1);
@@ -1038,13 +1174,12 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         }
                     }
                     const int32_t spare = (int32_t) (extra0[c + 1] - 1);   // takes the f of the chunk's last window
-                    for (int64_t x = 0; x + 1 < T; x++) pos_f[(size_t) (t0 + x)] = pos[(size_t) (t0 + x + 1)];
-                    pos_f[(size_t) (t0 + T - 1)] = spare;
+                    h_spare[c] = spare;
                     for (int k = cseg0[c]; k < cseg0[c + 1]; k++) ctx->h_segs[(size_t) k].spare_pos = spare;
                 }
             });
             n_pos = extra0[C];
-            cphase("plan: groups, row slots, positions");
+            cphase("plan: positions (third pass)");
             if (planned) {
                 // negative_binomial count data: the row slots of every (region, min(x, 249)) bin, in plan order
                 {
@@ -1081,8 +1216,14 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             }
             TRY(dev_upload(&ctx->d_seg, ctx->h_segs.data(), ctx->h_segs.size()));
             ctx->n_pos = n_pos;
-            TRY(dev_upload(&ctx->d_pos, pos, N));
-            TRY(dev_upload(&ctx->d_pos_f, pos_f, N));
+            DMALLOC(ctx->d_pos, N * 4); DMALLOC(ctx->d_pos_f, N * 4);
+            if (hipMemcpyAsync(ctx->d_pos, pos, N * 4, hipMemcpyHostToDevice, nullptr) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: record positions up"); }
+            {   // pos_f[t] = the position of window t + 1's record (which holds f_t), the chunk's spare record for its last window: on the device
+                // (round 5: 6 MB less to write on the host and to upload)
+                TRY(dev_upload(&d_spare, h_spare.data(), C));
+                if (w->chunk_off[0] != 0 || (size_t) w->chunk_off[C] != N) hipMemsetAsync(ctx->d_pos_f, 0, N * 4, nullptr);
+                hipLaunchKernelGGL(k_pos_f, dim3((unsigned) ((maxT + 255) / 256), (unsigned) C), dim3(256), 0, 0, ctx->d_off, ctx->d_pos, d_spare, ctx->d_pos_f);
+            }
             hipFree(ctx->d_recs); ctx->d_recs = nullptr;
             if (n_pos + (int64_t) ctx->nseg >= INT32_MAX) { hf_destroy(ctx); return set_err(HF_E_ARG, "hf_create: more than 2^31 record positions (shard the chunk list: hmm_flagger_multi.h)"); }
             DMALLOC(ctx->d_recs, ((size_t) n_pos + (size_t) ctx->nseg) * 64);   // + one spare record per segment (hf_seg.h: where lanes without a window write)
@@ -1170,25 +1311,23 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         hipMemcpyToSymbol(HIP_SYMBOL(g_seg_trace), &ctx->d_seg_trace, sizeof(void*));
     }
 #endif
-    hrec_buf.reset();
-    {   // un-pinning 18 MB takes ~3 ms: on a thread of the context (joined by hf_destroy) while the caller goes on
-        char *pa = arena.a.pinned ? arena.a.p : nullptr, *pb = arena.b.pinned ? arena.b.p : nullptr;
-        if (pa) arena.a.p = nullptr;
-        if (pb) arena.b.p = nullptr;
-        if (pa || pb) ctx->unpin = std::thread([pa, pb, device] {
-            (void) hipSetDevice(device);
-            if (pa) (void) hipHostFree(pa);
-            if (pb) (void) hipHostFree(pb);
-        });
+    cphase("switches, job list");
+    {   // the ONE synchronisation of this function: uploads and set-up kernels done, the staging buffers may go back to the cache
+        const hipError_t e = hipDeviceSynchronize();
+        if (ev_packed) hipEventDestroy(ev_packed);
+        hipFree(d_packed); hipFree(d_cov); hipFree(d_mapq); hipFree(d_clip); hipFree(d_annot); hipFree(d_cs); hipFree(d_ce); hipFree(d_cl); hipFree(d_spare);
+        if (e != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("setup: ") + hipGetErrorString(e)); }
+        unsigned fl = 0;
+        if (N > 0 && C > 0) hipMemcpy(&fl, ctx->d_flags, 4, hipMemcpyDeviceToHost);
+        if (fl & HF_FLAG_REGION) { hf_destroy(ctx); return set_err(HF_E_REGION, "a window's region index is >= n_regions"); }
     }
-    cphase("pinned buffers handed to the un-pinning thread");
+    cphase("uploads and set-up kernels done");
     *out = ctx;
     return HF_OK;
 }
 
 void hf_destroy(hf_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->unpin.joinable()) ctx->unpin.join();
     hipSetDevice(ctx->device);
 #ifdef HF_SEG_TRACE
     if (ctx->d_seg_trace) {
