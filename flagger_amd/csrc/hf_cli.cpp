@@ -137,42 +137,48 @@ static const char* run_error() { return g_run ? g_run->error() : hf_last_error()
 
 // writeBenchmarkingStats, hmm_flagger.c:134-162.  The tables are OUTPUT: the labels of the pass come down (pinned buffer), and the
 // tables are computed and written by a worker thread while the EM goes on (the "initial" tables used to sit inside
-// the EM phase, ~10 ms of a 21 ms run).  One job at a time; summary_join() before anything that needs the files or the table.
+// the EM phase).  Round 5: every table set has a worker of its own — the "final" tables no longer queue behind the
+// "initial" ones, and the final BED is written beside them; summary_join() before the process reports that it is done.
 struct SummaryJob {
     std::thread th;
     std::vector<int8_t> labels;
     int rc = 0;
     std::string err, path;
 };
-static SummaryJob g_summary;
-static void summary_wait_quietly() { if (g_summary.th.joinable()) g_summary.th.join(); }
+static std::vector<std::unique_ptr<SummaryJob>> g_summaries;
+static void summary_wait_quietly() { for (auto& j : g_summaries) if (j->th.joinable()) j->th.join(); }
 static void summary_join() {
-    if (g_summary.th.joinable()) g_summary.th.join();
-    if (g_summary.rc != 0) { fprintf(stderr, "[%s] %s\n", ts(), g_summary.err.c_str()); exit(EXIT_FAILURE); }
+    summary_wait_quietly();
+    for (auto& j : g_summaries)
+        if (j->rc != 0) { fprintf(stderr, "[%s] %s\n", ts(), j->err.c_str()); exit(EXIT_FAILURE); }
 }
+// `labels`: the labels of the pass when the caller has them already (N bytes), nullptr: they are fetched here
 static int write_summary(Run& run, const std::string& dir, const std::string& suffix, const std::vector<std::string>& labelNames,
-                         const char* binArrayFilePath, double overlapRatioThreshold, int threads, bool wait) {
-    summary_join();
+                         const char* binArrayFilePath, double overlapRatioThreshold, int threads, const int8_t* labels) {
     const double t_begin = real_time();
     const int64_t N = hfio_n_windows(run.tab);
-    g_summary.labels.resize((size_t) N);
-    int rc = run.labels(g_summary.labels.data());
-    if (rc != HF_OK) return rc;
-    g_summary.path = dir + "/prediction_summary_" + suffix + ".tsv";
+    g_summaries.emplace_back(new SummaryJob());
+    SummaryJob* job = g_summaries.back().get();
+    job->labels.resize((size_t) N);
+    if (labels) memcpy(job->labels.data(), labels, (size_t) N);
+    else {
+        const int rc = run.labels(job->labels.data());
+        if (rc != HF_OK) return rc;
+    }
+    job->path = dir + "/prediction_summary_" + suffix + ".tsv";
     const bool timing = getenv("HF_CLI_TIMING") != nullptr;
-    g_summary.th = std::thread([&run, labelNames, binArrayFilePath, overlapRatioThreshold, threads, suffix, timing, t_begin] {
+    job->th = std::thread([&run, job, labelNames, binArrayFilePath, overlapRatioThreshold, threads, suffix, timing, t_begin] {
         std::vector<const char*> names;
         for (const auto& s : labelNames) names.push_back(s.c_str());
-        if (hfio_write_summary(run.tab, g_summary.labels.data(), g_summary.path.c_str(), binArrayFilePath, names.empty() ? nullptr : names.data(),
+        if (hfio_write_summary(run.tab, job->labels.data(), job->path.c_str(), binArrayFilePath, names.empty() ? nullptr : names.data(),
                                (int) names.size(), overlapRatioThreshold, threads) != 0) {
-            g_summary.rc = -1; g_summary.err = hfio_last_error();
+            job->rc = -1; job->err = hfio_last_error();
             return;
         }
-        fprintf(stderr, "[%s] Writing tables to file %s is done.\n", ts(), g_summary.path.c_str());
-        if (timing) fprintf(stderr, "[phase]   (summary tables %s: %.1f ms, beside the EM)\n", suffix.c_str(), (real_time() - t_begin) * 1e3);
+        fprintf(stderr, "[%s] Writing tables to file %s is done.\n", ts(), job->path.c_str());
+        if (timing) fprintf(stderr, "[phase]   (summary tables %s: %.1f ms on their own thread)\n", suffix.c_str(), (real_time() - t_begin) * 1e3);
     });
     if (timing) fprintf(stderr, "[phase]   (summary tables %s: labels down + worker started in %.2f ms)\n", suffix.c_str(), (real_time() - t_begin) * 1e3);
-    if (wait) summary_join();
     return HF_OK;
 }
 
@@ -441,7 +447,7 @@ int main(int argc, char* argv[]) {
             char suffix[64];
             if (iter == 1) snprintf(suffix, sizeof suffix, "initial");
             else snprintf(suffix, sizeof suffix, acceleration ? "iteration_accelerated_%d" : "iteration_%d", iter - 1);
-            if ((rc = write_summary(run, dir, suffix, labelNames, binArrayFilePath, overlapRatioThreshold, threads, false)) != HF_OK) return die_estep(rc);
+            if ((rc = write_summary(run, dir, suffix, labelNames, binArrayFilePath, overlapRatioThreshold, threads, nullptr)) != HF_OK) return die_estep(rc);
         }
         if (acceleration) {                                  // hmm_flagger.c:382-416
             fprintf(stderr, "[%s] [Iteration accelerated = %d] Running SQUAREM acceleration.\n", ts(), iter);
@@ -480,9 +486,9 @@ int main(int argc, char* argv[]) {
     fprintf(llf, "%d\t%d\t%.4f\n", iter - 1, acceleration ? 3 * (iter - 1) : iter - 1, run.stats[0]);
     fclose(llf);
     write_params(model, dir, "final");
-    if ((rc = write_summary(run, dir, "final", labelNames, binArrayFilePath, overlapRatioThreshold, threads, true)) != HF_OK) return die_estep(rc);
     std::vector<int8_t> labels((size_t) N);
     if ((rc = run.labels(labels.data())) != HF_OK) return die_estep(rc);
+    if ((rc = write_summary(run, dir, "final", labelNames, binArrayFilePath, overlapRatioThreshold, threads, labels.data())) != HF_OK) return die_estep(rc);
     memcpy(hfio_prediction(tab), labels.data(), (size_t) N);
     if (writePosterior) {
         std::vector<double> post((size_t) N * 4);
@@ -506,6 +512,8 @@ int main(int argc, char* argv[]) {
     fprintf(stderr, "[%s] EM+decode: %d passes over %ld windows in %.4f s = %.3e windows/s on GPU %d (E-steps, M-steps; the loop with its "
             "log lines and output files took %.4f s)\n", ts(), passes, (long) N, emTime, (double) N * passes / emTime, device, emWall);
     phase("final BED");
+    summary_join();                                // the table workers (the reference writes the tables before the BED; the files are the same)
+    phase("summary tables joined");
     if (run.multi) hf_multi_destroy(run.multi);   // (joins the ranks' threads and communicators: RCCL wants an orderly end)
     // the one-GPU context, the model and the window table are NOT destroyed: the process ends below without unwinding anything
     // (freeing ~40 device allocations one by one was 5 ms of a 0.15 s run)

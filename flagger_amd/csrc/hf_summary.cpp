@@ -333,18 +333,62 @@ int hfs_write_all_tables(const hfs_input* in, const char* output_path, const cha
     // ---- windows in iterator order (chunk.c:915-950) ----
     Windows w;
     {
+        // contig name -> id in chunk order (chunks of one contig share it), then the runs: the chunk list is cut into parts of about equal
+        // window count, every part builds its runs on its own thread (the merging loop over 1.5 M windows was 6 of the 7 ms this function
+        // took on BASELINE configs[2], with the command line waiting for it: VERDICT r04 #6), and the parts are joined in order — the first run
+        // of a part merges with the last run before it under the same condition as inside a part.
         std::map<std::string, int32_t> ids;
-        const int8_t* tr = in->truth; const int8_t* pr = in->prediction;
+        std::vector<int32_t> chunk_id((size_t) in->n_chunks);
         for (int c = 0; c < in->n_chunks; c++) {
             const std::string name = in->chunk_ctg[c];
             auto it = ids.find(name);
             if (it == ids.end()) it = ids.emplace(name, (int32_t) ids.size()).first;
-            const int64_t t0 = in->chunk_off[c], T = in->chunk_off[c + 1] - t0;
-            const int s = in->chunk_s[c], e = in->chunk_e[c], W = in->window_len;
-            for (int64_t i = 0; i < T; i++) {
-                const int st = s + (int) i * W;
-                const int en0 = s + ((int) i + 1) * W - 1;
-                w.push(st, en0 < e ? en0 : e, it->second, in->annot[t0 + i], tr ? tr[t0 + i] : (int8_t) -1, pr ? pr[t0 + i] : (int8_t) -1);
+            chunk_id[(size_t) c] = it->second;
+        }
+        const int8_t* tr = in->truth; const int8_t* pr = in->prediction;
+        auto build = [&](Windows& dst, int c0, int c1) {
+            for (int c = c0; c < c1; c++) {
+                const int64_t t0 = in->chunk_off[c], T = in->chunk_off[c + 1] - t0;
+                const int s = in->chunk_s[c], e = in->chunk_e[c], W = in->window_len;
+                const int32_t id = chunk_id[(size_t) c];
+                for (int64_t i = 0; i < T; i++) {
+                    const int st = s + (int) i * W;
+                    const int en0 = s + ((int) i + 1) * W - 1;
+                    dst.push(st, en0 < e ? en0 : e, id, in->annot[t0 + i], tr ? tr[t0 + i] : (int8_t) -1, pr ? pr[t0 + i] : (int8_t) -1);
+                }
+            }
+        };
+        const int64_t total = in->n_chunks > 0 ? in->chunk_off[in->n_chunks] - in->chunk_off[0] : 0;
+        int np = std::max(1, std::min(std::min(threads, 8), in->n_chunks));
+        if (total < 200000) np = 1;
+        if (np == 1) build(w, 0, in->n_chunks);
+        else {
+            std::vector<int> cut((size_t) np + 1, 0);
+            int c = 0;
+            for (int k = 1; k < np; k++) {
+                const int64_t target = in->chunk_off[0] + total * k / np;
+                while (c < in->n_chunks && in->chunk_off[c] < target) c++;
+                cut[(size_t) k] = c;
+            }
+            cut[(size_t) np] = in->n_chunks;
+            std::vector<Windows> part((size_t) np);
+            std::vector<std::thread> th;
+            for (int k = 1; k < np; k++) th.emplace_back([&, k] { build(part[(size_t) k], cut[(size_t) k], cut[(size_t) k + 1]); });
+            build(part[0], cut[0], cut[1]);
+            for (auto& t : th) t.join();
+            for (int k = 0; k < np; k++) {
+                const Windows& p = part[(size_t) k];
+                for (int64_t i = 0; i < p.n; i++) {
+                    if (i == 0) { w.push(p.start[0], p.end[0], p.ctg[0], p.annot_v[0], p.truth_v[0], p.pred_v[0]); continue; }   // may merge with the part before
+                    if (i == 1) {   // the rest cannot merge (they did not inside the part): appended in bulk
+                        const size_t a = 1, b = (size_t) p.n;
+                        w.start.insert(w.start.end(), p.start.begin() + a, p.start.begin() + b); w.end.insert(w.end.end(), p.end.begin() + a, p.end.begin() + b);
+                        w.ctg.insert(w.ctg.end(), p.ctg.begin() + a, p.ctg.begin() + b); w.annot_v.insert(w.annot_v.end(), p.annot_v.begin() + a, p.annot_v.begin() + b);
+                        w.truth_v.insert(w.truth_v.end(), p.truth_v.begin() + a, p.truth_v.begin() + b); w.pred_v.insert(w.pred_v.end(), p.pred_v.begin() + a, p.pred_v.begin() + b);
+                        w.n += (int64_t) (b - a);
+                        break;
+                    }
+                }
             }
         }
         w.seal(tr != nullptr, pr != nullptr);
