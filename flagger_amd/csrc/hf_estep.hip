@@ -245,6 +245,9 @@ struct hf_ctx {
     // statistics by emission row (hf_rows.h): the static plan and its work arrays
     int stats_mode = HF_STATS_CHUNKS; bool rows_ready = false, pass_rows = false; int pass_kc = 0, pass_wpb = 4;
     double poll_seq = 0.0;         // completion stamp of the last polled pass (hf_finish)
+    // the total of a one-GPU pass summed by the HOST (hf_rows.h part_host): pinned partials [n_rw_blocks][NA] | [C] | flag word, their device address
+    double* h_part = nullptr; double* d_part_host = nullptr; size_t part_cap = 0; bool host_total_ok = true, pass_host_total = false; int pass_rw_blocks = 0;
+    std::vector<int32_t> h_rw_off;
     double* d_rank_out = nullptr; double* d_rank_flag = nullptr;   // hf_bind_rank_total: where a rows-mode pass writes its total / flag word
     bool pass_bound = false;       // the last pass wrote them there
     bool stream_stamp_ok = true; uint32_t stream_stamp = 0;   // wait_total: completion through hipStreamWriteValue32 (HF_STREAM_STAMP=0: off)
@@ -477,7 +480,7 @@ static void launch_pair_sums(hf_ctx* ctx, hipStream_t st) {
 
 template <int KT>
 static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
-    ctx->pass_rows = false;
+    ctx->pass_rows = false; ctx->pass_host_total = false;
     if (full && rows_pass(ctx)) {
         // statistics by emission row (hf_rows.h); the total of the pass comes out of k_row_stats' last blocks
         {
@@ -499,11 +502,26 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         const bool polled = !bound && poll_ok(ctx, HF_K_ROW_STATS);
         const double seq = polled ? next_stamp(ctx) : 0.0;
         ctx->pass_polled = polled; ctx->pass_bound = bound;
+        // one GPU, nobody polling, nothing bound: the blocks' partial vectors go to pinned host memory and the HOST sums them (host_rows_total)
+        bool host_total = !bound && !polled && ctx->host_total_ok && ctx->d_total_host != nullptr;
+        if (host_total) {
+            const size_t need = (size_t) n_rw_blocks * NA + (size_t) ctx->C + 1;
+            if (need > ctx->part_cap) {
+                if (ctx->h_part) hipHostFree(ctx->h_part);
+                ctx->h_part = nullptr; ctx->d_part_host = nullptr; ctx->part_cap = 0;
+                void* dp = nullptr;
+                if (hipHostMalloc((void**) &ctx->h_part, (need + 64) * 8) == hipSuccess && hipHostGetDevicePointer(&dp, ctx->h_part, 0) == hipSuccess) {
+                    ctx->d_part_host = (double*) dp; ctx->part_cap = need + 64;
+                } else { (void) hipGetLastError(); if (ctx->h_part) hipHostFree(ctx->h_part); ctx->h_part = nullptr; ctx->host_total_ok = false; host_total = false; }
+            }
+        }
+        ctx->pass_host_total = host_total; ctx->pass_rw_blocks = n_rw_blocks;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_stats<KT>), dim3((unsigned) (n_rw_blocks + n_ll_blocks)), dim3(g.threads), g.lds, st,
                            ctx->n_rowwaves, n_rw_blocks, ctx->d_rw_region, ctx->d_rowslots, ctx->d_grp_sums, row_src(ctx), ctx->d_params,
                            ctx->d_rw_stats, ctx->C, ll_off(ctx), ll_part(ctx), ctx->d_chunk_stats, ctx->V, ctx->d_chunk_ll,
                            ctx->d_rw_off, ctx->K, bound ? ctx->d_rank_out : ctx->d_total, bound ? (double*) nullptr : ctx->d_total_host,
-                           bound ? ctx->d_rank_flag : (double*) nullptr, ctx->d_flags, seq, ctx->d_done, ctx->n_parts, ctx->rs_bpw);
+                           bound ? ctx->d_rank_flag : (double*) nullptr, ctx->d_flags, seq, ctx->d_done, ctx->n_parts, ctx->rs_bpw,
+                           host_total ? ctx->d_part_host : (double*) nullptr);
         ctx->pass_wpb = wpb;
         ctx->pass_rows = true;
         ctx->pass_kc = ncol;
@@ -1209,6 +1227,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 TRY(dev_upload(&ctx->d_rowslots, rslots.data(), rslots.size()));
                 TRY(dev_upload(&ctx->d_rw_region, rwreg.data(), rwreg.size()));
                 TRY(dev_upload(&ctx->d_rw_off, rwoff.data(), rwoff.size()));
+                ctx->h_rw_off = rwoff;
                 DMALLOC(ctx->d_grp_sums, (size_t) grp_ar.size() * 16 * 8);
                 DMALLOC(ctx->d_chunk_ll, C * 8);
                 DMALLOC(ctx->d_rw_stats, (size_t) ctx->n_rowwaves * (16 + 9 + 2 + 3 * 16 + 1) * 8);
@@ -1299,7 +1318,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     }
     ctx->seg_test_timeout = std::getenv("HF_SEG_TEST_TIMEOUT") != nullptr;
     { const char* e = std::getenv("HF_STREAM_STAMP"); if (e && e[0] == '0') ctx->stream_stamp_ok = false; }
-    { const char* e = std::getenv("HF_PARAMS_COPY"); if (e && e[0] == '1') ctx->kp_ok = false; }   // the parameter block by a copy ahead of every pass
+    { const char* e = std::getenv("HF_PARAMS_COPY"); if (e && e[0] == '1') ctx->kp_ok = false; }
+    { const char* e = std::getenv("HF_TOTAL"); if (e && !std::strcmp(e, "device")) ctx->host_total_ok = false; }   // HF_TOTAL=device: the pass's last blocks sum the partials (rounds 3-4)   // the parameter block by a copy ahead of every pass
     {
         const char* e = std::getenv("HF_STATS");
         ctx->stats_mode = (e && std::strcmp(e, "chunks") == 0) ? HF_STATS_CHUNKS : HF_STATS_ROWS;
@@ -1356,6 +1376,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats);
     hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats);
     if (ctx->h_total) hipHostFree(ctx->h_total);   // one pinned block: h_flags and h_params live in it
+    if (ctx->h_part) hipHostFree(ctx->h_part);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 2 * HF_NKERNELS; i++) if (ctx->kev[i]) hipEventDestroy(ctx->kev[i]);
@@ -1692,6 +1713,16 @@ int hf_rank_total(hf_ctx* ctx, double* out_dev, void* stream) {
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->pass_rows && ctx->pass_nb) return launch_nb_total(ctx, (hipStream_t) stream, out_dev, false);
     if (ctx->pass_rows && ctx->pass_bound && out_dev == ctx->d_rank_out) return HF_OK;   // hf_bind_rank_total: already there
+    if (ctx->pass_rows && ctx->pass_host_total) {   // the pass sent its partials to the host: the total on the device from the copies in blk_stats / chunk_ll
+        const int wpb = ctx->pass_wpb;
+        const dim3 grid((unsigned) (ctx->R + 1)), blk((unsigned) (64 * wpb));
+#define HF_LATE(KT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rows_total_late<KT>), grid, blk, 0, (hipStream_t) stream, ctx->d_rw_off, wpb, ctx->d_rw_stats, ctx->d_params, \
+                                       ctx->K, ctx->d_chunk_ll, (int64_t) ctx->C, out_dev, done_scratch(ctx->d_done))
+        if (ctx->pass_kc <= 4) HF_LATE(4); else if (ctx->pass_kc <= 8) HF_LATE(8); else HF_LATE(16);
+#undef HF_LATE
+        HIPCHK(hipGetLastError());
+        return HF_OK;
+    }
     if (ctx->pass_rows) {   // the pass left its total in d_total (or where it was bound to)
         hipLaunchKernelGGL(k_copy_total, dim3(1), dim3(256), 0, (hipStream_t) stream, ctx->pass_bound ? ctx->d_rank_out : ctx->d_total, out_dev, ctx->V);
         HIPCHK(hipGetLastError());
@@ -1795,7 +1826,72 @@ static bool polled_block_consistent(const hf_ctx* ctx) {
     }
     return true;
 }
-static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_host) {
+// The total of a pass whose blocks wrote their partial vectors to the host (hf_rows.h part_host): rows_total_region and rows_total_ll restated —
+// the same additions in the same order (nq interleaved accumulators per element over the region's blocks, then their sum; the log-likelihood
+// by 64 strided sums and a halving tree), so h_total holds the bits the launch's own last blocks would have written.
+extern "C++" {
+template <int KT>
+static void host_rows_total_t(hf_ctx* ctx) {
+    constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
+    const double* part = ctx->h_part;
+    const int nblk = ctx->pass_rw_blocks, wpb = ctx->pass_wpb, nt = 64 * wpb, Kctx = ctx->K, nreg = ctx->R;
+    const int64_t V = ctx->V, C = ctx->C;
+    const DevParams* P = ctx->h_params;
+    const int ncol = P->ncomp[3];
+    const bool te = P->model_type == HF_MODEL_TRUNC_EXP_GAUSSIAN;
+    const int rstride = 24 * Kctx + 16;
+    double* out = ctx->h_total;
+    int nq = nt / NA;
+    nq = nq < 1 ? 1 : (nq > 16 ? 16 : nq);
+    for (int r = 0; r < nreg; r++) {
+        double* dst = out + 1 + (int64_t) r * rstride;
+        for (int v = 0; v < rstride; v++) dst[v] = 0.0;
+        const int w0 = ctx->h_rw_off[(size_t) r] / wpb, w1 = ctx->h_rw_off[(size_t) r + 1] / wpb;
+        if (w1 <= w0) continue;
+        double red[NA], acc[16][NA];
+        for (int q = 0; q < nq; q++) for (int i = 0; i < NA; i++) acc[q][i] = 0.0;
+        for (int k = w0; k < w1; k++) {                              // (blocks in order, whole vectors: accumulator (k - w0) % nq takes block k, as on the device)
+            double* a = acc[(k - w0) % nq];
+            const double* pk = part + (size_t) k * NA;
+            for (int i = 0; i < NA; i++) a[i] += pk[i];
+        }
+        for (int i = 0; i < NA; i++) {
+            double tot = 0.0;
+            for (int q = 0; q < nq; q++) tot += acc[q][i];
+            red[i] = tot;
+        }
+        const StatAcc<KT>* Sa = reinterpret_cast<const StatAcc<KT>*>(red);
+        for (int t = 0; t < 16; t++) dst[24 * Kctx + t] = Sa->trans[t];
+        if (te) { dst[(0 * 2 + 0) * Kctx] = Sa->te_num; dst[(0 * 2 + 1) * Kctx] = Sa->te_den; }
+        for (int st = 0; st < 3; st++)
+            if (!(st == 0 && te)) {
+                double* dd = dst + (st * 3) * 2 * Kctx;
+                dd[(0 * 2 + 0) * Kctx] = Sa->g_mnum[st]; dd[(0 * 2 + 1) * Kctx] = Sa->g_den[st];
+                dd[(1 * 2 + 0) * Kctx] = Sa->g_vnum[st]; dd[(1 * 2 + 1) * Kctx] = Sa->g_den[st];
+                dd[(2 * 2 + 0) * Kctx] = Sa->g_den[st];  dd[(2 * 2 + 1) * Kctx] = Sa->g_den[st];
+            }
+        for (int cc = 0; cc < KT && cc < ncol; cc++) {
+            double* dd = dst + (3 * 3) * 2 * Kctx;
+            dd[(0 * 2 + 0) * Kctx + cc] = Sa->c_mnum[cc]; dd[(0 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
+            dd[(1 * 2 + 0) * Kctx + cc] = Sa->c_vnum[cc]; dd[(1 * 2 + 1) * Kctx + cc] = Sa->c_den[cc];
+            dd[(2 * 2 + 0) * Kctx + cc] = Sa->c_den[cc];  dd[(2 * 2 + 1) * Kctx + cc] = Sa->c_wden;
+        }
+    }
+    {   // the log-likelihood: rows_total_ll's order
+        const double* ll = part + (size_t) nblk * NA;
+        double a[64];
+        for (int l = 0; l < 64; l++) { double acc = 0.0; for (int64_t c = l; c < C; c += 64) acc += ll[c]; a[l] = acc; }
+        for (int o = 32; o > 0; o >>= 1) for (int l = 0; l < o; l++) a[l] += a[l + o];
+        out[0] = a[0];
+    }
+    out[V] = part[(size_t) nblk * NA + (size_t) C];      // the flag word
+}
+}
+static void host_rows_total(hf_ctx* ctx) {
+    if (ctx->pass_kc <= 4) host_rows_total_t<4>(ctx); else if (ctx->pass_kc <= 8) host_rows_total_t<8>(ctx); else host_rows_total_t<16>(ctx);
+}
+
+static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_host, bool host_total = false) {
     bool seen = false;
     if (polled) {
         volatile double* stamp = ctx->h_total + ctx->V + 1;
@@ -1829,6 +1925,7 @@ static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_ho
         } else { (void) hipGetLastError(); ctx->stream_stamp_ok = false; }
         if (seen) {
             accumulate_kernel_times(ctx);
+            if (host_total) host_rows_total(ctx);
             std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
             const unsigned fl2 = (unsigned) ctx->h_total[ctx->V];
             if ((fl2 & HF_FLAG_SYNC) && ctx->seg_fused) {
@@ -1858,6 +1955,7 @@ static int wait_total(hf_ctx* ctx, hipStream_t st, bool polled, double* stats_ho
                              ctx->poll_kind, (long) v, snap[(size_t) v], ctx->h_total[v]);
     }
     accumulate_kernel_times(ctx);   // events of the kernels before the last one have completed
+    if (host_total) host_rows_total(ctx);
     std::memcpy(stats_host, ctx->h_total, (size_t) ctx->V * 8);
     const unsigned fl = (unsigned) ctx->h_total[ctx->V];
     if ((fl & HF_FLAG_SYNC) && ctx->seg_fused) {   // the one-launch segment kernel gave up a wait: this context runs two launches from now on
@@ -1888,7 +1986,7 @@ int hf_finish(hf_ctx* ctx, double* stats_host, void* stream) {
         HIPCHK(hipMemcpyAsync(ctx->h_total + ctx->V, ctx->d_rank_flag, 8, hipMemcpyDeviceToHost, st));
     } else if (!ctx->d_total_host)
         HIPCHK(hipMemcpyAsync(ctx->h_total, ctx->d_total, ((size_t) ctx->V + 1) * 8, hipMemcpyDeviceToHost, st));
-    rc = wait_total(ctx, st, polled, stats_host);
+    rc = wait_total(ctx, st, polled, stats_host, own_total && ctx->pass_host_total);
     if (rc == HF_E_RETRY) {   // the pass again, in two launches (the packed parameters are still in the pinned block)
         if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev0, st));
         rc = enqueue_pass(ctx, &ctx->last_p, ctx->last_mode, st, true);

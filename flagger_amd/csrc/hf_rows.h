@@ -149,7 +149,7 @@ __device__ __forceinline__ double xcu_load(const double* p) { return __hip_atomi
 #define HF_DONE_REGION0 1                                    // tickets of region r at HF_DONE_REGION0 + r, r = n_regions: the log-likelihood blocks
 #define HF_DONE_PARTS (HF_DONE_REGION0 + HF_MAXREGIONS + 1)  // ticket of the finished parts
 #define HF_DONE_WORDS (HF_DONE_PARTS + 1)                    // unsigned words; then (8-byte aligned) HF_MAXREGIONS + 1 doubles
-__device__ __forceinline__ double* done_scratch(unsigned* done) { return reinterpret_cast<double*>(done + ((HF_DONE_WORDS + 1) & ~1)); }
+__host__ __device__ __forceinline__ double* done_scratch(unsigned* done) { return reinterpret_cast<double*>(done + ((HF_DONE_WORDS + 1) & ~1)); }
 #define HF_DONE_BYTES ((((HF_DONE_WORDS + 1) & ~1) * 4) + (HF_MAXREGIONS + 1) * 8)
 
 #ifndef HF_RS_WPB
@@ -279,7 +279,13 @@ __global__ void __launch_bounds__(64 * HF_RS_WPB) k_row_stats(int n_rowwaves, in
                                                       const double* __restrict__ tile_ll, double* __restrict__ chunk_stats, int64_t V,
                                                       double* __restrict__ chunk_ll, const int32_t* __restrict__ rw_off, int Kctx,
                                                       double* __restrict__ out_dev, double* __restrict__ out_host, double* __restrict__ flag_row,
-                                                      const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done, int n_parts, int bpw) {
+                                                      const unsigned* __restrict__ flags, double seq, unsigned* __restrict__ done, int n_parts, int bpw,
+                                                      double* __restrict__ part_host) {
+    // part_host (round 5, the one-GPU path without a polling host): pinned HOST memory [n_rw_blocks][NA] | [C] | [1].  Every block writes its
+    // partial vector (a log-likelihood wavefront its chunk's value, block 0 the flag word) there and is done — the HOST sums them after the
+    // pass, in the order rows_total_region / rows_total_ll use (hf_estep.hip host_rows_total: the same bits).  Three dependent global round trips
+    // (drained partial -> ticket -> the last block's loads) leave the launch's critical path: k_row_stats 13 -> ~6 us.  The partials also stay in
+    // blk_stats / chunk_ll, so that a total on the DEVICE can still be had afterwards (k_rows_total_late: hf_rank_total).
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NS = 16 + 9 + 2;
     extern __shared__ __attribute__((aligned(16))) double s_rows[];
@@ -292,7 +298,7 @@ __global__ void __launch_bounds__(64 * HF_RS_WPB) k_row_stats(int n_rowwaves, in
             double s = 0.0;
             for (int k = lane; k < nt; k += 64) s += tile_ll[k0 + k];
             for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-            if (lane == 0) { chunk_stats[(int64_t) c * V] = s; xcu_store(chunk_ll + c, s); }
+            if (lane == 0) { chunk_stats[(int64_t) c * V] = s; xcu_store(chunk_ll + c, s); if (part_host) part_host[(int64_t) n_rw_blocks * NA + c] = s; }
         }
     } else {
     const int rw = (int) blockIdx.x * wpb + wave;
@@ -420,7 +426,12 @@ __global__ void __launch_bounds__(64 * HF_RS_WPB) k_row_stats(int n_rowwaves, in
         double v = 0.0;
         for (int w = 0; w < wpb; w++) v += s_blk[w * NA + i];
         xcu_store(blk_stats + (int64_t) blockIdx.x * NA + i, v);
+        if (part_host) part_host[(int64_t) blockIdx.x * NA + i] = v;
     }
+    }
+    if (part_host) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) part_host[(int64_t) n_rw_blocks * NA + C] = (double) (flags ? *flags : 0u);   // (final before this launch: k_seg_fb raised it)
+        return;
     }
     // ---- hand-offs: the last block of a part (a region / the log-likelihood blocks) sums the part; the last part writes flag
     // word, checksums and stamp (producer: write-through stores, drained, block barrier, ticket; consumer: cache-bypassing loads) ----
@@ -484,6 +495,16 @@ __global__ void __launch_bounds__(64 * HF_RS_WPB) k_row_stats(int n_rowwaves, in
             __threadfence_system();
         }
     }
+}
+
+// the total on the DEVICE after a pass whose partials went to the host (part_host): one block per region + one for the log-likelihood
+template <int KT>
+__global__ void __launch_bounds__(512) k_rows_total_late(const int32_t* __restrict__ rw_off, int wpb, const double* __restrict__ blk_stats,
+                                                         const DevParams* __restrict__ P, int Kctx, const double* __restrict__ chunk_ll, int64_t C,
+                                                         double* __restrict__ out_dev, double* __restrict__ scratch) {
+    const int nreg = P->n_regions;
+    if ((int) blockIdx.x < nreg) (void) rows_total_region<KT>((int) blockIdx.x, rw_off, wpb, blk_stats, P, Kctx, out_dev, nullptr);
+    else (void) rows_total_ll(rw_off, nreg, Kctx, chunk_ll, C, out_dev, nullptr, scratch);
 }
 
 // what ranks exchange (hf_rank_total): the total the pass left on the device, without the flag word

@@ -826,3 +826,35 @@ def test_cached_row_blocks_same_bits_and_chosen_by_residency(monkeypatch):
         assert np.array_equal(st2, ref[0]) and np.array_equal(em.labels(), ref[1])
     finally:
         em.close()
+
+
+def test_host_summed_total_equals_the_device_total_bit_for_bit(monkeypatch):
+    """Round 5: on the one-GPU path the blocks of k_row_stats write their partial vectors to pinned host memory and the HOST sums them in the
+    order the launch's own last blocks use (hf_estep.hip host_rows_total).  HF_TOTAL=device keeps the in-launch total: statistics, flag
+    behaviour and the forward-only log-likelihood must be the same bits — one region and seven, K = 4 / 6 / 10 (three kernel
+    instantiations), a sparse plan (four wavefronts per block, several batches per wavefront) — and hf_rank_total after such a pass
+    (k_rows_total_late) returns the same vector."""
+    cases = [(synth.config(2, scale=0.02), synth.HIFI_ALPHA, 4, 0.95), (synth.config(2, scale=0.05), synth.HIFI_ALPHA, None, 0.95),
+             (synth.config(4, scale=0.03), synth.ONT_R10_ALPHA, None, 0.8), (synth.config(5, scale=0.02), synth.ONT_R10_ALPHA, None, 0.8)]
+    for store, alpha, K, frac in cases:
+        K = hmm.getBestNumberOfCollapsedComps(store) if K is None else K
+        model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
+        got = []
+        for mode in ("host", "device"):
+            if mode == "device":
+                monkeypatch.setenv("HF_TOTAL", "device")
+            else:
+                monkeypatch.delenv("HF_TOTAL", raising=False)
+            em = hmm.EMList(store, model, True, frac)
+            other = hmm.EMList(store, model, True, frac)
+            scratch = other._L.hf_chunk_stats_dev(other._h)
+            try:
+                em.launch(model); st = em.finish().copy()
+                em.launch(model); em.rank_total(scratch); viax = em.finish_gathered(scratch, 0, 1).copy()
+                assert np.array_equal(viax, st), mode
+                em.launch(model, N.HF_MODE_FORWARD_ONLY); fwd = em.finish().copy()
+                got.append((st, fwd))
+            finally:
+                em.close(); other.close()
+        assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]), (K, store.n_regions)
+    monkeypatch.delenv("HF_TOTAL", raising=False)
