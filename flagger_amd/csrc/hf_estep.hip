@@ -1513,15 +1513,24 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
             // last copy has left it: a caller may enqueue the next pass before this one has run)
             const size_t nAll = nE + 2 * nP + 2 * nR;
             if (!ctx->d_nbE) {
-                HIPCHK(hipMalloc((void**) &ctx->d_nbE, nAll));
-                char* base = reinterpret_cast<char*>(ctx->d_nbE);
+                // everything into locals first: the context is touched only when ALL of it exists (a failure half way used to leave
+                // d_nbE set and a staging buffer null — the next pass skipped this block and copied through the null pointer)
+                double *dE = nullptr, *dH = nullptr; char* hb[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr};
+                bool ok = hipMalloc((void**) &dE, nAll) == hipSuccess &&
+                          hipMalloc((void**) &dH, ((size_t) ctx->ntiles * ctx->R * HF_NB_TILE_VEC + 1) * 8) == hipSuccess;
+                for (int b = 0; ok && b < 2; b++)
+                    ok = hipHostMalloc((void**) &hb[b], nAll) == hipSuccess && hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) == hipSuccess;
+                if (!ok) {
+                    const hipError_t e_ = hipGetLastError();
+                    for (int b = 0; b < 2; b++) { if (hb[b]) hipHostFree(hb[b]); if (ev[b]) hipEventDestroy(ev[b]); }
+                    hipFree(dE); hipFree(dH);
+                    return set_err(HF_E_HIP, std::string("hf_estep: negative-binomial staging: ") + hipGetErrorString(e_));
+                }
+                char* base = reinterpret_cast<char*>(dE);
+                ctx->d_nbE = dE; ctx->d_tile_hist = dH;
                 ctx->d_nbP = reinterpret_cast<double*>(base + nE); ctx->d_nbDig = reinterpret_cast<double*>(base + nE + nP);
                 ctx->d_nbR = reinterpret_cast<double*>(base + nE + 2 * nP); ctx->d_nbBeta = reinterpret_cast<double*>(base + nE + 2 * nP + nR);
-                HIPCHK(hipMalloc((void**) &ctx->d_tile_hist, ((size_t) ctx->ntiles * ctx->R * HF_NB_TILE_VEC + 1) * 8));
-                for (int b = 0; b < 2; b++) {
-                    HIPCHK(hipHostMalloc((void**) &ctx->h_nb[b], nAll));
-                    HIPCHK(hipEventCreateWithFlags(&ctx->nb_ev[b], hipEventDisableTiming));
-                }
+                for (int b = 0; b < 2; b++) { ctx->h_nb[b] = hb[b]; ctx->nb_ev[b] = ev[b]; }
             }
             if (!retry) {
                 const int b = (int) (ctx->nb_turn++ & 1u);

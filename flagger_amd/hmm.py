@@ -360,6 +360,7 @@ class EMList:
     # --- E-step pieces (used directly by the multi-GPU path in dist.py) ---
     def launch(self, model: HMM, mode: int = N.HF_MODE_FULL) -> None:
         p = model.params()
+        self._last_launch = (model, mode)
         N.check(self._L.hf_estep(self._h, C.byref(p), mode, self.stream), "hf_estep")
 
     def finish(self) -> np.ndarray:
@@ -368,7 +369,15 @@ class EMList:
         return out
 
     def check(self) -> None:
-        N.check(self._L.hf_check(self._h, self.stream), "hf_check")
+        """hf_check: the error flags of the last pass.  HF_E_RETRY (a hand-off of the one-launch segment kernel timed out; the context has
+        switched to two launches) is not an error of the data: the pass is enqueued again and checked once more — hf_finish
+        does the same inside the library.  A caller that drives several ranks itself must take that decision for all ranks together:
+        hf_finish_exchange ORs the flag rows for exactly that reason."""
+        rc = self._L.hf_check(self._h, self.stream)
+        if rc == N.HF_E_RETRY and getattr(self, "_last_launch", None) is not None:
+            self.launch(*self._last_launch)
+            rc = self._L.hf_check(self._h, self.stream)
+        N.check(rc, "hf_check")
 
     def rank_total(self, dst_dev_ptr: int) -> None:
         """This context's statistics vector (either statistics mode) into device memory."""

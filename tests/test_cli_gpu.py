@@ -137,6 +137,27 @@ def test_cli_argument_errors(tmp_path):
         os.path.join(GOLD, "cfg1_expected", "final_flagger_prediction.bed")).read()
 
 
+def test_bench_multi_gpu_line_is_complete_on_one_gpu():
+    """the line `bench.py --gpus N` prints on the first real multi-GPU run must not fail on its formatting — with one rank
+    (`--gpus 1 --dist-path --force-weak-leg`) it carries every object of the N > 1 line: rccl_ranks, other_exchange, n_invariance,
+    weak_scaling, roofline, cpu_baseline."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-path", "--force-weak-leg", "--scale", "0.05",
+                        "--steps", "5", "--warmup", "2"], capture_output=True, text=True,
+                       env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{"metric"')][-1])
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["scaling"] == "strong" and d["unit"] == "windows/s" and d["value"] > 0
+    assert d["other_exchange"]["exchange"] == "chunks" and d["other_exchange"]["value"] > 0
+    ni = d["n_invariance"]
+    assert ni["loglikelihoods_bit_identical"] is True and ni["label_mismatches"] == 0
+    assert ni["exchange_ranks_vs_one_context"]["label_mismatches"] == 0
+    w = d["weak_scaling"]
+    assert w["value"] > 0 and w["unit"] == "windows/s" and "error" not in w
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["cpu_baseline"]["kind"] == "port"
+
+
 def test_bench_single_gpu_and_distributed_code_paths_agree():
     """bench.py --dist-path runs the multi-GPU code path (RCCL process group of one rank, all-gather of the
     per-chunk vectors, indexed fixed-order reduction): the log-likelihood trajectory of the direct path."""
