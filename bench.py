@@ -449,6 +449,11 @@ def main():
         if args.no_kernel_events:
             dom_ms = kavg.get(dom, 0.0)
         local_windows = sharded.n_local_windows if hasattr(sharded, "n_local_windows") else sharded.local_store.n_windows
+        # a context past the Infinity Cache runs a pass in sub-passes (hf_sub_passes): the timed launch of the dominant kernel is the FIRST
+        # sub-pass's, so the units of one launch are that sub-pass's windows (one sub-pass — every BASELINE configuration — all of them)
+        sub_passes = getattr(em, "sub_passes", 1) or 1
+        if dom == "k_seg_fb" and sub_passes > 1:
+            local_windows = em.sub_pass_windows(0)
         achieved = ALGO_BYTES_PER_WINDOW * local_windows / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/pmc_traffic.json,
         # made by profiles/pmc_summary.py on this same command; FETCH_SIZE x2 on gfx950): full workload, 1 GPU only
@@ -540,7 +545,7 @@ def main():
                          "limiter": "fp64 VALU issue and dependent fp64 chains at three wavefronts per SIMD (see roofline_fp64), not HBM bytes",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_WINDOW * local_windows,
                          "kernel_ms_all": kavg, "algorithmic_bytes_per_window": ALGO_BYTES_PER_WINDOW,
-                         "windows_per_launch": local_windows,
+                         "windows_per_launch": local_windows, "sub_passes": sub_passes,
                          "valu_busy_frac_of_simd_time": valu_busy, "valu_busy_source": valu_src,
                          "note": "`bound` names the ceiling this object is priced against (bytes: SURVEY 8d classifies the path as a streaming scan); "
                                  "what limits the kernel is in `limiter` and `roofline_fp64` (DESIGN.md section 5)"},

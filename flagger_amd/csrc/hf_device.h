@@ -41,7 +41,7 @@ struct SegDesc {
     long long t0;            // global index of the segment's first window
     int n, L;                // windows of the segment, windows per lane
     int slot0, next_slot;    // first slot (scales, lane products: slot0 + step*64 + lane); first slot of the chunk's next segment
-    int slow0;               // slow-list position of the first slow window at or after t0 (hf_scan.h)
+    int trash_pos;           // record position of the segment's own spare record: where lanes without a window store (hf_seg.h)
     int chunk_slow0;         // row of A (hf_seg.h) of the chunk's first window: start∘e
     int seg0, k, nseg;       // first segment of the chunk, this segment's position in it, segments of the chunk
     int reg_first, reg_last; // region of the chunk's first / last window

@@ -259,8 +259,16 @@ struct hf_ctx {
     bool pass_nb = false;          // the last rows-mode pass ran the negative_binomial kernels (hf_nb_rows.h)
     int32_t* d_bin_off = nullptr; int32_t* d_bin_list = nullptr; double* d_slot_h = nullptr; double* d_H = nullptr;   // count-data plan
     double* d_chunk_ll = nullptr;  // [C] log-likelihood per chunk (rows mode)
-    double* d_recs = nullptr;      // [n_slots] pair records { f_{t-1}, b_t } of k_seg_fb, slot order; fb_recs: the last full pass wrote them
-    bool fb_recs = false;
+    double* d_recs = nullptr;      // pair records { f_{t-1}, b_t } of k_seg_fb, plan order; fb_recs: the last full pass wrote them
+    bool fb_recs = false, pass_pairs_done = false;   // pass_pairs_done: enqueue_pass ran k_pair_sums itself (per sub-pass)
+    // SUB-PASSES (round 5): a context whose records would not fit the Infinity Cache (256 MB; BASELINE configs[2] writes 130 MB) cuts its
+    // chunk list into sub-passes of whole chunks; a pass runs k_seg_fb then k_pair_sums per sub-pass through ONE buffer that holds a
+    // sub-pass's positions [p0, p1) at a time (d_recs; the plan's groups are numbered sub-pass by sub-pass, so a sub-pass's records are
+    // contiguous) — the records never travel to HBM and back.  Everything that needs the records of ALL windows at once (the getters,
+    // per-chunk statistics) runs the segment kernel into d_recs_all instead (allocated on first use; = d_recs with one sub-pass).
+    struct SubPass { int c0, c1, seg0, seg1, g0, g1; int64_t p0, p1; };
+    std::vector<SubPass> subs;
+    double* d_recs_all = nullptr; bool recs_all = false;   // recs_all: d_recs_all holds the records of every window of the last full pass
     int32_t* d_grp_off = nullptr;     // compact plan: first position of every group (+ the end)
     bool plan_compact = false;        // the groups' records back to back (sparse rows) instead of 64 positions per group
     int rs_bpw = 1;                   // batches of 16 row slots per wavefront of k_row_stats
@@ -469,13 +477,45 @@ static bool poll_ok(const hf_ctx* ctx, int last_kernel) {
 static double next_stamp(hf_ctx* ctx) { ctx->poll_seq += 1.0; ctx->h_total[ctx->V + 1] = 0.0; return ctx->poll_seq; }
 
 // the groups' sums of f (x) b, times their row of A: padded plan (whole groups streamed) or compact plan (hf_create)
-static void launch_pair_sums(hf_ctx* ctx, hipStream_t st) {
+// the groups of ONE sub-pass (hf_ctx::SubPass): padded plan — whole groups streamed from the sub-pass's first position on; compact plan — the
+// groups' own (global) positions.  recs_eff: the address position 0 would have (a pass buffer that holds one sub-pass starts p0 records later)
+static void launch_pair_sums(hf_ctx* ctx, hipStream_t st, const hf_ctx::SubPass& sb, const double* recs_eff) {
+    const int n = sb.g1 - sb.g0;
+    if (n <= 0) return;
     if (ctx->plan_compact)
-        hipLaunchKernelGGL(k_pair_sums_compact, dim3((unsigned) ((ctx->n_groups + 63) / 64)), dim3(256), 0, st, ctx->n_groups, ctx->d_grp_ar, ctx->d_grp_off,
-                           ctx->d_lutA, ctx->d_recs, ctx->d_grp_sums);
+        hipLaunchKernelGGL(k_pair_sums_compact, dim3((unsigned) ((n + 63) / 64)), dim3(256), 0, st, n, ctx->d_grp_ar + sb.g0, ctx->d_grp_off + sb.g0,
+                           ctx->d_grp_n + sb.g0, ctx->d_lutA, recs_eff, ctx->d_grp_sums + (size_t) sb.g0 * 16);
     else
-        hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) ((ctx->n_groups + 15) / 16)), dim3(256), 0, st, ctx->n_groups, ctx->d_grp_ar, ctx->d_grp_n,
-                           ctx->d_lutA, ctx->d_recs, ctx->d_grp_sums);
+        hipLaunchKernelGGL(k_pair_sums, dim3((unsigned) ((n + 15) / 16)), dim3(256), 0, st, n, ctx->d_grp_ar + sb.g0, ctx->d_grp_n + sb.g0,
+                           ctx->d_lutA, recs_eff + sb.p0 * 8, ctx->d_grp_sums + (size_t) sb.g0 * 16);
+}
+
+// k_seg_fb over the segments [g0, g0 + n) (hf_seg.h); timed: by the dispatch's own start / stop timestamps (hipExtLaunchKernelGGL hands the two
+// events to the launch: what rocprofv3 reports for the kernel, without the two marker packets of an event pair around it — those measured 3 us
+// more than the kernel and cost the step ~15 us)
+static void launch_seg_fb(hf_ctx* ctx, hipStream_t st, bool full, double* recs_eff, int g0, int n, unsigned epoch, unsigned wait_epoch, bool timed) {
+    if (n <= 0) return;
+    const int nc = ctx->seg_fused ? ctx->seg_nc : 0;     // cached row blocks: one-launch mode only (the lane products are computed in the same kernel)
+    const size_t lds = seg_lds_bytes(nc);
+#define HF_SEG_FB_ARGS ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_seg_ready, epoch, wait_epoch, ctx->d_pos, recs_eff, \
+                        ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags, (int32_t) g0, nc
+#define HF_SEG_FB_LAUNCH(B, F) do { \
+        if (timed) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) n), dim3(64), (uint32_t) lds, st, \
+                                         ctx->kev[2 * HF_K_SEG_FB], ctx->kev[2 * HF_K_SEG_FB + 1], 0, HF_SEG_FB_ARGS); \
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) n), dim3(64), lds, st, HF_SEG_FB_ARGS); } while (0)
+    if (full) { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(true, true); else HF_SEG_FB_LAUNCH(true, false); }
+    else { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(false, true); else HF_SEG_FB_LAUNCH(false, false); }
+#undef HF_SEG_FB_LAUNCH
+#undef HF_SEG_FB_ARGS
+}
+
+// the buffer that holds the records of ALL windows (one sub-pass: the pass buffer itself)
+static int all_records_buffer(hf_ctx* ctx) {
+    if (ctx->d_recs_all) return HF_OK;
+    int64_t n_pos = 0;
+    for (const auto& sb : ctx->subs) if (sb.p1 > n_pos) n_pos = sb.p1;
+    HIPCHK(hipMalloc((void**) &ctx->d_recs_all, (size_t) (n_pos + 1) * 64));
+    return HF_OK;
 }
 
 template <int KT>
@@ -483,10 +523,7 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
     ctx->pass_rows = false; ctx->pass_host_total = false;
     if (full && rows_pass(ctx)) {
         // statistics by emission row (hf_rows.h); the total of the pass comes out of k_row_stats' last blocks
-        {
-            KTimer t(ctx, st, HF_K_PAIR_SUMS);
-            launch_pair_sums(ctx, st);
-        }
+        // (k_pair_sums ran behind every sub-pass's k_seg_fb: enqueue_pass)
         KTimer t(ctx, st, HF_K_ROW_STATS);
         constexpr size_t NA = 16 + 9 + 2 + 3 * KT + 1;
         // the wavefronts' sums: HF_RS_WPB wavefronts per block (a block stays inside one region: hf_create pads the regions to that multiple) — four
@@ -532,7 +569,7 @@ static void launch_stats(hf_ctx* ctx, hipStream_t st, int full, int ncol) {
         const TileGeom g = tile_geom(ctx, k_stats_tile<KT>, (size_t) (3 * ncol > 28 ? 3 * ncol : 28) * 65 * 8);
         TILE_GEOM_OR_FAIL(g);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile<KT>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles,
-                           ctx->d_tile_desc, ctx->d_rec, row_src(ctx), ctx->d_params, ctx->pass_seg ? ctx->d_recs : ctx->d_f, ctx->d_b, ctx->d_regmask,
+                           ctx->d_tile_desc, ctx->d_rec, row_src(ctx), ctx->d_params, ctx->pass_seg ? ctx->d_recs_all : ctx->d_f, ctx->d_b, ctx->d_regmask,
                            ctx->d_tile_stats, ctx->pass_seg ? ctx->d_pos : (const int32_t*) nullptr);
     }
     KTimer t(ctx, st, HF_K_CHUNK_STATS);
@@ -906,7 +943,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         DMALLOC(ctx->d_tile_stats, nt * (size_t) n_regions * (16 + 9 + 2 + 3 * 16 + 1) * 8);
         cphase("tiles + work arrays");
         // ---- segments of the workgroup-per-segment forward-backward (hf_seg.h) and the record slot of every window ----
-        std::vector<std::vector<int32_t>> pcnt(HF_PARTS);   // pairs per row of A, per part of the chunk list
+        std::vector<std::vector<int32_t>> pcnt(HF_PARTS);   // pairs per (sub-pass, row of A), per part of the chunk list
+        int n_sub = 1; std::vector<int32_t> sub_of(C, 0);    // sub-pass of every chunk
         if (arena.th.joinable()) arena.th.join();
         if (N > 0 && !arena.b) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of host memory"); }
         P1 = reinterpret_cast<int32_t*>(arena.b); P2 = reinterpret_cast<int32_t*>(arena.b + N * 4);
@@ -955,11 +993,28 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 const size_t n_ar_all = a_src.size();
                 int32_t* const arow = h_arow;
                 cphase("(key, class) list");
-                // second pass: every window's row of A, and the pairs per row of A (x >= 2: hmm.c:638-642) as one histogram per part
-                // of the chunk list (popular rows: no contended atomics)
+                // sub-passes (hf_ctx::SubPass): whole chunks, about equal window counts, <= ~1.6 M windows (~140 MB of records) each
+                {
+                    int S = 1;
+                    if ((int64_t) N > 2200000) S = (int) (((int64_t) N + 1599999) / 1600000);
+                    if (const char* e = std::getenv("HF_SUBPASSES")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) S = v; }   // tests, A/B runs
+                    if ((size_t) S > C) S = (int) C;
+                    if (S < 1) S = 1;
+                    n_sub = S;
+                    sub_of.assign(C, 0);
+                    const int64_t total = w->chunk_off[C] - w->chunk_off[0];
+                    for (size_t c = 0; c < C; c++) {
+                        const int64_t mid = (w->chunk_off[c] + w->chunk_off[c + 1]) / 2 - w->chunk_off[0];
+                        int sidx = total > 0 ? (int) (mid * S / total) : 0;
+                        sub_of[c] = sidx < 0 ? 0 : (sidx >= S ? S - 1 : sidx);
+                    }
+                    for (size_t c = 1; c < C; c++) if (sub_of[c] < sub_of[c - 1]) sub_of[c] = sub_of[c - 1];   // (monotone: contiguous chunk ranges)
+                }
+                // second pass: every window's row of A, and the pairs per (sub-pass, row of A) (x >= 2: hmm.c:638-642) as one histogram per
+                // part of the chunk list (popular rows: no contended atomics)
                 par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
                     std::vector<int32_t>& h = pcnt[part];
-                    h.assign(n_ar_all, 0);
+                    h.assign(n_ar_all * (size_t) n_sub, 0);
                     for (size_t c = c0; c < c1; c++) {
                         const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
                         int32_t sp = soff[c];
@@ -974,7 +1029,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                                 arow[t] = id | (x == 0 ? (int32_t) 0x80000000 : 0);
                                 sp++;
                             } else arow[t] = id = cid[key_of(t) * NC + cls_of(r)] - 1;
-                            if (x >= 2) h[(size_t) id]++;
+                            if (x >= 2) h[(size_t) sub_of[c] * n_ar_all + (size_t) id]++;
                         }
                     }
                 });
@@ -1012,7 +1067,6 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     const int64_t w0 = k * sz, n = T - w0 < sz ? T - w0 : sz;
                     d.t0 = t0 + w0; d.n = (int) n; d.L = (int) ((n + NL - 1) / NL);
                     d.slot0 = (int32_t) nslots; nslots += (int64_t) d.L * NL;
-                    d.slow0 = (int32_t) (std::lower_bound(slow.begin(), slow.end(), (int64_t) d.t0) - slow.begin());
                     d.chunk_slow0 = ctx->n_combo + soff[c];               // the A row of the chunk's first window
                     d.seg0 = first; d.k = (int) k; d.chunk = (int) c; d.ident_row = ctx->n_arows;
                     d.reg_first = (int32_t) ((w->annot[t0] & 0xFC00000000000000ULL) >> 58);
@@ -1049,25 +1103,26 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         // without a pair (the first two of a chunk) and the f of a chunk's last window get positions after the groups.
         if (N > 0 && C > 0 && ctx->nseg > 0) {
             const size_t n_ar = h_arow_src.size();
-            std::vector<int32_t> cnt(n_ar + 1, 0);
+            const size_t S = (size_t) n_sub;
+            std::vector<int32_t> cnt(S * n_ar + 1, 0);            // pairs per (sub-pass, row of A)
             std::vector<size_t> pair0(C + 1, 0);
             for (size_t c = 0; c < C; c++) {
                 const int64_t T = w->chunk_off[c + 1] - w->chunk_off[c];
                 pair0[c + 1] = pair0[c] + (size_t) (T > 2 ? T - 2 : 0);
             }
             const size_t np = pair0[C];
-            // pairs per row of A: the sum of the parts' histograms; the per-part counts become the parts' starting ranks for the
-            // positions below
+            // pairs per (sub-pass, row of A): the sum of the parts' histograms; the per-part counts become the parts' starting ranks for
+            // the positions below
             for (auto& h : pcnt)
                 if (!h.empty())
-                    for (size_t r = 0; r < n_ar; r++) { const int32_t here = h[r]; h[r] = cnt[r]; cnt[r] += here; }   // exclusive prefix over the parts
+                    for (size_t r = 0; r < S * n_ar; r++) { const int32_t here = h[r]; h[r] = cnt[r]; cnt[r] += here; }   // exclusive prefix over the parts
             // Two layouts of the groups' records.  PADDED: group g at positions g*64.. — k_pair_sums streams whole groups with a fixed
             // geometry (the layout of inputs whose rows are popular: BASELINE configs[2], [4]).  When most pairs sit in rows of their
             // own (coverage spread over the whole range, or reads longer than the contigs: every window a contig-end window) that
             // would cost up to 64 positions per pair; then COMPACT: the groups back to back, group g at grp_off[g] —
             // k_pair_sums_compact, four lanes per group.
             int64_t n_groups_all = 0;
-            for (size_t r = 0; r < n_ar; r++) n_groups_all += (cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS;
+            for (size_t r = 0; r < S * n_ar; r++) n_groups_all += (cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS;
             const bool dense = n_groups_all * HF_GRP_PAIRS <= 4 * (int64_t) np + (4 << 20);   // 32 MiB of slack
             bool compact = !dense;
             const char* const force = std::getenv("HF_STATS_PLAN");     // tests: "compact" / "padded" [",bpw=N"] on inputs of any size
@@ -1085,103 +1140,165 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             if (w->chunk_off[0] != 0 || (size_t) w->chunk_off[C] != N) std::memset(pos, 0, N * 4);   // windows outside every chunk
             int64_t n_pos = 0;
             bool planned = false;
-            std::vector<int32_t> g_pos0;                          // position of the first pair of every row of A
+            std::vector<int32_t> g_pos0;                          // position of the first pair of every (sub-pass, row of A)
             std::vector<int32_t> grp_ar, grp_n, grp_off;
             std::vector<RowSlot> rslots; std::vector<int32_t> rwreg, rwoff((size_t) n_regions + 1, 0);
-            if (np > 0 && (compact ? (int64_t) np : n_groups_all * HF_GRP_PAIRS) + 3 * (int64_t) C + 4 * HF_GRP_PAIRS < INT32_MAX && N < (size_t) INT32_MAX) {
+            std::vector<int64_t> extra0(C + 1, 0);                // first of the chunk's positions behind its sub-pass's groups: its windows 0, 1 and its spare record
+            std::vector<int32_t> h_spare(C, 0);
+            // the sub-passes' chunk and segment ranges
+            std::vector<hf_ctx::SubPass>& subs = ctx->subs;
+            subs.assign(S, hf_ctx::SubPass{0, 0, 0, 0, 0, 0, 0, 0});
+            for (size_t sp = 0; sp < S; sp++) { subs[sp].c0 = (int) C; subs[sp].c1 = 0; }
+            for (size_t c = 0; c < C; c++) {
+                hf_ctx::SubPass& sb = subs[(size_t) sub_of[c]];
+                if ((int) c < sb.c0) sb.c0 = (int) c;
+                if ((int) c + 1 > sb.c1) sb.c1 = (int) c + 1;
+            }
+            for (size_t sp = 0; sp < S; sp++) {
+                if (subs[sp].c1 < subs[sp].c0) { subs[sp].c0 = subs[sp].c1 = sp ? subs[sp - 1].c1 : 0; }   // (an empty sub-pass)
+                subs[sp].seg0 = cseg0[(size_t) subs[sp].c0]; subs[sp].seg1 = cseg0[(size_t) subs[sp].c1];
+            }
+            const bool can_plan = np > 0 && (compact ? (int64_t) np : n_groups_all * HF_GRP_PAIRS) + 3 * (int64_t) C + 4 * HF_GRP_PAIRS + (int64_t) ctx->nseg < INT32_MAX && N < (size_t) INT32_MAX;
+            // extras and spare records of sub-pass sp from position `from` on: windows 0, 1 of its chunks (with a plan) and the chunk's spare record,
+            // then one spare record per segment
+            auto place_extras = [&](size_t sp, int64_t from, bool with_first_two) {
+                int64_t p = from;
+                for (int c = subs[sp].c0; c < subs[sp].c1; c++) {
+                    const int64_t T = w->chunk_off[c + 1] - w->chunk_off[c];
+                    extra0[(size_t) c] = p;
+                    p += T <= 0 ? 0 : (with_first_two ? (T < 2 ? T : 2) : 0) + 1;
+                    extra0[(size_t) c + 1] = p;      // (read as "end of chunk c" below: the chunks of a sub-pass are consecutive)
+                }
+                for (int k = subs[sp].seg0; k < subs[sp].seg1; k++) ctx->h_segs[(size_t) k].trash_pos = (int32_t) p++;
+                return p;
+            };
+            if (can_plan) {
                 // rows of A that occur, ordered by (region, row of A): combos are numbered by (emission key, class), keys are
                 // region-major; the contig-end windows' rows follow in window order
                 struct Occ { int32_t region, ar; };
                 std::vector<Occ> occ;
                 const size_t MMr = (size_t) ctx->M * ctx->M;
                 for (size_t r = 0; r < n_ar; r++) {
-                    if (!cnt[r]) continue;
+                    bool any = false;
+                    for (size_t sp = 0; sp < S && !any; sp++) any = cnt[sp * n_ar + r] != 0;
+                    if (!any) continue;
                     const int64_t er = h_arow_src[r];            // emission row: a key, or n_lut + slow index
                     int32_t reg;
                     if (er < ctx->n_lut) reg = (int32_t) ((size_t) er / MMr);
                     else reg = (int32_t) ((w->annot[(size_t) slow[(size_t) (er - ctx->n_lut)]] & 0xFC00000000000000ULL) >> 58);
                     occ.push_back({reg, (int32_t) r});
                 }
-                cphase("plan: occ list");
                 if (n_regions > 1) std::stable_sort(occ.begin(), occ.end(), [](const Occ& a, const Occ& b) { return a.region < b.region; });
-                cphase("plan: occ sort");
-                g_pos0.assign(n_ar, 0);
-                int64_t next_pos = 0;
+                const size_t nocc = occ.size();
+                g_pos0.assign(S * n_ar, 0);
                 const size_t unit = (size_t) 16 * (size_t) bpw;     // row slots per wavefront of k_row_stats
-                // Groups and row slots by INDEX (round 5; a push_back per group cost 0.5 ms of this function): first the rows' bases — groups,
-                // positions, and the row slots of every run of rows of one EMISSION row (its transition classes are adjacent: a slot takes up to
-                // HF_ROWSLOT_GROUPS consecutive groups of the run) — then the arrays are sized once and filled by plain stores.
+                // Groups and row slots by INDEX (a push_back per group cost 0.5 ms of this function): first the bases — the groups and their
+                // positions SUB-PASS BY SUB-PASS (a sub-pass's records are contiguous: [groups | windows 0, 1 and spare record of its chunks | one
+                // spare record per segment]), then the row slots REGION BY REGION (k_row_stats' blocks belong to one region): within a (region,
+                // sub-pass) every run of rows of one EMISSION row (its transition classes are adjacent) fills slots of up to HF_ROWSLOT_GROUPS
+                // consecutive groups — then the arrays are sized once and filled by plain stores.
                 struct RowBase { int32_t g0, slot0, go; int64_t p0; };   // first group, first slot of the row's run, groups of the run before this row, first position
-                std::vector<RowBase> rb(occ.size());
+                std::vector<RowBase> rb(S * nocc, RowBase{0, 0, 0, 0});
                 size_t n_grp = 0, n_slot = 0;
+                int64_t next_pos = 0;
+                for (size_t sp = 0; sp < S; sp++) {
+                    subs[sp].g0 = (int) n_grp; subs[sp].p0 = next_pos;
+                    for (size_t oi = 0; oi < nocc; oi++) {
+                        const size_t r = (size_t) occ[oi].ar;
+                        const int32_t c_ = cnt[sp * n_ar + r];
+                        if (!c_) continue;
+                        RowBase& B = rb[sp * nocc + oi];
+                        B.g0 = (int32_t) n_grp;
+                        B.p0 = compact ? next_pos : subs[sp].p0 + (int64_t) (n_grp - (size_t) subs[sp].g0) * HF_GRP_PAIRS;
+                        n_grp += (size_t) ((c_ + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS);
+                        if (compact) next_pos += c_;
+                    }
+                    if (!compact) next_pos = subs[sp].p0 + (int64_t) (n_grp - (size_t) subs[sp].g0) * HF_GRP_PAIRS;
+                    subs[sp].g1 = (int) n_grp;
+                    next_pos = place_extras(sp, next_pos, true);
+                    subs[sp].p1 = next_pos;
+                }
+                n_pos = next_pos;
                 {
-                    size_t oi = 0;
+                    size_t oi0 = 0;
                     for (int reg = 0; reg < n_regions; reg++) {
                         rwoff[(size_t) reg] = (int32_t) (n_slot / unit);
-                        int64_t open_row = -1; size_t run_slot0 = n_slot; int32_t run_groups = 0;
-                        for (; oi < occ.size() && occ[oi].region == reg; oi++) {
-                            const size_t r = (size_t) occ[oi].ar;
-                            const int64_t er = h_arow_src[r];
-                            const int32_t ng = (int32_t) ((cnt[r] + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS);
-                            if (er != open_row) { n_slot = run_slot0 + (size_t) ((run_groups + HF_ROWSLOT_GROUPS - 1) / HF_ROWSLOT_GROUPS); run_slot0 = n_slot; run_groups = 0; open_row = er; }
-                            rb[oi].g0 = (int32_t) n_grp; rb[oi].slot0 = (int32_t) run_slot0; rb[oi].go = run_groups; rb[oi].p0 = next_pos;
-                            n_grp += (size_t) ng; run_groups += ng; next_pos += cnt[r];
+                        size_t oi1 = oi0;
+                        while (oi1 < nocc && occ[oi1].region == reg) oi1++;
+                        for (size_t sp = 0; sp < S; sp++) {
+                            int64_t open_row = -1; size_t run_slot0 = n_slot; int32_t run_groups = 0;
+                            for (size_t oi = oi0; oi < oi1; oi++) {
+                                const size_t r = (size_t) occ[oi].ar;
+                                const int32_t c_ = cnt[sp * n_ar + r];
+                                if (!c_) continue;
+                                const int64_t er = h_arow_src[r];
+                                const int32_t ng = (c_ + HF_GRP_PAIRS - 1) / HF_GRP_PAIRS;
+                                if (er != open_row) { n_slot = run_slot0 + (size_t) ((run_groups + HF_ROWSLOT_GROUPS - 1) / HF_ROWSLOT_GROUPS); run_slot0 = n_slot; run_groups = 0; open_row = er; }
+                                rb[sp * nocc + oi].slot0 = (int32_t) run_slot0; rb[sp * nocc + oi].go = run_groups;
+                                run_groups += ng;
+                            }
+                            n_slot = run_slot0 + (size_t) ((run_groups + HF_ROWSLOT_GROUPS - 1) / HF_ROWSLOT_GROUPS);
                         }
-                        n_slot = run_slot0 + (size_t) ((run_groups + HF_ROWSLOT_GROUPS - 1) / HF_ROWSLOT_GROUPS);
                         n_slot = (n_slot + HF_RS_WPB * unit - 1) / (HF_RS_WPB * unit) * (HF_RS_WPB * unit);   // whole blocks of k_row_stats per region
                         for (size_t k = (size_t) rwoff[(size_t) reg]; k < n_slot / unit; k++) rwreg.push_back(reg);
+                        oi0 = oi1;
                     }
                 }
                 grp_ar.assign((n_grp + 3) / 4 * 4, 0); grp_n.assign((n_grp + 3) / 4 * 4, 0);   // (k_pair_sums: four groups per wavefront)
                 grp_off.assign(n_grp + 1, 0);
                 rslots.assign(n_slot, RowSlot{-1, 0, 0, 0});
-                for (size_t oi = 0; oi < occ.size(); oi++) {
-                    const size_t r = (size_t) occ[oi].ar;
-                    const int64_t er = h_arow_src[r];
-                    const RowBase B = rb[oi];
-                    g_pos0[r] = (int32_t) (compact ? B.p0 : (int64_t) B.g0 * HF_GRP_PAIRS);
-                    int32_t xpx;
-                    if (er < ctx->n_lut) xpx = (int32_t) (((size_t) er / (size_t) ctx->M) % (size_t) ctx->M) | ((int32_t) ((size_t) er % (size_t) ctx->M) << 8);
-                    else { const size_t t = (size_t) slow[(size_t) (er - ctx->n_lut)]; xpx = (int32_t) (w->cov[t] & 0xffu) | ((int32_t) (w->cov[t - 1] & 0xffu) << 8); }
-                    int64_t p = B.p0;
-                    for (int32_t j = 0, left = cnt[r]; left > 0; j++, left -= HF_GRP_PAIRS) {
-                        const size_t g = (size_t) (B.g0 + j);
-                        const int32_t here = left < HF_GRP_PAIRS ? left : HF_GRP_PAIRS;
-                        grp_ar[g] = (int32_t) r; grp_n[g] = here; grp_off[g] = (int32_t) p;
-                        p += here;
-                        RowSlot& sl = rslots[(size_t) B.slot0 + (size_t) ((B.go + j) / HF_ROWSLOT_GROUPS)];
-                        if ((B.go + j) % HF_ROWSLOT_GROUPS == 0) { sl.row = (int32_t) er; sl.g0 = (int32_t) g; sl.ng = 1; sl.xpx = xpx; }
-                        else sl.ng++;
+                for (size_t sp = 0; sp < S; sp++)
+                    for (size_t oi = 0; oi < nocc; oi++) {
+                        const size_t r = (size_t) occ[oi].ar;
+                        const int32_t c_ = cnt[sp * n_ar + r];
+                        if (!c_) continue;
+                        const int64_t er = h_arow_src[r];
+                        const RowBase B = rb[sp * nocc + oi];
+                        g_pos0[sp * n_ar + r] = (int32_t) B.p0;
+                        int32_t xpx;
+                        if (er < ctx->n_lut) xpx = (int32_t) (((size_t) er / (size_t) ctx->M) % (size_t) ctx->M) | ((int32_t) ((size_t) er % (size_t) ctx->M) << 8);
+                        else { const size_t t = (size_t) slow[(size_t) (er - ctx->n_lut)]; xpx = (int32_t) (w->cov[t] & 0xffu) | ((int32_t) (w->cov[t - 1] & 0xffu) << 8); }
+                        int64_t p = B.p0;
+                        for (int32_t j = 0, left = c_; left > 0; j++, left -= HF_GRP_PAIRS) {
+                            const size_t g = (size_t) (B.g0 + j);
+                            const int32_t here = left < HF_GRP_PAIRS ? left : HF_GRP_PAIRS;
+                            grp_ar[g] = (int32_t) r; grp_n[g] = here; grp_off[g] = (int32_t) p;
+                            p += compact ? here : HF_GRP_PAIRS;
+                            RowSlot& sl = rslots[(size_t) B.slot0 + (size_t) ((B.go + j) / HF_ROWSLOT_GROUPS)];
+                            if ((B.go + j) % HF_ROWSLOT_GROUPS == 0) { sl.row = (int32_t) er; sl.g0 = (int32_t) g; sl.ng = 1; sl.xpx = xpx; }
+                            else sl.ng++;
+                        }
                     }
-                }
                 rwoff[(size_t) n_regions] = (int32_t) (rslots.size() / unit);
                 ctx->n_parts = 1;
                 for (int reg = 0; reg < n_regions; reg++) if (rwoff[(size_t) reg + 1] > rwoff[(size_t) reg]) ctx->n_parts++;
                 ctx->n_groups = (int) n_grp;
-                grp_off[n_grp] = (int32_t) next_pos;
-                n_pos = compact ? next_pos : (int64_t) grp_ar.size() * HF_GRP_PAIRS;
+                grp_off[n_grp] = (int32_t) (n_grp ? grp_off[n_grp - 1] + (compact ? grp_n[n_grp - 1] : HF_GRP_PAIRS) : 0);
                 ctx->plan_compact = compact;
                 planned = true;
-                cphase("plan: group loop");
-            } else n_pos = ctx->n_slots;    // no plan (sparse rows): the per-chunk statistics read the records by window; positions in slot order
-            // third pass: the position of every window's record.  Pairs of a row of A in window order; the windows without a pair
-            // of their own (x = 0, 1) and the f of every chunk's last window after the groups, chunk by chunk
-            cphase("plan: groups, row slots");
-            std::vector<int64_t> extra0(C + 1, n_pos);
-            std::vector<int32_t> h_spare(C, 0);
-            for (size_t c = 0; c < C; c++) {
-                const int64_t T = w->chunk_off[c + 1] - w->chunk_off[c];
-                extra0[c + 1] = extra0[c] + (T <= 0 ? 0 : (planned ? (T < 2 ? T : 2) : 0) + 1);
+                cphase("plan: groups, row slots");
+            } else {
+                // no plan (sparse rows past the position range): the per-chunk statistics read the records by window; positions in slot order,
+                // one "sub-pass" holds everything
+                n_sub = 1;
+                subs.assign(1, hf_ctx::SubPass{0, (int) C, 0, ctx->nseg, 0, 0, 0, 0});
+                std::fill(sub_of.begin(), sub_of.end(), 0);
+                n_pos = place_extras(0, ctx->n_slots, false);
+                subs[0].p1 = n_pos;
             }
+            // third pass: the position of every window's record.  Pairs of a (sub-pass, row of A) in window order; the windows without a
+            // pair of their own (x = 0, 1) and the f of every chunk's last window behind the sub-pass's groups, chunk by chunk
             par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
-                int32_t* const fill = pcnt[part].data();      // rank of the part's next pair of every row of A
+                int32_t* const fill = pcnt[part].data();      // rank of the part's next pair of every (sub-pass, row of A)
                 for (size_t c = c0; c < c1; c++) {
                     const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
                     if (T <= 0) continue;
+                    const int64_t ex = extra0[c];
                     if (planned) {
-                        for (int64_t x = 0; x < T && x < 2; x++) pos[(size_t) (t0 + x)] = (int32_t) (extra0[c] + x);
+                        const size_t sb = (size_t) sub_of[c] * n_ar;
+                        for (int64_t x = 0; x < T && x < 2; x++) pos[(size_t) (t0 + x)] = (int32_t) (ex + x);
                         for (int64_t x = 2; x < T; x++) {
-                            const size_t r = (size_t) (h_arow[(size_t) (t0 + x)] & 0x7fffffff);
+                            const size_t r = sb + (size_t) (h_arow[(size_t) (t0 + x)] & 0x7fffffff);
                             const int64_t k = fill[r]++;
                             pos[(size_t) (t0 + x)] = g_pos0[r] + (int32_t) k;
                         }
@@ -1191,12 +1308,11 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                             for (int64_t x = 0; x < d.n; x++) pos[(size_t) (d.t0 + x)] = seg_slot(d, x);
                         }
                     }
-                    const int32_t spare = (int32_t) (extra0[c + 1] - 1);   // takes the f of the chunk's last window
+                    const int32_t spare = (int32_t) (ex + (planned ? (T < 2 ? T : 2) : 0));   // takes the f of the chunk's last window
                     h_spare[c] = spare;
                     for (int k = cseg0[c]; k < cseg0[c + 1]; k++) ctx->h_segs[(size_t) k].spare_pos = spare;
                 }
             });
-            n_pos = extra0[C];
             cphase("plan: positions (third pass)");
             if (planned) {
                 // negative_binomial count data: the row slots of every (region, min(x, 249)) bin, in plan order
@@ -1244,11 +1360,14 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 hipLaunchKernelGGL(k_pos_f, dim3((unsigned) ((maxT + 255) / 256), (unsigned) C), dim3(256), 0, 0, ctx->d_off, ctx->d_pos, d_spare, ctx->d_pos_f);
             }
             hipFree(ctx->d_recs); ctx->d_recs = nullptr;
-            if (n_pos + (int64_t) ctx->nseg >= INT32_MAX) { hf_destroy(ctx); return set_err(HF_E_ARG, "hf_create: more than 2^31 record positions (shard the chunk list: hmm_flagger_multi.h)"); }
-            DMALLOC(ctx->d_recs, ((size_t) n_pos + (size_t) ctx->nseg) * 64);   // + one spare record per segment (hf_seg.h: where lanes without a window write)
-            if (ctrace) std::fprintf(stderr, "[hf_create] statistics plan: %s, %d groups, %d row-slot wavefronts of %d x 16 slots, %lld positions for %lld pairs\n",
+            if (n_pos >= INT32_MAX) { hf_destroy(ctx); return set_err(HF_E_ARG, "hf_create: more than 2^31 record positions (shard the chunk list: hmm_flagger_multi.h)"); }
+            int64_t cap = 0;                          // positions the pass buffer holds: the largest sub-pass (everything, with one)
+            for (const auto& sb : ctx->subs) if (sb.p1 - sb.p0 > cap) cap = sb.p1 - sb.p0;
+            DMALLOC(ctx->d_recs, (size_t) (cap + 1) * 64);
+            if (ctx->subs.size() == 1) ctx->d_recs_all = ctx->d_recs;      // (several sub-passes: the all-windows buffer on first use, ensure_all_records)
+            if (ctrace) std::fprintf(stderr, "[hf_create] statistics plan: %s, %d groups, %d row-slot wavefronts of %d x 16 slots, %lld positions for %lld pairs; %zu sub-pass(es), record buffer %.0f MB\n",
                                      !planned ? "none (per-chunk statistics)" : ctx->plan_compact ? "compact" : "padded", ctx->n_groups, ctx->n_rowwaves,
-                                     ctx->rs_bpw, (long long) n_pos, (long long) np);
+                                     ctx->rs_bpw, (long long) n_pos, (long long) np, ctx->subs.size(), (double) (cap + 1) * 64 / 1e6);
             cphase("plan: uploads, allocations");
         }
     }
@@ -1370,7 +1489,7 @@ void hf_destroy(hf_ctx* ctx) {
     hipFree(ctx->d_nbE); hipFree(ctx->d_tile_hist);   // (d_nbP .. d_nbBeta point into d_nbE's buffer)
     for (int b = 0; b < 2; b++) { if (ctx->h_nb[b]) hipHostFree(ctx->h_nb[b]); if (ctx->nb_ev[b]) hipEventDestroy(ctx->nb_ev[b]); }
     hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0);
-    hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_grp_ar); hipFree(ctx->d_grp_n); hipFree(ctx->d_grp_off); hipFree(ctx->d_pos); hipFree(ctx->d_pos_f); hipFree(ctx->d_slot_of); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
+    hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); if (ctx->d_recs_all != ctx->d_recs) hipFree(ctx->d_recs_all); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_grp_ar); hipFree(ctx->d_grp_n); hipFree(ctx->d_grp_off); hipFree(ctx->d_pos); hipFree(ctx->d_pos_f); hipFree(ctx->d_slot_of); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
     hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_seg_ready); hipFree(ctx->d_scale_s);
     hipFree(ctx->d_jobs); hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
     hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats);
@@ -1585,7 +1704,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 }
             } else if (seg_pass(ctx)) {
                 // one workgroup per chunk segment does the whole forward-backward (hf_seg.h)
-                const int nc = ctx->seg_fused ? ctx->seg_nc : 0;     // cached row blocks: one-launch mode only (the lane products are computed in the same kernel)
+                const int nc = ctx->seg_fused ? ctx->seg_nc : 0;
                 const size_t lds = seg_lds_bytes(nc);
                 if (ctx->host_trace && !ctx->ht_n) {
                     int o1 = 0, o2 = 0;
@@ -1605,25 +1724,36 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                     KTimer t(ctx, st, HF_K_SEG_PROD);
                     hipLaunchKernelGGL(k_seg_prod, dim3((unsigned) ctx->nseg), dim3(64), seg_lds_bytes(), st, ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
                 }
-                // the dominant kernel is timed by the dispatch's OWN start / stop timestamps (hipExtLaunchKernelGGL hands the two events to
-                // the launch): what rocprofv3 reports for the kernel, without the two marker packets of an event pair around it (those
-                // measured 3 us more than the kernel and cost the step ~15 us)
                 const bool tfb = ((ctx->prof_mask >> HF_K_SEG_FB) & 1u) && ctx->prof_now;
                 if (tfb) ctx->kran[HF_K_SEG_FB] = true;
                 const unsigned epoch = ++ctx->seg_epoch;
                 // HF_SEG_TEST_TIMEOUT=1 (tests/test_estep_gpu.py): the first one-launch pass waits for flags nobody writes, so that
                 // the time-out, HF_E_RETRY and the fall-back to two launches are exercised
                 const unsigned wait_epoch = (ctx->seg_test_timeout && epoch == 1) ? 0xffffffffu : epoch;
-#define HF_SEG_FB_ARGS ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_seg_ready, epoch, wait_epoch, ctx->d_pos, ctx->d_recs, \
-                        ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags, (int32_t) ctx->n_pos, nc
-#define HF_SEG_FB_LAUNCH(B, F) do { \
-                    if (tfb) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) ctx->nseg), dim3(64), (uint32_t) lds, st, \
-                                                   ctx->kev[2 * HF_K_SEG_FB], ctx->kev[2 * HF_K_SEG_FB + 1], 0, HF_SEG_FB_ARGS); \
-                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) ctx->nseg), dim3(64), lds, st, HF_SEG_FB_ARGS); } while (0)
-                if (full) { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(true, true); else HF_SEG_FB_LAUNCH(true, false); }
-                else { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(false, true); else HF_SEG_FB_LAUNCH(false, false); }
-#undef HF_SEG_FB_LAUNCH
-#undef HF_SEG_FB_ARGS
+                // Sub-passes (hf_ctx::SubPass).  A full pass whose statistics go by emission row runs sub-pass by sub-pass through the pass
+                // buffer: k_seg_fb writes a sub-pass's records, k_pair_sums reads them back while they are still in the Infinity Cache, the next
+                // sub-pass overwrites them.  Any other pass (per-chunk statistics read the records by window afterwards; a forward-only pass writes
+                // none) is ONE launch over all segments into the all-windows buffer.
+                const bool want_rows = full && rows_pass(ctx);
+                ctx->pass_pairs_done = false;
+                if (want_rows) {
+                    const bool alias = ctx->subs.size() > 1;
+                    bool first = true;
+                    for (const auto& sb : ctx->subs) {
+                        double* const recs_eff = alias ? ctx->d_recs - sb.p0 * 8 : ctx->d_recs;
+                        launch_seg_fb(ctx, st, true, recs_eff, sb.seg0, sb.seg1 - sb.seg0, epoch, wait_epoch, tfb && first);   // (timed: the first sub-pass's launch, hf_sub_pass_windows)
+                        first = false;
+                        KTimer t(ctx, st, HF_K_PAIR_SUMS);              // (event pairs around k_pair_sums: the last sub-pass's is what is read)
+                        launch_pair_sums(ctx, st, sb, recs_eff);
+                    }
+                    ctx->pass_pairs_done = true;
+                    ctx->recs_all = !alias;
+                } else {
+                    double* recs = ctx->d_recs;
+                    if (full && ctx->subs.size() > 1) { const int rc_ = all_records_buffer(ctx); if (rc_) return rc_; recs = ctx->d_recs_all; }
+                    launch_seg_fb(ctx, st, full, recs, 0, ctx->nseg, epoch, wait_epoch, tfb);
+                    if (full) ctx->recs_all = true;
+                }
                 ctx->pass_seg = true;
                 if (full) ctx->fb_recs = true;
             } else
@@ -1633,11 +1763,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
         const int fl = full && ctx->ntiles > 0;
         ctx->pass_nb = false;
         if (nbm && fl && rows_pass(ctx)) {   // statistics by emission row, negative_binomial (hf_nb_rows.h)
-            {
-                KTimer t(ctx, st, HF_K_PAIR_SUMS);
-                launch_pair_sums(ctx, st);
-            }
-            {
+            {   // (k_pair_sums ran behind every sub-pass's k_seg_fb, above)
                 KTimer t(ctx, st, HF_K_ROW_STATS);
                 const int n_rw_blocks = (ctx->n_rowwaves + 3) / 4, n_ll_blocks = (ctx->C + 3) / 4;
                 hipLaunchKernelGGL(k_row_stats_nb, dim3((unsigned) (n_rw_blocks + n_ll_blocks)), dim3(256), 0, st, ctx->n_rowwaves, n_rw_blocks,
@@ -1655,7 +1781,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 const TileGeom g = tile_geom(ctx, k_stats_tile_nb<HF_SCAN_L>, (size_t) HF_NB_WAVE_LDS * 8);
                 if (!g.ok) return set_err(HF_E_ARG, "the per-region tables do not fit the LDS of one workgroup");
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_stats_tile_nb<HF_SCAN_L>), dim3(g.blocks), dim3(g.threads), g.lds, st, ctx->ntiles, ctx->d_tile_desc,
-                                   ctx->d_rec, S, ctx->d_params, ctx->pass_seg ? ctx->d_recs : ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_hist,
+                                   ctx->d_rec, S, ctx->d_params, ctx->pass_seg ? ctx->d_recs_all : ctx->d_f, ctx->d_b, ctx->d_regmask, ctx->d_tile_hist,
                                    ctx->pass_seg ? ctx->d_pos : (const int32_t*) nullptr);
             }
             NbTables nt;
@@ -1705,6 +1831,11 @@ int hf_get_stats_mode(const hf_ctx* ctx) {
 }
 
 int hf_seg_launches(const hf_ctx* ctx) { return !ctx || !seg_pass(ctx) ? 0 : (ctx->seg_fused ? 1 : 2); }
+int hf_sub_passes(const hf_ctx* ctx) { return !ctx || !seg_pass(ctx) ? 0 : (int) ctx->subs.size(); }
+int64_t hf_sub_pass_windows(const hf_ctx* ctx, int k) {
+    if (!ctx || k < 0 || (size_t) k >= ctx->subs.size()) return 0;
+    return ctx->h_off[(size_t) ctx->subs[(size_t) k].c1] - ctx->h_off[(size_t) ctx->subs[(size_t) k].c0];
+}
 int hf_seg_cached_steps(const hf_ctx* ctx) { return !ctx || !seg_pass(ctx) || !ctx->seg_fused ? 0 : ctx->seg_nc; }
 
 int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
@@ -2132,6 +2263,19 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
     if (scales_host && !ctx->fb_recs) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
     if (!f_host && !b_host && !ctx->fb_recs) return HF_OK;
     if (ctx->fb_recs) {   // pair records (hf_seg.h): b_t is the second half of the record at pos[t], f_t the first half of the one at pos_f[t]
+        if (!ctx->recs_all) {
+            // the last full pass ran in sub-passes through the pass buffer: only its last sub-pass's records are left.  The segment kernel once
+            // more over all segments, into the all-windows buffer (the tables of the pass are still in place: rows of A, parameters; labels,
+            // scales and log-likelihood partials are rewritten with the same values)
+            const int rc_ = all_records_buffer(ctx);
+            if (rc_) return rc_;
+            if (!ctx->seg_fused) hipLaunchKernelGGL(k_seg_prod, dim3((unsigned) ctx->nseg), dim3(64), seg_lds_bytes(), nullptr, ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
+            const unsigned epoch = ++ctx->seg_epoch;
+            launch_seg_fb(ctx, nullptr, true, ctx->d_recs_all, 0, ctx->nseg, epoch, epoch, false);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(nullptr));
+            ctx->recs_all = true;
+        }
         // the positions of a range are scattered over the plan: gathered on the device, one copy back (maps uploaded on first use)
         if (!ctx->d_slot_of) {
             HIPCHK(hipMalloc((void**) &ctx->d_slot_of, (size_t) ctx->N * 4));
@@ -2143,7 +2287,7 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
         double* d_out = nullptr;
         HIPCHK(hipMalloc((void**) &d_out, (size_t) n * 9 * 8));
         hipLaunchKernelGGL(k_gather_fb, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, first, n, ctx->d_pos, ctx->d_pos_f, ctx->d_slot_of,
-                           ctx->d_recs, ctx->d_scale_s, d_out, d_out + n * 4, d_out + n * 8);
+                           ctx->d_recs_all, ctx->d_scale_s, d_out, d_out + n * 4, d_out + n * 8);
         hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
         if (f_host) e1 = hipMemcpy(f_host, d_out, (size_t) n * 32, hipMemcpyDeviceToHost);
         if (b_host) e2 = hipMemcpy(b_host, d_out + n * 4, (size_t) n * 32, hipMemcpyDeviceToHost);

@@ -94,13 +94,14 @@ __global__ void __launch_bounds__(256) k_pair_sums(int n_groups, const int32_t* 
 // 16 groups per wavefront, the wavefront runs as long as its largest group (<= 64 pairs).  The quad multiplies by its row of A
 // and writes its group's 128 bytes.
 __global__ void __launch_bounds__(256) k_pair_sums_compact(int n_groups, const int32_t* __restrict__ grp_ar, const int32_t* __restrict__ grp_off,
+                                                           const int32_t* __restrict__ grp_n,
                                                            const double* __restrict__ lutA, const double* __restrict__ recs,
                                                            double* __restrict__ grp_sums) {
     const int wave = (int) ((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     const int ql = lane & 3, g = wave * 16 + (lane >> 2);
     const int pi = ql & 1, si = ql >> 1;
     int base = 0, n = 0;
-    if (g < n_groups) { base = grp_off[g]; n = grp_off[g + 1] - base; }
+    if (g < n_groups) { base = grp_off[g]; n = grp_n[g]; }   // (its own count: behind a sub-pass's last group come that sub-pass's spare records, not the next group)
     const double2* __restrict__ R2 = reinterpret_cast<const double2*>(recs) + (int64_t) base * 4 + ql;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int k0 = 0; __any(k0 < n); k0 += 4) {

@@ -509,7 +509,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                                                            const double* __restrict__ Qs, double* Pseg, unsigned* ready, unsigned epoch, unsigned wait_epoch,
                                                            const int32_t* __restrict__ pos, double* __restrict__ recs, double* __restrict__ scale_s,
                                                            int8_t* __restrict__ label, double* __restrict__ seg_ll,
-                                                           unsigned* __restrict__ flags, int32_t trash0, int nc) {
+                                                           unsigned* __restrict__ flags, int32_t g0, int nc) {
     constexpr int LM = HF_SEG_LMAX;
     extern __shared__ __attribute__((aligned(16))) double s_W[];
     // nc (wave-uniform, hf_create): the rows of the lane's steps 0 .. nc-1 stay in LDS blocks 0 .. nc-1 after the first walk (one-launch mode
@@ -520,7 +520,10 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     int8_t* __restrict__ s_lab = reinterpret_cast<int8_t*>(s_W + (nc + 1) * 1024) + 64 * LM * 4;   // [64 * LM] labels of the segment
     double* s_P = blk;                                                        // prologue (two launches): the chunk's segment products, in the (still idle) row block
     double* __restrict__ s_T = reinterpret_cast<double*>(s_lab);             // phase B: the suffix products of rows 1..3 (384 of the label area's 512 bytes, idle until phase D)
-    const int g = blockIdx.x, lane = threadIdx.x;
+    // g0: the launch's first segment (round 5: a context whose pair records exceed the Infinity Cache runs the pass in SUB-PASSES of whole
+    // chunks — k_seg_fb, then k_pair_sums, per sub-pass — through one record buffer that holds a sub-pass at a time; `recs` then points
+    // p0 records before the buffer, so that the plan's global positions land inside it: hf_estep.hip enqueue_pass)
+    const int g = (int) blockIdx.x + g0, lane = threadIdx.x;
     const SegDesc d = sd[g];
     const int L = d.L, n = d.n;
     const int a = lane * L;
@@ -811,9 +814,9 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + lane;
             const double2 v0 = img[0], v1 = img[64], v2 = img[128], v3 = img[192];
             double2* __restrict__ R2 = reinterpret_cast<double2*>(recs) + (lane & 3);
-            // lanes without a window k write THE SEGMENT'S SPARE RECORD (position trash0 + g, behind the plan's positions) and a padding slot
+            // lanes without a window k write THE SEGMENT'S SPARE RECORD (SegDesc.trash_pos, behind the sub-pass's positions) and a padding slot
             // of the scales (a segment owns 64 L slots): straight-line stores instead of five regions of masked execution per step
-            const int32_t pact = act ? pk : trash0 + g;     // the record of lane r goes to position pact(r): lanes 4r .. 4r+3 of instruction r >> 4
+            const int32_t pact = act ? pk : d.trash_pos;    // the record of lane r goes to position pact(r): lanes 4r .. 4r+3 of instruction r >> 4
             const int32_t p0 = __shfl(pact, lane >> 2), p1 = __shfl(pact, 16 + (lane >> 2)), p2 = __shfl(pact, 32 + (lane >> 2)), p3 = __shfl(pact, 48 + (lane >> 2));
             R2[(int64_t) p0 * 4] = v0;
             R2[(int64_t) p1 * 4] = v1;

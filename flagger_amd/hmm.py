@@ -357,6 +357,14 @@ class EMList:
         """Row blocks a segment workgroup keeps in LDS across its three walks (hf_seg_cached_steps; 0 on a device full of segments)."""
         return int(self._L.hf_seg_cached_steps(self._h))
 
+    @property
+    def sub_passes(self) -> int:
+        """Sub-passes of a full pass (hf_sub_passes: 1 unless the pair records would not fit the Infinity Cache)."""
+        return int(self._L.hf_sub_passes(self._h))
+
+    def sub_pass_windows(self, k: int = 0) -> int:
+        return int(self._L.hf_sub_pass_windows(self._h, int(k)))
+
     # --- E-step pieces (used directly by the multi-GPU path in dist.py) ---
     def launch(self, model: HMM, mode: int = N.HF_MODE_FULL) -> None:
         p = model.params()

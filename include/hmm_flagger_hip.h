@@ -206,6 +206,12 @@ int hf_seg_launches(const hf_ctx *ctx);
  * instead of fetching them again: hf_create's choice — the largest number at which all segments are still resident together, 0 on a
  * device full of segments, 8 for the reference's default window length or a 1/8 shard (environment HF_SEG_CACHED_STEPS forces it). */
 int hf_seg_cached_steps(const hf_ctx *ctx);
+/* Sub-passes of a full pass: a context whose pair records (64 bytes per window) would not fit the 256 MB Infinity Cache — more than ~2.2 M
+ * windows on one GPU — cuts its chunk list into sub-passes of whole chunks (<= ~1.6 M windows each) and runs the segment kernel and the
+ * per-group sums sub-pass by sub-pass through one record buffer; 1 for BASELINE configs[2] (environment HF_SUBPASSES forces a number).
+ * hf_sub_pass_windows: the windows of sub-pass k (what ONE launch of the segment kernel processes: hf_set_profiling times the first). */
+int hf_sub_passes(const hf_ctx *ctx);
+int64_t hf_sub_pass_windows(const hf_ctx *ctx, int k);
 
 /* Results of the last HF_MODE_FULL pass (HF_E_ARG when the last pass was HF_MODE_FORWARD_ONLY: f and scales would be new,
  * b and the labels stale). */

@@ -858,3 +858,65 @@ def test_host_summed_total_equals_the_device_total_bit_for_bit(monkeypatch):
                 em.close(); other.close()
         assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]), (K, store.n_regions)
     monkeypatch.delenv("HF_TOTAL", raising=False)
+
+
+def test_sub_passes_through_one_record_buffer(monkeypatch):
+    """VERDICT r04 #5 (inputs past the Infinity Cache).  A context with more than ~2.2 M windows runs a full pass in SUB-PASSES of whole chunks —
+    k_seg_fb then k_pair_sums per sub-pass through one record buffer that holds a sub-pass at a time (hf_sub_passes).  Forced here on small
+    inputs (HF_SUBPASSES): the statistics regroup the pairs per sub-pass, so they equal the one-sub-pass run to rounding (1e-12) and the oracle
+    to 1e-9; labels, forward / backward vectors, scales, posteriors and the forward-only log-likelihood are the SAME BITS (the segment kernel does
+    not depend on where a record goes); the getters fetch ranges that span sub-passes (the segment kernel runs once more, into the all-windows
+    buffer); per-chunk statistics, the negative-binomial model, a compact plan and seven regions take the same route."""
+    cases = [(synth.config(2, scale=0.03), hmm.MODEL_TRUNC_EXP_GAUSSIAN, synth.HIFI_ALPHA, None, 0.95, None),
+             (synth.config(4, scale=0.03), hmm.MODEL_TRUNC_EXP_GAUSSIAN, synth.ONT_R10_ALPHA, None, 0.8, None),
+             (synth.config(5, scale=0.02), hmm.MODEL_TRUNC_EXP_GAUSSIAN, synth.ONT_R10_ALPHA, None, 0.8, "compact"),
+             (synth.config(2, scale=0.01), hmm.MODEL_NEGATIVE_BINOMIAL, np.zeros((4, 4)), 5, 0.95, None)]
+    for store, mt, alpha, K, frac, plan in cases:
+        K = hmm.getBestNumberOfCollapsedComps(store) if K is None else K
+        model = hmm.createModel(mt, K, store, alpha)
+        if plan:
+            monkeypatch.setenv("HF_STATS_PLAN", plan)
+        orc = Oracle(store, mt, K, alpha, 0.25, 0.75, True, frac, threads=8)
+        try:
+            assert orc.run_iteration() == 0
+            ref = orc.stats_vector(model.maxNumberOfComps)
+            scale = np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+            base = None
+            for S in (1, 2, 3, 7):
+                monkeypatch.setenv("HF_SUBPASSES", str(S))
+                em = hmm.EMList(store, model, True, frac)
+                try:
+                    assert em.sub_passes == min(S, store.n_chunks)
+                    assert sum(em.sub_pass_windows(k) for k in range(em.sub_passes)) == store.n_windows
+                    em.launch(model); st = em.finish().copy()
+                    assert np.all(np.abs(st - ref) <= STAT_RTOL * scale), (S, np.max(np.abs(st - ref) / scale))
+                    lab = em.labels().copy()
+                    assert np.array_equal(lab, orc.labels()), S
+                    n = store.n_windows
+                    f, b, sc = em.forward_backward()
+                    f1, b1, s1 = em.forward_backward(n // 3, n // 2)                 # a range across sub-pass boundaries
+                    assert np.array_equal(f1, f[n // 3:n // 3 + n // 2]) and np.array_equal(b1, b[n // 3:n // 3 + n // 2])
+                    post = em.posterior(5, 1000)
+                    em.launch(model); st2 = em.finish().copy()                       # a pass after the getters' own run of the segment kernel
+                    assert np.array_equal(st2, st)
+                    em.set_stats_mode(N.HF_STATS_CHUNKS)
+                    em.launch(model); stc = em.finish().copy()
+                    assert np.all(np.abs(stc - ref) <= STAT_RTOL * scale), S
+                    assert np.array_equal(em.labels(), lab)
+                    fc, bc, scc = em.forward_backward(7, 500)
+                    assert np.array_equal(fc, f[7:507]) and np.array_equal(bc, b[7:507])
+                    em.set_stats_mode(N.HF_STATS_ROWS)
+                    em.launch(model, N.HF_MODE_FORWARD_ONLY); fwd = em.finish().copy()
+                    got = (lab, f, b, sc, post, fwd[0])
+                    if base is None:
+                        base, st_base = got, st
+                    else:
+                        for x, y in zip(base, got):
+                            assert np.array_equal(x, y), S
+                        assert np.all(np.abs(st - st_base) <= 1e-11 * scale), S
+                finally:
+                    em.close()
+        finally:
+            orc.close()
+            monkeypatch.delenv("HF_STATS_PLAN", raising=False)
+    monkeypatch.delenv("HF_SUBPASSES", raising=False)
