@@ -18,6 +18,11 @@ for seed in range(first, first + count):
     plan = PLANS[seed % len(PLANS)]
     if plan: os.environ["HF_STATS_PLAN"] = plan
     else: os.environ.pop("HF_STATS_PLAN", None)
+    # round 5: forced sub-passes (hf_sub_passes) and cached row blocks (hf_seg_cached_steps) as further axes of the seed
+    sp, ncs = [None, "1", "2", "3", "5"][(seed // 5) % 5], [None, "0", "2", "8"][(seed // 3) % 4]
+    for k, v in (("HF_SUBPASSES", sp), ("HF_SEG_CACHED_STEPS", ncs)):
+        if v is None: os.environ.pop(k, None)
+        else: os.environ[k] = v
     window_len = int(rng.choice([500, 1000, 4000]))
     chunk_len = int(rng.choice([20, 77, 300])) * window_len
     lengths = [int(rng.integers(2, 3000)) * window_len + int(rng.integers(0, window_len)) for _ in range(int(rng.integers(1, 6)))]
