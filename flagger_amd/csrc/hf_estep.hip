@@ -138,11 +138,14 @@ struct PinCache {
 };
 PinCache& pin_cache() { static PinCache* c = new PinCache(); return *c; }   // (never destroyed: the process leaves without unwinding HIP)
 
-// Validity masks of hmm_utils.c:2229-2254 by table: bits 0, 1 from (coverage, high-mapq coverage), bit 2 from (coverage, clipped coverage), every
-// value below 256 — the reference's own divisions and comparisons, evaluated once per (thresholds) instead of twice per window.
+// Validity masks of hmm_utils.c:2229-2254 by THRESHOLD per coverage value (every value below 256): the ratio v / (0.1 + cv) is monotone in v,
+// so "Dup valid" = !(ratio > max_mapq) holds for v up to a largest value, "Col valid" = !(ratio < min_mapq) and "End valid" = !(ratio <
+// min_clip) from a smallest value on — found with window_record's own divisions and comparisons, once per set of thresholds; the first pass
+// of hf_create then needs three byte-sized table entries of its window's coverage (768 bytes: L1) instead of two divisions.
 struct ValidityLut {
     double max_mapq = -1.0, min_mapq = -1.0, min_clip = -1.0;
-    std::vector<uint8_t> m, c;      // [cv << 8 | mq] -> bits 0, 1;  [cv << 8 | cp] -> bit 2
+    uint16_t dup_le[256], col_ge[256], end_ge[256];     // Dup valid iff mq <= dup_le[cv] (0xffff: never... see below); Col iff mq >= col_ge[cv]; End iff cp >= end_ge[cv]
+    bool monotone = true;                               // (false: a NaN threshold or the like broke the monotone pattern — hf_create then takes window_record everywhere)
 };
 std::shared_ptr<const ValidityLut> validity_lut(double max_mapq, double min_mapq, double min_clip) {
     static std::mutex mu;
@@ -151,13 +154,20 @@ std::shared_ptr<const ValidityLut> validity_lut(double max_mapq, double min_mapq
     if (cached && cached->max_mapq == max_mapq && cached->min_mapq == min_mapq && cached->min_clip == min_clip) return cached;
     auto L = std::make_shared<ValidityLut>();
     L->max_mapq = max_mapq; L->min_mapq = min_mapq; L->min_clip = min_clip;
-    L->m.resize(65536); L->c.resize(65536);
-    for (unsigned cv = 0; cv < 256; cv++)
+    for (unsigned cv = 0; cv < 256; cv++) {
+        int n_dup = 0, n_col = 0, n_end = 0;            // values v for which the bit is set; then check that they form a prefix / suffixes
+        bool dup[256], col[256], end[256];
         for (unsigned v = 0; v < 256; v++) {
             const double ratio = (double) v / (0.1 + cv);                 // window_record's own expressions
-            L->m[(cv << 8) | v] = (uint8_t) ((!(ratio > max_mapq) ? 1u : 0u) | (!(ratio < min_mapq) ? 2u : 0u));
-            L->c[(cv << 8) | v] = (uint8_t) (!(ratio < min_clip) ? 4u : 0u);
+            dup[v] = !(ratio > max_mapq); col[v] = !(ratio < min_mapq); end[v] = !(ratio < min_clip);
+            n_dup += dup[v]; n_col += col[v]; n_end += end[v];
         }
+        for (unsigned v = 0; v < 256; v++)
+            if (dup[v] != ((int) v < n_dup) || col[v] != ((int) v >= 256 - n_col) || end[v] != ((int) v >= 256 - n_end)) L->monotone = false;
+        L->dup_le[cv] = (uint16_t) (n_dup - 1 < 0 ? 0xffff : n_dup - 1);   // 0xffff: no value is valid (compared as signed below)
+        L->col_ge[cv] = (uint16_t) (256 - n_col);                          // 256: no value
+        L->end_ge[cv] = (uint16_t) (256 - n_end);
+    }
     cached = L;
     return cached;
 }
@@ -742,24 +752,32 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             // windows, and which (region, x, x_prev) emission keys and (key, transition class) rows of A occur (tables at a stride
             // of 256 per coverage value: the largest coverage is only known afterwards)
             const std::shared_ptr<const ValidityLut> vlut = validity_lut(w->max_high_mapq_ratio, w->min_high_mapq_ratio, w->min_highly_clipped_ratio);
-            const uint8_t* const lut_m = vlut->m.data();
-            const uint8_t* const lut_c = vlut->c.data();
+            const bool lut_ok = vlut->monotone;
             par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
                 bool big = false, badr = false;
                 unsigned mx = 0;
                 std::vector<int64_t>& mine = part_slow[part];
-                uint8_t* const seen_p = seen256.data();
-                uint8_t* const mark_p = mark256.data();
+                // (everything the loop touches through LOCAL restrict pointers: the key tables are bytes, and a byte store may alias anything a
+                // closure or a struct holds — the compiler reloaded every base pointer in every iteration; 2.4 -> ~0.5 ms per pass on one box)
+                uint8_t* const __restrict__ seen_p = seen256.data();
+                uint8_t* const __restrict__ mark_p = mark256.data();
+                const uint16_t* const __restrict__ covp = w->cov; const uint16_t* const __restrict__ mqp = w->mapq; const uint16_t* const __restrict__ clp = w->clip;
+                const uint64_t* const __restrict__ annp = w->annot;
+                uint32_t* const __restrict__ stagep = stage; uint32_t* const __restrict__ hrecp = hrec_w;
+                const int16_t* const __restrict__ dup_le = reinterpret_cast<const int16_t*>(vlut->dup_le);
+                const uint16_t* const __restrict__ col_ge = vlut->col_ge; const uint16_t* const __restrict__ end_ge = vlut->end_ge;
+                const unsigned nreg = (unsigned) n_regions;
                 for (size_t c = c0; c < c1; c++) {
                     const size_t before = mine.size();
                     const size_t t0 = (size_t) w->chunk_off[c], te = (size_t) w->chunk_off[c + 1];
                     const int cs_ = w->chunk_s[c], ce_ = w->chunk_e[c], cl_ = w->chunk_ctg_len[c];
                     // INTERIOR columns [ia, ib): beta_t is beta_star by construction (hmm.c:301-316: l = mid - L + 1 and u = mid, so u - l = L - 1)
                     // — mid is non-decreasing in the column, so the two conditions cut a prefix and a suffix of the chunk.  Those windows take
-                    // their record from the validity tables (no division, no beta arithmetic); the others — and any window with a value above
-                    // 255 — go through window_record, the function k_setup runs.  The result is the same bits either way (HF_CREATE_VERIFY).
+                    // their record from the validity thresholds (no division, no beta arithmetic); the others — and any window with a value
+                    // above 255 — go through window_record, the function k_setup runs.  The result is the same bits either way (HF_CREATE_VERIFY).
                     int64_t ia = 1, ib = (int64_t) (te - t0);
-                    if (w->adjust_contig_ends) {
+                    if (!lut_ok) ib = ia;
+                    else if (w->adjust_contig_ends) {
                         const int Lr = w->mean_read_len;
                         const int l2 = (int) (-(1 - w->min_read_frac) * Lr), u2 = (int) (cl_ - w->min_read_frac * Lr);
                         auto mid_of = [&](int64_t col) {
@@ -772,35 +790,49 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                         while (ib > ia && !(mid_of(ib - 1) <= u2)) ib--;
                     }
                     unsigned pre_region = 0, xp = 0;
-                    for (size_t t = t0; t < te; t++) {
-                        const unsigned cv = w->cov[t], mq = w->mapq[t], cp = w->clip[t];
-                        const unsigned region = (unsigned) (w->annot[t] >> 58);
+                    auto slow_window = [&](size_t t) {              // the general path: window_record
+                        const unsigned cv = covp[t], mq = mqp[t], cp = clp[t];
+                        const unsigned region = (unsigned) (annp[t] >> 58);
                         const unsigned x = cv & 0xffu;
-                        const bool wide_v = (cv | mq | cp) > 0xffu;
-                        big |= wide_v;
+                        big |= (cv | mq | cp) > 0xffu;
                         if (x > mx) mx = x;
-                        stage[t] = cv | (mq << 8) | (cp << 16) | (region << 24);
-                        const int64_t col = (int64_t) (t - t0);
-                        uint32_t r;
-                        if (col >= ia && col < ib && !wide_v) {
-                            r = cv | (region << 8) | ((uint32_t) (lut_m[(cv << 8) | mq] | lut_c[(cv << 8) | cp]) << 16) | (pre_region != region ? 1u << 20 : 0u);
-                        } else {
-                            double bt;
-                            r = window_record(cv, mq, cp, region, pre_region, col, cs_, ce_, cl_, w->window_len,
-                                              w->mean_read_len, w->adjust_contig_ends, w->min_read_frac, w->max_high_mapq_ratio,
-                                              w->min_high_mapq_ratio, w->min_highly_clipped_ratio, ctx->beta_star, &bt);
-                        }
-                        hrec_w[t] = r;
-                        if (region >= (unsigned) n_regions) badr = true;
+                        stagep[t] = cv | (mq << 8) | (cp << 16) | (region << 24);
+                        double bt;
+                        const uint32_t r = window_record(cv, mq, cp, region, pre_region, (int64_t) (t - t0), cs_, ce_, cl_, w->window_len,
+                                                         w->mean_read_len, w->adjust_contig_ends, w->min_read_frac, w->max_high_mapq_ratio,
+                                                         w->min_high_mapq_ratio, w->min_highly_clipped_ratio, ctx->beta_star, &bt);
+                        hrecp[t] = r;
+                        if (region >= nreg) badr = true;
                         else if (REC_SLOW(r)) mine.push_back((int64_t) t);
                         else {
                             const size_t key = ((size_t) region << 16) | (x << 8) | xp;
-                            if (!__atomic_load_n(seen_p + key, __ATOMIC_RELAXED)) __atomic_store_n(seen_p + key, (uint8_t) 1, __ATOMIC_RELAXED);   // a few thousand cells, all threads: read-mostly
+                            if (!seen_p[key]) __atomic_store_n(seen_p + key, (uint8_t) 1, __ATOMIC_RELAXED);   // a few thousand cells, all threads: read-mostly
                             uint8_t* const cell = mark_p + key * HF_AROW_CLASSES + (REC_REGCHG(r) ? 8u : REC_VMASK(r));
-                            if (!__atomic_load_n(cell, __ATOMIC_RELAXED)) __atomic_store_n(cell, (uint8_t) 1, __ATOMIC_RELAXED);
+                            if (!*cell) __atomic_store_n(cell, (uint8_t) 1, __ATOMIC_RELAXED);
                         }
                         pre_region = region; xp = x;
+                    };
+                    const size_t ta = t0 + (size_t) ia < te ? t0 + (size_t) ia : te, tb = t0 + (size_t) ib > ta ? t0 + (size_t) ib : ta;
+                    for (size_t t = t0; t < ta; t++) slow_window(t);
+                    for (size_t t = ta; t < tb; t++) {              // the interior: thresholds, no beta, never slow
+                        const unsigned cv = covp[t], mq = mqp[t], cp = clp[t];
+                        if ((cv | mq | cp) > 0xffu) { slow_window(t); continue; }
+                        const unsigned region = (unsigned) (annp[t] >> 58);
+                        if (cv > mx) mx = cv;
+                        stagep[t] = cv | (mq << 8) | (cp << 16) | (region << 24);
+                        const unsigned vm = ((int) mq <= (int) dup_le[cv] ? 1u : 0u) | (mq >= col_ge[cv] ? 2u : 0u) | (cp >= end_ge[cv] ? 4u : 0u);
+                        const bool regchg = pre_region != region;
+                        hrecp[t] = cv | (region << 8) | (vm << 16) | (regchg ? 1u << 20 : 0u);
+                        if (region >= nreg) badr = true;
+                        else {
+                            const size_t key = ((size_t) region << 16) | (cv << 8) | xp;
+                            if (!seen_p[key]) __atomic_store_n(seen_p + key, (uint8_t) 1, __ATOMIC_RELAXED);
+                            uint8_t* const cell = mark_p + key * HF_AROW_CLASSES + (regchg ? 8u : vm);
+                            if (!*cell) __atomic_store_n(cell, (uint8_t) 1, __ATOMIC_RELAXED);
+                        }
+                        pre_region = region; xp = cv;
                     }
+                    for (size_t t = tb; t < te; t++) slow_window(t);
                     nslow[c] = (int32_t) (mine.size() - before);
                 }
                 if (big) wide.store(1, std::memory_order_relaxed);
