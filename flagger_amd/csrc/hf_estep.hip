@@ -509,12 +509,13 @@ static void launch_seg_fb(hf_ctx* ctx, hipStream_t st, bool full, double* recs_e
     const size_t lds = seg_lds_bytes(nc);
 #define HF_SEG_FB_ARGS ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_seg_ready, epoch, wait_epoch, ctx->d_pos, recs_eff, \
                         ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags, (int32_t) g0, nc
-#define HF_SEG_FB_LAUNCH(B, F) do { \
-        if (timed) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) n), dim3(64), (uint32_t) lds, st, \
+#define HF_SEG_FB_LAUNCH(B, F, CA) do { \
+        if (timed) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F, CA>), dim3((unsigned) n), dim3(64), (uint32_t) lds, st, \
                                          ctx->kev[2 * HF_K_SEG_FB], ctx->kev[2 * HF_K_SEG_FB + 1], 0, HF_SEG_FB_ARGS); \
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F>), dim3((unsigned) n), dim3(64), lds, st, HF_SEG_FB_ARGS); } while (0)
-    if (full) { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(true, true); else HF_SEG_FB_LAUNCH(true, false); }
-    else { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(false, true); else HF_SEG_FB_LAUNCH(false, false); }
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F, CA>), dim3((unsigned) n), dim3(64), lds, st, HF_SEG_FB_ARGS); } while (0)
+    if (nc > 0) { if (full) HF_SEG_FB_LAUNCH(true, true, true); else HF_SEG_FB_LAUNCH(false, true, true); }
+    else if (full) { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(true, true, false); else HF_SEG_FB_LAUNCH(true, false, false); }
+    else { if (ctx->seg_fused) HF_SEG_FB_LAUNCH(false, true, false); else HF_SEG_FB_LAUNCH(false, false, false); }
 #undef HF_SEG_FB_LAUNCH
 #undef HF_SEG_FB_ARGS
 }
@@ -1425,11 +1426,11 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             for (int c = HF_SEG_LMAX; c >= 1; c--) {
                 const size_t lds = seg_lds_bytes(c);
                 if (lds > ctx->lds_max && lds > 64 * 1024) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess ||
-                        hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) { (void) hipGetLastError(); continue; }
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess ||
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess) { (void) hipGetLastError(); continue; }
                 }
                 int pc = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_seg_fb<true, true>, 64, lds) != hipSuccess) { (void) hipGetLastError(); continue; }
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pc, k_seg_fb<true, true, true>, 64, lds) != hipSuccess) { (void) hipGetLastError(); continue; }
                 int64_t res_c = (int64_t) pc * cus;
                 if (std::getenv("HF_SEG_RESIDENT") && per_cu > 0) res_c = resident * pc / per_cu;     // the pretended device, scaled alike
                 // 15 % of room to spare: where the segments filled the device to the last workgroup the API allows (1 531 segments at six
@@ -1442,8 +1443,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 if (v >= 0 && v <= HF_SEG_LMAX) nc = v;
                 const size_t lds = seg_lds_bytes(nc);
                 if (lds > 64 * 1024 &&
-                    (hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess ||
-                     hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess)) { (void) hipGetLastError(); nc = 0; }
+                    (hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess ||
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(k_seg_fb<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess)) { (void) hipGetLastError(); nc = 0; }
             }
         }
         ctx->seg_nc = nc;

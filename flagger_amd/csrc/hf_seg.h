@@ -425,19 +425,29 @@ __device__ __forceinline__ void seg_suffix_apply(const double u[4], const double
 // together, at most seven steps = 56 DMA instructions in flight (vmcnt counts 63); a further step is issued as soon as its block is free.
 // On entry nothing has been issued; on return nothing is in flight and blocks 0 .. nc-1 hold the rows of steps 0 .. nc-1.
 // ------------------------------------------------------------------------------------------
+template <bool CACHED>
 __device__ __forceinline__ void seg_lane_product(const RowFetch& F, const double* s_rows, int lane, int L, bool chunk_first, M4& Q) {
     double E[16];
     M4 A, R;
 #define HF_ROW_TO_M4(dst) _Pragma("unroll") for (int k_ = 0; k_ < 16; k_++) (dst).m[k_] = E[HF_PS(k_ >> 2, k_ & 3)]
-    int issued = F.nc + 1 < L ? F.nc + 1 : L;
-    if (issued > 7) issued = 7;
-    for (int st = 0; st < issued; st++) rows_issue(F, st);
+    int issued = 1;
+    if constexpr (CACHED) {
+        issued = F.nc + 1 < L ? F.nc + 1 : L;
+        if (issued > 7) issued = 7;
+        for (int st = 0; st < issued; st++) rows_issue(F, st);
+    } else rows_issue(F, 0);
     // step i: wait for its rows, read them, issue the next step whose block is free (a block of its own, or the streaming block once
-    // the step before it has been read out)
+    // the step before it has been read out).  Without cached blocks: one block, the next step's fetch issued behind every read — no counting
     auto step_rows = [&](int i) {
-        rows_wait(issued - i - 1);
-        rows_read(F, s_rows, i, lane, E);
-        if (issued < L && (issued <= F.nc || issued - 1 <= i)) { rows_issue(F, issued); issued++; }
+        if constexpr (CACHED) {
+            rows_wait(issued - i - 1);
+            rows_read(F, s_rows, i, lane, E);
+            if (issued < L && (issued <= F.nc || issued - 1 <= i)) { rows_issue(F, issued); issued++; }
+        } else {
+            rows_wait(0);
+            rows_read(F, s_rows, i, lane, E);
+            if (i + 1 < L) rows_issue(F, i + 1);
+        }
     };
     step_rows(0);
     HF_ROW_TO_M4(Q);                                             // the first factor: no product with the identity
@@ -484,7 +494,7 @@ __global__ void __launch_bounds__(64, 4) k_seg_prod(const SegDesc* __restrict__ 
     }
     const RowFetch F = rowfetch_init(lutA, s_off, blk, 0, lane);
     M4 Q;
-    seg_lane_product(F, blk, lane, L, a == 0 && d.k == 0, Q);      // the chunk's first window starts the chain (hmm.c:333-364)
+    seg_lane_product<false>(F, blk, lane, L, a == 0 && d.k == 0, Q);   // the chunk's first window starts the chain (hmm.c:333-364)
     {
         double2* __restrict__ dst = reinterpret_cast<double2*>(Qs) + (int64_t) g * 8 * 64 + lane;
 #pragma unroll
@@ -503,13 +513,17 @@ __global__ void __launch_bounds__(64, 4) k_seg_prod(const SegDesc* __restrict__ 
 // k_seg_fb: one workgroup per segment: phases B-D of the header.  BWD = false: forward only (EM_runForwardForList,
 // hmm.c:790-816): log-likelihood and error flags, nothing else is written.
 // ------------------------------------------------------------------------------------------
-template <bool BWD, bool FUSED>
+// CACHED = false: nc is the constant 0 (a device full of segments: BASELINE configs[2]) — with nc a run-time value the same kernel was 4-5 us
+// slower at that size (scalar branches and block arithmetic in every step of the three walks; profiles/r05_ab_segfb_regression.txt)
+template <bool BWD, bool FUSED, bool CACHED = false>
 __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __restrict__ sd, const int32_t* __restrict__ arow,
                                                            const double* __restrict__ lutA, const DevParams* __restrict__ P,
                                                            const double* __restrict__ Qs, double* Pseg, unsigned* ready, unsigned epoch, unsigned wait_epoch,
                                                            const int32_t* __restrict__ pos, double* __restrict__ recs, double* __restrict__ scale_s,
                                                            int8_t* __restrict__ label, double* __restrict__ seg_ll,
-                                                           unsigned* __restrict__ flags, int32_t g0, int nc) {
+                                                           unsigned* __restrict__ flags, int32_t g0, int nc_arg) {
+    static_assert(FUSED || !CACHED, "cached row blocks: one-launch mode only");
+    const int nc = CACHED ? nc_arg : 0;
     constexpr int LM = HF_SEG_LMAX;
     extern __shared__ __attribute__((aligned(16))) double s_W[];
     // nc (wave-uniform, hf_create): the rows of the lane's steps 0 .. nc-1 stay in LDS blocks 0 .. nc-1 after the first walk (one-launch mode
@@ -553,7 +567,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             // ---- A (one launch): the lane product is computed here (k_seg_prod's loop); the segment's product is what the prefix
             // scan leaves in lane 63: it is PUBLISHED for the chunk's other segments, theirs are awaited (seg_gather) ----
             seg_offsets_store(rr, L, lane, s_off);
-            seg_lane_product(F, s_rows, lane, L, chunk_first, Q);
+            seg_lane_product<CACHED>(F, s_rows, lane, L, chunk_first, Q);
             TR_STAMP(1);
             if (BWD) m4_park(Q, lane, blk);
             m4_scan_prefix(Q, lane);
@@ -712,8 +726,6 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     // ---- C: forward replay (hmm.c:333-434).  fs[i], ss[i]: forward vector and scale of the lane's i-th window (registers) ----
     double f[4] = {fin[0], fin[1], fin[2], fin[3]};
     double fs[LM][4], ss[LM];
-#pragma unroll
-    for (int i = 0; i < LM; i++) { ss[i] = 0.0; fs[i][0] = fs[i][1] = fs[i][2] = fs[i][3] = 0.0; }   // (lanes without a window i store these to the spare record: defined values)
     double A[16];
     // log-likelihood of the lane's windows: sum of log(scale) (hmm.c:428) as log(product of the mantissas) + (sum of the
     // exponents)·ln 2 — one log per lane instead of one (~95 instructions) per window; <= HF_SEG_LMAX mantissas in [0.5, 1)
@@ -741,16 +753,14 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 const double sc = ((nf[0] + nf[1]) + nf[2]) + nf[3];
                 if (!(chunk_first && i == 0) && sc < 1e-50) bad |= HF_FLAG_SCALE;   // hmm.c:412-415 (not at the chunk's first window)
                 if (!(sc == sc)) bad |= HF_FLAG_NAN;                      // a NaN emission value (hmm_utils.c:783-786)
-                // one division per window: f = nf * (1 / sc) differs from nf / sc in the last bit at most.  A subnormal scale (possible only at a
-                // chunk's first window, which is exempt from the 1e-50 test) has no finite reciprocal: that window divides
+                // one division per window: f = nf * (1 / sc) differs from nf / sc in the last bit at most.  (ADVICE r04 asked what a SUBNORMAL scale
+                // does to the reciprocal: it cannot occur.  Only a chunk's first window is exempt from the 1e-50 test, and there the scale is a
+                // sum of start x emission values of which the Gaussian states' carry the reference's 1e-40 floor per component
+                // (hmm_utils.c:787-790): >= 0.25e-40.  The negative-binomial tables have no floor, but a zero row gives 0 / 0 in the reference too.
+                // A guard here — even in the unrolled first step only — cost the kernel 1-2 us: profiles/r05_ab_segfb_regression.txt.)
                 const double rsc = 1.0 / sc;
-                if (__builtin_expect(sc < 0x1p-1021, 0)) {
 #pragma unroll
-                    for (int s = 0; s < 4; s++) { f[s] = nf[s] / sc; fs[i][s] = f[s]; }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; s++) { f[s] = nf[s] * rsc; fs[i][s] = f[s]; }
-                }
+                for (int s = 0; s < 4; s++) { f[s] = nf[s] * rsc; fs[i][s] = f[s]; }
                 { int e2; lm *= frexp(sc, &e2); le += e2; }                // hmm.c:428, see above
                 scl = sc; ss[i] = sc;
             }
@@ -806,7 +816,13 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             double2* __restrict__ mine = reinterpret_cast<double2*>(blk) + lane * 4;
             // (rotating the pieces so that these writes are free of bank conflicts — lane by lane at a 64-byte stride they hit four banks of
             // 64 — was measured 0.3 us SLOWER, profiles/r04e_ab_variants.txt: the conflicts are not on the kernel's critical path)
-            mine[0] = make_double2(fk[0], fk[1]); mine[1] = make_double2(fk[2], fk[3]);
+            // (a lane without a window k passes forward values it never computed — they go to the segment's spare record, which nobody reads.
+            // They pass through an empty asm where they are used: to the compiler a value the asm defines — whatever the register holds,
+            // but nothing indeterminate to exploit — at no instruction; zero-filling the forty registers ahead of the replays cost
+            // the kernel ~1 us, profiles/r05_ab_segfb_regression.txt)
+            double f0 = fk[0], f1 = fk[1], f2 = fk[2], f3 = fk[3], sc_ = sck;
+            asm("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(sc_));
+            mine[0] = make_double2(f0, f1); mine[1] = make_double2(f2, f3);
             mine[2] = make_double2(b[0], b[1]); mine[3] = make_double2(b[2], b[3]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -822,7 +838,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             R2[(int64_t) p1 * 4] = v1;
             R2[(int64_t) p2 * 4] = v2;
             R2[(int64_t) p3 * 4] = v3;
-            scale_s[slot_ij + (int64_t) k * 64] = sck;   // (non-temporal stores: k_pair_sums +3.5 us, it reads these records out of the cache; profiles/r04i_ab_variants.txt)
+            scale_s[slot_ij + (int64_t) k * 64] = sc_;   // (non-temporal stores: k_pair_sums +3.5 us, it reads these records out of the cache; profiles/r04i_ab_variants.txt)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                    // the block has been read out: the next row fetch may land
         };

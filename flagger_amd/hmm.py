@@ -360,7 +360,7 @@ class EMList:
     @property
     def sub_passes(self) -> int:
         """Sub-passes of a full pass (hf_sub_passes: 1 unless the pair records would not fit the Infinity Cache)."""
-        return int(self._L.hf_sub_passes(self._h))
+        return int(self._L.hf_sub_passes(self._h)) if hasattr(self._L, "hf_sub_passes") else 1
 
     def sub_pass_windows(self, k: int = 0) -> int:
         return int(self._L.hf_sub_pass_windows(self._h, int(k)))
