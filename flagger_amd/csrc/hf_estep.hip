@@ -1438,6 +1438,10 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 // wait for each other (profiles/r05_scale_nc.txt)
                 if (res_c * 85 / 100 >= ctx->nseg) { nc = c; break; }
             }
+            // all of a lane's steps or none: with only some of them cached the kernel's run-time block arithmetic costs what the saved fetches
+            // bring (same box, 3 of 8 steps at 1/4 of configs[2]: 29.2 us against 28.9 without; all 8 at 1/8: 25.6 against 26.5 —
+            // profiles/r05g_scale_nc.txt); HF_SEG_CACHED_STEPS still forces any number
+            if (nc < HF_SEG_LMAX) nc = 0;
             if (const char* e = std::getenv("HF_SEG_CACHED_STEPS")) {
                 const int v = std::atoi(e);
                 if (v >= 0 && v <= HF_SEG_LMAX) nc = v;

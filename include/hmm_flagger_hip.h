@@ -203,8 +203,8 @@ int hf_get_stats_mode(const hf_ctx *ctx);          /* the mode the NEXT full pas
  * environment HF_SEG_LAUNCHES=2, or after a hand-off timed out), 0 = the context does not run the segment kernels (HF_ALGO_SEQ, empty). */
 int hf_seg_launches(const hf_ctx *ctx);
 /* Row blocks (of at most 8 = windows per lane) that a segment workgroup of the NEXT one-launch pass keeps in LDS across its three walks
- * instead of fetching them again: hf_create's choice — the largest number at which all segments are still resident together, 0 on a
- * device full of segments, 8 for the reference's default window length or a 1/8 shard (environment HF_SEG_CACHED_STEPS forces it). */
+ * instead of fetching them again: hf_create's choice — all 8 when every segment is still resident together with that much LDS each (up to
+ * ~430 segments on 256 CUs: a 1/8 shard of BASELINE configs[2]), 0 otherwise (environment HF_SEG_CACHED_STEPS forces any number). */
 int hf_seg_cached_steps(const hf_ctx *ctx);
 /* Sub-passes of a full pass: a context whose pair records (64 bytes per window) would not fit the 256 MB Infinity Cache — more than ~2.2 M
  * windows on one GPU — cuts its chunk list into sub-passes of whole chunks (<= ~1.6 M windows each) and runs the segment kernel and the

@@ -815,8 +815,8 @@ def test_cached_row_blocks_same_bits_and_chosen_by_residency(monkeypatch):
             em.close()
     monkeypatch.delenv("HF_SEG_RESIDENT")
     assert chosen[0] == 8 and chosen[-1] <= 0, chosen
-    assert all(a >= b for a, b in zip(chosen, chosen[1:])), chosen          # less room, fewer cached blocks
-    assert len(set(chosen)) >= 3, chosen
+    assert all(a >= b for a, b in zip(chosen, chosen[1:])), chosen          # less room: no cached blocks (all eight steps or none)
+    assert set(chosen) <= {8, 0, -1} and 0 in chosen, chosen
     # two launches (the lane products come from k_seg_prod): nothing is cached
     monkeypatch.setenv("HF_SEG_LAUNCHES", "2")
     em = hmm.EMList(store, model, True, 0.8)
