@@ -38,13 +38,14 @@
 #include <cstdlib>
 
 #include <thread>
+#include <immintrin.h>
 static thread_local std::string g_err;
 
 // hf_create's host loops over the windows are independent per chunk: run fn(first chunk, last chunk + 1, part) on up to
 // HF_PARTS threads, the chunk list cut into parts of about equal window count (1.5 M windows: 6-8 ms per loop on one thread).
 // The threads are a process-wide pool (hf_warmup starts it): spawning 16 threads per loop was measured at 1-2 ms a loop, as much
 // as the loops themselves.  A caller that finds the pool busy (hf_multi's ranks create their contexts concurrently) spawns its own.
-constexpr size_t HF_PARTS = 16;
+constexpr size_t HF_PARTS = 64;      // parts at most; host_threads() of them are used
 namespace {
 struct HostPool {
     std::mutex run_m, m;
@@ -172,10 +173,21 @@ std::shared_ptr<const ValidityLut> validity_lut(double max_mapq, double min_mapq
     return cached;
 }
 }
+// threads of hf_create's passes over the windows: 16 (what rounds 2-4 used), fewer on a smaller host; HF_HOST_THREADS=n (<= 64) overrides
+static size_t host_threads() {
+    static const size_t n = [] {
+        const unsigned hw = std::thread::hardware_concurrency();
+        size_t t = std::min<size_t>(16, hw ? hw : 1);
+        if (const char* e = std::getenv("HF_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1) t = std::min<size_t>((size_t) v, HF_PARTS); }
+        return t;
+    }();
+    return n;
+}
 template <class Fn>
 static void par_chunks(const int64_t* chunk_off, size_t C, Fn fn) {
     const unsigned hw = std::thread::hardware_concurrency();
-    const size_t T = C < 16 ? 1 : std::min<size_t>(HF_PARTS, hw ? hw : 1);
+    (void) hw;
+    const size_t T = C < 16 ? 1 : std::min<size_t>(host_threads(), C);
     if (T <= 1) { fn((size_t) 0, C, (size_t) 0); return; }
     std::vector<size_t> cut(T + 1, 0);
     const int64_t total = chunk_off[C] - chunk_off[0];
@@ -200,6 +212,10 @@ static int set_err(int code, const std::string& msg) { g_err = msg; return code;
 
 struct hf_ctx {
     int device = 0, algo = HF_ALGO_SCAN;
+    // device memory of hf_create comes out of a few SLABS (round 5: ~45 hipMalloc calls and as many hipFree were ~0.5 ms of a 4 ms hf_create):
+    // bump allocation, 256-byte aligned; what hf_create frees again (temporaries) simply stays until hf_destroy.  ctx_free knows which
+    // pointers are the context's own later hipMallocs.
+    std::vector<std::pair<char*, size_t>> slabs; char* slab_cur = nullptr; size_t slab_left = 0, slab_first = 0;
     int64_t N = 0; int32_t C = 0; int32_t maxT = 0;
     int R = 1, K = 2;
     int64_t V = 0;                 // per-chunk stats vector length
@@ -305,6 +321,32 @@ struct hf_ctx {
     unsigned long long* d_seg_trace = nullptr;   // -DHF_SEG_TRACE builds only
     int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_Es = nullptr; double* d_Cs = nullptr;
 };
+
+static void* ctx_alloc(hf_ctx* ctx, size_t bytes) {
+    bytes = (bytes ? bytes : 8);
+    bytes = (bytes + 255) & ~(size_t) 255;
+    if (bytes > ctx->slab_left) {
+        const size_t want = std::max(bytes, ctx->slabs.empty() ? ctx->slab_first : (size_t) 64 << 20);
+        char* p = nullptr;
+        if (hipMalloc((void**) &p, want) != hipSuccess) {
+            (void) hipGetLastError();
+            if (want == bytes || hipMalloc((void**) &p, bytes) != hipSuccess) return nullptr;   // (a smaller slab: just this request)
+            ctx->slabs.emplace_back(p, bytes);
+            return p;                                                                         // (the current slab keeps its remainder)
+        }
+        ctx->slabs.emplace_back(p, want);
+        ctx->slab_cur = p; ctx->slab_left = want;
+    }
+    char* r = ctx->slab_cur;
+    ctx->slab_cur += bytes; ctx->slab_left -= bytes;
+    return r;
+}
+static void ctx_free(hf_ctx* ctx, void* p) {          // hipFree unless the pointer lives in a slab
+    if (!p) return;
+    for (const auto& sl : ctx->slabs)
+        if ((char*) p >= sl.first && (char*) p < sl.first + sl.second) return;
+    hipFree(p);
+}
 
 // ------------------------------------------------------------------------------------------
 // setup: packed records + contig-end factor beta (hmm.c:301-316), once per run
@@ -417,10 +459,20 @@ static bool pass_events(const hf_ctx* ctx) {
     return (ctx->prof_mask & HF_PROF_PASS) != 0 || ctx->host_trace;
 }
 
+// small uploads of hf_create: out of the context's slab, through a pinned staging area when there is room (memcpy + ASYNCHRONOUS copy on the
+// null stream: hf_create synchronises once, at its end) — a hipMalloc and a synchronous copy out of pageable memory per array were ~30 us each
+struct UploadStage { char* p = nullptr; size_t cap = 0, used = 0; };
 template <typename T>
-static int dev_upload(T** dst, const T* src, size_t n) {
-    HIPCHK(hipMalloc((void**) dst, (n ? n : 1) * sizeof(T)));
-    if (n) HIPCHK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+static int dev_upload(hf_ctx* ctx, UploadStage& stg, T** dst, const T* src, size_t n) {
+    *dst = static_cast<T*>(ctx_alloc(ctx, (n ? n : 1) * sizeof(T)));
+    if (!*dst) return set_err(HF_E_HIP, "hf_create: out of device memory");
+    if (!n) return 0;
+    const size_t bytes = n * sizeof(T), need = (bytes + 63) & ~(size_t) 63;
+    if (stg.p && stg.used + need <= stg.cap) {
+        std::memcpy(stg.p + stg.used, src, bytes);
+        HIPCHK(hipMemcpyAsync(*dst, stg.p + stg.used, bytes, hipMemcpyHostToDevice, nullptr));
+        stg.used += need;
+    } else HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -640,7 +692,8 @@ int hf_warmup(int device) {
     if (hf_device_count() <= 0) return set_err(HF_E_NOGPU, "hf_warmup: no HIP device");
     {   // the host threads of hf_create's passes over the windows
         const unsigned hw = std::thread::hardware_concurrency();
-        host_pool().start(std::min<size_t>(HF_PARTS, hw ? hw : 1) - 1);
+        (void) hw;
+        host_pool().start(host_threads() - 1);
     }
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipFree(nullptr));      // forces the context
@@ -662,7 +715,8 @@ int hf_warmup(int device) {
         PinCache& pc = pin_cache();
         char* a = pc.acquire((size_t) 4 * (2u << 20));
         char* b = pc.acquire((size_t) 12 * (2u << 20));
-        pc.release(a); pc.release(b);
+        char* c = pc.acquire((size_t) 8 << 20);
+        pc.release(a); pc.release(b); pc.release(c);
     }
     return HF_OK;
 }
@@ -710,21 +764,26 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     int32_t *d_cs = nullptr, *d_ce = nullptr, *d_cl = nullptr, *d_spare = nullptr;
     int rc = 0;
 #define TRY(x) do { rc = (x); if (rc) { hf_destroy(ctx); return rc; } } while (0)
-    TRY(dev_upload(&ctx->d_off, w->chunk_off, C + 1));
+    ctx->slab_first = N * 136 + ((size_t) 32 << 20);      // (BASELINE configs[2]: everything hf_create allocates, 205 MB, in one slab)
+    // Pinned staging buffers of 4 bytes per window for everything this function moves between host and device (pageable copies were
+    // measured at ~1 GB/s): P0 packed windows up; P1 the rows of A up; P2 the record positions up; P3 (never uploaded) the packed records as
+    // the host computes them; and 8 MiB for the small arrays (UploadStage).  They come from the process-wide cache (PinCache: pinning costs
+    // ~0.2 ms per MB, 1.2 ms of this function until round 5); a first-time P1 | P2 | P3 is pinned on a helper thread while the first pass over
+    // the windows runs.  Back to the cache when the function leaves (its uploads are complete by then).
+    struct Staging {
+        char *a = nullptr, *b = nullptr, *c = nullptr; std::thread th;
+        ~Staging() { if (th.joinable()) th.join(); pin_cache().release(a); pin_cache().release(b); pin_cache().release(c); }
+    } arena;
+    UploadStage stg;
+    arena.c = pin_cache().acquire((size_t) 8 << 20);
+    stg.p = arena.c; stg.cap = arena.c ? (size_t) 8 << 20 : 0;
+    TRY(dev_upload(ctx, stg, &ctx->d_off, w->chunk_off, C + 1));
     cphase("context, chunk offsets up");
     // The four per-window arrays (16 B per window, pageable host memory: measured at ~1 GB/s) go up as ONE packed word per window
     // through a pinned staging buffer when every value fits a byte (window values are at most 250); as they are otherwise.
     // Pinned buffers of 4 bytes per window for everything this function moves between host and device (pageable copies were
     // measured at ~1 GB/s): P0 packed windows up, then the f-positions up; P1 the rows of A up; P2 the record positions up.  Pinning
     // costs ~0.2 ms per MB: P0 here, P1 and P2 on a helper thread while the first pass over the windows runs.
-    // Pinned staging buffers of 4 bytes per window for everything this function moves between host and device (pageable copies were
-    // measured at ~1 GB/s): P0 packed windows up; P1 the rows of A up; P2 the record positions up; P3 (never uploaded) the packed records as the host computes them.  They come from the process-wide cache
-    // (PinCache: pinning costs ~0.2 ms per MB, 1.2 ms of this function until round 5); a first-time P1 | P2 is pinned on a helper thread while
-    // the first pass over the windows runs.  Back to the cache when the function leaves (its uploads are complete by then).
-    struct Staging {
-        char *a = nullptr, *b = nullptr; std::thread th;
-        ~Staging() { if (th.joinable()) th.join(); pin_cache().release(a); pin_cache().release(b); }
-    } arena;
     if (N > 0) {
         arena.a = pin_cache().acquire(N * 4);
         if (!arena.a) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of host memory"); }
@@ -846,21 +905,22 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             if (bad_region.load()) { hf_destroy(ctx); return set_err(HF_E_REGION, "a window's region index is >= n_regions"); }
             if (w->chunk_off[0] != 0 || (size_t) w->chunk_off[C] != N) wide.store(1);   // (a window outside every chunk: take the plain path)
             if (!wide.load()) {
-                hipError_t e1 = hipMalloc((void**) &d_packed, N * 4);
+                d_packed = static_cast<uint32_t*>(ctx_alloc(ctx, N * 4));
+                hipError_t e1 = d_packed ? hipSuccess : hipErrorOutOfMemory;
                 if (e1 == hipSuccess) e1 = hipMemcpyAsync(d_packed, stage, N * 4, hipMemcpyHostToDevice, nullptr);   // (k_setup follows on the same stream; P0 is written again only by the third pass, behind ev_packed)
                 if (e1 == hipSuccess && hipEventCreateWithFlags(&ev_packed, hipEventDisableTiming) == hipSuccess) (void) hipEventRecord(ev_packed, nullptr);
-                if (e1 != hipSuccess) { (void) hipGetLastError(); if (d_packed) hipFree(d_packed); d_packed = nullptr; }
+                if (e1 != hipSuccess) { (void) hipGetLastError(); d_packed = nullptr; }
             }
         }
     }
     if (!d_packed) {
-        TRY(dev_upload(&d_cov, w->cov, N)); TRY(dev_upload(&d_mapq, w->mapq, N)); TRY(dev_upload(&d_clip, w->clip, N));
-        TRY(dev_upload(&d_annot, w->annot, N));
+        TRY(dev_upload(ctx, stg, &d_cov, w->cov, N)); TRY(dev_upload(ctx, stg, &d_mapq, w->mapq, N)); TRY(dev_upload(ctx, stg, &d_clip, w->clip, N));
+        TRY(dev_upload(ctx, stg, &d_annot, w->annot, N));
     }
-    TRY(dev_upload(&d_cs, w->chunk_s, C)); TRY(dev_upload(&d_ce, w->chunk_e, C)); TRY(dev_upload(&d_cl, w->chunk_ctg_len, C));
+    TRY(dev_upload(ctx, stg, &d_cs, w->chunk_s, C)); TRY(dev_upload(ctx, stg, &d_ce, w->chunk_e, C)); TRY(dev_upload(ctx, stg, &d_cl, w->chunk_ctg_len, C));
     cphase("window arrays up");
-#define DMALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void**) &(p), (bytes) ? (bytes) : 8); \
-    if (e_ != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("hipMalloc: ") + hipGetErrorString(e_)); } } while (0)
+#define DMALLOC(p, bytes) do { (p) = static_cast<decltype(p)>(ctx_alloc(ctx, (bytes))); \
+    if (!(p)) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of device memory"); } } while (0)
     DMALLOC(ctx->d_rec, N * 4); DMALLOC(ctx->d_beta, N * 8); DMALLOC(ctx->d_regmask, C * 8);
 
     if (algo == HF_ALGO_SEQ) DMALLOC(ctx->d_E, N * 16 * 8);
@@ -936,9 +996,9 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     if (seen256[(reg << 16) | (x << 8) | xp]) keys.push_back((int32_t) ((reg * ctx->M + x) * ctx->M + xp));
         ctx->n_slow = (int) slow.size();
         ctx->n_keys = (int) keys.size();
-        TRY(dev_upload(&ctx->d_slow_w, slow.data(), slow.size()));
-        TRY(dev_upload(&ctx->d_slow_off, soff.data(), soff.size()));
-        TRY(dev_upload(&ctx->d_keys, keys.data(), keys.size()));
+        TRY(dev_upload(ctx, stg, &ctx->d_slow_w, slow.data(), slow.size()));
+        TRY(dev_upload(ctx, stg, &ctx->d_slow_off, soff.data(), soff.size()));
+        TRY(dev_upload(ctx, stg, &ctx->d_keys, keys.data(), keys.size()));
         // one buffer per table: rows of the (region, x, x_prev) keys first, then the private rows of the slow windows
         // (a row index fits 32 bits; + 1 row of padding)
         ctx->n_lut = (int64_t) n_regions * (int64_t) MM;
@@ -964,8 +1024,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         }
         ctile0[C] = (int32_t) desc.size();
         ctx->ntiles = (int) desc.size();
-        TRY(dev_upload(&ctx->d_tile_desc, desc.data(), desc.size()));
-        TRY(dev_upload(&ctx->d_chunk_tile0, ctile0.data(), ctile0.size()));
+        TRY(dev_upload(ctx, stg, &ctx->d_tile_desc, desc.data(), desc.size()));
+        TRY(dev_upload(ctx, stg, &ctx->d_chunk_tile0, ctile0.data(), ctile0.size()));
         const size_t nt = (size_t) ctx->ntiles;
         DMALLOC(ctx->d_tile_ll, nt * 8);
         if (algo == HF_ALGO_SEQ) {   // f, b tile-major / lane-minor (hf_device.h fb_slot): only the sequential cross-check keeps them
@@ -1074,8 +1134,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 }
                 DMALLOC(ctx->d_arow, N * 4);
                 if (hipMemcpyAsync(ctx->d_arow, arow, N * 4, hipMemcpyHostToDevice, nullptr) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: rows of A up"); }   // (P1: pinned, not written again)
-                TRY(dev_upload(&ctx->d_arow_src, a_src.data(), a_src.size()));
-                TRY(dev_upload(&ctx->d_arow_cls, a_cls.data(), a_cls.size()));
+                TRY(dev_upload(ctx, stg, &ctx->d_arow_src, a_src.data(), a_src.size()));
+                TRY(dev_upload(ctx, stg, &ctx->d_arow_cls, a_cls.data(), a_cls.size()));
                 DMALLOC(ctx->d_lutA, (a_src.size() + 1) * 16 * 8);
                 {   // one row behind the rows of A: the IDENTITY (hf_seg.h: what a lane multiplies by past its last window); no kernel writes it
                     double ident[16];
@@ -1116,7 +1176,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             cseg0[C] = (int32_t) segs.size();
             if (nslots < INT32_MAX) {
                 ctx->nseg = (int) segs.size(); ctx->n_slots = nslots;
-                TRY(dev_upload(&ctx->d_chunk_seg0, cseg0.data(), cseg0.size()));   // (the descriptors go up with the plan's positions in them)
+                TRY(dev_upload(ctx, stg, &ctx->d_chunk_seg0, cseg0.data(), cseg0.size()));   // (the descriptors go up with the plan's positions in them)
                 DMALLOC(ctx->d_seg_ready, segs.size() * 4);
                 hipMemset(ctx->d_seg_ready, 0, segs.size() * 4);
                 DMALLOC(ctx->d_seg_ll, segs.size() * 8);
@@ -1364,35 +1424,35 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                             const int x = rslots[k].xpx & 0xff;
                             blist[(size_t) fill[(size_t) rwreg[k / ((size_t) 16 * (size_t) ctx->rs_bpw)] * 256 + (size_t) (x < HF_NB_MAX_COVERAGE ? x : HF_NB_MAX_COVERAGE - 1)]++] = (int32_t) k;
                         }
-                    TRY(dev_upload(&ctx->d_bin_off, boff.data(), boff.size()));
-                    TRY(dev_upload(&ctx->d_bin_list, blist.data(), blist.size()));
+                    TRY(dev_upload(ctx, stg, &ctx->d_bin_off, boff.data(), boff.size()));
+                    TRY(dev_upload(ctx, stg, &ctx->d_bin_list, blist.data(), blist.size()));
                     DMALLOC(ctx->d_slot_h, rslots.size() * 4 * 8);
                     DMALLOC(ctx->d_H, (size_t) n_regions * 4 * 256 * 8);
                 }
                 ctx->n_rowwaves = (int) (rslots.size() / ((size_t) 16 * (size_t) ctx->rs_bpw));   // 16 * bpw slots per wavefront, four wavefronts per region pad
-                TRY(dev_upload(&ctx->d_grp_ar, grp_ar.data(), grp_ar.size()));
-                TRY(dev_upload(&ctx->d_grp_n, grp_n.data(), grp_n.size()));
-                if (compact) TRY(dev_upload(&ctx->d_grp_off, grp_off.data(), grp_off.size()));
-                TRY(dev_upload(&ctx->d_rowslots, rslots.data(), rslots.size()));
-                TRY(dev_upload(&ctx->d_rw_region, rwreg.data(), rwreg.size()));
-                TRY(dev_upload(&ctx->d_rw_off, rwoff.data(), rwoff.size()));
+                TRY(dev_upload(ctx, stg, &ctx->d_grp_ar, grp_ar.data(), grp_ar.size()));
+                TRY(dev_upload(ctx, stg, &ctx->d_grp_n, grp_n.data(), grp_n.size()));
+                if (compact) TRY(dev_upload(ctx, stg, &ctx->d_grp_off, grp_off.data(), grp_off.size()));
+                TRY(dev_upload(ctx, stg, &ctx->d_rowslots, rslots.data(), rslots.size()));
+                TRY(dev_upload(ctx, stg, &ctx->d_rw_region, rwreg.data(), rwreg.size()));
+                TRY(dev_upload(ctx, stg, &ctx->d_rw_off, rwoff.data(), rwoff.size()));
                 ctx->h_rw_off = rwoff;
                 DMALLOC(ctx->d_grp_sums, (size_t) grp_ar.size() * 16 * 8);
                 DMALLOC(ctx->d_chunk_ll, C * 8);
                 DMALLOC(ctx->d_rw_stats, (size_t) ctx->n_rowwaves * (16 + 9 + 2 + 3 * 16 + 1) * 8);
                 ctx->rows_ready = true;
             }
-            TRY(dev_upload(&ctx->d_seg, ctx->h_segs.data(), ctx->h_segs.size()));
+            TRY(dev_upload(ctx, stg, &ctx->d_seg, ctx->h_segs.data(), ctx->h_segs.size()));
             ctx->n_pos = n_pos;
             DMALLOC(ctx->d_pos, N * 4); DMALLOC(ctx->d_pos_f, N * 4);
             if (hipMemcpyAsync(ctx->d_pos, pos, N * 4, hipMemcpyHostToDevice, nullptr) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: record positions up"); }
             {   // pos_f[t] = the position of window t + 1's record (which holds f_t), the chunk's spare record for its last window: on the device
                 // (round 5: 6 MB less to write on the host and to upload)
-                TRY(dev_upload(&d_spare, h_spare.data(), C));
+                TRY(dev_upload(ctx, stg, &d_spare, h_spare.data(), C));
                 if (w->chunk_off[0] != 0 || (size_t) w->chunk_off[C] != N) hipMemsetAsync(ctx->d_pos_f, 0, N * 4, nullptr);
                 hipLaunchKernelGGL(k_pos_f, dim3((unsigned) ((maxT + 255) / 256), (unsigned) C), dim3(256), 0, 0, ctx->d_off, ctx->d_pos, d_spare, ctx->d_pos_f);
             }
-            hipFree(ctx->d_recs); ctx->d_recs = nullptr;
+            ctx_free(ctx, ctx->d_recs); ctx->d_recs = nullptr;
             if (n_pos >= INT32_MAX) { hf_destroy(ctx); return set_err(HF_E_ARG, "hf_create: more than 2^31 record positions (shard the chunk list: hmm_flagger_multi.h)"); }
             int64_t cap = 0;                          // positions the pass buffer holds: the largest sub-pass (everything, with one)
             for (const auto& sb : ctx->subs) if (sb.p1 - sb.p0 > cap) cap = sb.p1 - sb.p0;
@@ -1491,7 +1551,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     {   // the ONE synchronisation of this function: uploads and set-up kernels done, the staging buffers may go back to the cache
         const hipError_t e = hipDeviceSynchronize();
         if (ev_packed) hipEventDestroy(ev_packed);
-        hipFree(d_packed); hipFree(d_cov); hipFree(d_mapq); hipFree(d_clip); hipFree(d_annot); hipFree(d_cs); hipFree(d_ce); hipFree(d_cl); hipFree(d_spare);
+        (void) d_cov; (void) d_mapq; (void) d_clip; (void) d_annot; (void) d_cs; (void) d_ce; (void) d_cl; (void) d_spare;   // (temporaries: slab memory, released with the context)
         if (e != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, std::string("setup: ") + hipGetErrorString(e)); }
         unsigned fl = 0;
         if (N > 0 && C > 0) hipMemcpy(&fl, ctx->d_flags, 4, hipMemcpyDeviceToHost);
@@ -1513,29 +1573,30 @@ void hf_destroy(hf_ctx* ctx) {
         if (FILE* fp = std::fopen(std::getenv("HF_SEG_TRACE_FILE"), "wb")) { std::fwrite(h.data(), 8, h.size(), fp); std::fclose(fp); }
         unsigned long long* null_p = nullptr;
         hipMemcpyToSymbol(HIP_SYMBOL(g_seg_trace), &null_p, sizeof(void*));
-        hipFree(ctx->d_seg_trace);
+        ctx_free(ctx, ctx->d_seg_trace);
     }
 #endif
     if (ctx->host_trace && ctx->ht_n)
         std::fprintf(stderr, "[hf host trace] %ld EM steps: parameter view (hfm_params: the negative-binomial tables) %.1f us, enqueue %.1f us, wait %.1f us, m-step %.1f us, gpu span (first launch .. reduction) %.1f us\n",
                      ctx->ht_n, ctx->ht[4] / ctx->ht_n, ctx->ht[0] / ctx->ht_n, ctx->ht[1] / ctx->ht_n, ctx->ht[2] / ctx->ht_n, ctx->ht[3] / ctx->ht_n);
-    hipFree(ctx->d_off); hipFree(ctx->d_rec); hipFree(ctx->d_beta); hipFree(ctx->d_regmask); hipFree(ctx->d_E);
-    hipFree(ctx->d_f); hipFree(ctx->d_b); hipFree(ctx->d_scale); hipFree(ctx->d_label); if (ctx->own_chunk_stats) hipFree(ctx->d_chunk_stats);
-    hipFree(ctx->d_total); hipFree(ctx->d_flags); hipFree(ctx->d_params);
-    hipFree(ctx->d_lutE); hipFree(ctx->d_lutC); hipFree(ctx->d_slow_w); hipFree(ctx->d_slow_off); hipFree(ctx->d_keys);
-    hipFree(ctx->d_nbE); hipFree(ctx->d_tile_hist);   // (d_nbP .. d_nbBeta point into d_nbE's buffer)
+    ctx_free(ctx, ctx->d_off); ctx_free(ctx, ctx->d_rec); ctx_free(ctx, ctx->d_beta); ctx_free(ctx, ctx->d_regmask); ctx_free(ctx, ctx->d_E);
+    ctx_free(ctx, ctx->d_f); ctx_free(ctx, ctx->d_b); ctx_free(ctx, ctx->d_scale); ctx_free(ctx, ctx->d_label); if (ctx->own_chunk_stats) ctx_free(ctx, ctx->d_chunk_stats);
+    ctx_free(ctx, ctx->d_total); ctx_free(ctx, ctx->d_flags); ctx_free(ctx, ctx->d_params);
+    ctx_free(ctx, ctx->d_lutE); ctx_free(ctx, ctx->d_lutC); ctx_free(ctx, ctx->d_slow_w); ctx_free(ctx, ctx->d_slow_off); ctx_free(ctx, ctx->d_keys);
+    ctx_free(ctx, ctx->d_nbE); ctx_free(ctx, ctx->d_tile_hist);   // (d_nbP .. d_nbBeta point into d_nbE's buffer)
     for (int b = 0; b < 2; b++) { if (ctx->h_nb[b]) hipHostFree(ctx->h_nb[b]); if (ctx->nb_ev[b]) hipEventDestroy(ctx->nb_ev[b]); }
-    hipFree(ctx->d_tile_desc); hipFree(ctx->d_chunk_tile0);
-    hipFree(ctx->d_done); hipFree(ctx->d_cks); hipFree(ctx->d_bin_off); hipFree(ctx->d_bin_list); hipFree(ctx->d_slot_h); hipFree(ctx->d_H); if (ctx->d_recs_all != ctx->d_recs) hipFree(ctx->d_recs_all); hipFree(ctx->d_recs); hipFree(ctx->d_chunk_ll); hipFree(ctx->d_grp_ar); hipFree(ctx->d_grp_n); hipFree(ctx->d_grp_off); hipFree(ctx->d_pos); hipFree(ctx->d_pos_f); hipFree(ctx->d_slot_of); hipFree(ctx->d_grp_sums); hipFree(ctx->d_rowslots); hipFree(ctx->d_rw_region);
-    hipFree(ctx->d_seg); hipFree(ctx->d_chunk_seg0); hipFree(ctx->d_seg_ll); hipFree(ctx->d_Pseg); hipFree(ctx->d_segQ); hipFree(ctx->d_seg_ready); hipFree(ctx->d_scale_s);
-    hipFree(ctx->d_jobs); hipFree(ctx->d_arow); hipFree(ctx->d_arow_src); hipFree(ctx->d_arow_cls); hipFree(ctx->d_lutA);
-    hipFree(ctx->d_rw_off); hipFree(ctx->d_rw_stats);
-    hipFree(ctx->d_tile_ll); hipFree(ctx->d_tile_stats);
+    ctx_free(ctx, ctx->d_tile_desc); ctx_free(ctx, ctx->d_chunk_tile0);
+    ctx_free(ctx, ctx->d_done); ctx_free(ctx, ctx->d_cks); ctx_free(ctx, ctx->d_bin_off); ctx_free(ctx, ctx->d_bin_list); ctx_free(ctx, ctx->d_slot_h); ctx_free(ctx, ctx->d_H); if (ctx->d_recs_all != ctx->d_recs) ctx_free(ctx, ctx->d_recs_all); ctx_free(ctx, ctx->d_recs); ctx_free(ctx, ctx->d_chunk_ll); ctx_free(ctx, ctx->d_grp_ar); ctx_free(ctx, ctx->d_grp_n); ctx_free(ctx, ctx->d_grp_off); ctx_free(ctx, ctx->d_pos); ctx_free(ctx, ctx->d_pos_f); ctx_free(ctx, ctx->d_slot_of); ctx_free(ctx, ctx->d_grp_sums); ctx_free(ctx, ctx->d_rowslots); ctx_free(ctx, ctx->d_rw_region);
+    ctx_free(ctx, ctx->d_seg); ctx_free(ctx, ctx->d_chunk_seg0); ctx_free(ctx, ctx->d_seg_ll); ctx_free(ctx, ctx->d_Pseg); ctx_free(ctx, ctx->d_segQ); ctx_free(ctx, ctx->d_seg_ready); ctx_free(ctx, ctx->d_scale_s);
+    ctx_free(ctx, ctx->d_jobs); ctx_free(ctx, ctx->d_arow); ctx_free(ctx, ctx->d_arow_src); ctx_free(ctx, ctx->d_arow_cls); ctx_free(ctx, ctx->d_lutA);
+    ctx_free(ctx, ctx->d_rw_off); ctx_free(ctx, ctx->d_rw_stats);
+    ctx_free(ctx, ctx->d_tile_ll); ctx_free(ctx, ctx->d_tile_stats);
     if (ctx->h_total) hipHostFree(ctx->h_total);   // one pinned block: h_flags and h_params live in it
     if (ctx->h_part) hipHostFree(ctx->h_part);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 2 * HF_NKERNELS; i++) if (ctx->kev[i]) hipEventDestroy(ctx->kev[i]);
+    for (auto& sl : ctx->slabs) hipFree(sl.first);
     delete ctx;
 }
 
@@ -2212,7 +2273,7 @@ int hf_bind_chunk_stats(hf_ctx* ctx, double* rows_dev) {
     if (!ctx) return set_err(HF_E_ARG, "hf_bind_chunk_stats: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
     if (rows_dev) {
-        if (ctx->own_chunk_stats) hipFree(ctx->d_chunk_stats);
+        if (ctx->own_chunk_stats) ctx_free(ctx, ctx->d_chunk_stats);
         ctx->d_chunk_stats = rows_dev; ctx->own_chunk_stats = false;
     } else if (!ctx->own_chunk_stats) {
         ctx->d_chunk_stats = nullptr;
