@@ -248,7 +248,7 @@ struct hf_ctx {
     KParams kparams{};             // the parameter block as kernel arguments of k_tables (one region: pack_kparams)
     bool kp_ok = true, kp_now = false;   // HF_PARAMS_COPY=1 switches the kernel-argument path off; this pass uses it
     unsigned* h_flags = nullptr;
-    int8_t* h_label = nullptr;     // pinned [N] (same block as h_total): staging of hf_get_labels
+    int8_t* h_label = nullptr;     // pinned [N]: staging of hf_get_labels, taken from the process's pinned cache on first use (1.5 MB of pinning = 0.15 ms of hf_create until round 5)
     int8_t* d_label_host = nullptr; // its device address (a kernel writes the labels there)
     double* h_total = nullptr;     // pinned [V+1]: reduced vector + flag word, one copy per pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr; bool ev_valid = false;
@@ -939,18 +939,16 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         const size_t tot_bytes = (((size_t) ctx->V + 2 + HF_MAXREGIONS) * 8 + 63) / 64 * 64;   // (what follows stays 64-byte aligned)
         char* pin = nullptr;
         const size_t par_bytes = (ctx->params_bytes + 63) / 64 * 64;
-        if (hipHostMalloc((void**) &pin, tot_bytes + 64 + par_bytes + N + 16) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed"); }
+        if (hipHostMalloc((void**) &pin, tot_bytes + 64 + par_bytes) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed"); }
         ctx->h_total = reinterpret_cast<double*>(pin);
         ctx->h_flags = reinterpret_cast<unsigned*>(pin + tot_bytes);
         ctx->h_params = reinterpret_cast<DevParams*>(pin + tot_bytes + 64);
-        ctx->h_label = reinterpret_cast<int8_t*>(pin + tot_bytes + 64 + par_bytes);   // hf_get_labels: the labels come down through pinned memory
         std::memset(ctx->h_params, 0, ctx->params_bytes);   // (pack_params fills the derived constants of the components in use only)
     }
     {
         void* dp = nullptr;
         if (hipHostGetDevicePointer(&dp, ctx->h_total, 0) == hipSuccess) {
             ctx->d_total_host = (double*) dp;
-            ctx->d_label_host = reinterpret_cast<int8_t*>(dp) + (reinterpret_cast<char*>(ctx->h_label) - reinterpret_cast<char*>(ctx->h_total));
         } else (void) hipGetLastError();
     }
     cphase("device + pinned allocations");
@@ -1593,6 +1591,7 @@ void hf_destroy(hf_ctx* ctx) {
     ctx_free(ctx, ctx->d_tile_ll); ctx_free(ctx, ctx->d_tile_stats);
     if (ctx->h_total) hipHostFree(ctx->h_total);   // one pinned block: h_flags and h_params live in it
     if (ctx->h_part) hipHostFree(ctx->h_part);
+    if (ctx->h_label) pin_cache().release(reinterpret_cast<char*>(ctx->h_label));
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 2 * HF_NKERNELS; i++) if (ctx->kev[i]) hipEventDestroy(ctx->kev[i]);
@@ -2341,6 +2340,12 @@ int hf_get_labels(hf_ctx* ctx, int8_t* labels_host) {
     // A KERNEL writes them into the context's pinned block (as the passes write their totals), the host copies them on: a process's first
     // device-to-host COPY into a fresh pinned block was measured at 8.9 ms (the second at 0.15 ms: profiles/r04e_cli_wall.txt) — in the
     // middle of the command line's EM loop, for the "initial" summary tables; the kernel takes ~0.1 ms the first time too.
+    if (!ctx->h_label && ctx->N > 0 && ctx->d_total_host) {
+        char* p = pin_cache().acquire((size_t) ctx->N + 16);
+        void* dp = nullptr;
+        if (p && hipHostGetDevicePointer(&dp, p, 0) == hipSuccess) { ctx->h_label = reinterpret_cast<int8_t*>(p); ctx->d_label_host = reinterpret_cast<int8_t*>(dp); }
+        else { (void) hipGetLastError(); pin_cache().release(p); }
+    }
     if (ctx->d_label_host && ctx->N > 0) {
         const int64_t n16 = (ctx->N + 15) / 16;      // (d_label and the pinned block are padded to 16 bytes)
         hipLaunchKernelGGL(k_copy16, dim3((unsigned) ((n16 + 255) / 256)), dim3(256), 0, nullptr, reinterpret_cast<const uint4*>(ctx->d_label),
