@@ -1047,7 +1047,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
             static_assert(HF_SEG_SPLIT <= 64 * HF_SEG_LMAX, "a segment has at most HF_SEG_LMAX windows per lane");
             // (cutting small inputs finer than this was tried: more, shorter workgroups are slower — the scans are a fixed cost)
             // (shorter segments for small inputs were measured again in round 3, 128..384 windows at 0.19 M .. 1.5 M windows: never
-            // faster — a workgroup's life is mostly the scans and the carried-in chains, not the replay; profiles/r03f_split_sweep.txt)
+            // faster — a workgroup's life is mostly the scans and the carried-in chains, not the replay; profiles/r03f_split_sweep.txt; again in
+            // round 5 with the one-launch kernel: 384 windows gain 6 % at 1/8 of configs[2] and lose at 1/4 and above, profiles/r05_split_sweep.txt)
             constexpr int64_t SMAX = HF_SEG_SPLIT;
             // ---- rows of A = T∘e: the (key, transition class) pairs that occur, then the slow windows ----
             {

@@ -66,7 +66,7 @@ __device__ __forceinline__ double seg_xcu_load(const double* p) { return __hip_a
 
 // -DHF_SEG_TRACE: s_memtime stamps of k_seg_fb<true>'s phases, one row of HF_SEG_TRACE_N words per workgroup, dumped by
 // hf_destroy to $HF_SEG_TRACE_FILE (profiles/tools/seg_trace.sh / seg_trace.py).  Not in a normal build.
-#define HF_SEG_TRACE_N 24
+#define HF_SEG_TRACE_N 25
 #ifdef HF_SEG_TRACE
 __device__ unsigned long long* g_seg_trace = nullptr;
 #define TR_DECL unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long tr_t = clock64(); (void) tr_acc; (void) tr_t
@@ -547,6 +547,9 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     double fin[4], bdir[4];
     TR_DECL;
     TR_STAMP(0);
+#ifdef HF_SEG_TRACE
+    if (BWD && g_seg_trace && lane == 0) g_seg_trace[(size_t) g * HF_SEG_TRACE_N + 24] = wall_clock64();
+#endif
     const RowFetch F = rowfetch_init(lutA, s_off, s_rows, nc, lane);
     {
         int32_t rr[LM];

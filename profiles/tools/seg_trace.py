@@ -4,7 +4,7 @@ phases of every workgroup (one wavefront), the per-step laps of both replays, wo
 the workgroups spread over the CUs (HW_ID)."""
 import sys
 import numpy as np
-N = 24
+N = 25
 t = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, N).astype(np.int64)
 t = t[t[:, 19] > 0]
 L = t[:, 19].astype(float)
@@ -44,6 +44,20 @@ print("windows per lane: fastest tenth %.2f, slowest tenth %.2f" % (L[fast].mean
 for x in sorted(set((xcc & 0xf).tolist())):
     sel = (xcc & 0xf) == x
     print("  XCD %d: %4d workgroups, lifetime mean %.0f  p90 %.0f" % (x, int(sel.sum()), life[sel].mean(), np.percentile(life[sel], 90)))
+# dispatch skew (s_memrealtime, 100 MHz, one clock for the device): starts and ends relative to the launch's first start; the
+# trace buffer is shared by every context of the process, so only workgroups of the LAST launch are looked at
+ws, we = t[:, 24].astype(float) / 100.0, t[:, 21].astype(float) / 100.0
+last = we > we.max() - 300.0
+print("workgroups of the last launch: %d of %d" % (int(last.sum()), len(t)))
+ws0 = ws[last].min()
+print("start, us after the launch's first start: p10 %.1f  p50 %.1f  p90 %.1f  max %.1f" % tuple(np.percentile(ws[last] - ws0, q) for q in (10, 50, 90, 100)))
+print("end,   us after the launch's first start: p10 %.1f  p50 %.1f  p90 %.1f  max %.1f" % tuple(np.percentile(we[last] - ws0, q) for q in (10, 50, 90, 100)))
+print("life (wall), us: p10 %.1f  p50 %.1f  p90 %.1f  max %.1f" % tuple(np.percentile((we - ws)[last], q) for q in (10, 50, 90, 100)))
+print("correlation(start, life) %.2f   correlation(start, end) %.2f" % (np.corrcoef(ws[last], (we - ws)[last])[0, 1], np.corrcoef(ws[last], we[last])[0, 1]))
+# by position of the segment inside its chunk's run of workgroups (blockIdx order): first / middle / last thirds of the grid
+gi = np.arange(len(t))[last]
+for nm, sel in (("first third of the grid", gi < len(t) / 3), ("middle third", (gi >= len(t) / 3) & (gi < 2 * len(t) / 3)), ("last third", gi >= 2 * len(t) / 3)):
+    print("  %-24s start mean %.1f us, life mean %.1f us, end mean %.1f us" % (nm, (ws[last][sel] - ws0).mean(), (we - ws)[last][sel].mean(), (we[last][sel] - ws0).mean()))
 simd = (hw >> 4) & 3
 for x in range(4):
     sel = simd == x
