@@ -210,13 +210,16 @@ class MultiEMList:
 
     def em_iterate(self, model: "HMM", do_mstep: bool = True, tol: float = 1e-3, mode: int = N.HF_MODE_FULL) -> bool:
         """Sharded EM_runOneIterationForList + exchange + HMM_estimateParameters in one native call (hf_multi_em_iterate)."""
-        cv = C.c_int(0)
-        rc = self._L.hf_multi_em_iterate(self._h, model._h, mode, int(do_mstep), float(tol), _dptr(self._stats), C.byref(cv))
+        if getattr(self, "_stats_ptr_of", None) is not self._stats:
+            self._stats_ptr, self._stats_ptr_of = _dptr(self._stats), self._stats   # (a new ctypes object per .ctypes access: 2 us of host time per call)
+            self._cv = C.c_int(0)
+            self._cv_ref = C.byref(self._cv)
+        rc = self._L.hf_multi_em_iterate(self._h, model._h, mode, int(do_mstep), tol, self._stats_ptr, self._cv_ref)
         if rc != N.HF_OK:
             raise MultiHFError(rc, "hf_multi_em_iterate")
         model.estimators = self._stats
         model.loglikelihood = float(self._stats[0])
-        return bool(cv.value)
+        return bool(self._cv.value)
 
     def rank_stats(self, r: int) -> np.ndarray:
         out = np.empty(self.stats_len, dtype=np.float64)
@@ -433,12 +436,15 @@ class EMList:
         statistics in model.estimators; returns the convergence flag of the M-step."""
         if not hasattr(self, "_stats_buf"):
             self._stats_buf = np.empty(self.stats_len, dtype=np.float64)
-        cv = C.c_int(0)
-        N.check(self._L.hf_em_iterate(self._h, model._h, mode, int(do_mstep), float(tol), _dptr(self._stats_buf),
-                                      C.byref(cv), self.stream), "hf_em_iterate")
+            self._stats_ptr = _dptr(self._stats_buf)       # (numpy builds a new ctypes object per .ctypes access: 2 us of host time per call)
+            self._cv = C.c_int(0)
+            self._cv_ref = C.byref(self._cv)
+        rc = self._L.hf_em_iterate(self._h, model._h, mode, int(do_mstep), tol, self._stats_ptr, self._cv_ref, self.stream)
+        if rc != N.HF_OK:
+            N.check(rc, "hf_em_iterate")
         model.estimators = self._stats_buf
         model.loglikelihood = float(self._stats_buf[0])
-        return bool(cv.value)
+        return bool(self._cv.value)
 
     def kernel_ms(self) -> float:
         ms = C.c_float()
