@@ -295,6 +295,8 @@ struct hf_ctx {
     struct SubPass { int c0, c1, seg0, seg1, g0, g1; int64_t p0, p1; };
     std::vector<SubPass> subs;
     double* d_recs_all = nullptr; bool recs_all = false;   // recs_all: d_recs_all holds the records of every window of the last full pass
+    bool scales_all = false;       // ... and d_scale_s its scales (a pass whose statistics go by emission row writes none: 8 of its 72 bytes per window
+                                   // that only hf_get_forward_backward reads — the getter runs the segment kernel again, with the array)
     int32_t* d_grp_off = nullptr;     // compact plan: first position of every group (+ the end)
     bool plan_compact = false;        // the groups' records back to back (sparse rows) instead of 64 positions per group
     int rs_bpw = 1;                   // batches of 16 row slots per wavefront of k_row_stats
@@ -555,12 +557,12 @@ static void launch_pair_sums(hf_ctx* ctx, hipStream_t st, const hf_ctx::SubPass&
 // k_seg_fb over the segments [g0, g0 + n) (hf_seg.h); timed: by the dispatch's own start / stop timestamps (hipExtLaunchKernelGGL hands the two
 // events to the launch: what rocprofv3 reports for the kernel, without the two marker packets of an event pair around it — those measured 3 us
 // more than the kernel and cost the step ~15 us)
-static void launch_seg_fb(hf_ctx* ctx, hipStream_t st, bool full, double* recs_eff, int g0, int n, unsigned epoch, unsigned wait_epoch, bool timed) {
+static void launch_seg_fb(hf_ctx* ctx, hipStream_t st, bool full, double* recs_eff, int g0, int n, unsigned epoch, unsigned wait_epoch, bool timed, bool with_scales = true) {
     if (n <= 0) return;
     const int nc = ctx->seg_fused ? ctx->seg_nc : 0;     // cached row blocks: one-launch mode only (the lane products are computed in the same kernel)
     const size_t lds = seg_lds_bytes(nc);
 #define HF_SEG_FB_ARGS ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_seg_ready, epoch, wait_epoch, ctx->d_pos, recs_eff, \
-                        ctx->d_scale_s, ctx->d_label, ctx->d_seg_ll, ctx->d_flags, (int32_t) g0, nc
+                        with_scales ? ctx->d_scale_s : (double*) nullptr, ctx->d_label, ctx->d_seg_ll, ctx->d_flags, (int32_t) g0, nc
 #define HF_SEG_FB_LAUNCH(B, F, CA) do { \
         if (timed) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F, CA>), dim3((unsigned) n), dim3(64), (uint32_t) lds, st, \
                                          ctx->kev[2 * HF_K_SEG_FB], ctx->kev[2 * HF_K_SEG_FB + 1], 0, HF_SEG_FB_ARGS); \
@@ -1839,18 +1841,19 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                     bool first = true;
                     for (const auto& sb : ctx->subs) {
                         double* const recs_eff = alias ? ctx->d_recs - sb.p0 * 8 : ctx->d_recs;
-                        launch_seg_fb(ctx, st, true, recs_eff, sb.seg0, sb.seg1 - sb.seg0, epoch, wait_epoch, tfb && first);   // (timed: the first sub-pass's launch, hf_sub_pass_windows)
+                        launch_seg_fb(ctx, st, true, recs_eff, sb.seg0, sb.seg1 - sb.seg0, epoch, wait_epoch, tfb && first, false);   // (timed: the first sub-pass's launch, hf_sub_pass_windows; no scales)
                         first = false;
                         KTimer t(ctx, st, HF_K_PAIR_SUMS);              // (event pairs around k_pair_sums: the last sub-pass's is what is read)
                         launch_pair_sums(ctx, st, sb, recs_eff);
                     }
                     ctx->pass_pairs_done = true;
                     ctx->recs_all = !alias;
+                    ctx->scales_all = false;
                 } else {
                     double* recs = ctx->d_recs;
                     if (full && ctx->subs.size() > 1) { const int rc_ = all_records_buffer(ctx); if (rc_) return rc_; recs = ctx->d_recs_all; }
                     launch_seg_fb(ctx, st, full, recs, 0, ctx->nseg, epoch, wait_epoch, tfb);
-                    if (full) ctx->recs_all = true;
+                    if (full) { ctx->recs_all = true; ctx->scales_all = true; }
                 }
                 ctx->pass_seg = true;
                 if (full) ctx->fb_recs = true;
@@ -2367,8 +2370,8 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
     if (scales_host && !ctx->fb_recs) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
     if (!f_host && !b_host && !ctx->fb_recs) return HF_OK;
     if (ctx->fb_recs) {   // pair records (hf_seg.h): b_t is the second half of the record at pos[t], f_t the first half of the one at pos_f[t]
-        if (!ctx->recs_all) {
-            // the last full pass ran in sub-passes through the pass buffer: only its last sub-pass's records are left.  The segment kernel once
+        if (!ctx->recs_all || !ctx->scales_all) {
+            // the last full pass wrote no scales (statistics by emission row), or ran in sub-passes through the pass buffer (only its last sub-pass's records are left).  The segment kernel once
             // more over all segments, into the all-windows buffer (the tables of the pass are still in place: rows of A, parameters; labels,
             // scales and log-likelihood partials are rewritten with the same values)
             const int rc_ = all_records_buffer(ctx);
@@ -2378,7 +2381,7 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
             launch_seg_fb(ctx, nullptr, true, ctx->d_recs_all, 0, ctx->nseg, epoch, epoch, false);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(nullptr));
-            ctx->recs_all = true;
+            ctx->recs_all = true; ctx->scales_all = true;
         }
         // the positions of a range are scattered over the plan: gathered on the device, one copy back (maps uploaded on first use)
         if (!ctx->d_slot_of) {

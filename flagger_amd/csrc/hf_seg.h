@@ -841,7 +841,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             R2[(int64_t) p1 * 4] = v1;
             R2[(int64_t) p2 * 4] = v2;
             R2[(int64_t) p3 * 4] = v3;
-            scale_s[slot_ij + (int64_t) k * 64] = sc_;   // (non-temporal stores: k_pair_sums +3.5 us, it reads these records out of the cache; profiles/r04i_ab_variants.txt)
+            if (scale_s) scale_s[slot_ij + (int64_t) k * 64] = sc_;   // (wave-uniform: an EM pass passes no scale array — only the host getters read it, and they run the kernel again with one; non-temporal stores: k_pair_sums +3.5 us, it reads these records out of the cache; profiles/r04i_ab_variants.txt)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();                    // the block has been read out: the next row fetch may land
         };
