@@ -295,8 +295,8 @@ struct hf_ctx {
     struct SubPass { int c0, c1, seg0, seg1, g0, g1; int64_t p0, p1; };
     std::vector<SubPass> subs;
     double* d_recs_all = nullptr; bool recs_all = false;   // recs_all: d_recs_all holds the records of every window of the last full pass
-    bool scales_all = false;       // ... and d_scale_s its scales (a pass whose statistics go by emission row writes none: 8 of its 72 bytes per window
-                                   // that only hf_get_forward_backward reads — the getter runs the segment kernel again, with the array)
+    bool scales_all = false;       // ... and d_scale_s its scales (an EM pass writes none: 8 of its 72 bytes per window that only
+                                   // hf_get_forward_backward reads — the getter runs the segment kernel again, with the array)
     int32_t* d_grp_off = nullptr;     // compact plan: first position of every group (+ the end)
     bool plan_compact = false;        // the groups' records back to back (sparse rows) instead of 64 positions per group
     int rs_bpw = 1;                   // batches of 16 row slots per wavefront of k_row_stats
@@ -1090,7 +1090,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 // sub-passes (hf_ctx::SubPass): whole chunks, about equal window counts, <= ~1.6 M windows (~140 MB of records) each
                 {
                     int S = 1;
-                    if ((int64_t) N > 2200000) S = (int) (((int64_t) N + 1599999) / 1600000);
+                    if ((int64_t) N > 2800000) S = (int) (((int64_t) N + 1599999) / 1600000);   // (one launch wins up to ~2.8 M windows, sub-passes of ~1.5 M beyond: profiles/r05_subpass_count2.txt)
                     if (const char* e = std::getenv("HF_SUBPASSES")) { const int v = std::atoi(e); if (v >= 1 && v <= 256) S = v; }   // tests, A/B runs
                     if ((size_t) S > C) S = (int) C;
                     if (S < 1) S = 1;
@@ -1852,8 +1852,8 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 } else {
                     double* recs = ctx->d_recs;
                     if (full && ctx->subs.size() > 1) { const int rc_ = all_records_buffer(ctx); if (rc_) return rc_; recs = ctx->d_recs_all; }
-                    launch_seg_fb(ctx, st, full, recs, 0, ctx->nseg, epoch, wait_epoch, tfb);
-                    if (full) { ctx->recs_all = true; ctx->scales_all = true; }
+                    launch_seg_fb(ctx, st, full, recs, 0, ctx->nseg, epoch, wait_epoch, tfb, false);
+                    if (full) { ctx->recs_all = true; ctx->scales_all = false; }
                 }
                 ctx->pass_seg = true;
                 if (full) ctx->fb_recs = true;

@@ -206,7 +206,7 @@ int hf_seg_launches(const hf_ctx *ctx);
  * instead of fetching them again: hf_create's choice — all 8 when every segment is still resident together with that much LDS each (up to
  * ~430 segments on 256 CUs: a 1/8 shard of BASELINE configs[2]), 0 otherwise (environment HF_SEG_CACHED_STEPS forces any number). */
 int hf_seg_cached_steps(const hf_ctx *ctx);
-/* Sub-passes of a full pass: a context whose pair records (64 bytes per window) would not fit the 256 MB Infinity Cache — more than ~2.2 M
+/* Sub-passes of a full pass: a context whose pair records (64 bytes per window) would not fit the 256 MB Infinity Cache — more than ~2.8 M
  * windows on one GPU — cuts its chunk list into sub-passes of whole chunks (<= ~1.6 M windows each) and runs the segment kernel and the
  * per-group sums sub-pass by sub-pass through one record buffer; 1 for BASELINE configs[2] (environment HF_SUBPASSES forces a number).
  * hf_sub_pass_windows: the windows of sub-pass k (what ONE launch of the segment kernel processes: hf_set_profiling times the first). */

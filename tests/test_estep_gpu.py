@@ -861,7 +861,7 @@ def test_host_summed_total_equals_the_device_total_bit_for_bit(monkeypatch):
 
 
 def test_sub_passes_through_one_record_buffer(monkeypatch):
-    """VERDICT r04 #5 (inputs past the Infinity Cache).  A context with more than ~2.2 M windows runs a full pass in SUB-PASSES of whole chunks —
+    """VERDICT r04 #5 (inputs past the Infinity Cache).  A context with more than ~2.8 M windows runs a full pass in SUB-PASSES of whole chunks —
     k_seg_fb then k_pair_sums per sub-pass through one record buffer that holds a sub-pass at a time (hf_sub_passes).  Forced here on small
     inputs (HF_SUBPASSES): the statistics regroup the pairs per sub-pass, so they equal the one-sub-pass run to rounding (1e-12) and the oracle
     to 1e-9; labels, forward / backward vectors, scales, posteriors and the forward-only log-likelihood are the SAME BITS (the segment kernel does
