@@ -766,7 +766,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     int32_t *d_cs = nullptr, *d_ce = nullptr, *d_cl = nullptr, *d_spare = nullptr;
     int rc = 0;
 #define TRY(x) do { rc = (x); if (rc) { hf_destroy(ctx); return rc; } } while (0)
-    ctx->slab_first = N * 136 + ((size_t) 32 << 20);      // (BASELINE configs[2]: everything hf_create allocates, 205 MB, in one slab)
+    ctx->slab_first = N * 128 + ((size_t) 32 << 20);      // (BASELINE configs[2]: everything hf_create allocates, ~195 MB, in one slab)
     // Pinned staging buffers of 4 bytes per window for everything this function moves between host and device (pageable copies were
     // measured at ~1 GB/s): P0 packed windows up; P1 the rows of A up; P2 the record positions up; P3 (never uploaded) the packed records as
     // the host computes them; and 8 MiB for the small arrays (UploadStage).  They come from the process-wide cache (PinCache: pinning costs
@@ -1182,7 +1182,6 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 hipMemset(ctx->d_seg_ready, 0, segs.size() * 4);
                 DMALLOC(ctx->d_seg_ll, segs.size() * 8);
                 DMALLOC(ctx->d_Pseg, segs.size() * 16 * 8);
-                DMALLOC(ctx->d_scale_s, (size_t) ctx->n_slots * 8);
             } else segs.clear();
             cphase("segments");
         }
@@ -2376,6 +2375,7 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
             // scales and log-likelihood partials are rewritten with the same values)
             const int rc_ = all_records_buffer(ctx);
             if (rc_) return rc_;
+            if (!ctx->d_scale_s) HIPCHK(hipMalloc((void**) &ctx->d_scale_s, (size_t) ctx->n_slots * 8));   // the scales: on first use (an EM pass writes none)
             if (!ctx->seg_fused) hipLaunchKernelGGL(k_seg_prod, dim3((unsigned) ctx->nseg), dim3(64), seg_lds_bytes(), nullptr, ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
             const unsigned epoch = ++ctx->seg_epoch;
             launch_seg_fb(ctx, nullptr, true, ctx->d_recs_all, 0, ctx->nseg, epoch, epoch, false);
