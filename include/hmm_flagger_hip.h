@@ -214,7 +214,9 @@ int hf_sub_passes(const hf_ctx *ctx);
 int64_t hf_sub_pass_windows(const hf_ctx *ctx, int k);
 
 /* Results of the last HF_MODE_FULL pass (HF_E_ARG when the last pass was HF_MODE_FORWARD_ONLY: f and scales would be new,
- * b and the labels stale). */
+ * b and the labels stale).  hf_get_posterior / hf_get_forward_backward: an EM pass of the default algorithm keeps no per-window scale (and,
+ * in several sub-passes, only the last sub-pass's records) — the first call after a pass runs the segment kernel once more over the pass's
+ * tables, with the scale array (~0.05 ms per 1.5 M windows; the array itself is allocated by that first call); same values as the pass. */
 int hf_get_labels(hf_ctx *ctx, int8_t *labels_host);                                   /* hmm.c:730-736 */
 int hf_get_posterior(hf_ctx *ctx, int64_t first, int64_t n, double *post_host);        /* [n][4] hmm.c:671-685 */
 int hf_get_forward_backward(hf_ctx *ctx, int64_t first, int64_t n, double *f_host, double *b_host,
