@@ -718,7 +718,8 @@ int hf_warmup(int device) {
         char* a = pc.acquire((size_t) 4 * (2u << 20));
         char* b = pc.acquire((size_t) 12 * (2u << 20));
         char* c = pc.acquire((size_t) 8 << 20);
-        pc.release(a); pc.release(b); pc.release(c);
+        char* d = pc.acquire((size_t) 64 << 10);     // a context's result / parameter block
+        pc.release(a); pc.release(b); pc.release(c); pc.release(d);
     }
     return HF_OK;
 }
@@ -931,17 +932,20 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     DMALLOC(ctx->d_chunk_stats, C * (size_t) ctx->V * 8); DMALLOC(ctx->d_total, ((size_t) ctx->V + 1) * 8);
     DMALLOC(ctx->d_flags, 4);
     DMALLOC(ctx->d_done, HF_DONE_BYTES);         // tickets and scratch of the in-launch hand-offs (hf_rows.h)
-    hipMemset(ctx->d_done, 0, HF_DONE_BYTES);
+    hipMemsetAsync(ctx->d_done, 0, HF_DONE_BYTES, nullptr);
     DMALLOC(ctx->d_cks, 8);
-    hipMemset(ctx->d_cks, 0, 8);
+    hipMemsetAsync(ctx->d_cks, 0, 8, nullptr);
     ctx->params_bytes = sizeof(DevParams) + (size_t) (n_regions - 1) * sizeof(DevRegion);
     DMALLOC(ctx->d_params, ctx->params_bytes);
-    hipMemset(ctx->d_params, 0, ctx->params_bytes);   // (the kernel-argument path writes the bytes in use only)
+    hipMemsetAsync(ctx->d_params, 0, ctx->params_bytes, nullptr);   // (the kernel-argument path writes the bytes in use only)
     {   // one pinned block: the result vector (+ flag word, stamp, checksums) | the flag word of hf_check | the parameter block
         const size_t tot_bytes = (((size_t) ctx->V + 2 + HF_MAXREGIONS) * 8 + 63) / 64 * 64;   // (what follows stays 64-byte aligned)
         char* pin = nullptr;
         const size_t par_bytes = (ctx->params_bytes + 63) / 64 * 64;
-        if (hipHostMalloc((void**) &pin, tot_bytes + 64 + par_bytes) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hipHostMalloc failed"); }
+        // (from the process-wide cache: pinning even this small block was 0.1-0.2 ms of hf_create; zeroed — a stale stamp word must not look like a future one)
+        pin = pin_cache().acquire(tot_bytes + 64 + par_bytes);
+        if (!pin) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of host memory"); }
+        std::memset(pin, 0, tot_bytes + 64 + par_bytes);
         ctx->h_total = reinterpret_cast<double*>(pin);
         ctx->h_flags = reinterpret_cast<unsigned*>(pin + tot_bytes);
         ctx->h_params = reinterpret_cast<DevParams*>(pin + tot_bytes + 64);
@@ -955,8 +959,8 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     }
     cphase("device + pinned allocations");
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
-    hipMemset(ctx->d_flags, 0, 4);
-    hipMemset(ctx->d_label, 0xff, N ? N : 1);
+    hipMemsetAsync(ctx->d_flags, 0, 4, nullptr);
+    hipMemsetAsync(ctx->d_label, 0xff, N ? N : 1, nullptr);
     if (N > 0 && C > 0) {
         dim3 grid((unsigned) ((maxT + 255) / 256), (unsigned) C);
         hipLaunchKernelGGL(k_setup, grid, dim3(256), 0, 0, ctx->d_off, d_packed, d_cov, d_mapq, d_clip, d_annot, d_cs, d_ce, d_cl,
@@ -1141,7 +1145,14 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 {   // one row behind the rows of A: the IDENTITY (hf_seg.h: what a lane multiplies by past its last window); no kernel writes it
                     double ident[16];
                     for (int k = 0; k < 16; k++) ident[k] = (k % 5 == 0) ? 1.0 : 0.0;
-                    if (hipMemcpy(ctx->d_lutA + a_src.size() * 16, ident, sizeof ident, hipMemcpyHostToDevice) != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: the identity row"); }
+                    // (through the staging buffer: a synchronous copy here waited for the 6 MB of rows of A enqueued just above — 0.25 ms)
+                    hipError_t ei;
+                    if (stg.p && stg.used + 128 <= stg.cap) {
+                        std::memcpy(stg.p + stg.used, ident, sizeof ident);
+                        ei = hipMemcpyAsync(ctx->d_lutA + a_src.size() * 16, stg.p + stg.used, sizeof ident, hipMemcpyHostToDevice, nullptr);
+                        stg.used += 128;
+                    } else ei = hipMemcpy(ctx->d_lutA + a_src.size() * 16, ident, sizeof ident, hipMemcpyHostToDevice);
+                    if (ei != hipSuccess) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: the identity row"); }
                 }
                 if (ctrace) std::fprintf(stderr, "[hf_create] %d emission keys, %d (key, transition class) rows, %d slow windows\n",
                                          ctx->n_keys, n_combo, ctx->n_slow);
@@ -1179,7 +1190,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 ctx->nseg = (int) segs.size(); ctx->n_slots = nslots;
                 TRY(dev_upload(ctx, stg, &ctx->d_chunk_seg0, cseg0.data(), cseg0.size()));   // (the descriptors go up with the plan's positions in them)
                 DMALLOC(ctx->d_seg_ready, segs.size() * 4);
-                hipMemset(ctx->d_seg_ready, 0, segs.size() * 4);
+                hipMemsetAsync(ctx->d_seg_ready, 0, segs.size() * 4, nullptr);
                 DMALLOC(ctx->d_seg_ll, segs.size() * 8);
                 DMALLOC(ctx->d_Pseg, segs.size() * 16 * 8);
             } else segs.clear();
@@ -1543,7 +1554,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
 #ifdef HF_SEG_TRACE
     if (ctx->nseg > 0 && std::getenv("HF_SEG_TRACE_FILE")) {
         DMALLOC(ctx->d_seg_trace, (size_t) ctx->nseg * HF_SEG_TRACE_N * 8);
-        hipMemset(ctx->d_seg_trace, 0, (size_t) ctx->nseg * HF_SEG_TRACE_N * 8);
+        hipMemsetAsync(ctx->d_seg_trace, 0, (size_t) ctx->nseg * HF_SEG_TRACE_N * 8, nullptr);
         hipMemcpyToSymbol(HIP_SYMBOL(g_seg_trace), &ctx->d_seg_trace, sizeof(void*));
     }
 #endif
@@ -1591,13 +1602,13 @@ void hf_destroy(hf_ctx* ctx) {
     ctx_free(ctx, ctx->d_jobs); ctx_free(ctx, ctx->d_arow); ctx_free(ctx, ctx->d_arow_src); ctx_free(ctx, ctx->d_arow_cls); ctx_free(ctx, ctx->d_lutA);
     ctx_free(ctx, ctx->d_rw_off); ctx_free(ctx, ctx->d_rw_stats);
     ctx_free(ctx, ctx->d_tile_ll); ctx_free(ctx, ctx->d_tile_stats);
-    if (ctx->h_total) hipHostFree(ctx->h_total);   // one pinned block: h_flags and h_params live in it
     if (ctx->h_part) hipHostFree(ctx->h_part);
     if (ctx->h_label) pin_cache().release(reinterpret_cast<char*>(ctx->h_label));
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     for (int i = 0; i < 2 * HF_NKERNELS; i++) if (ctx->kev[i]) hipEventDestroy(ctx->kev[i]);
     for (auto& sl : ctx->slabs) hipFree(sl.first);
+    if (ctx->h_total) { hipDeviceSynchronize(); pin_cache().release(reinterpret_cast<char*>(ctx->h_total)); }   // one pinned block (h_flags and h_params live in it), back to the cache once nothing can write it any more
     delete ctx;
 }
 
