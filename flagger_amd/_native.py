@@ -123,6 +123,9 @@ def lib() -> C.CDLL:
     sig("hf_seg_cached_steps", C.c_int, vp)
     sig("hf_sub_passes", C.c_int, vp)
     sig("hf_sub_pass_windows", C.c_int64, vp, C.c_int)
+    sig("hf_seg_xcd_plan", C.c_int, vp)
+    sig("hf_seg_block_table", C.c_int64, vp, C.POINTER(C.c_int32), C.c_int64)
+    sig("hf_create_phases", C.c_int, vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_char_p))
     sig("hf_finish_exchange", C.c_int, vp, vp, vp, i64, C.c_int, C.c_int, C.c_int, pd, vp)
     sig("hf_bind_chunk_stats", C.c_int, vp, vp)
     sig("hf_write_flag_row", C.c_int, vp, vp, vp)

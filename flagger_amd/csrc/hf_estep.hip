@@ -76,11 +76,12 @@ struct HostPool {
             active.fetch_sub(1, std::memory_order_release);
         }
     }
-    // f(k) for k = 0..P-1 (the caller takes parts too); false if another caller holds the pool
-    bool run(size_t P, const std::function<void(size_t)>& f) {
+    // f(k) for k = 0..P-1 on the caller and up to `workers` pool threads (parts are handed out one at a time: a thread that wakes late
+    // takes fewer); false if another caller holds the pool
+    bool run(size_t P, const std::function<void(size_t)>& f, size_t workers) {
         std::unique_lock<std::mutex> only(run_m, std::try_to_lock);
         if (!only.owns_lock()) return false;
-        start(P - 1);
+        start(std::min(workers, P - 1));
         next.store(0); done.store(0);
         { std::lock_guard<std::mutex> g(m); job = &f; parts = P; gen++; }
         cv.notify_all();
@@ -184,11 +185,16 @@ static size_t host_threads() {
     return n;
 }
 template <class Fn>
-static void par_chunks(const int64_t* chunk_off, size_t C, Fn fn) {
+static void par_chunks(const int64_t* chunk_off, size_t C, Fn fn, size_t parts_per_thread = 4) {
     const unsigned hw = std::thread::hardware_concurrency();
     (void) hw;
-    const size_t T = C < 16 ? 1 : std::min<size_t>(host_threads(), C);
-    if (T <= 1) { fn((size_t) 0, C, (size_t) 0); return; }
+    // Round 6: FOUR parts per thread, handed out dynamically (HostPool::run), instead of one static part each — on a box the driver leased
+    // fresh, hf_create took 8.35 ms against 2.9-4.3 on others: a pass over the windows lasted as long as the thread that woke last.  Parts stay
+    // consecutive chunk ranges in order (what the slow-window lists and the plan's per-part ranks rely on), and the cut depends on the chunk
+    // list and the thread count only: the second and third pass of hf_create see the same parts.
+    const size_t NT = C < 16 ? 1 : std::min<size_t>(host_threads(), C);
+    if (NT <= 1) { fn((size_t) 0, C, (size_t) 0); return; }
+    const size_t T = std::min<size_t>(std::min<size_t>(HF_PARTS, parts_per_thread * NT), C);
     std::vector<size_t> cut(T + 1, 0);
     const int64_t total = chunk_off[C] - chunk_off[0];
     size_t c = 0;
@@ -199,11 +205,16 @@ static void par_chunks(const int64_t* chunk_off, size_t C, Fn fn) {
     }
     cut[T] = C;
     const std::function<void(size_t)> part = [&](size_t k) { fn(cut[k], cut[k + 1], k); };
-    if (host_pool().run(T, part)) return;
+    if (host_pool().run(T, part, NT - 1)) return;
+    std::atomic<size_t> next{0};                       // the pool is busy (hf_multi's ranks create their contexts concurrently): threads of our own
+    auto work = [&] { for (size_t k; (k = next.fetch_add(1, std::memory_order_relaxed)) < T;) part(k); };
     std::vector<std::thread> th;
-    for (size_t k = 0; k < T; k++) th.emplace_back([&, k] { part(k); });
+    for (size_t k = 1; k < NT; k++) th.emplace_back(work);
+    work();
     for (auto& t : th) t.join();
 }
+struct hf_ctx;
+static int cseg0_of(const hf_ctx* ctx, int c);      // first segment of chunk c (c = C: the number of segments)
 // slot of a segment's x-th window: lane x / L holds it as its x % L-th (hf_seg.h)
 static inline int32_t seg_slot(const SegDesc& d, int64_t x) { return d.slot0 + (int32_t) ((x % d.L) * 64 + x / d.L); }
 static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
@@ -292,7 +303,7 @@ struct hf_ctx {
     // sub-pass's positions [p0, p1) at a time (d_recs; the plan's groups are numbered sub-pass by sub-pass, so a sub-pass's records are
     // contiguous) — the records never travel to HBM and back.  Everything that needs the records of ALL windows at once (the getters,
     // per-chunk statistics) runs the segment kernel into d_recs_all instead (allocated on first use; = d_recs with one sub-pass).
-    struct SubPass { int c0, c1, seg0, seg1, g0, g1; int64_t p0, p1; };
+    struct SubPass { int c0, c1, seg0, seg1, g0, g1; int64_t p0, p1; int b0 = 0, b1 = 0; };   // b0, b1: its blocks in the XCD plan (d_seg_of_block)
     std::vector<SubPass> subs;
     double* d_recs_all = nullptr; bool recs_all = false;   // recs_all: d_recs_all holds the records of every window of the last full pass
     bool scales_all = false;       // ... and d_scale_s its scales (an EM pass writes none: 8 of its 72 bytes per window that only
@@ -312,18 +323,25 @@ struct hf_ctx {
     // each other inside the launch (flags stamped with the launch's epoch); a timed-out wait switches the context to two launches
     unsigned* d_seg_ready = nullptr; unsigned seg_epoch = 0; bool seg_fused = true, seg_test_timeout = false;
     int seg_nc = 0;                    // row blocks a segment workgroup keeps in LDS across its three walks (hf_seg.h: chosen so that all segments stay resident)
+    // XCD plan (round 6): block b of k_seg_fb runs segment seg_of_block[b]; the segments of a chunk sit on block indices congruent mod 8
+    // (observed: block b runs on XCD b % 8 — for speed only, the hand-off protocol is system-scope whatever the placement).  Null: identity.
+    int32_t* d_seg_of_block = nullptr; std::vector<int32_t> h_seg_of_block;
     hf_params last_p{}; int last_mode = HF_MODE_FULL;   // what the last hf_estep was given (the fallback re-runs the pass)
+    hipStream_t last_stream = nullptr;                  // ... and the stream it ran on (the getters' re-run of the segment kernel goes there)
     // rows of A_t = T_t∘e_t (hf_seg.h): one per (emission key, transition class) that occurs at an interior window, then one
     // per slow window; d_arow[t] = the row of window t (bit 31: chunk-first), d_arow_src / d_arow_cls = where a row comes from
     int32_t* d_arow = nullptr; int32_t* d_arow_src = nullptr; int32_t* d_arow_cls = nullptr; double* d_lutA = nullptr;
     int n_arows = 0, n_combo = 0;
     double* d_scale_s = nullptr; int64_t n_slots = 0;
     std::vector<SegDesc> h_segs;                // the segment descriptors (the getters derive a window's slot from them)
+    std::vector<int32_t> h_cseg0;               // first segment of every chunk (+ the end)
+    std::vector<std::pair<const char*, double>> create_phases;   // hf_create_phases
     bool pass_seg = false;             // the last pass ran the segment kernels (log-likelihood partials per segment)
     unsigned long long* d_seg_trace = nullptr;   // -DHF_SEG_TRACE builds only
     int n_slow = 0; int64_t* d_slow_w = nullptr; int32_t* d_slow_off = nullptr; double* d_Es = nullptr; double* d_Cs = nullptr;
 };
 
+static int cseg0_of(const hf_ctx* ctx, int c) { return ctx->h_cseg0[(size_t) c]; }
 static void* ctx_alloc(hf_ctx* ctx, size_t bytes) {
     bytes = (bytes ? bytes : 8);
     bytes = (bytes + 255) & ~(size_t) 255;
@@ -557,12 +575,19 @@ static void launch_pair_sums(hf_ctx* ctx, hipStream_t st, const hf_ctx::SubPass&
 // k_seg_fb over the segments [g0, g0 + n) (hf_seg.h); timed: by the dispatch's own start / stop timestamps (hipExtLaunchKernelGGL hands the two
 // events to the launch: what rocprofv3 reports for the kernel, without the two marker packets of an event pair around it — those measured 3 us
 // more than the kernel and cost the step ~15 us)
-static void launch_seg_fb(hf_ctx* ctx, hipStream_t st, bool full, double* recs_eff, int g0, int n, unsigned epoch, unsigned wait_epoch, bool timed, bool with_scales = true) {
+// sub >= 0: the segments of that sub-pass; < 0: all segments
+static void launch_seg_fb(hf_ctx* ctx, hipStream_t st, bool full, double* recs_eff, int sub, unsigned epoch, unsigned wait_epoch, bool timed, bool with_scales = true) {
+    int g0 = sub >= 0 ? ctx->subs[(size_t) sub].seg0 : 0, n = sub >= 0 ? ctx->subs[(size_t) sub].seg1 - g0 : ctx->nseg;
+    const int32_t* const sob = ctx->seg_fused ? ctx->d_seg_of_block : nullptr;   // (the XCD plan: one-launch mode only — two launches have no hand-off inside the launch)
+    if (sob) {       // blocks of the plan instead of segments (a sub-pass's blocks are contiguous, and so are all of them)
+        g0 = sub >= 0 ? ctx->subs[(size_t) sub].b0 : 0;
+        n = (sub >= 0 ? ctx->subs[(size_t) sub].b1 : ctx->subs.back().b1) - g0;
+    }
     if (n <= 0) return;
     const int nc = ctx->seg_fused ? ctx->seg_nc : 0;     // cached row blocks: one-launch mode only (the lane products are computed in the same kernel)
     const size_t lds = seg_lds_bytes(nc);
 #define HF_SEG_FB_ARGS ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_params, ctx->d_segQ, ctx->d_Pseg, ctx->d_seg_ready, epoch, wait_epoch, ctx->d_pos, recs_eff, \
-                        with_scales ? ctx->d_scale_s : (double*) nullptr, ctx->d_label, ctx->d_seg_ll, ctx->d_flags, (int32_t) g0, nc
+                        with_scales ? ctx->d_scale_s : (double*) nullptr, ctx->d_label, ctx->d_seg_ll, ctx->d_flags, (int32_t) g0, nc, sob
 #define HF_SEG_FB_LAUNCH(B, F, CA) do { \
         if (timed) hipExtLaunchKernelGGL(HIP_KERNEL_NAME(k_seg_fb<B, F, CA>), dim3((unsigned) n), dim3(64), (uint32_t) lds, st, \
                                          ctx->kev[2 * HF_K_SEG_FB], ctx->kev[2 * HF_K_SEG_FB + 1], 0, HF_SEG_FB_ARGS); \
@@ -733,11 +758,13 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
     hf_ctx* ctx = new hf_ctx();
     ctx->device = device; ctx->algo = algo;
     const bool ctrace = std::getenv("HF_HOST_TRACE") != nullptr;
-    auto ct0 = std::chrono::steady_clock::now();
-    auto cphase = [&](const char* name) {
-        if (!ctrace) return;
+    const auto ct_begin = std::chrono::steady_clock::now();
+    auto ct0 = ct_begin;
+    auto cphase = [&](const char* name) {            // (always recorded: ~25 clock reads; hf_create_phases)
         const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[hf_create] %-34s %7.2f ms\n", name, std::chrono::duration<double, std::milli>(now - ct0).count());
+        const double ms = std::chrono::duration<double, std::milli>(now - ct0).count();
+        ctx->create_phases.emplace_back(name, ms);
+        if (ctrace) std::fprintf(stderr, "[hf_create] %-34s %7.2f ms\n", name, ms);
         ct0 = now;
     };
     {
@@ -1041,6 +1068,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         cphase("tiles + work arrays");
         // ---- segments of the workgroup-per-segment forward-backward (hf_seg.h) and the record slot of every window ----
         std::vector<std::vector<int32_t>> pcnt(HF_PARTS);   // pairs per (sub-pass, row of A), per part of the chunk list
+        size_t plan_ppt = 4;
         int n_sub = 1; std::vector<int32_t> sub_of(C, 0);    // sub-pass of every chunk
         if (arena.th.joinable()) arena.th.join();
         if (N > 0 && !arena.b) { hf_destroy(ctx); return set_err(HF_E_HIP, "hf_create: out of host memory"); }
@@ -1110,9 +1138,10 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 }
                 // second pass: every window's row of A, and the pairs per (sub-pass, row of A) (x >= 2: hmm.c:638-642) as one histogram per
                 // part of the chunk list (popular rows: no contended atomics)
+                plan_ppt = n_ar_all * (size_t) n_sub > 65536 ? 1 : 4;      // parts per thread of the second AND third pass (the same parts: pcnt)
                 par_chunks(w->chunk_off, C, [&](size_t c0, size_t c1, size_t part) {
                     std::vector<int32_t>& h = pcnt[part];
-                    h.assign(n_ar_all * (size_t) n_sub, 0);
+                    h.assign(n_ar_all * (size_t) n_sub, 0);      // (one histogram per part: few parts when the histogram is long — plan_ppt)
                     for (size_t c = c0; c < c1; c++) {
                         const int64_t t0 = w->chunk_off[c], T = w->chunk_off[c + 1] - t0;
                         int32_t sp = soff[c];
@@ -1130,7 +1159,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                             if (x >= 2) h[(size_t) sub_of[c] * n_ar_all + (size_t) id]++;
                         }
                     }
-                });
+                }, plan_ppt);
                 cphase("rows of A (second pass)");
                 ctx->n_combo = n_combo; ctx->n_arows = (int) a_src.size();
                 if (a_src.size() >= ((size_t) 1 << 25)) {   // the segment kernels address a row by a 32-bit BYTE offset (index << 7)
@@ -1186,6 +1215,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                 }
             }
             cseg0[C] = (int32_t) segs.size();
+            ctx->h_cseg0 = cseg0;
             if (nslots < INT32_MAX) {
                 ctx->nseg = (int) segs.size(); ctx->n_slots = nslots;
                 TRY(dev_upload(ctx, stg, &ctx->d_chunk_seg0, cseg0.data(), cseg0.size()));   // (the descriptors go up with the plan's positions in them)
@@ -1416,7 +1446,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
                     h_spare[c] = spare;
                     for (int k = cseg0[c]; k < cseg0[c + 1]; k++) ctx->h_segs[(size_t) k].spare_pos = spare;
                 }
-            });
+            }, plan_ppt);
             cphase("plan: positions (third pass)");
             if (planned) {
                 // negative_binomial count data: the row slots of every (region, min(x, 249)) bin, in plan order
@@ -1489,6 +1519,39 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         int64_t resident = (int64_t) per_cu * cus;
         if (const char* e = std::getenv("HF_SEG_RESIDENT")) resident = std::atoll(e);   // tests: pretend a smaller device
         if (resident > 0 && max_nseg > resident) ctx->seg_fused = false;
+        // XCD plan (VERDICT r05 #2b): within every sub-pass the chunks are dealt to eight lists, each chunk to the list with the fewest segments so
+        // far (ties: the lowest list), and list x's r-th segment runs as block b0 + 8 r + x — all segments of a chunk on blocks congruent mod 8,
+        // the lists within one chunk's segments of each other (padding blocks: -1, they leave at once).  A chunk's segments then span 8 x nseg
+        // block indices instead of nseg: the plan is only used where that span is resident with room to spare, so the one-launch guard above
+        // still holds for it.  MEASURED AND NOT THE DEFAULT (profiles/r06_ab_handoff.txt): on configs[2] the plan makes k_seg_fb 13 us SLOWER
+        // (60 us against 47, same box, three alternations), at 1/4 and 1/8 of the size it changes nothing — the segments of a chunk then run on the
+        // CUs of one XCD in lockstep and meet in its L2 channels.  Block b runs segment b, as in rounds 3-5; HF_SEG_XCD=1 switches the plan on.
+        {
+            const char* e = std::getenv("HF_SEG_XCD");
+            const bool want = e && e[0] == '1';
+            if (want && ctx->seg_fused && resident > 0 && (int64_t) max_nseg * 8 * 2 <= resident && !ctx->subs.empty()) {
+                std::vector<int32_t>& tab = ctx->h_seg_of_block;
+                tab.clear();
+                for (auto& sb : ctx->subs) {
+                    std::vector<int32_t> lane[8];
+                    for (int c = sb.c0; c < sb.c1; c++) {
+                        const int s0 = cseg0_of(ctx, c), s1 = cseg0_of(ctx, c + 1);
+                        if (s1 <= s0) continue;
+                        int best = 0;
+                        for (int x = 1; x < 8; x++) if (lane[x].size() < lane[best].size()) best = x;
+                        for (int k = s0; k < s1; k++) lane[best].push_back(k);
+                    }
+                    size_t rows = 0;
+                    for (int x = 0; x < 8; x++) rows = std::max(rows, lane[x].size());
+                    sb.b0 = (int) tab.size();
+                    tab.resize(tab.size() + rows * 8, -1);
+                    for (int x = 0; x < 8; x++)
+                        for (size_t r = 0; r < lane[x].size(); r++) tab[(size_t) sb.b0 + r * 8 + (size_t) x] = lane[x][r];
+                    sb.b1 = (int) tab.size();
+                }
+                if (dev_upload(ctx, stg, &ctx->d_seg_of_block, tab.data(), tab.size()) != 0) { hf_destroy(ctx); return HF_E_HIP; }
+            }
+        }
         // Cached row blocks (hf_seg.h, round 5): the LDS that a device with FEWER segments than it could hold leaves idle goes to the
         // workgroups — the largest nc at which every segment is still resident at once.  Decided from the occupancy the runtime reports for
         // that much dynamic LDS; HF_SEG_CACHED_STEPS forces a value (tests, A/B runs).
@@ -1569,6 +1632,7 @@ int hf_create(const hf_windows* w, int n_regions, int max_comps, int device, int
         if (fl & HF_FLAG_REGION) { hf_destroy(ctx); return set_err(HF_E_REGION, "a window's region index is >= n_regions"); }
     }
     cphase("uploads and set-up kernels done");
+    ctx->create_phases.emplace_back("total", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ct_begin).count());
     *out = ctx;
     return HF_OK;
 }
@@ -1598,7 +1662,7 @@ void hf_destroy(hf_ctx* ctx) {
     for (int b = 0; b < 2; b++) { if (ctx->h_nb[b]) hipHostFree(ctx->h_nb[b]); if (ctx->nb_ev[b]) hipEventDestroy(ctx->nb_ev[b]); }
     ctx_free(ctx, ctx->d_tile_desc); ctx_free(ctx, ctx->d_chunk_tile0);
     ctx_free(ctx, ctx->d_done); ctx_free(ctx, ctx->d_cks); ctx_free(ctx, ctx->d_bin_off); ctx_free(ctx, ctx->d_bin_list); ctx_free(ctx, ctx->d_slot_h); ctx_free(ctx, ctx->d_H); if (ctx->d_recs_all != ctx->d_recs) ctx_free(ctx, ctx->d_recs_all); ctx_free(ctx, ctx->d_recs); ctx_free(ctx, ctx->d_chunk_ll); ctx_free(ctx, ctx->d_grp_ar); ctx_free(ctx, ctx->d_grp_n); ctx_free(ctx, ctx->d_grp_off); ctx_free(ctx, ctx->d_pos); ctx_free(ctx, ctx->d_pos_f); ctx_free(ctx, ctx->d_slot_of); ctx_free(ctx, ctx->d_grp_sums); ctx_free(ctx, ctx->d_rowslots); ctx_free(ctx, ctx->d_rw_region);
-    ctx_free(ctx, ctx->d_seg); ctx_free(ctx, ctx->d_chunk_seg0); ctx_free(ctx, ctx->d_seg_ll); ctx_free(ctx, ctx->d_Pseg); ctx_free(ctx, ctx->d_segQ); ctx_free(ctx, ctx->d_seg_ready); ctx_free(ctx, ctx->d_scale_s);
+    ctx_free(ctx, ctx->d_seg_of_block); ctx_free(ctx, ctx->d_seg); ctx_free(ctx, ctx->d_chunk_seg0); ctx_free(ctx, ctx->d_seg_ll); ctx_free(ctx, ctx->d_Pseg); ctx_free(ctx, ctx->d_segQ); ctx_free(ctx, ctx->d_seg_ready); ctx_free(ctx, ctx->d_scale_s);
     ctx_free(ctx, ctx->d_jobs); ctx_free(ctx, ctx->d_arow); ctx_free(ctx, ctx->d_arow_src); ctx_free(ctx, ctx->d_arow_cls); ctx_free(ctx, ctx->d_lutA);
     ctx_free(ctx, ctx->d_rw_off); ctx_free(ctx, ctx->d_rw_stats);
     ctx_free(ctx, ctx->d_tile_ll); ctx_free(ctx, ctx->d_tile_stats);
@@ -1849,9 +1913,10 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 if (want_rows) {
                     const bool alias = ctx->subs.size() > 1;
                     bool first = true;
-                    for (const auto& sb : ctx->subs) {
+                    for (size_t si = 0; si < ctx->subs.size(); si++) {
+                        const auto& sb = ctx->subs[si];
                         double* const recs_eff = alias ? ctx->d_recs - sb.p0 * 8 : ctx->d_recs;
-                        launch_seg_fb(ctx, st, true, recs_eff, sb.seg0, sb.seg1 - sb.seg0, epoch, wait_epoch, tfb && first, false);   // (timed: the first sub-pass's launch, hf_sub_pass_windows; no scales)
+                        launch_seg_fb(ctx, st, true, recs_eff, (int) si, epoch, wait_epoch, tfb && first, false);   // (timed: the first sub-pass's launch, hf_sub_pass_windows; no scales)
                         first = false;
                         KTimer t(ctx, st, HF_K_PAIR_SUMS);              // (event pairs around k_pair_sums: the last sub-pass's is what is read)
                         launch_pair_sums(ctx, st, sb, recs_eff);
@@ -1862,7 +1927,7 @@ static int enqueue_pass(hf_ctx* ctx, const hf_params* p, int mode, hipStream_t s
                 } else {
                     double* recs = ctx->d_recs;
                     if (full && ctx->subs.size() > 1) { const int rc_ = all_records_buffer(ctx); if (rc_) return rc_; recs = ctx->d_recs_all; }
-                    launch_seg_fb(ctx, st, full, recs, 0, ctx->nseg, epoch, wait_epoch, tfb, false);
+                    launch_seg_fb(ctx, st, full, recs, -1, epoch, wait_epoch, tfb, false);
                     if (full) { ctx->recs_all = true; ctx->scales_all = false; }
                 }
                 ctx->pass_seg = true;
@@ -1916,7 +1981,7 @@ int hf_estep(hf_ctx* ctx, const hf_params* p, int mode, void* stream) {
     HIPCHK(hipSetDevice(ctx->device));
     int rc = pack_params(ctx, p);
     if (rc) return rc;
-    ctx->last_p = *p; ctx->last_mode = mode;
+    ctx->last_p = *p; ctx->last_mode = mode; ctx->last_stream = st;
     if (pass_events(ctx)) HIPCHK(hipEventRecord(ctx->ev0, st));
     rc = enqueue_pass(ctx, p, mode, st);
     if (rc) return rc;
@@ -1948,6 +2013,19 @@ int64_t hf_sub_pass_windows(const hf_ctx* ctx, int k) {
     return ctx->h_off[(size_t) ctx->subs[(size_t) k].c1] - ctx->h_off[(size_t) ctx->subs[(size_t) k].c0];
 }
 int hf_seg_cached_steps(const hf_ctx* ctx) { return !ctx || !seg_pass(ctx) || !ctx->seg_fused ? 0 : ctx->seg_nc; }
+int hf_seg_xcd_plan(const hf_ctx* ctx) { return ctx && seg_pass(ctx) && ctx->seg_fused && ctx->d_seg_of_block ? 1 : 0; }
+int64_t hf_seg_block_table(const hf_ctx* ctx, int32_t* seg_of_block, int64_t n) {
+    if (!ctx) return 0;
+    const int64_t have = (int64_t) ctx->h_seg_of_block.size();
+    if (seg_of_block) for (int64_t i = 0; i < n && i < have; i++) seg_of_block[i] = ctx->h_seg_of_block[(size_t) i];
+    return have;
+}
+int hf_create_phases(const hf_ctx* ctx, int max, double* ms, const char** names) {
+    if (!ctx) return 0;
+    const int n = (int) ctx->create_phases.size();
+    for (int i = 0; i < n && i < max; i++) { if (ms) ms[i] = ctx->create_phases[(size_t) i].second; if (names) names[i] = ctx->create_phases[(size_t) i].first; }
+    return n;
+}
 
 int hf_copy_chunk_stats(hf_ctx* ctx, double* dst_dev, void* stream) {
     if (!ctx || !dst_dev) return set_err(HF_E_ARG, "hf_copy_chunk_stats: bad argument");
@@ -2362,12 +2440,12 @@ int hf_get_labels(hf_ctx* ctx, int8_t* labels_host) {
     }
     if (ctx->d_label_host && ctx->N > 0) {
         const int64_t n16 = (ctx->N + 15) / 16;      // (d_label and the pinned block are padded to 16 bytes)
-        hipLaunchKernelGGL(k_copy16, dim3((unsigned) ((n16 + 255) / 256)), dim3(256), 0, nullptr, reinterpret_cast<const uint4*>(ctx->d_label),
-                           reinterpret_cast<uint4*>(ctx->d_label_host), n16);
+        hipLaunchKernelGGL(k_copy16, dim3((unsigned) ((n16 + 255) / 256)), dim3(256), 0, ctx->last_stream, reinterpret_cast<const uint4*>(ctx->d_label),
+                           reinterpret_cast<uint4*>(ctx->d_label_host), n16);   // (behind the pass, on its stream)
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(nullptr));
+        HIPCHK(hipStreamSynchronize(ctx->last_stream));
         std::memcpy(labels_host, ctx->h_label, (size_t) ctx->N);
-    } else HIPCHK(hipMemcpy(labels_host, ctx->d_label, (size_t) ctx->N, hipMemcpyDeviceToHost));
+    } else { HIPCHK(hipStreamSynchronize(ctx->last_stream)); HIPCHK(hipMemcpy(labels_host, ctx->d_label, (size_t) ctx->N, hipMemcpyDeviceToHost)); }
     return HF_OK;
 }
 
@@ -2377,6 +2455,7 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
         return set_err(HF_E_ARG, "hf_get_forward_backward: the last pass was not HF_MODE_FULL (forward, backward and scale values would be stale)");
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return HF_OK;
+    HIPCHK(hipStreamSynchronize(ctx->last_stream));   // (the copies below run on the null stream: not ordered against a non-blocking stream by itself)
     if (scales_host && !ctx->fb_recs) HIPCHK(hipMemcpy(scales_host, ctx->d_scale + first, (size_t) n * 8, hipMemcpyDeviceToHost));
     if (!f_host && !b_host && !ctx->fb_recs) return HF_OK;
     if (ctx->fb_recs) {   // pair records (hf_seg.h): b_t is the second half of the record at pos[t], f_t the first half of the one at pos_f[t]
@@ -2387,11 +2466,33 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
             const int rc_ = all_records_buffer(ctx);
             if (rc_) return rc_;
             if (!ctx->d_scale_s) HIPCHK(hipMalloc((void**) &ctx->d_scale_s, (size_t) ctx->n_slots * 8));   // the scales: on first use (an EM pass writes none)
-            if (!ctx->seg_fused) hipLaunchKernelGGL(k_seg_prod, dim3((unsigned) ctx->nseg), dim3(64), seg_lds_bytes(), nullptr, ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
-            const unsigned epoch = ++ctx->seg_epoch;
-            launch_seg_fb(ctx, nullptr, true, ctx->d_recs_all, 0, ctx->nseg, epoch, epoch, false);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(nullptr));
+            // On the stream of the pass itself (the null stream is not ordered against a non-blocking user stream), and its flag
+            // word is read like a pass's: a hand-off that timed out in THIS launch would otherwise leave silently wrong vectors — the context
+            // falls back to two launches and the re-run is repeated; any other flag is the pass's own error, reported as hf_check would.
+            hipStream_t st = ctx->last_stream;
+            for (int attempt = 0;; attempt++) {
+                if (!ctx->seg_fused) {
+                    if (!ctx->d_segQ) HIPCHK(hipMalloc((void**) &ctx->d_segQ, (size_t) ctx->nseg * 64 * 16 * 8));
+                    hipLaunchKernelGGL(k_seg_prod, dim3((unsigned) ctx->nseg), dim3(64), seg_lds_bytes(), st, ctx->d_seg, ctx->d_arow, ctx->d_lutA, ctx->d_segQ, ctx->d_Pseg);
+                }
+                const unsigned epoch = ++ctx->seg_epoch;
+                launch_seg_fb(ctx, st, true, ctx->d_recs_all, -1, epoch, epoch, false);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(ctx->h_flags, ctx->d_flags, 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                const unsigned fl = *ctx->h_flags;
+                if ((fl & HF_FLAG_SYNC) && ctx->seg_fused && attempt == 0) {
+                    ctx->seg_fused = false;
+                    std::fprintf(stderr, "[hmm_flagger_hip] one-launch segment kernel: a hand-off timed out; this context falls back to k_seg_prod + k_seg_fb\n");
+                    unsigned keep = fl & ~(unsigned) HF_FLAG_SYNC;        // (the pass's own flags stay for a later hf_check)
+                    HIPCHK(hipMemcpyAsync(ctx->d_flags, &keep, 4, hipMemcpyHostToDevice, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    continue;
+                }
+                const int code = flags_to_code(fl);
+                if (code != HF_OK) return code;
+                break;
+            }
             ctx->recs_all = true; ctx->scales_all = true;
         }
         // the positions of a range are scattered over the plan: gathered on the device, one copy back (maps uploaded on first use)
@@ -2404,8 +2505,9 @@ int hf_get_forward_backward(hf_ctx* ctx, int64_t first, int64_t n, double* f_hos
         }
         double* d_out = nullptr;
         HIPCHK(hipMalloc((void**) &d_out, (size_t) n * 9 * 8));
-        hipLaunchKernelGGL(k_gather_fb, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, first, n, ctx->d_pos, ctx->d_pos_f, ctx->d_slot_of,
+        hipLaunchKernelGGL(k_gather_fb, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, ctx->last_stream, first, n, ctx->d_pos, ctx->d_pos_f, ctx->d_slot_of,
                            ctx->d_recs_all, ctx->d_scale_s, d_out, d_out + n * 4, d_out + n * 8);
+        HIPCHK(hipStreamSynchronize(ctx->last_stream));
         hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
         if (f_host) e1 = hipMemcpy(f_host, d_out, (size_t) n * 32, hipMemcpyDeviceToHost);
         if (b_host) e2 = hipMemcpy(b_host, d_out + n * 4, (size_t) n * 32, hipMemcpyDeviceToHost);

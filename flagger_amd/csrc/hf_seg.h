@@ -63,6 +63,52 @@
 #define HF_SEG_SPIN_MAX (1 << 16)            // polls of one flag before the wait is given up (HF_FLAG_SYNC: the host falls back to two launches)
 __device__ __forceinline__ void seg_xcu_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ double seg_xcu_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// Round 6 (VERDICT r05 #2a): a segment product travels as 8 x 16-byte `sc0 sc1` accesses instead of 16 + 16 eight-byte system-scope atomics
+// (MI355X_MICROARCH.md, Workgroup dispatch: a dwordx2 sc1 store costs 2.7x a dwordx4's time per byte, 8-byte sc1 loads run at 0.54-0.70x the
+// 16-byte rate).  Same scope bits as the atomics' lowering, same protocol: write-through data, drained queue, then the flag; the reader polls
+// the flag, then loads past its caches.  Inline assembly: hipcc has no builtin for a 16-byte store with both scope bits (a volatile access
+// gets them, with an s_waitcnt vmcnt(0) behind EVERY access).  -DHF_SEG_WIDE=0: the 8-byte atomics of rounds 3-5 (same-box A/B).
+#ifndef HF_SEG_WIDE
+#define HF_SEG_WIDE 1
+#endif
+typedef unsigned hf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void seg_xcu_store_m4(double* p, const double m[16]) {
+#if HF_SEG_WIDE
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        hf_u32x4 v;
+        v.x = (unsigned) __double2loint(m[2 * k]); v.y = (unsigned) __double2hiint(m[2 * k]);
+        v.z = (unsigned) __double2loint(m[2 * k + 1]); v.w = (unsigned) __double2hiint(m[2 * k + 1]);
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p + 2 * k), "v"(v) : "memory");
+    }
+#else
+#pragma unroll
+    for (int k = 0; k < 16; k++) seg_xcu_store(p + k, m[k]);
+#endif
+}
+// (the loads and their wait in ONE asm statement: the compiler does not count an asm load on its vmcnt scoreboard, so the registers are only
+// valid behind the statement's own s_waitcnt; nothing else of the wavefront is in flight at the two places this is called from)
+__device__ __forceinline__ void seg_xcu_load_m4(const double* p, double m[16]) {
+#if HF_SEG_WIDE
+    hf_u32x4 v0, v1, v2, v3, v4, v5, v6, v7;
+    asm volatile("global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
+                 "global_load_dwordx4 %1, %8, off offset:16 sc0 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:32 sc0 sc1\n\t"
+                 "global_load_dwordx4 %3, %8, off offset:48 sc0 sc1\n\t"
+                 "global_load_dwordx4 %4, %8, off offset:64 sc0 sc1\n\t"
+                 "global_load_dwordx4 %5, %8, off offset:80 sc0 sc1\n\t"
+                 "global_load_dwordx4 %6, %8, off offset:96 sc0 sc1\n\t"
+                 "global_load_dwordx4 %7, %8, off offset:112 sc0 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7) : "v"(p) : "memory");
+    const hf_u32x4 v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+    for (int k = 0; k < 8; k++) { m[2 * k] = __hiloint2double((int) v[k].y, (int) v[k].x); m[2 * k + 1] = __hiloint2double((int) v[k].w, (int) v[k].z); }
+#else
+#pragma unroll
+    for (int k = 0; k < 16; k++) m[k] = seg_xcu_load(p + k);
+#endif
+}
 
 // -DHF_SEG_TRACE: s_memtime stamps of k_seg_fb<true>'s phases, one row of HF_SEG_TRACE_N words per workgroup, dumped by
 // hf_destroy to $HF_SEG_TRACE_FILE (profiles/tools/seg_trace.sh / seg_trace.py).  Not in a normal build.
@@ -521,7 +567,8 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                                                            const double* __restrict__ Qs, double* Pseg, unsigned* ready, unsigned epoch, unsigned wait_epoch,
                                                            const int32_t* __restrict__ pos, double* __restrict__ recs, double* __restrict__ scale_s,
                                                            int8_t* __restrict__ label, double* __restrict__ seg_ll,
-                                                           unsigned* __restrict__ flags, int32_t g0, int nc_arg) {
+                                                           unsigned* __restrict__ flags, int32_t g0, int nc_arg,
+                                                           const int32_t* __restrict__ seg_of_block) {
     static_assert(FUSED || !CACHED, "cached row blocks: one-launch mode only");
     const int nc = CACHED ? nc_arg : 0;
     constexpr int LM = HF_SEG_LMAX;
@@ -537,7 +584,11 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     // g0: the launch's first segment (round 5: a context whose pair records exceed the Infinity Cache runs the pass in SUB-PASSES of whole
     // chunks — k_seg_fb, then k_pair_sums, per sub-pass — through one record buffer that holds a sub-pass at a time; `recs` then points
     // p0 records before the buffer, so that the plan's global positions land inside it: hf_estep.hip enqueue_pass)
-    const int g = (int) blockIdx.x + g0, lane = threadIdx.x;
+    // seg_of_block (round 6, hf_create's XCD plan): the launch's block b runs segment seg_of_block[g0 + b] — all segments of a chunk on block
+    // indices congruent mod 8, i.e. (observed, for speed only) on one XCD; < 0: a padding block of the plan.  Null: block b runs segment g0 + b.
+    int g = (int) blockIdx.x + g0;
+    const int lane = threadIdx.x;
+    if (seg_of_block) { g = seg_of_block[g]; if (g < 0) return; }
     const SegDesc d = sd[g];
     const int L = d.L, n = d.n;
     const int a = lane * L;
@@ -575,10 +626,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             if (BWD) m4_park(Q, lane, blk);
             m4_scan_prefix(Q, lane);
             if (d.nseg > 1) {
-                if (lane == 63) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) seg_xcu_store(Pseg + (int64_t) g * 16 + k, Q.m[k]);
-                }
+                if (lane == 63) seg_xcu_store_m4(Pseg + (int64_t) g * 16, Q.m);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the product has left this CU before the flag does
                 if (lane == 63) __hip_atomic_store(ready + g, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
@@ -635,8 +683,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                             if (++spins > HF_SEG_SPIN_MAX) { bad |= HF_FLAG_SYNC; break; }
                             __builtin_amdgcn_s_sleep(2);
                         }
-#pragma unroll
-                        for (int k = 0; k < 16; k++) Tm[k] = seg_xcu_load(Pseg + (int64_t) (d.seg0 + q) * 16 + k);
+                        seg_xcu_load_m4(Pseg + (int64_t) (d.seg0 + q) * 16, Tm);
                     }
                     stage();
                 };

@@ -108,7 +108,12 @@ class ShardedEMList:
             return None if st is None else st.copy()
         self.local.reduce_into(rows, self.row_index, self.n_rows, self.total)
         stats = self.total.cpu().numpy().copy()           # device->host copy synchronises the stream
-        self.local.check()
+        try:
+            self.local.check()
+        except Exception as e:            # hmm.RetryPass: what was gathered and summed above came from a timed-out pass — the whole sequence again
+            if getattr(e, "code", None) == N.HF_E_RETRY:
+                return None
+            raise
         return stats
 
     def gather_labels(self) -> np.ndarray:

@@ -166,6 +166,10 @@ def _windows_struct(store: WindowStore, model: "HMM", adjustContigEnds: bool, mi
     return w, k
 
 
+class RetryPass(N.HFError):
+    """HF_E_RETRY out of EMList.check(): repeat the pass and everything that consumed its statistics."""
+
+
 class MultiHFError(RuntimeError):
     def __init__(self, code: int, where: str):
         self.code = code
@@ -368,10 +372,32 @@ class EMList:
     def sub_pass_windows(self, k: int = 0) -> int:
         return int(self._L.hf_sub_pass_windows(self._h, int(k)))
 
+    @property
+    def seg_xcd_plan(self) -> bool:
+        """True when the one-launch segment kernel runs its blocks through hf_create's block -> segment table (hf_seg_xcd_plan)."""
+        return bool(self._L.hf_seg_xcd_plan(self._h)) if hasattr(self._L, "hf_seg_xcd_plan") else False
+
+    def seg_block_table(self) -> np.ndarray:
+        n = int(self._L.hf_seg_block_table(self._h, None, 0))
+        out = np.empty(n, dtype=np.int32)
+        self._L.hf_seg_block_table(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), n)
+        return out
+
+    def create_phases(self) -> dict:
+        """{phase: ms} of this context's hf_create, in call order; the last entry is "total" (hf_create_phases)."""
+        if not hasattr(self._L, "hf_create_phases"):
+            return {}
+        ms, names = (C.c_double * 64)(), (C.c_char_p * 64)()
+        n = min(int(self._L.hf_create_phases(self._h, 64, ms, names)), 64)
+        out = {}
+        for i in range(n):
+            k = names[i].decode()
+            out[k] = out.get(k, 0.0) + float(ms[i])
+        return out
+
     # --- E-step pieces (used directly by the multi-GPU path in dist.py) ---
     def launch(self, model: HMM, mode: int = N.HF_MODE_FULL) -> None:
         p = model.params()
-        self._last_launch = (model, mode)
         N.check(self._L.hf_estep(self._h, C.byref(p), mode, self.stream), "hf_estep")
 
     def finish(self) -> np.ndarray:
@@ -381,13 +407,13 @@ class EMList:
 
     def check(self) -> None:
         """hf_check: the error flags of the last pass.  HF_E_RETRY (a hand-off of the one-launch segment kernel timed out; the context has
-        switched to two launches) is not an error of the data: the pass is enqueued again and checked once more — hf_finish
-        does the same inside the library.  A caller that drives several ranks itself must take that decision for all ranks together:
-        hf_finish_exchange ORs the flag rows for exactly that reason."""
+        switched to two launches) is not an error of the data, but what the timed-out pass left behind — statistics the caller has already
+        copied, reduced or all-gathered — is garbage: it is raised as `RetryPass` so that the caller repeats its WHOLE sequence
+        (launch, exchange, reduction, check), as ShardedEMList.run_sharded does for all ranks together; hf_finish repeats the pass inside
+        the library, where it reads the result itself.  (round 5 re-launched here and returned success over the stale copy.)"""
         rc = self._L.hf_check(self._h, self.stream)
-        if rc == N.HF_E_RETRY and getattr(self, "_last_launch", None) is not None:
-            self.launch(*self._last_launch)
-            rc = self._L.hf_check(self._h, self.stream)
+        if rc == N.HF_E_RETRY:
+            raise RetryPass(rc, "hf_check")
         N.check(rc, "hf_check")
 
     def rank_total(self, dst_dev_ptr: int) -> None:

@@ -317,4 +317,8 @@ def config(n: int, scale: float = 1.0, overdispersion: float = 3.0) -> WindowSto
         # sequencing coverage looks like next to the Gaussian of SURVEY §8d), VERDICT r02 #5
         lens = [int(x * scale) for x in _HUMAN_CHROMS] * 2
         return synthesize(lens, 4000, 20_000_000, [20], seed, contig_prefix="hap_ctg", overdispersion=overdispersion)
+    if n == 7:   # NOT a BASELINE config: configs[2]'s genome at the window length the reference's hifi / ont-r9 presets default to
+        # (16 kb, hmm_flagger.c:27,44,951-953: what a user who passes no -W runs) — ~380 k windows: the latency-bound regime
+        lens = [int(x * scale) for x in _HUMAN_CHROMS] * 2
+        return synthesize(lens, 16000, 20_000_000, [20], seed, contig_prefix="hap_ctg")
     raise ValueError("configs[0] is generated by tests/golden/make_golden.py (simulated .cov)")

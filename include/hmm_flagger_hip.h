@@ -212,6 +212,16 @@ int hf_seg_cached_steps(const hf_ctx *ctx);
  * hf_sub_pass_windows: the windows of sub-pass k (what ONE launch of the segment kernel processes: hf_set_profiling times the first). */
 int hf_sub_passes(const hf_ctx *ctx);
 int64_t hf_sub_pass_windows(const hf_ctx *ctx, int k);
+/* XCD plan of the one-launch segment kernel (round 6): 1 when the blocks of the NEXT pass run the segments through hf_create's block ->
+ * segment table (all segments of a chunk on block indices congruent mod 8 — observed: one XCD; the hand-off stays system-scope, so this is
+ * for speed only), 0 when block b runs segment b (environment HF_SEG_XCD=0, two-launch mode, or a chunk whose segments would span more
+ * than half of the resident workgroups).  hf_seg_block_table: the table (n entries copied, -1 = padding block); returns its length. */
+int hf_seg_xcd_plan(const hf_ctx *ctx);
+int64_t hf_seg_block_table(const hf_ctx *ctx, int32_t *seg_of_block, int64_t n);
+/* Where hf_create's wall time went (what EM_construct + EM_renewParametersAndEstimatorsFromModel cost the reference per chunk and
+ * iteration, hmm.c:253-298, paid once here): up to `max` phases in call order, ms[i] and a static name each; returns the number of
+ * phases recorded.  The last entry is the total. */
+int hf_create_phases(const hf_ctx *ctx, int max, double *ms, const char **names);
 
 /* Results of the last HF_MODE_FULL pass (HF_E_ARG when the last pass was HF_MODE_FORWARD_ONLY: f and scales would be new,
  * b and the labels stale).  hf_get_posterior / hf_get_forward_backward: an EM pass of the default algorithm keeps no per-window scale (and,

@@ -393,6 +393,39 @@ def test_full_size_ont_r10_seven_regions_em_to_convergence_equals_the_oracle_com
     assert len(emis[1].split("\t")) == 4 + 7, emis[1]
 
 
+@pytest.mark.parametrize("extra", [[], ["--accelerate"]], ids=["em", "squarem"])
+@pytest.mark.parametrize("preset", ["hifi", "ont-r9"])
+def test_reference_default_presets_at_genome_size_equal_the_oracle_command_line(preset, extra, tmp_path):
+    """what a user of the reference types — `hmm_flagger -i x.cov.gz -x hifi` (or ont-r9) with NO -W and NO -A: 16 kb
+    windows (hmm_flagger.c:27,44,951-953), alpha all zero (the preset arrays are `int`, :21,36: SURVEY Q25), minReadFractionAtEnds
+    0.95 / 1.0, -n 100 -t 1e-3 — on a human diploid genome: ~380 k windows, the latency-bound regime of the segment kernel (every
+    workgroup alone on its SIMD: cached row blocks).  From the `.cov.gz` (one run per window) on the HIP side, the same windows as `.bin`
+    on the oracle side (its per-base loop needs minutes for 6 Gb).  Plain EM: every TSV / BED byte for byte; --accelerate: BED and
+    summary tables byte for byte, the numbers to 1e-6 relative / 1e-8 absolute (as the full-size ONT-R10 run above)."""
+    store = synth.config(7)
+    assert store.window_len == 16000 and 350_000 < store.n_windows < 420_000
+    cov = tmp_path / "g16k.cov.gz"
+    store.write_cov(str(cov))
+    args = ["-i", str(cov), "-x", preset, "-n", "100", "-t", "1e-3", "-w"] + extra
+    r = _run(CLI, args, tmp_path / "gpu")
+    assert "Parameters converged after" in r.stderr or "Parameter estimation stopped" in r.stderr
+    assert f"{store.n_chunks} chunks are parsed ({store.n_windows} windows of 16000 bases)" in r.stderr
+    binp = tmp_path / "g16k.bin"
+    store.write_bin(str(binp))
+    _run(ORACLE, ["-i", str(binp)] + args[2:] + ["--threads", "16"], tmp_path / "cpu")
+    names = sorted(os.listdir(tmp_path / "cpu"))
+    assert len(names) > 8 and "final_flagger_prediction.bed" in names and "loglikelihood.tsv" in names
+    for n in names:
+        if n.endswith((".tsv", ".bed")):
+            a, b = (tmp_path / "gpu" / n).read_text(), (tmp_path / "cpu" / n).read_text()
+            if not extra or n.endswith(".bed") or n.startswith("prediction_summary"):
+                assert a == b, n
+            elif n == "loglikelihood.tsv":
+                _numbers_close(a, b, n, rtol=1e-6, atol=0.0)
+            else:
+                _numbers_close(a, b, n)
+
+
 @pytest.mark.parametrize("seed", [8955])
 def test_accelerated_runs_of_the_residue_study_stay_within_tolerance(seed, tmp_path):
     """VERDICT r03 #5.  One of the twelve `--accelerate` runs of profiles/r03_fuzz.txt whose outputs differ from the oracle command line

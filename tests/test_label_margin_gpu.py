@@ -25,12 +25,16 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 CASES = [("configs[2], full size", None, hmm.MODEL_TRUNC_EXP_GAUSSIAN, 1e-3),
          # the 7-region ONT-R10 workload (region-change windows with the uniform T = 0.2 of hmm.c:398-400, K = 10) had not been studied
          ("configs[4], full size", "cfg4", hmm.MODEL_TRUNC_EXP_GAUSSIAN, 1e-3),
+         # the reference's real defaults — `-x hifi` / `-x ont-r9` with no -W: 16 kb windows (hmm_flagger.c:27,44,951-953), ~380 k
+         # windows for a human diploid assembly, alpha all zero (the preset arrays are `int`, :21,36), minReadFractionAtEnds 0.95 / 1.0
+         ("hifi preset defaults (16 kb windows), genome size", "hifi16k", hmm.MODEL_TRUNC_EXP_GAUSSIAN, 1e-3),
+         ("ont-r9 preset defaults (16 kb windows), genome size", "r9_16k", hmm.MODEL_TRUNC_EXP_GAUSSIAN, 1e-3),
          ("sim100k_exp_gaussian", "sim100k_exp_gaussian.cov.gz", hmm.MODEL_TRUNC_EXP_GAUSSIAN, 1e-4),
          ("sim100k_gaussian", "sim100k_gaussian.cov.gz", hmm.MODEL_GAUSSIAN, 1e-4),
          ("sim100k_negative_binomial", "sim100k_negative_binomial.cov.gz", hmm.MODEL_NEGATIVE_BINOMIAL, 1e-4)]
 
 
-@pytest.mark.parametrize("name,cov,model_type,tol", CASES, ids=[c[0].split(",")[0] for c in CASES])
+@pytest.mark.parametrize("name,cov,model_type,tol", CASES, ids=[c[0].split(",")[0].split(" (")[0] for c in CASES])
 def test_margin_of_the_final_labels(name, cov, model_type, tol):
     frac = 0.95
     if cov is None:
@@ -38,6 +42,10 @@ def test_margin_of_the_final_labels(name, cov, model_type, tol):
         max_mapq, min_mapq = 0.25, 0.75
     elif cov == "cfg4":   # -x ont-r10: minReadFractionAtEnds 0.8 (hmm_flagger.c:36-58)
         store, alpha, K, adjust, frac = synth.config(4), synth.ONT_R10_ALPHA, None, True, 0.8
+        max_mapq, min_mapq = 0.25, 0.75
+    elif cov in ("hifi16k", "r9_16k"):
+        store, alpha, K, adjust, frac = synth.config(7), np.zeros((4, 4)), None, True, (0.95 if cov == "hifi16k" else 1.0)
+        assert store.window_len == 16000 and 350_000 < store.n_windows < 420_000
         max_mapq, min_mapq = 0.25, 0.75
     else:   # the docs/hmm_test recipe (tests/test_cli_gpu.py): --chunkLen 1000 --windowLen 1 --collapsedComps 4 --minHighMapqRatio 0 -e
         store, alpha, K, adjust = Table(os.path.join(GOLD, cov), 1000, 1).store(), np.zeros((4, 4)), 4, False

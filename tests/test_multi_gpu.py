@@ -345,3 +345,135 @@ def test_cfg2_accelerated_default_exchange_is_identical_for_every_number_of_rank
         assert r.returncode == 0, r.stderr[-2000:]
         for n in names:
             assert (tmp_path / "one" / n).read_text() == (tmp_path / f"w{world}" / n).read_text(), (world, n)
+
+
+# ------------------------------------------------------------------------------------------
+# Real RCCL, N > 1.  These tests switch themselves on: with n = min(visible GPUs, 8) >= 2 they run the sharded
+# E-step over n RCCL ranks on n devices (xGMI on an MI355X node); on a 1-GPU lease they report SKIPPED — not absent — so that the
+# first `pytest -m gpu` on an 8-GPU node exercises BASELINE configs[3] and configs[4]@8 with no edit.  The fan-out / in-order merge
+# they stand in for: hmm.c:739-763.
+# ------------------------------------------------------------------------------------------
+def _rccl_world():
+    n = min(N.lib().hf_device_count(), 8)
+    if n < 2:
+        pytest.skip("real RCCL with more than one rank needs >= 2 visible GPUs (this box: %d)" % N.lib().hf_device_count())
+    return n
+
+
+def _multi(store, model, world, exchange, transport, frac=0.95):
+    m = hmm.MultiEMList(store, model, world, True, frac, exchange=exchange, transport=transport)
+    if transport == N.HF_TRANSPORT_RCCL:
+        assert int(N.lib().hf_multi_comm_ranks(m._h)) == world          # what ncclCommCount says, not what was asked for
+    return m
+
+
+@pytest.mark.parametrize("model_type", [hmm.MODEL_TRUNC_EXP_GAUSSIAN, hmm.MODEL_NEGATIVE_BINOMIAL])
+def test_rccl_chunk_order_exchange_does_not_depend_on_the_number_of_ranks(model_type):
+    """test_chunk_order_exchange_does_not_depend_on_the_number_of_ranks over real RCCL: 2 .. n ranks, one device each."""
+    n = _rccl_world()
+    store = synth.config(2, scale=0.02)
+    K = 4
+    model = hmm.createModel(model_type, K, store, synth.HIFI_ALPHA)
+    one = _single(store, model, N.HF_STATS_CHUNKS)
+    try:
+        one.launch(model); ref = one.finish().copy(); ref_lab = one.labels()
+        one.launch(model, N.HF_MODE_FORWARD_ONLY); ref_fwd = one.finish().copy()
+        for world in sorted({2, (n + 1) // 2, n}):
+            m = _multi(store, model, world, N.HF_EXCHANGE_CHUNKS, N.HF_TRANSPORT_RCCL)
+            try:
+                sizes = m.shard_sizes()
+                assert sum(c for c, _ in sizes) == store.n_chunks and sum(w for _, w in sizes) == store.n_windows
+                for _ in range(3):                                     # the exchange buffer is reused: every pass the same bits
+                    got = m.run_sharded(model, N.HF_MODE_FULL)
+                    assert np.array_equal(got, ref), (world, np.max(np.abs(got - ref)))
+                for r in range(world):
+                    assert np.array_equal(m.rank_stats(r), ref), (world, r)
+                assert np.array_equal(m.labels(), ref_lab)
+                assert np.array_equal(m.run_sharded(model, N.HF_MODE_FORWARD_ONLY), ref_fwd)
+            finally:
+                m.close()
+    finally:
+        one.close()
+
+
+def test_rccl_configs3_rank_order_exchange_at_full_size_prints_the_same_files(tmp_path):
+    """BASELINE configs[3]: configs[2] at full size sharded over n GPUs with the north-star's single collective (`--exchange ranks`),
+    plain EM to convergence through the command line: every printed file equals the one-GPU run's; and the default (chunks) exchange
+    with --accelerate equals a one-context run of the per-chunk statistics."""
+    n = _rccl_world()
+    store = synth.config(2)
+    binp = tmp_path / "cfg2.bin"
+    store.write_bin(str(binp))
+    args = ["-i", str(binp), "-n", "100", "-t", "1e-3", "-W", "4000", "-A", ALPHA, "-w"]
+    r0 = _cli(args, tmp_path / "one")
+    assert r0.returncode == 0 and "Parameters converged after" in r0.stderr, r0.stderr[-2000:]
+    names = sorted(x for x in os.listdir(tmp_path / "one") if x.endswith((".tsv", ".bed")))
+    r = _cli(args + ["--gpus", str(n), "--exchange", "ranks"], tmp_path / "rccl")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "GPU %d:" % (n - 1) in r.stderr
+    for x in names:
+        assert (tmp_path / "one" / x).read_text() == (tmp_path / "rccl" / x).read_text(), x
+    acc = ["-i", str(binp), "-n", "40", "-t", "1e-3", "-W", "4000", "-A", ALPHA, "--accelerate"]
+    ra = _cli(acc, tmp_path / "acc1", env={"HF_STATS": "chunks"})
+    rb = _cli(acc + ["--gpus", str(n)], tmp_path / "accn")
+    assert ra.returncode == 0 and rb.returncode == 0, (ra.stderr[-1000:], rb.stderr[-1000:])
+    for x in OUTPUTS:
+        assert (tmp_path / "acc1" / x).read_text() == (tmp_path / "accn" / x).read_text(), x
+
+
+def test_rccl_cfg4_at_full_size_sharded_over_all_gpus():
+    """BASELINE configs[4] on n GPUs (8 on an MI355X node): ONT-R10 preset, 7 bias regions, full size.  Chunk-order exchange: the
+    631-double vector, the labels and a forward-only pass bit-identical to one context; rank-order exchange: equal to rounding, labels
+    identical; both within 1e-9 of the oracle."""
+    n = _rccl_world()
+    store = synth.config(4)
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.ONT_R10_ALPHA)
+    one = hmm.EMList(store, model, True, 0.8)
+    one.set_stats_mode(N.HF_STATS_CHUNKS)
+    orc = Oracle(store, hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, synth.ONT_R10_ALPHA, min_read_frac=0.8, threads=16)
+    try:
+        hmm.EM_runOneIterationForList(one, model)
+        hmm.HMM_estimateParameters(model, 1e-3)
+        hmm.HMM_resetEstimators(model)
+        orc.set_param_vector(model.param_vector())
+        one.launch(model); ref = one.finish().copy(); ref_lab = one.labels().copy()
+        one.launch(model, N.HF_MODE_FORWARD_ONLY); ref_fwd = one.finish().copy()
+        assert orc.run_iteration() == 0
+        o = orc.stats_vector(K)
+        assert np.allclose(ref, o, rtol=1e-9, atol=1e-9 * np.abs(o).max()) and np.array_equal(ref_lab, orc.labels())
+        m = _multi(store, model, n, N.HF_EXCHANGE_CHUNKS, N.HF_TRANSPORT_RCCL, 0.8)
+        try:
+            got = m.run_sharded(model, N.HF_MODE_FULL)
+            assert np.array_equal(got, ref), np.max(np.abs(got - ref))
+            for r in range(n):
+                assert np.array_equal(m.rank_stats(r), ref), r
+            assert np.array_equal(m.labels(), ref_lab)
+            assert np.array_equal(m.run_sharded(model, N.HF_MODE_FORWARD_ONLY), ref_fwd)
+        finally:
+            m.close()
+        m = _multi(store, model, n, N.HF_EXCHANGE_RANKS, N.HF_TRANSPORT_RCCL, 0.8)
+        try:
+            got = m.run_sharded(model, N.HF_MODE_FULL)
+            scale = np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+            assert np.all(np.abs(got - ref) <= 1e-11 * scale)
+            assert np.array_equal(m.labels(), ref_lab)
+        finally:
+            m.close()
+    finally:
+        one.close(); orc.close()
+
+
+def test_rccl_command_line_gpus_option_cfg4(tmp_path):
+    """`hmm_flagger -x ont-r10 --gpus n` (default exchange) on configs[4] at full size: the files of a one-context run of the per-chunk
+    statistics, byte for byte."""
+    n = _rccl_world()
+    store = synth.config(4)
+    binp = tmp_path / "cfg4.bin"
+    store.write_bin(str(binp))
+    args = ["-i", str(binp), "-x", "ont-r10", "-n", "100", "-t", "1e-3", "-A", ALPHA_ONT]
+    r0 = _cli(args, tmp_path / "one", env={"HF_STATS": "chunks"})
+    r1 = _cli(args + ["--gpus", str(n)], tmp_path / "rccl")
+    assert r0.returncode == 0 and r1.returncode == 0, (r0.stderr[-1000:], r1.stderr[-1000:])
+    for x in OUTPUTS:
+        assert (tmp_path / "one" / x).read_text() == (tmp_path / "rccl" / x).read_text(), x
