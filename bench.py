@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-em-run", action="store_true", help="skip the `em_run` leg (a real EM to convergence in a fresh context, and the cold "
                                                              "command line) that follows the timed region")
+    ap.add_argument("--creates", type=int, default=9, help="fresh contexts of the em_run leg's hf_create timing (median / min / max reported)")
     ap.add_argument("--event-stride", type=int, default=0,
                     help="the dominant kernel is bracketed by a pair of HIP events in every n-th timed step; default 0 = max(1, min(32, steps // 8)): "
                          "at least 8 samples however short the timed region is (the driver's --steps 20: every 2nd step, 10 samples; a pair "
@@ -97,7 +98,7 @@ def main():
                          "north_star's single collective over the EM sufficient statistics; statistics by emission row on every rank, "
                          "equal to a one-GPU run up to the rounding of the order), or the per-chunk vectors summed in chunk-list order "
                          "(statistics, EM trajectory and BED labels identical for every N bit for bit by construction; slower per-chunk "
-                         "statistics kernels; `hmm_flagger --gpus N` defaults to `ranks` too since round 4)")
+                         "statistics kernels: what `hmm_flagger --gpus N` defaults to since round 5 — its files must not depend on N under --accelerate)")
     ap.add_argument("--collective", choices=["native", "torch"], default="native",
                     help="multi-GPU path: native = pass + RCCL all-gather + ordered reduction in ONE library call per EM pass on the "
                          "pass's own stream (hf_multi_create_rank; torch.distributed only carries the RCCL id at start-up); "
@@ -261,9 +262,19 @@ def main():
         try:
             rmodel = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, alpha)
             frac = 0.8 if args.config in (4, 5) else 0.95
-            c0 = time.perf_counter()
-            rem = hmm.EMList(store, rmodel, True, frac, device=local_rank, algo=algo)
-            create_ms = (time.perf_counter() - c0) * 1e3
+            # hf_create (windows up, records, plan: what EM_construct + EM_renewParametersAndEstimatorsFromModel cost the reference per chunk and
+            # iteration, hmm.c:253-298 — paid once here): `args.creates` fresh contexts one after another while the timed context is still alive
+            # (one sample on a fresh box said 8.35 ms where the docs said 2.5-3.0); the line carries the median, min and max and the
+            # library's own phases (hf_create_phases) of the median context; the last context runs the EM below
+            creates, rem = [], None
+            for ci in range(max(1, args.creates)):
+                if rem is not None:
+                    rem.close()
+                c0 = time.perf_counter()
+                rem = hmm.EMList(store, rmodel, True, frac, device=local_rank, algo=algo)
+                creates.append(((time.perf_counter() - c0) * 1e3, rem.create_phases()))
+            order = sorted(range(len(creates)), key=lambda i: creates[i][0])
+            create_ms, create_phases = creates[order[len(order) // 2]]
             torch.cuda.synchronize()
             r0 = time.perf_counter()
             passes, conv = 0, False
@@ -276,7 +287,12 @@ def main():
             rem.close()
             em_run = {"value": n_windows * passes / rdt, "unit": "windows/s", "passes": passes, "converged": bool(conv), "ms": rdt * 1e3,
                       "ms_per_pass": rdt / passes * 1e3, "vs_steady_state_step": (rdt / passes) / (dt / args.steps),
-                      "hf_create_ms": create_ms, "final_loglikelihood": rmodel.loglikelihood,
+                      "hf_create_ms": create_ms, "hf_create_ms_min": creates[order[0]][0], "hf_create_ms_max": creates[order[-1]][0],
+                      "hf_create_ms_all": [round(c[0], 3) for c in creates],
+                      "hf_create_phases_ms": {k: round(v, 3) for k, v in create_phases.items()},
+                      "hf_create_what": "%d fresh contexts, one after another, the timed context still alive; median / min / max of the wall time "
+                                        "around EMList(...) and the library's phases of the median context" % len(creates),
+                      "final_loglikelihood": rmodel.loglikelihood,
                       "what": "fresh context in this (warm) process: EM to convergence (100 iterations at most, tol 1e-3) + final pass, wall-timed, "
                               "hf_create not included (reported beside it)"}
             cli = os.path.join(ROOT, "flagger_amd", "csrc", "hmm_flagger")

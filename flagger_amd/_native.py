@@ -161,6 +161,7 @@ def lib() -> C.CDLL:
     sig("hf_multi_rank_stats", C.c_int, vp, C.c_int, pd)
     sig("hf_multi_last_error", C.c_char_p)
     sig("hf_selftest_division", C.c_int, C.c_int, i64, pd, pd, pd, pd, C.POINTER(C.c_int32))
+    sig("hf_selftest_exp", C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double))
     # host model
     sig("hfm_create", vp, C.c_int, C.c_int, C.POINTER(i32), C.c_int, C.c_int, C.c_int, C.c_int, pd, dbl, dbl)
     sig("hfm_copy", vp, vp)

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/hmm_flagger_hip.h"
+#include "hf_exp.h"
 
 #define HF_PI 3.14159              // common.h:15 (sic)
 #define HF_TERMINATION_PROB 1e-4   // hmm_utils.c:2112
@@ -162,12 +163,24 @@ __device__ __forceinline__ bool hf_err_is_truncexp(const DevParams* __restrict__
     return P->model_type == HF_MODEL_TRUNC_EXP_GAUSSIAN;
 }
 
+// exp() of the emission densities: the host's (glibc's) algorithm, bit for bit (hf_exp.h); -DHF_EXP_OCML=1: the device library's own (rounds 1-5)
+#ifndef HF_EXP_OCML
+#define HF_EXP_OCML 0
+#endif
+__device__ __forceinline__ double hf_emit_exp(double x) {
+#if HF_EXP_OCML
+    return exp(x);
+#else
+    return hf_exp(x);
+#endif
+}
+
 // hmm_utils.c:941-947 TruncExponential_getProb
 __device__ __forceinline__ double hf_trunc_exp(double lambda, double trunc_point, double x, double beta) {
     double lam = lambda / beta;
     double b = beta * trunc_point;
     if (trunc_point < x) return 0.0;
-    return lam * exp(-lam * x) / (1 - exp(-lam * b));
+    return lam * hf_emit_exp(-lam * x) / (1 - hf_emit_exp(-lam * b));
 }
 
 // one mixture component, hmm_utils.c:775-790; sets *nan when the reference would exit
@@ -177,7 +190,7 @@ __device__ __forceinline__ double hf_gauss_comp(double mu, double var_c, double 
     mean *= beta;
     double var = var_c * beta;
     double d = x - mean;
-    double p = w / (sqrt(var * 2 * HF_PI)) * exp(-0.5 * (d * d) / var);
+    double p = w / (sqrt(var * 2 * HF_PI)) * hf_emit_exp(-0.5 * (d * d) / var);
     if (p != p) *nan |= HF_FLAG_NAN;
     if (p < 1e-40) p = 1e-40;
     return p;
@@ -189,7 +202,7 @@ __device__ __forceinline__ double hf_gauss_comp_star(double m1, double gvar, dou
     double mean = m1 + alpha * pre_x;
     mean *= beta;
     const double d = x - mean;
-    double p = gnorm * exp(-0.5 * (d * d) / gvar);
+    double p = gnorm * hf_emit_exp(-0.5 * (d * d) / gvar);
     if (p != p) *nan |= HF_FLAG_NAN;
     if (p < 1e-40) p = 1e-40;
     return p;
@@ -197,7 +210,7 @@ __device__ __forceinline__ double hf_gauss_comp_star(double m1, double gvar, dou
 
 __device__ __forceinline__ double hf_trunc_exp_star(const DevRegion* __restrict__ R, double x) {
     if (R->trunc_point < x) return 0.0;
-    return R->te_lam * exp(-R->te_lam * x) / R->te_den;
+    return R->te_lam * hf_emit_exp(-R->te_lam * x) / R->te_den;
 }
 
 // Gaussian_getProb, hmm_utils.c:753-758 (sum over components in index order)

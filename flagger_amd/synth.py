@@ -9,6 +9,7 @@ trailing partial window (chunk.c:539-543).
 from __future__ import annotations
 
 import dataclasses
+import os
 import struct
 from typing import List, Sequence
 
@@ -289,6 +290,26 @@ def synthesize(contig_lengths: Sequence[int], window_len: int, chunk_len: int, r
         chunk_ctg_len=np.asarray(ctg_len_l, np.int32), chunk_s=np.asarray(cs, np.int32),
         chunk_e=np.asarray(ce, np.int32), window_len=window_len, chunk_len=chunk_len,
         region_coverages=[int(x) for x in region_coverages], avg_alignment_len=avg_alignment_len)
+
+
+def write_cov_dense(path: str, lengths: Sequence[int], seed: int = 77, min_run: int = 50, max_run: int = 500, only: int = -1) -> dict:
+    """A bam2cov-like `.cov` / `.cov.gz` at real row density: coverage / mapq / clip change every min_run..max_run bases (VERDICT r05 #5:
+    tens of millions of rows for a human diploid assembly, one DEFLATE stream; rows straddle window and chunk boundaries).  Written by the
+    native tool flagger_amd/csrc/dense_cov (formatting 50 M rows in Python takes minutes).  `only` >= 0: just that contig — the same rows it
+    has in the full file.  Returns {"rows", "bases", "text_bytes"}."""
+    import json
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "dense_cov")
+    if not os.path.exists(tool):
+        subprocess.run(["make", "-C", os.path.dirname(tool), "dense_cov"], check=True, capture_output=True)
+    r = subprocess.run([tool, path, str(seed), str(min_run), str(max_run), str(only)] + [str(int(x)) for x in lengths],
+                       check=True, capture_output=True, text=True)
+    return json.loads(r.stdout)
+
+
+def human_diploid_lengths(scale: float = 1.0) -> List[int]:
+    """Contig lengths of BASELINE configs[2]'s genome (2 x 3.03 Gb)."""
+    return [int(x * scale) for x in _HUMAN_CHROMS] * 2
 
 
 def config(n: int, scale: float = 1.0, overdispersion: float = 3.0) -> WindowStore:

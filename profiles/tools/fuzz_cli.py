@@ -71,7 +71,11 @@ def show(outs, diff, limit=6):
 if __name__ == "__main__":
     first, count = int(sys.argv[1]), int(sys.argv[2])
     bad = 0
+    n_acc = 0
     for seed in range(first, first + count):
+        if os.environ.get("FUZZ_ONLY_ACCELERATED") and seed % 5 != 0:     # (round 6: the --accelerate runs only — every fifth seed)
+            continue
+        n_acc += seed % 5 == 0
         d, store, model, extra, args = make_case(seed, bool(os.environ.get("FUZZ_OPTIONS")))
         outs = run_pair(d, args)
         if outs[0][0] != outs[1][0]:
@@ -83,4 +87,4 @@ if __name__ == "__main__":
             bad += 1; print("seed", seed, model, extra, "windows", store.n_windows, "DIFFERENT:", diff)
             if os.environ.get("FUZZ_SHOW"):          # the lines that differ (first 6 per file)
                 show(outs, diff)
-    print("seeds", first, "..", first + count - 1, "runs with a difference:", bad)
+    print("seeds", first, "..", first + count - 1, "runs with a difference:", bad, "(accelerated runs among them: %d)" % n_acc)

@@ -920,3 +920,107 @@ def test_sub_passes_through_one_record_buffer(monkeypatch):
             orc.close()
             monkeypatch.delenv("HF_STATS_PLAN", raising=False)
     monkeypatch.delenv("HF_SUBPASSES", raising=False)
+
+
+def test_device_exp_is_the_hosts_exp_bit_for_bit():
+    """the emission densities' exp (hmm_utils.c:782, 945 call libm's) is glibc's algorithm restated with the fused
+    multiply-adds of the host's FMA build (csrc/hf_exp.h) — the same bits on the device as the same function on the host, and (where the
+    host's libm runs its FMA variant: every x86-64 with FMA) as libm's exp itself.  Arguments: what the Gaussian and truncated-exponential
+    densities produce (-0.5 d^2 / var, -lambda x: mostly -60..0), the whole finite range, tiny, huge, non-finite."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    x = np.concatenate([-rng.uniform(0, 60, 300_000), rng.uniform(-760, 720, 100_000), rng.normal(0, 1e-3, 20_000),
+                        -rng.uniform(0, 1, 50_000) ** 4 * 1e-8, rng.integers(0, 2 ** 63, 40_000).astype(np.uint64).view(np.float64),
+                        -rng.integers(0, 2 ** 63, 40_000).astype(np.uint64).view(np.float64),
+                        np.array([0.0, -0.0, 709.78, 709.79, -708.4, -745.13, -745.14, -1074.0, np.inf, -np.inf, np.nan, 512.0, -512.0, 1024.0, -1024.0])])
+    n = x.size
+    dev, host, libm = np.empty(n), np.empty(n), np.empty(n)
+    pd = C.POINTER(C.c_double)
+    N.check(N.lib().hf_selftest_exp(0, n, x.ctypes.data_as(pd), dev.ctypes.data_as(pd), host.ctypes.data_as(pd), libm.ctypes.data_as(pd)), "hf_selftest_exp")
+    same = lambda a, b: (a.view(np.uint64) == b.view(np.uint64)) | (np.isnan(a) & np.isnan(b))      # noqa: E731
+    bad = ~same(dev, host)
+    assert not bad.any(), (int(bad.sum()), x[bad][:5], dev[bad][:5], host[bad][:5])
+    if "fma" in open("/proc/cpuinfo").read().split("flags", 1)[-1].split("\n", 1)[0].split():
+        bad = ~same(dev, libm)
+        assert not bad.any(), (int(bad.sum()), x[bad][:5], dev[bad][:5], libm[bad][:5])
+
+
+def test_check_raises_retry_pass_instead_of_returning_a_stale_result():
+    """EMList.check() after a hand-off timed out (HF_SEG_TEST_TIMEOUT: the first one-launch pass waits for flags nobody
+    writes) must not look like success — what the caller copied out of that pass is garbage.  It raises RetryPass (the context has
+    switched to two launches); the repeated launch + check succeeds and gives the statistics of an ordinary two-launch run."""
+    import subprocess, sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from flagger_amd import hmm, synth, _native as N
+store = synth.config(2, scale=0.05)
+K = hmm.getBestNumberOfCollapsedComps(store)
+model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+em = hmm.EMList(store, model, True, 0.95)
+em.set_stats_mode(N.HF_STATS_CHUNKS)
+assert em.seg_launches == 1
+em.launch(model)
+try:
+    em.check()
+    print("NO RETRY")
+except hmm.RetryPass as e:
+    assert e.code == N.HF_E_RETRY
+    assert em.seg_launches == 2
+    em.launch(model); em.check()
+    a = em.finish().copy()
+    em.launch(model); b = em.finish()
+    print("RETRY", bool(np.array_equal(a, b)), a[0])
+em.close()
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, HF_SEG_TEST_TIMEOUT="1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "RETRY True" in r.stdout, (r.stdout, r.stderr[-1000:])
+
+
+def test_xcd_block_plan_same_bits_and_every_chunk_on_one_residue_class(monkeypatch):
+    """VERDICT r05 #2b: HF_SEG_XCD=1 runs the segments through hf_create's block -> segment table: every segment exactly once, all segments
+    of a chunk on block indices congruent mod 8, the eight lists within one chunk's segments of each other; same arithmetic, so the same
+    bits as block b = segment b; not built where a chunk's segments would span more than half of the resident workgroups (the static guard
+    of the one-launch hand-off, extended to the plan); sub-passes have block ranges of their own.  Measured slower at full size
+    (profiles/r06_ab_handoff.txt): off unless asked for."""
+    store = synth.config(2, scale=0.05)
+    K = hmm.getBestNumberOfCollapsedComps(store)
+    model = hmm.createModel(hmm.MODEL_TRUNC_EXP_GAUSSIAN, K, store, synth.HIFI_ALPHA)
+
+    def one(env):
+        for k in ("HF_SEG_XCD", "HF_SUBPASSES", "HF_SEG_RESIDENT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        em = hmm.EMList(store, model, True, 0.95)
+        try:
+            em.launch(model); st = em.finish().copy(); lab = em.labels().copy()
+            f, b, sc = em.forward_backward(100, 3000)
+            em.launch(model, N.HF_MODE_FORWARD_ONLY); fwd = em.finish()[0]
+            return em.seg_xcd_plan, em.seg_block_table(), st, lab, f.copy(), b.copy(), sc.copy(), fwd, em.seg_launches
+        finally:
+            em.close()
+    base = one({})
+    assert not base[0] and base[1].size == 0                      # the default: no plan
+    for env in ({"HF_SEG_XCD": "1"}, {"HF_SEG_XCD": "1", "HF_SUBPASSES": "3"}):
+        got = one(env)
+        assert got[0] and got[8] == 1
+        tab = got[1]
+        segs = tab[tab >= 0]
+        assert np.array_equal(np.sort(segs), np.arange(segs.size)) and tab.size % 8 == 0 and tab.size - segs.size < 8 * (3 if "HF_SUBPASSES" in env else 1) * 16
+        # segments of a chunk: consecutive indices; chunk boundaries from the store (ceil(T / 512) equal segments per chunk)
+        nseg = [int(-(-int(store.chunk_off[c + 1] - store.chunk_off[c]) // 512)) for c in range(store.n_chunks)]
+        assert sum(nseg) == segs.size
+        block_of = np.empty(segs.size, dtype=np.int64); block_of[tab[tab >= 0]] = np.nonzero(tab >= 0)[0]
+        s0 = 0
+        for n in nseg:
+            res = block_of[s0:s0 + n] % 8
+            assert (res == res[0]).all()
+            assert (np.diff(block_of[s0:s0 + n]) == 8).all()      # consecutive rows of its list
+            s0 += n
+        for a, b in zip(got[2:8], base[2:8]):
+            assert np.array_equal(a, b)
+    # a device that holds fewer than 2 x 8 x (segments of the longest chunk) workgroups: no plan, the one-launch kernel as before
+    got = one({"HF_SEG_XCD": "1", "HF_SEG_RESIDENT": str(8 * 2 * max(nseg) - 1)})
+    assert not got[0] and got[8] == 1 and np.array_equal(got[2], base[2])

@@ -201,3 +201,31 @@ def test_truncated_gz_is_an_error(tmp_path):
     p.write_bytes(bytes(bad))
     with pytest.raises(Exception):
         fio.Table(str(p), 1000, 1)
+
+
+def test_loader_at_real_row_density_matches_the_oracle_loader(tmp_path):
+    """a bam2cov-like track changes value every few hundred bases (synth.write_cov_dense: runs of 50-500 bases, ~15 rows per
+    4 kb window, every window and chunk boundary straddled by a run), where synth.WindowStore.write_cov has one run per window.  Reduced size
+    here (3.2 Mb, 11 k rows); the full-size run (51 M rows, 1.5 GB of text in one DEFLATE stream) is profiles/r06_loader_dense.txt.
+    The product loader against the oracle's per-base loop (chunk.c:393-483, track_reader.c:751-818) for several chunk / window lengths,
+    and a single-contig file (`only`) against the same contig of the full file — what the full-size run samples."""
+    lengths = [2_511_003, 611_999, 40_004, 3_000]
+    full = str(tmp_path / "dense.cov.gz")
+    info = synth.write_cov_dense(full, lengths, seed=11, min_run=50, max_run=500)
+    assert info["bases"] == sum(lengths) and 9_000 < info["rows"] < 16_000
+    for chunk_len, window_len in [(1_000_000, 4000), (300_000, 16000), (2_000_000, 777)]:
+        mine = fio.Table(full, chunk_len, window_len).store()
+        _same_store(mine, _oracle_load_cov(full, chunk_len, window_len, tmp_path))
+        assert mine.n_windows >= sum((L + window_len - 1) // window_len for L in lengths) - 8
+    # the plain-text twin (no DEFLATE) and zlib's reader give the same windows
+    txt = str(tmp_path / "dense.cov")
+    assert synth.write_cov_dense(txt, lengths, seed=11, min_run=50, max_run=500) == info
+    _same_store(fio.Table(txt, 1_000_000, 4000).store(), fio.Table(full, 1_000_000, 4000).store())
+    # contig 1 alone: the rows it has in the full file
+    one = str(tmp_path / "c1.cov.gz")
+    synth.write_cov_dense(one, lengths, seed=11, min_run=50, max_run=500, only=1)
+    a, b = fio.Table(one, 1_000_000, 4000).store(), fio.Table(full, 1_000_000, 4000).store()
+    sel = [c for c in range(b.n_chunks) if b.chunk_ctg[c] == "hap_ctg1"]
+    want = b.subset_chunks(sel)
+    assert a.n_chunks == len(sel) and np.array_equal(a.cov, want.cov) and np.array_equal(a.mapq, want.mapq) and np.array_equal(a.clip, want.clip)
+    assert np.array_equal(a.annot, want.annot) and list(a.chunk_ctg) == list(want.chunk_ctg)
