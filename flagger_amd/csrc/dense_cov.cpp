@@ -32,7 +32,7 @@ struct Out {
     std::vector<char> buf; size_t n = 0; uint64_t bytes = 0;
     bool open(const std::string& path) {
         buf.resize(8u << 20);
-        if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) { gz = gzopen(path.c_str(), "wb1"); if (gz) gzbuffer(gz, 1 << 20); return gz != nullptr; }
+        if (path.size() > 3 && path.compare(path.size() - 3, 3, ".gz") == 0) { gz = gzopen(path.c_str(), "w6h")      /* as the reference writes a .cov.gz: level 6, Z_HUFFMAN_ONLY (ptBlock.c:2271) */; if (gz) gzbuffer(gz, 1 << 20); return gz != nullptr; }
         fp = std::fopen(path.c_str(), "wb"); return fp != nullptr;
     }
     void flush() { if (!n) return; if (gz) gzwrite(gz, buf.data(), (unsigned) n); else std::fwrite(buf.data(), 1, n, fp); bytes += n; n = 0; }

@@ -163,9 +163,15 @@ __device__ __forceinline__ bool hf_err_is_truncexp(const DevParams* __restrict__
     return P->model_type == HF_MODEL_TRUNC_EXP_GAUSSIAN;
 }
 
-// exp() of the emission densities: the host's (glibc's) algorithm, bit for bit (hf_exp.h); -DHF_EXP_OCML=1: the device library's own (rounds 1-5)
+// exp() of the emission densities.  Round 6 restated glibc's algorithm bit for bit (hf_exp.h: 0 of 63 M arguments differ from
+// the host's libm, on the device too) to test the standing explanation of the --accelerate residue — "the device's exp is 1 ulp from glibc's
+// for 6 % of the arguments and SQUAREM amplifies it".  It is NOT the cause: of 800 accelerated fuzz runs 67 differ from the oracle command
+// line with the host's exp against 69 with the device library's, the same seeds (profiles/r06_exp_fuzz.txt) — what SQUAREM amplifies is the
+// order of the additions in the scans, which no exp can change.  The restatement costs k_tables 0.5-5 us per pass (a table look-up per
+// value; profiles/r06_ab_exp.txt) and buys nothing, so the device library's exp stays; -DHF_EXP_OCML=0 builds the other one
+// (profiles/tools/build_variants.sh), and the self-test hook keeps checking it on the device.
 #ifndef HF_EXP_OCML
-#define HF_EXP_OCML 0
+#define HF_EXP_OCML 1
 #endif
 __device__ __forceinline__ double hf_emit_exp(double x) {
 #if HF_EXP_OCML

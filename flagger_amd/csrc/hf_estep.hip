@@ -1770,7 +1770,7 @@ int hf_selftest_division(int device, int64_t n, const double* a, const double* d
 // self-test hook (tests/test_estep_gpu.py): the emission densities' exp on the device (hf_exp.h) next to the same function and libm's exp on the host
 __global__ void k_selftest_exp(int64_t n, const double* __restrict__ x, double* __restrict__ y) {
     const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = hf_emit_exp(x[i]);
+    if (i < n) y[i] = hf_exp(x[i]);      // (the restatement itself, whichever exp the emission kernels were built with)
 }
 int hf_selftest_exp(int device, int64_t n, const double* x, double* dev_out, double* host_out, double* libm_out) {
     if (n < 0 || !x || !dev_out || !host_out || !libm_out) return set_err(HF_E_ARG, "hf_selftest_exp: bad argument");

@@ -1,7 +1,7 @@
 // hf_exp.h — exp() for double as the HOST computes it (round 6).  The reference's emission densities call libm's exp
 // (hmm_utils.c:782, 945); the device's own exp (ocml) is a different algorithm and lands 1 ulp away from glibc's for ~6 % of the arguments
-// of a pass — harmless for a plain EM run (every printed file byte-identical), but SQUAREM (hmm.c:871-914) amplifies it into the last
-// printed digits of secondary parameters in ~1 of 10 accelerated runs (profiles/r04_squarem_residue.txt, r05_fuzz.txt).  This is a
+// of a pass.  Rounds 4-5 blamed that for the last-digit differences of ~1 in 10 --accelerate runs; this file was written to test it, and
+// the answer is no (hf_device.h, profiles/r06_exp_fuzz.txt) — it is an opt-in build (-DHF_EXP_OCML=0) and a self-test.  It is a
 // restatement of the algorithm glibc >= 2.28 uses (sysdeps/ieee754/dbl-64/e_exp.c, from ARM's Optimized Routines:
 //     x = k ln2 / N + r, N = 128;   exp(x) = 2^(k/N) exp(r);   2^(k/N) from a table of 128 {rest, value} pairs;   exp(r) - 1 ~ degree-5 polynomial)
 // with a fused multiply-add EXACTLY where the image's libm fuses — glibc selects its FMA build of the routine (__exp_fma, compiled with

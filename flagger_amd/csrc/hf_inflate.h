@@ -21,10 +21,37 @@ constexpr int kLitBits = 11, kDistBits = 8;
 //   distance symbol with bits 8-12 = number of extra bits; bits 16-31: literal value or base
 constexpr uint32_t F_LIT = 0x8000u, F_EOB = 0x4000u, F_SUB = 0x2000u;
 
+// Round 6: PAIRS of literals.  The reference writes its .cov.gz with gzopen(path, "w6h") — Z_HUFFMAN_ONLY (ptBlock.c:2271): a real bam2cov
+// track is literals only, a dozen symbols (digits, tab, newline) with codes of 3-5 bits.  A second table indexed by the next kPairBits bits
+// resolves TWO literals at once where both codes fit: bits 0-7 = bits of both codes, bits 8-15 / 16-23 = the two bytes, F_PAIR marks a
+// valid entry.  One look-up and one 2-byte store per pair; up to five pairs per refill of the bit buffer.
+constexpr int kPairBits = 10;
+constexpr uint32_t F_PAIR = 0x80000000u;
+
 struct Tables {
     uint32_t lit[(1 << kLitBits) + 4096];     // primary + second-level entries (far above what 288 symbols of <= 15 bits can need)
     uint32_t dist[(1 << kDistBits) + 2048];
+    uint32_t pair[1 << kPairBits];
 };
+
+// the pair table out of the primary literal table: index i decodes to literal A (code length la <= kPairBits) followed by literal B when
+// B's code fits the bits that are left (the primary entry of the remaining bits, zero-extended, is then decided by B's own bits alone)
+inline void build_pairs(const uint32_t* lit, uint32_t* pair) {
+    static_assert(kPairBits <= kLitBits, "pairs are read out of the primary table");
+    for (uint32_t i = 0; i < (1u << kPairBits); i++) {
+        uint32_t out = 0;
+        const uint32_t a = lit[i];                      // (the primary table's index is kLitBits wide: the bits above kPairBits are zero here, and
+        const uint32_t la = a & 0xffu;                  //  an entry with a code of <= kPairBits bits does not depend on them)
+        if ((a & F_LIT) && !(a & F_SUB) && la >= 1 && la <= (uint32_t) kPairBits) {
+            const uint32_t left = (uint32_t) kPairBits - la;
+            const uint32_t b = lit[i >> la];
+            const uint32_t lb = b & 0xffu;
+            if ((b & F_LIT) && !(b & F_SUB) && lb >= 1 && lb <= left)
+                out = F_PAIR | (la + lb) | (((a >> 16) & 0xffu) << 8) | (((b >> 16) & 0xffu) << 16);
+        }
+        pair[i] = out;
+    }
+}
 
 inline uint32_t rev_bits(uint32_t v, int n) {
     uint32_t r = 0;
@@ -117,6 +144,8 @@ struct Inflater {
     uint32_t stored_left = 0;
     uint64_t total_out = 0;         // bytes of the current member produced so far (history available to matches)
     Tables t;
+    uint8_t prev_len[288 + 32] = {0};   // the code lengths t was built from (valid while have_tables)
+    bool have_tables = false;
 
     void reset_member() { bits = 0; nbits = 0; block = 0; final_block = false; stored_left = 0; total_out = 0; }
 
@@ -245,8 +274,15 @@ struct Inflater {
             for (int k = nlit; k < 288; k++) len[k] = 0;
             for (int k = ndist; k < 32; k++) len[288 + k] = 0;
         }
+        // (a Huffman-only stream starts a new block every 16 K literals, and the code of a coverage track — a dozen symbols — is often the
+        // same as the block's before: the tables are rebuilt only when a code length changed; building them cost as much as decoding the block)
+        if (have_tables && std::memcmp(len, prev_len, sizeof prev_len) == 0) { block = 2; return OK; }
+        have_tables = false;
         if (!build_table(len, type == 1 ? 288 : nlit, kLitBits, t.lit, (int) (sizeof t.lit / 4), lit_payload, true)) return ERR_DATA;
         if (!build_table(len + 288, type == 1 ? 32 : ndist, kDistBits, t.dist, (int) (sizeof t.dist / 4), dist_payload, true)) return ERR_DATA;
+        build_pairs(t.lit, t.pair);
+        std::memcpy(prev_len, len, sizeof prev_len);
+        have_tables = true;
         block = 2;
         return OK;
     }
@@ -288,9 +324,24 @@ struct Inflater {
                 else { while (nb <= 56 && ip < ilen) { bb |= (uint64_t) inp[ip++] << nb; nb += 8; } } } while (0)
 #define HFZ_PEEK(n) ((uint32_t) (bb & ((1ull << (n)) - 1ull)))
 #define HFZ_DROP(n) do { bb >>= (n); nb -= (n); } while (0)
+            const uint32_t* const pt = t.pair;
             for (;;) {
                 if ((size_t) (oend - o) < 258 + 8) { full = true; break; }   // the next symbol might not fit
                 HFZ_REFILL();
+                {   // pairs of literals: up to five per refill (5 x kPairBits <= the 56 bits a refill guarantees)
+                    uint32_t p2 = pt[HFZ_PEEK(kPairBits)];
+                    if (p2 & F_PAIR) {
+                        int left = 5;
+                        do {
+                            const uint16_t two = (uint16_t) (p2 >> 8);
+                            std::memcpy(o, &two, 2); o += 2;
+                            HFZ_DROP((int) (p2 & 0xffu));
+                            p2 = pt[HFZ_PEEK(kPairBits)];
+                        } while ((p2 & F_PAIR) && --left);
+                        if (nb < 0) { rc = ERR_TRUNCATED; break; }
+                        continue;                                   // room check and refill again
+                    }
+                }
                 uint32_t e = lt[HFZ_PEEK(kLitBits)];
                 if (e & F_SUB) { HFZ_DROP((int) (e & 0xffu)); e = lt[(e >> 16) + HFZ_PEEK((int) ((e >> 8) & 0x1fu))]; }
                 int l = (int) (e & 0xffu);

@@ -258,9 +258,10 @@ const char *hf_kernel_name(int k);   /* "k_tables", "k_seg_fb", ... as they appe
  * prediv / divp), exact[i] = the plain division, safe[i] = whether the kernel's guard would take the fast form.
  * fast must equal exact bit for bit wherever safe is set. */
 int hf_selftest_division(int device, int64_t n, const double *a, const double *d, double *fast, double *exact, int32_t *safe);
-/* Self-test hook: exp() of the emission densities (hmm_utils.c:782, 945 call libm's) for n arguments — dev_out[i] as the kernels compute it
- * (csrc/hf_exp.h: glibc's algorithm restated, fused where the host's FMA build fuses), host_out[i] the same function compiled for the host,
- * libm_out[i] = the host's libm exp.  All three must hold the same bits on a host whose libm runs its FMA variant. */
+/* Self-test hook: csrc/hf_exp.h — glibc's exp for double restated, fused where the host's FMA build fuses (the emission densities of the
+ * reference call libm's: hmm_utils.c:782, 945) — for n arguments: dev_out[i] computed on the device, host_out[i] by the same function compiled
+ * for the host, libm_out[i] = the host's libm exp.  All three must hold the same bits on a host whose libm runs its FMA variant.  (The
+ * emission kernels themselves use the device library's exp unless built with -DHF_EXP_OCML=0: hf_device.h says why.) */
 int hf_selftest_exp(int device, int64_t n, const double *x, double *dev_out, double *host_out, double *libm_out);
 
 #ifdef __cplusplus
