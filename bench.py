@@ -563,7 +563,7 @@ def main():
                          "limiter": "fp64 VALU issue and dependent fp64 chains at three wavefronts per SIMD (see roofline_fp64), not HBM bytes",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_WINDOW * local_windows,
                          "kernel_ms_all": kavg, "algorithmic_bytes_per_window": ALGO_BYTES_PER_WINDOW,
-                         "windows_per_launch": local_windows, "sub_passes": sub_passes,
+                         "windows_per_launch": local_windows, "sub_passes": sub_passes, "cached_row_blocks": getattr(em, "seg_cached_steps", None),
                          "valu_busy_frac_of_simd_time": valu_busy, "valu_busy_source": valu_src,
                          "note": "`bound` names the ceiling this object is priced against (bytes: SURVEY 8d classifies the path as a streaming scan); "
                                  "what limits the kernel is in `limiter` and `roofline_fp64` (DESIGN.md section 5)"},

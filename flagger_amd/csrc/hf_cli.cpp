@@ -102,6 +102,9 @@ static double random_factor(double dev) {                  // hmm_flagger.c:113-
 
 struct Run;
 static const char* run_error();
+static std::string g_cli_error;      // an error of the command line's own (a table set that failed), reported like the library's
+static void hf_cli_set_error(const std::string& e) { g_cli_error = e; }
+static const char* cli_error_or(const char* lib) { return g_cli_error.empty() ? lib : g_cli_error.c_str(); }
 static void summary_wait_quietly();
 static int die_estep(int rc) {
     summary_wait_quietly();                                                         // (a worker still writing tables: let it finish before the process unwinds)
@@ -133,7 +136,7 @@ struct Run {
     const char* error() const { return multi ? hf_multi_last_error() : hf_last_error(); }
 };
 static Run* g_run = nullptr;
-static const char* run_error() { return g_run ? g_run->error() : hf_last_error(); }
+static const char* run_error() { return cli_error_or(g_run ? g_run->error() : hf_last_error()); }
 
 // writeBenchmarkingStats, hmm_flagger.c:134-162.  The tables are OUTPUT: the labels of the pass come down (pinned buffer), and the
 // tables are computed and written by a worker thread while the EM goes on (the "initial" tables used to sit inside
@@ -157,6 +160,19 @@ static int write_summary(Run& run, const std::string& dir, const std::string& su
                          const char* binArrayFilePath, double overlapRatioThreshold, int threads, const int8_t* labels) {
     const double t_begin = real_time();
     const int64_t N = hfio_n_windows(run.tab);
+    // At most three table sets in flight (--writeBenchmarkingStatsPerIteration starts one per EM iteration, an iteration takes
+    // 0.1 ms and a table set several: a hundred jobs with an N-byte label copy and `threads` workers each would pile up) — the oldest is
+    // joined first, and a table set that failed is reported at the next call instead of at the very end.
+    {
+        size_t running = 0;
+        for (auto& j : g_summaries) running += j->th.joinable();
+        for (auto& j : g_summaries) {
+            if (running < 3) break;
+            if (j->th.joinable()) { j->th.join(); running--; std::vector<int8_t>().swap(j->labels); }
+        }
+        for (auto& j : g_summaries)
+            if (!j->th.joinable() && j->rc != 0) { hf_cli_set_error(j->err); return HF_E_ARG; }
+    }
     g_summaries.emplace_back(new SummaryJob());
     SummaryJob* job = g_summaries.back().get();
     job->labels.resize((size_t) N);

@@ -124,7 +124,12 @@ struct PinCache {
             for (size_t i = 0; i < slots.size(); i++)
                 if (!slots[i].busy) { if (slots[i].pinned) (void) hipHostFree(slots[i].p); else std::free(slots[i].p); slots.erase(slots.begin() + (long) i); break; }
         }
-        if (hipHostMalloc((void**) &s.p, s.cap, hipHostMallocPortable) == hipSuccess) s.pinned = true;
+        // Portable AND coherent: with a non-zero flag word and no Coherent / Mapped bit the runtime lets HIP_HOST_COHERENT decide, and
+        // its default is non-coherent — the kernels' zero-copy writes into the result block (totals, partial vectors, labels) would then be visible
+        // at the end of the kernel only, and the HF_POLL stamp never while it runs.  Plain flags as the fall-back, pageable memory as the last one
+        // (a context whose result block is not device-addressable completes its passes through a copy: create_device_store).
+        if (hipHostMalloc((void**) &s.p, s.cap, hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess) s.pinned = true;
+        else if ((void) hipGetLastError(), hipHostMalloc((void**) &s.p, s.cap, hipHostMallocDefault) == hipSuccess) s.pinned = true;
         else { (void) hipGetLastError(); s.p = (char*) std::malloc(s.cap); }
         if (!s.p) return nullptr;
         s.busy = true;

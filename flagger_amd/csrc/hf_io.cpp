@@ -735,8 +735,13 @@ int32_t hfio_n_labels(const hfio_table* t) { return t->n_labels; }
 int hfio_write_summary(hfio_table* t, const int8_t* labels, const char* output_path, const char* bin_array_path,
                        const char* const* label_names_with_unknown, int n_label_names, double overlap_ratio_threshold,
                        int threads) {
-    t->prediction_available = true;                    // hmm_flagger.c:353-354
-    t->n_labels = 4;
+    {   // hmm_flagger.c:353-354.  (Several table sets may be written at once, each on a thread of its own: one writer at a time; whoever
+        // reads the two fields afterwards has joined those threads.)
+        static std::mutex mark_m;
+        std::lock_guard<std::mutex> g(mark_m);
+        t->prediction_available = true;
+        t->n_labels = 4;
+    }
     std::vector<const char*> ctg(t->chunks.size()), ann(t->annotation_names.size());
     for (size_t c = 0; c < ctg.size(); c++) ctg[c] = t->chunks[c].ctg.c_str();
     for (size_t a = 0; a < ann.size(); a++) ann[a] = t->annotation_names[a].c_str();
@@ -745,7 +750,7 @@ int hfio_write_summary(hfio_table* t, const int8_t* labels, const char* output_p
     in.chunk_off = t->chunk_off.data(); in.chunk_s = t->chunk_s.data(); in.chunk_e = t->chunk_e.data();
     in.chunk_ctg = ctg.data(); in.window_len = t->window_len;
     in.annot = t->annot.data(); in.truth = t->truth.empty() ? nullptr : t->truth.data(); in.prediction = labels;
-    in.truth_available = t->truth_available; in.prediction_available = 1; in.n_labels = t->n_labels;
+    in.truth_available = t->truth_available; in.prediction_available = 1; in.n_labels = 4;
     in.n_regions = (int32_t) t->region_coverages.size(); in.n_annotations = (int32_t) ann.size();
     in.annotation_names = ann.data();
     const int rc = hfs_write_all_tables(&in, output_path, bin_array_path, label_names_with_unknown, n_label_names,
