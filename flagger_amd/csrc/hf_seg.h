@@ -128,6 +128,23 @@ __device__ unsigned long long* g_seg_trace = nullptr;
 #define TR_FLUSH(k0, n)
 #endif
 
+// 1 / sc of the replays.  The scale of a window is a normal number (> 1e-50: hmm.c:412-415 raises an error below; at a chunk's first window
+// >= 0.25e-40 by the emission floor), so the special cases that the IEEE division's expansion carries (v_div_scale / v_div_fmas / v_div_fixup:
+// twelve instructions) cannot occur.  -DHF_SEG_FASTRCP=1: v_rcp_f64 and two Newton steps (five instructions, within 1 ulp of the quotient: the
+// product nf * (1 / sc) already differs from nf / sc in the last bit); measured in round 6: profiles/r06_ab_micro.txt.
+#ifndef HF_SEG_FASTRCP
+#define HF_SEG_FASTRCP 0
+#endif
+__device__ __forceinline__ double seg_recip(double sc) {
+#if HF_SEG_FASTRCP
+    double r = __builtin_amdgcn_rcp(sc);
+    r = fma(fma(-sc, r, 1.0), r, r);
+    r = fma(fma(-sc, r, 1.0), r, r);
+    return r;
+#else
+    return 1.0 / sc;
+#endif
+}
 __device__ __forceinline__ void v4_renorm(double v[4]) {
     int e;
     (void) frexp(fmax(fmax(v[0], v[1]), fmax(v[2], v[3])), &e);
@@ -808,7 +825,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                 // sum of start x emission values of which the Gaussian states' carry the reference's 1e-40 floor per component
                 // (hmm_utils.c:787-790): >= 0.25e-40.  The negative-binomial tables have no floor, but a zero row gives 0 / 0 in the reference too.
                 // A guard here — even in the unrolled first step only — cost the kernel 1-2 us: profiles/r05_ab_segfb_regression.txt.)
-                const double rsc = 1.0 / sc;
+                const double rsc = seg_recip(sc);
 #pragma unroll
                 for (int s = 0; s < 4; s++) { f[s] = nf[s] * rsc; fs[i][s] = f[s]; }
                 { int e2; lm *= frexp(sc, &e2); le += e2; }                // hmm.c:428, see above
@@ -863,7 +880,16 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
         // (measured: partial-line writes, profiles/r03c_ablation.txt).  Lanes without a window k write nothing.
         const int32_t* __restrict__ pos_seg = pos + d.t0;
         auto store_rec = [&](int k, bool act, int32_t pk, const double* __restrict__ fk, double sck) {
-            double2* __restrict__ mine = reinterpret_cast<double2*>(blk) + lane * 4;
+            // Round 6 (HF_SEG_RECPAD, default on): the staged records lie 80 bytes apart instead of 64 — at a 64-byte stride the sixteen lanes of a
+            // quarter-wavefront hit four groups of four banks (a 16-way conflict on a quarter of the LDS: 1 024 conflict cycles per wavefront and
+            // launch, 32 % of the LDS cycles: profiles/r05h_pmc_sq_b.json); 20 dwords apart they cover all 64 banks exactly once, on the write and
+            // on the read side.  No extra instruction: only the address constants change (round 4 had ROTATED the pieces instead — selects per
+            // register — and lost 0.3 us).  5 120 of the row block's 8 192 bytes.
+#ifndef HF_SEG_RECPAD
+#define HF_SEG_RECPAD 1
+#endif
+            constexpr int RS = HF_SEG_RECPAD ? 5 : 4;           // double2 per staged record
+            double2* __restrict__ mine = reinterpret_cast<double2*>(blk) + lane * RS;
             // (rotating the pieces so that these writes are free of bank conflicts — lane by lane at a 64-byte stride they hit four banks of
             // 64 — was measured 0.3 us SLOWER, profiles/r04e_ab_variants.txt: the conflicts are not on the kernel's critical path)
             // (a lane without a window k passes forward values it never computed — they go to the segment's spare record, which nobody reads.
@@ -877,8 +903,9 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + lane;
-            const double2 v0 = img[0], v1 = img[64], v2 = img[128], v3 = img[192];
+            // store instruction q writes records 16 q .. 16 q + 15: lane l holds piece l & 3 of record 16 q + (l >> 2)
+            const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + (lane >> 2) * RS + (lane & 3);
+            const double2 v0 = img[0], v1 = img[16 * RS], v2 = img[32 * RS], v3 = img[48 * RS];
             double2* __restrict__ R2 = reinterpret_cast<double2*>(recs) + (lane & 3);
             // lanes without a window k write THE SEGMENT'S SPARE RECORD (SegDesc.trash_pos, behind the sub-pass's positions) and a padding slot
             // of the scales (a segment owns 64 L slots): straight-line stores instead of five regions of masked execution per step
@@ -921,7 +948,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
                     }
                     const double sc = ss[k - 1];
                     if (sc < 1e-50) bad |= HF_FLAG_SCALE;                     // hmm.c:521-524
-                    const double rsc = 1.0 / sc;
+                    const double rsc = seg_recip(sc);
 #pragma unroll
                     for (int s = 0; s < 4; s++) b[s] = nb[s] * rsc;
                     s_lab[a + k - 1] = (int8_t) posterior_label_fast(fs[k - 1], b, sc);
