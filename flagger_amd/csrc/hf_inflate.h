@@ -13,7 +13,7 @@
 
 namespace hfz {
 
-enum { OK = 0, END_OF_MEMBER = 1, NEED_ROOM = 2, ERR_DATA = -1, ERR_TRUNCATED = -2, ERR_HEADER = -3 };
+enum { OK = 0, END_OF_MEMBER = 1, NEED_ROOM = 2, AT_BOUNDARY = 3, ERR_DATA = -1, ERR_TRUNCATED = -2, ERR_HEADER = -3, ERR_MATCH = -4 };
 
 constexpr int kLitBits = 11, kDistBits = 8;
 // table entry: bits 0-7 code length to consume (primary: whole code or, for a sub-table pointer, the primary bits); bits 8-15 kind:
@@ -148,6 +148,36 @@ struct Inflater {
     bool have_tables = false;
 
     void reset_member() { bits = 0; nbits = 0; block = 0; final_block = false; stored_left = 0; total_out = 0; }
+
+    // ---- speculative decoding (hf_io.cpp ParallelInflate): several decoders inside ONE stream ----
+    // A stream without matches (the reference writes its .cov.gz with Z_HUFFMAN_ONLY: ptBlock.c:2271) has no history to resolve, so a decoder may
+    // start at any block boundary.  stop_bit: run() returns AT_BOUNDARY at the first block boundary at or behind that bit of the input;
+    // literal_only: a length / distance symbol ends the run with ERR_MATCH (the caller falls back to one decoder).
+    size_t stop_bit = (size_t) -1;
+    uint64_t stop_out = (uint64_t) -1;   // ... or at the first block boundary once the member has produced that many bytes
+    bool literal_only = false;
+    bool saw_match = false;          // run() decoded a match since the flag was cleared
+    size_t bit_pos() const { return pos * 8 - (size_t) nbits; }
+    // continue at bit `b` of the input, at a block header (`produced_so_far`: bytes of the member before it — what matches may reach back into)
+    void seek_bit(size_t b, uint64_t produced_so_far) {
+        pos = b >> 3; bits = 0; nbits = 0;
+        refill();
+        drop((int) (b & 7));
+        block = 0; final_block = false; stored_left = 0; total_out = produced_so_far;
+    }
+    // Is there a plausible NON-FINAL DYNAMIC block header at bit b?  Everything read_block_header checks (code-length code and literal / distance
+    // codes complete, an end-of-block code, repeats in range); the decoder is left behind that header, ready to decode the block.
+    bool try_dynamic_header_at(size_t b) {
+        if ((b >> 3) + 16 > in_len) return false;
+        uint64_t v;
+        std::memcpy(&v, in + (b >> 3), 8);
+        v >>= (b & 7);
+        if ((v & 7u) != 4u) return false;                       // BFINAL = 0, BTYPE = 2 (LSB first: bits 1-2 = 0b10)
+        if (((v >> 3) & 31u) > 29u || ((v >> 8) & 31u) > 29u) return false;   // HLIT, HDIST
+        seek_bit(b, 0);
+        have_tables = false;                                    // (whatever a failed attempt left in the tables is not the last block's code)
+        return read_block_header() == OK && block == 2 && !final_block;
+    }
 
     inline void refill() {
         if (pos + 8 <= in_len) {
@@ -297,6 +327,7 @@ struct Inflater {
         for (;;) {
             if (block == 0) {
                 if (final_block) { rc = END_OF_MEMBER; break; }
+                if (bit_pos() >= stop_bit || total_out + (uint64_t) (o - out) >= stop_out) { rc = AT_BOUNDARY; break; }
                 rc = read_block_header();
                 if (rc != OK) break;
             }
@@ -362,6 +393,8 @@ struct Inflater {
                 if (e & F_EOB) { if (nb < 0) { rc = ERR_TRUNCATED; break; } block = 0; break; }
                 const int xb = (int) ((e >> 8) & 0x1fu);
                 if (xb == 0x1f) { rc = ERR_DATA; break; }
+                if (literal_only) { rc = ERR_MATCH; break; }
+                saw_match = true;
                 const unsigned length = (unsigned) (e >> 16) + HFZ_PEEK(xb);
                 HFZ_DROP(xb);
                 if (nb < 32) HFZ_REFILL();                       // a distance needs at most 15 + 13 bits

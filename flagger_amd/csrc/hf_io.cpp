@@ -56,9 +56,11 @@ struct WindowAcc {
 
 // n repeated additions of v onto sum, as the reference does per base (chunk.c:459-461); when both are
 // integers below 2^53 every partial sum is exact, so one multiply-add gives the identical double
+// (whole(): v == floor(v) without the libm call a baseline x86-64 build makes of floor — a conversion there and back; only asked of |v| < 2^52)
+inline bool whole(double v) { return std::fabs(v) < 4503599627370496.0 && (double) (long long) v == v; }
 inline void add_run(double& sum, double v, int n) {
     const double lim = 4503599627370496.0;  // 2^52
-    if (v == std::floor(v) && sum == std::floor(sum) && std::fabs(v) * n + std::fabs(sum) < lim) { sum += v * n; return; }
+    if (whole(v) && whole(sum) && std::fabs(v) * n + std::fabs(sum) < lim) { sum += v * n; return; }
     for (int i = 0; i < n; i++) sum += v;
 }
 
@@ -173,7 +175,15 @@ class BlockReader {
             gzbuffer(gz_, 1 << 20);
         }
         unsigned hw = std::thread::hardware_concurrency();
-        int nw = hw >= 8 ? 4 : (hw >= 4 ? 2 : 1);
+        {   // decoders inside one stream (spec_* below): as many as half the threads, at most eight
+            if (const char* e = std::getenv("HF_IO_PARALLEL")) { if (e[0] == '0') spec_off_ = true; else { const int v = std::atoi(e); if (v >= 2 && v <= 32) spec_k_ = (size_t) v; } }
+            else spec_k_ = hw >= 16 ? 8 : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));
+            if (spec_k_ < 2) spec_off_ = true;
+            if (const char* e = std::getenv("HF_IO_PARALLEL_MIN")) spec_min_ = (size_t) std::atoll(e);
+            if (const char* e = std::getenv("HF_IO_PIECE")) { const long long v = std::atoll(e); if (v >= 4096) spec_piece_ = (size_t) v; }
+            if (const char* e = std::getenv("HF_IO_PROBE")) { const long long v = std::atoll(e); if (v >= 1) kSpecProbe = (size_t) v; }
+        }
+        int nw = hw >= 16 ? 6 : (hw >= 8 ? 4 : (hw >= 4 ? 2 : 1));   // (six: with the decoders running ahead, four parsers were the next stage to fill up)
         if (const char* e = std::getenv("HF_IO_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) nw = v; }
         prod_ = std::thread([this] { produce(); });
         for (int i = 0; i < nw; i++) work_.emplace_back([this] { parse_loop(); });
@@ -183,6 +193,8 @@ class BlockReader {
         cv_.notify_all();
         if (prod_.joinable()) prod_.join();
         for (auto& t : work_) if (t.joinable()) t.join();
+        spec_abort_.store(true);
+        for (auto& r : spec_round_) if (r && r->th.joinable()) r->th.join();
         if (gz_) gzclose(gz_);
         if (map_ && !map_is_static_) munmap(const_cast<uint8_t*>(map_), map_len_);
         if (fd_ >= 0) close(fd_);
@@ -256,8 +268,21 @@ class BlockReader {
             if (inf_.pos == map_len_) eof = true;
             return n;
         }
+        if (spec_on_) {                                             // several decoders inside the member (below): their pieces, in order
+            const size_t n = spec_fetch(reinterpret_cast<uint8_t*>(b.text.data()) + have, want);
+            if (n || spec_on_) return n;
+            // (the speculative section is over — the member's last block, or a fall-back: the one decoder goes on where it was left)
+        }
         size_t got = 0;
-        const int rc = inf_.run(reinterpret_cast<uint8_t*>(b.text.data()) + have, want, hist, &got);
+        int rc = inf_.run(reinterpret_cast<uint8_t*>(b.text.data()) + have, want, hist, &got);
+        if (rc == hfz::AT_BOUNDARY) {                               // the probe: a block boundary behind the member's first megabytes
+            inf_.stop_out = (uint64_t) -1;
+            if (!inf_.saw_match) spec_begin(inf_.bit_pos(), inf_.total_out);   // no match so far: go parallel from here (total_out counts this call's bytes)
+            if (got) return got;
+            const size_t n = spec_on_ ? spec_fetch(reinterpret_cast<uint8_t*>(b.text.data()) + have, want) : 0;
+            if (n || spec_on_) return n;
+            rc = inf_.run(reinterpret_cast<uint8_t*>(b.text.data()) + have, want, hist, &got);   // (matches, or it did not start: the one decoder)
+        }
         // the mapped file behind the decoder is not needed again: hand its pages back every 32 MiB, or a multi-GB .cov.gz of a real
         // bam2cov track sits in this process's resident set to the end (round 6: 450 MB of a 577 MB peak on the dense synthetic track)
         if (!map_is_static_ && inf_.pos > released_ + ((size_t) 32 << 20)) {
@@ -272,14 +297,193 @@ class BlockReader {
             const int nm = inf_.next_member();
             if (nm == hfz::ERR_TRUNCATED) { failed_ = true; eof = true; }      // the file ends inside the next member's header
             else if (nm != hfz::OK) eof = true;
+            else spec_member_start();
         } else if (rc != hfz::OK) { failed_ = true; eof = true; }
         return got;
     }
+    // ------------------------------------------------------------------------------------------
+    // Several decoders inside ONE DEFLATE stream (round 6).  The loader is bound by the one thread that inflates.  A
+    // .cov.gz as the reference writes it is Z_HUFFMAN_ONLY (ptBlock.c:2271): literals only, no history to resolve — a decoder can start at
+    // any block boundary.  After a member's first megabytes have shown no match, the stream is cut into pieces of kSpecPiece compressed bytes:
+    // the first piece of a round starts at a KNOWN boundary, every other one searches the first bit position behind its nominal start at
+    // which a complete dynamic block header parses AND whose block decodes to printable text; each decodes up to the start of the next.
+    // Nothing is taken on trust: a round counts only if every piece ended exactly where the next began; a match symbol, a piece that
+    // cannot find or reach its neighbour, any decode error — the one decoder takes over at the last verified boundary (the text before it
+    // is its history); and CRC-32 and length of the member are checked over everything as before.
+    // HF_IO_PARALLEL=0 switches it off, HF_IO_PARALLEL_MIN=<bytes> sets the smallest member it is tried on (default 32 MiB), HF_IO_PIECE=<bytes>.
+    // ------------------------------------------------------------------------------------------
+    size_t kSpecProbe = 2u << 20;                                   // text a member must have produced without a match (HF_IO_PROBE: tests)
+    struct SpecPiece {
+        std::atomic<size_t> start_bit{(size_t) -1};                 // -1: not searched yet, -2: none found
+        size_t end_bit = 0;
+        std::vector<uint8_t> out; size_t n = 0;
+        int rc = hfz::ERR_DATA;
+    };
+    struct SpecRound {
+        std::vector<std::unique_ptr<SpecPiece>> pc;
+        std::thread th;
+        size_t start_bit = 0, end_bit = 0, good = 0;               // good: pieces that form a verified chain from start_bit
+        bool member_end = false, failed = false;
+    };
+    static bool text_like(const uint8_t* p, size_t n) {
+        for (size_t i = 0; i < n; i++) { const uint8_t c = p[i]; if (!((c >= 0x20 && c < 0x7f) || c == '\t' || c == '\n' || c == '\r')) return false; }
+        return true;
+    }
+    void spec_member_start() {
+        spec_want_ = false; inf_.saw_match = false; inf_.stop_bit = (size_t) -1; inf_.stop_out = (uint64_t) -1;
+        if (spec_off_ || !map_) return;
+        if (map_len_ - inf_.pos >= spec_min_) { spec_want_ = true; inf_.stop_out = kSpecProbe; }
+    }
+    void spec_decode_piece(SpecRound* R, size_t k, size_t nominal_bit, size_t round_end_bit) {
+        SpecPiece& P = *R->pc[k];
+        hfz::Inflater z;
+        z.in = map_; z.in_len = map_len_; z.literal_only = true;
+        P.out.resize(spec_piece_ * 3 + (1u << 16));
+        size_t start = nominal_bit;
+        if (k == 0) z.seek_bit(start, 0);
+        else {
+            // the first bit position at which a whole dynamic header parses and the block behind it is text
+            const size_t limit = std::min(map_len_ * 8, nominal_bit + spec_piece_ * 8);
+            bool found = false;
+            for (size_t b = nominal_bit; b < limit && !spec_abort_.load(std::memory_order_relaxed); b++) {
+                if (!z.try_dynamic_header_at(b)) continue;
+                z.stop_bit = b + 1;                                 // (this block only)
+                size_t got = 0;
+                const int rc = z.run(P.out.data(), P.out.size(), 0, &got);
+                if (rc == hfz::AT_BOUNDARY && got > 0 && text_like(P.out.data(), got)) { P.n = got; start = b; found = true; break; }
+            }
+            if (!found) { P.start_bit.store((size_t) -2, std::memory_order_release); P.rc = hfz::ERR_DATA; return; }
+        }
+        P.start_bit.store(start, std::memory_order_release);
+        // up to the next piece's start (the last piece: the first boundary behind the round's nominal end)
+        size_t stop = round_end_bit;
+        bool open_end = false;
+        if (k + 1 < R->pc.size()) {
+            size_t nb;
+            while ((nb = R->pc[k + 1]->start_bit.load(std::memory_order_acquire)) == (size_t) -1) {
+                if (spec_abort_.load(std::memory_order_relaxed)) { P.rc = hfz::ERR_DATA; return; }
+                std::this_thread::yield();
+            }
+            if (nb != (size_t) -2) stop = nb;
+            else {
+                // no block start behind this piece.  Near the end of the file that is the member's tail: run to its last block.  Anywhere else the
+                // search has failed: stop at the first boundary behind the neighbour's nominal start — the chain breaks there and the one decoder goes on.
+                const size_t nominal_next = (nominal_bit >> 3) + spec_piece_;
+                if (map_len_ - std::min(map_len_, nominal_next) <= 2 * spec_piece_) open_end = true; else stop = nominal_next * 8;
+            }
+        }
+        z.stop_bit = open_end ? (size_t) -1 : stop;
+        for (;;) {
+            size_t got = 0;
+            const int rc = z.run(P.out.data() + P.n, P.out.size() - P.n, 0, &got);
+            P.n += got;
+            if (rc == hfz::OK) {                                    // output full
+                if (P.out.size() > spec_piece_ * 64 + ((size_t) 64 << 20)) { P.rc = hfz::ERR_DATA; break; }   // (nothing inflates like that here)
+                P.out.resize(P.out.size() + P.out.size() / 2);
+                continue;
+            }
+            P.rc = rc;
+            break;
+        }
+        P.end_bit = z.bit_pos();
+    }
+    void spec_run_round(SpecRound* R) {
+        const size_t K = R->pc.size();
+        const size_t start_byte = R->start_bit >> 3;
+        const size_t round_end_bit = std::min(map_len_, start_byte + K * spec_piece_) * 8;
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < K; k++) th.emplace_back([this, R, k, start_byte, round_end_bit] { spec_decode_piece(R, k, (start_byte + k * spec_piece_) * 8, round_end_bit); });
+        spec_decode_piece(R, 0, R->start_bit, round_end_bit);
+        for (auto& t : th) t.join();
+        // the verified chain: piece k counts if it decoded cleanly and ended exactly where piece k + 1 began (or at the member's last block)
+        size_t at = R->start_bit;
+        for (size_t k = 0; k < K; k++) {
+            SpecPiece& P = *R->pc[k];
+            if (P.start_bit.load() != at) break;
+            if (P.rc == hfz::END_OF_MEMBER) { R->good = k + 1; R->member_end = true; at = P.end_bit; break; }
+            if (P.rc != hfz::AT_BOUNDARY) break;
+            R->good = k + 1; at = P.end_bit;
+        }
+        R->end_bit = at;
+        R->failed = R->good == 0 || (!R->member_end && R->good < K);   // (a partial chain is used as far as it goes, then the one decoder)
+    }
+    std::unique_ptr<SpecRound> spec_launch(size_t start_bit) {
+        std::unique_ptr<SpecRound> R(new SpecRound());
+        R->start_bit = start_bit;
+        const size_t left = map_len_ - (start_bit >> 3);
+        size_t K = (left + spec_piece_ - 1) / spec_piece_;
+        if (K > spec_k_) K = spec_k_;
+        if (K < 1) K = 1;
+        for (size_t k = 0; k < K; k++) R->pc.emplace_back(new SpecPiece());
+        SpecRound* r = R.get();
+        R->th = std::thread([this, r] { spec_run_round(r); });
+        return R;
+    }
+    void spec_begin(size_t bit, uint64_t produced) {
+        spec_on_ = true; spec_cur_ = 0; spec_piece_i_ = 0; spec_off_in_piece_ = 0; spec_produced_ = produced;
+        spec_round_[0] = spec_launch(bit);
+        spec_round_[0]->th.join();
+        spec_rounds_++;
+        if (!spec_round_[0]->member_end && !spec_round_[0]->failed) spec_round_[1] = spec_launch(spec_round_[0]->end_bit);
+    }
+    // the one decoder again, at bit `bit` of the input (a verified block boundary), with `produced` bytes of the member before it
+    void spec_leave(size_t bit, uint64_t produced, bool member_end) {
+        spec_abort_.store(true);
+        for (auto& r : spec_round_) if (r) { if (r->th.joinable()) r->th.join(); r.reset(); }
+        spec_abort_.store(false);
+        spec_on_ = false; spec_want_ = false;
+        inf_.seek_bit(bit, produced);
+        inf_.literal_only = false; inf_.stop_bit = (size_t) -1; inf_.stop_out = (uint64_t) -1;
+        if (member_end) inf_.final_block = true;                    // (run() answers END_OF_MEMBER at once: the trailer follows)
+        else spec_fallbacks_++;
+    }
+    size_t spec_fetch(uint8_t* dst, size_t want) {
+        size_t got = 0;
+        while (got < want && spec_on_) {
+            SpecRound* R = spec_round_[spec_cur_].get();
+            if (spec_piece_i_ < R->good) {
+                SpecPiece& P = *R->pc[spec_piece_i_];
+                const size_t n = std::min(want - got, P.n - spec_off_in_piece_);
+                std::memcpy(dst + got, P.out.data() + spec_off_in_piece_, n);
+                got += n; spec_off_in_piece_ += n; spec_produced_ += n;
+                if (spec_off_in_piece_ == P.n) { std::vector<uint8_t>().swap(P.out); spec_piece_i_++; spec_off_in_piece_ = 0; }
+                continue;
+            }
+            // the round is used up
+            if (!map_is_static_) {                                  // its part of the mapped file is not needed again
+                const size_t upto = ((R->end_bit >> 3) > ((size_t) 1 << 20) ? (R->end_bit >> 3) - ((size_t) 1 << 20) : 0) & ~(size_t) 4095;
+                if (upto > released_) { madvise(const_cast<uint8_t*>(map_) + released_, upto - released_, MADV_DONTNEED); released_ = upto; }
+            }
+            if (R->member_end || R->failed) { spec_leave(R->end_bit, spec_produced_, R->member_end); break; }
+            const int nxt = spec_cur_ ^ 1;
+            SpecRound* N = spec_round_[nxt].get();
+            if (N->th.joinable()) N->th.join();
+            spec_rounds_++;
+            spec_round_[spec_cur_].reset();
+            spec_cur_ = nxt; spec_piece_i_ = 0; spec_off_in_piece_ = 0;
+            if (N->good == 0) { spec_leave(N->start_bit, spec_produced_, false); break; }
+            if (!N->member_end && !N->failed) spec_round_[nxt ^ 1] = spec_launch(N->end_bit);
+        }
+        return got;
+    }
+  public:
+    size_t spec_rounds() const { return spec_rounds_; }
+    size_t spec_fallbacks() const { return spec_fallbacks_; }
+  private:
+    bool spec_on_ = false, spec_want_ = false, spec_off_ = false;
+    std::atomic<bool> spec_abort_{false};
+    size_t spec_min_ = (size_t) 32 << 20, spec_piece_ = (size_t) 2 << 20, spec_k_ = 4;
+    std::unique_ptr<SpecRound> spec_round_[2];
+    int spec_cur_ = 0;
+    size_t spec_piece_i_ = 0, spec_off_in_piece_ = 0, spec_rounds_ = 0, spec_fallbacks_ = 0;
+    uint64_t spec_produced_ = 0;
+
     void produce() {
         if (map_) {
             inf_.in = map_; inf_.in_len = map_len_; inf_.pos = 0;
             gzip_ = map_len_ >= 2 && map_[0] == 0x1f && map_[1] == 0x8b;
             if (gzip_ && inf_.read_gzip_header() != hfz::OK) failed_ = true;
+            if (gzip_) spec_member_start();
         }
         std::vector<char> carry;                                    // the end of the block before: >= the decoder's 32 KiB of history and
         size_t tail = 0;                                            // ... the unfinished line (its last `tail` bytes)
@@ -422,6 +626,50 @@ void parse_block(char* text, size_t len, std::vector<CovRec>& out) {
             continue;
         }
         // start end cov mapq clip annots region [truth [prediction]]
+        // Fast path (round 6): the shape every row of a bam2cov track has — non-negative integers in every column, annotation indices separated by
+        // commas — read in ONE scan of the line, digits accumulated as they pass.  Anything else (a sign, a decimal point, an exponent, a field of
+        // ten or more digits, a missing column) leaves `ok` false and the row takes the general path below, which accepts what strtod / atoi accept.
+        {
+            const char* q = p;
+            uint32_t v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            uint64_t flag = 0;
+            int f = 0;
+            bool ok = true;
+            while (ok && f < 9) {
+                if (f == 5) {                                       // annotation indices: i[,j...]   (ptBlock.c:225-236: 1-based bits, 0 = none)
+                    for (;;) {
+                        uint32_t a = 0; int nd = 0;
+                        while ((unsigned) (*q - '0') <= 9u && nd < 4) { a = a * 10 + (uint32_t) (*q - '0'); q++; nd++; }
+                        if (nd == 0 || nd >= 4) { ok = false; break; }
+                        if (a > 0 && a <= 64) flag |= 1ULL << (a - 1);
+                        if (*q == ',') { q++; continue; }
+                        break;
+                    }
+                } else {
+                    uint32_t a = 0; int nd = 0;
+                    while ((unsigned) (*q - '0') <= 9u && nd < 10) { a = a * 10 + (uint32_t) (*q - '0'); q++; nd++; }
+                    if (nd == 0 || nd >= 10) ok = false;            // (at most nine digits: no overflow, and the double of it is exact)
+                    v[f] = a;
+                }
+                if (!ok) break;
+                f++;
+                if (*q == '\t') { q++; continue; }
+                if (q == le) break;                                 // (the line's end: *le is the terminator written above)
+                ok = false;
+            }
+            if (ok && q == le && f >= 7) {
+                r.kind = CovRec::ROW;
+                r.s = (int32_t) v[0] - 1; r.e = (int32_t) v[1] - 1;
+                r.cov = (double) v[2]; r.mapq = (double) v[3]; r.clip = (double) v[4];
+                r.flag = flag;
+                r.region = (int16_t) clampi((int) v[6], 0, 100);
+                r.truth = (int16_t) (clampi((f >= 8 ? (int) v[7] : -1), -1, 10) + 1);
+                r.pred = (int16_t) (clampi((f >= 9 ? (int) v[8] : -1), -1, 10) + 1);
+                out.push_back(r);
+                p = next;
+                continue;
+            }
+        }
         char* fld[10]; int nf = 0;
         for (char* q = p; nf < 10;) {
             fld[nf++] = q;
@@ -457,6 +705,7 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
     ChunkMeta cur{};
     WindowAcc acc;
     int next_pos = 0;                                               // next base expected in the current contig
+    int open_ws = 0, open_we = -1, open_cs = -1;                    // the open window: first / last base, and the chunk start it was computed for
     auto fail = [&](const std::string& m) { g_io_err = m; delete reader; delete t; return (hfio_table*) nullptr; };
     auto first_chunk = [&]() {
         cur.ctg = ctg; cur.ctg_len = ctg_len; cur.s = 0;
@@ -508,7 +757,7 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
             ctg_len = sp ? std::atoi(sp + 1) : 0;
             if (sp) *sp = '\0';
             ctg = line + 1;
-            in_contig = true; next_pos = 0; acc.reset();
+            in_contig = true; next_pos = 0; acc.reset(); open_we = -1; open_cs = -1;
             first_chunk();
             continue;
         }
@@ -521,9 +770,14 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
         if (s != next_pos || e < s) return fail("Error: coverage rows must tile each contig without gaps (chunk.c:451)");
         int pos = s;
         while (pos <= e && pos <= ctg_len - 1) {
-            const int wi = (pos - cur.s) / window_len;
-            int wend = cur.s + (wi + 1) * window_len - 1;
-            if (wend > cur.e) wend = cur.e;
+            // the open window's last base: kept from row to row (a row of a real track is a few hundred bases, a window thousands: the division
+            // by the window length is needed once per window, not once per row)
+            if (pos < open_ws || pos > open_we || open_cs != cur.s) {
+                const int wi = (pos - cur.s) / window_len;
+                open_ws = cur.s + wi * window_len; open_we = open_ws + window_len - 1; open_cs = cur.s;
+                if (open_we > cur.e) open_we = cur.e;
+            }
+            const int wend = open_we;
             const int seg_end = e < wend ? e : wend;
             const int n = seg_end - pos + 1;
             add_run(acc.cov, v_cov, n); add_run(acc.mapq, v_mapq, n); add_run(acc.clip, v_clip, n);
@@ -535,7 +789,8 @@ hfio_table* load_cov(const char* path, int chunk_len, int window_len) {
         next_pos = e + 1;
     }
     if (std::getenv("HF_IO_TRACE"))
-        std::fprintf(stderr, "[hfio] the consumer waited %.3f s for parsed blocks, the inflating thread %.3f s for free blocks\n", reader->consumer_wait(), reader->producer_wait());
+        std::fprintf(stderr, "[hfio] the consumer waited %.3f s for parsed blocks, the inflating thread %.3f s for free blocks; %zu rounds of parallel decoders, %zu fall-backs to one\n",
+                     reader->consumer_wait(), reader->producer_wait(), reader->spec_rounds(), reader->spec_fallbacks());
     if (reader->failed()) return fail(std::string("Error: ") + path + " is truncated or corrupt (the deflate stream ended on an error, or a gzip member's CRC-32 / length does not match)");
     delete reader;
     if (in_contig) { t->push_window(acc); t->close_chunk(cur); }

@@ -229,3 +229,83 @@ def test_loader_at_real_row_density_matches_the_oracle_loader(tmp_path):
     want = b.subset_chunks(sel)
     assert a.n_chunks == len(sel) and np.array_equal(a.cov, want.cov) and np.array_equal(a.mapq, want.mapq) and np.array_equal(a.clip, want.clip)
     assert np.array_equal(a.annot, want.annot) and list(a.chunk_ctg) == list(want.chunk_ctg)
+
+
+def _load_in_subprocess(path, env, chunk_len=1_000_000, window_len=4000):
+    """(digest of the loaded store, the loader's trace line) from a fresh process with `env` (the loader reads its switches once per file)."""
+    import subprocess
+    import sys
+    code = ("import sys, hashlib\nsys.path.insert(0, %r)\nfrom flagger_amd import io as fio\n"
+            "try:\n    st = fio.Table(%r, %d, %d).store()\nexcept OSError as e:\n    print('ERROR', e); sys.exit(0)\n"
+            "h = hashlib.sha256()\n"
+            "for f in ('cov', 'mapq', 'clip', 'annot', 'truth', 'chunk_off', 'chunk_s', 'chunk_e', 'chunk_ctg_len'):\n    h.update(getattr(st, f).tobytes())\n"
+            "print('OK', st.n_windows, st.n_chunks, h.hexdigest())\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path, chunk_len, window_len)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, HF_IO_TRACE="1", **env))
+    assert r.returncode == 0, r.stderr[-2000:]
+    trace = [l for l in r.stderr.splitlines() if l.startswith("[hfio]")]
+    return r.stdout.strip(), (trace[-1] if trace else "")
+
+
+def _rounds_and_fallbacks(trace):
+    import re
+    m = re.search(r"(\d+) rounds of parallel decoders, (\d+) fall-backs", trace)
+    return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+
+
+SPEC = {"HF_IO_PARALLEL": "4", "HF_IO_PARALLEL_MIN": "0", "HF_IO_PIECE": "40000", "HF_IO_PROBE": "100000"}
+
+
+def test_parallel_decoders_inside_one_deflate_stream(tmp_path):
+    """Round 6: a `.cov.gz` as the reference writes it (gzopen "w6h": Z_HUFFMAN_ONLY, ptBlock.c:2271) has no matches, so several decoders
+    can work inside the one stream — every piece but the first FINDS its block boundary (a complete dynamic header whose block decodes to
+    text) and must end exactly where the next began.  Forced onto a small file with small pieces: the windows equal the one decoder's and
+    the oracle loader's; a default-strategy file (matches) never starts the decoders; a stream that turns to matches half way falls back to
+    the one decoder at a verified boundary; two members; a flipped bit and a truncated file fail loudly either way."""
+    import gzip
+    import zlib
+    lengths = [2_511_003, 611_999, 40_004]
+    hfile = str(tmp_path / "h.cov.gz")                              # Huffman-only (dense_cov writes it like the reference)
+    synth.write_cov_dense(hfile, lengths, seed=3, min_run=20, max_run=120)
+    text = gzip.open(hfile, "rb").read()
+    assert len(text) > 600_000
+    one, _ = _load_in_subprocess(hfile, {"HF_IO_PARALLEL": "0"})
+    par, trace = _load_in_subprocess(hfile, SPEC)
+    rounds, fallbacks = _rounds_and_fallbacks(trace)
+    assert one.startswith("OK") and par == one and rounds >= 2 and fallbacks == 0, (one, par, trace)
+    _same_store(fio.Table(hfile, 1_000_000, 4000).store(), _oracle_load_cov(hfile, 1_000_000, 4000, tmp_path))
+    # the default strategy: matches from the first block on — the probe sees them, no decoder is started
+    dfile = str(tmp_path / "d.cov.gz")
+    with gzip.open(dfile, "wb", compresslevel=6) as f:
+        f.write(text)
+    got, trace = _load_in_subprocess(dfile, SPEC)
+    assert got == one and _rounds_and_fallbacks(trace) == (0, 0), trace
+    # literals only for the first 60 %, matches behind (one raw DEFLATE stream out of two: the first flushed, not finished)
+    cut = text.rfind(b"\n", 0, int(len(text) * 0.6)) + 1
+    c1 = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_HUFFMAN_ONLY)
+    c2 = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_DEFAULT_STRATEGY)
+    raw = c1.compress(text[:cut]) + c1.flush(zlib.Z_FULL_FLUSH) + c2.compress(text[cut:]) + c2.flush()
+    import struct
+    mfile = str(tmp_path / "m.cov.gz")
+    open(mfile, "wb").write(b"\x1f\x8b\x08\x00\x00\x00\x00\x00\x00\x03" + raw + struct.pack("<II", zlib.crc32(text) & 0xffffffff, len(text) & 0xffffffff))
+    assert gzip.open(mfile, "rb").read() == text
+    got, trace = _load_in_subprocess(mfile, SPEC)
+    rounds, fallbacks = _rounds_and_fallbacks(trace)
+    assert got == one and rounds >= 1 and fallbacks == 1, (got, trace)
+    # two members: the header lines and the first contig in one, the rest in another
+    cut2 = text.find(b">hap_ctg1 ")
+    tfile = str(tmp_path / "t.cov.gz")
+    with open(tfile, "wb") as f:
+        for part in (text[:cut2], text[cut2:]):
+            c = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_HUFFMAN_ONLY)
+            f.write(c.compress(part) + c.flush())
+    got, trace = _load_in_subprocess(tfile, SPEC)
+    assert got == one and _rounds_and_fallbacks(trace)[0] >= 2, (got, trace)
+    # a flipped bit in the middle, a truncated file: an error with and without the parallel decoders
+    blob = bytearray(open(hfile, "rb").read())
+    blob[len(blob) // 2] ^= 0x10
+    bad = str(tmp_path / "bad.cov.gz"); open(bad, "wb").write(bytes(blob))
+    cutf = str(tmp_path / "cut.cov.gz"); open(cutf, "wb").write(open(hfile, "rb").read()[:-70_000])
+    for path in (bad, cutf):
+        for env in (SPEC, {"HF_IO_PARALLEL": "0"}):
+            out, _ = _load_in_subprocess(path, env)
+            assert out.startswith("ERROR"), (path, env, out)          # (the CRC-32 check, or — a changed digit — rows that no longer tile the contig)
