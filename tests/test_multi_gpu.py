@@ -5,8 +5,10 @@ device; what `hmm_flagger --gpus N` drives) on a 1-GPU box:
   flag rows and the ordered reduction run for N = 1, 2, 3, 5 and more ranks than chunks — with the chunk-order exchange the
   statistics, the labels and whole EM runs must not depend on N, bit for bit;
 * HF_TRANSPORT_RCCL with one rank takes the product's RCCL path (ncclCommInitAll, ncclAllGather in place);
-* asking for more GPUs than are visible fails loudly (HF_E_NOGPU) instead of running fewer ranks.
-No N > 1 RCCL run is possible on this box: the 8-GPU curve is the driver's to measure.
+* asking for more GPUs than are visible fails loudly (HF_E_NOGPU) instead of running fewer ranks;
+* the `test_rccl_*` tests at the end switch themselves on with a second visible GPU (n = min(GPUs, 8) real RCCL ranks: BASELINE configs[3] and
+  configs[4]@n through the C ABI and the command line) and report SKIPPED on a 1-GPU lease.
+The 8-GPU throughput curve is the driver's to measure.
 """
 import os
 import subprocess
