@@ -355,17 +355,32 @@ def test_cfg2_accelerated_default_exchange_is_identical_for_every_number_of_rank
 # first `pytest -m gpu` on an 8-GPU node exercises BASELINE configs[3] and configs[4]@8 with no edit.  The fan-out / in-order merge
 # they stand in for: hmm.c:739-763.
 # ------------------------------------------------------------------------------------------
+# HF_TEST_RCCL_REHEARSAL=n (development only): the bodies of these tests with n LOOPBACK ranks on one GPU instead of n RCCL ranks on n GPUs — so
+# that their shapes and assertions have run at least once before the first multi-GPU box meets them (gpurun_out/r06_rccl_rehearsal.txt).
+_REHEARSAL = int(os.environ.get("HF_TEST_RCCL_REHEARSAL", "0") or 0)
+
+
 def _rccl_world():
+    if _REHEARSAL >= 2:
+        return _REHEARSAL
     n = min(N.lib().hf_device_count(), 8)
     if n < 2:
         pytest.skip("real RCCL with more than one rank needs >= 2 visible GPUs (this box: %d)" % N.lib().hf_device_count())
     return n
 
 
+def _rccl_transport():
+    return N.HF_TRANSPORT_LOOPBACK if _REHEARSAL >= 2 else N.HF_TRANSPORT_RCCL
+
+
+def _gpus(n):
+    """(extra command-line arguments, extra environment) that shard a run over n GPUs."""
+    return ([], {"HF_LOOPBACK_RANKS": str(n)}) if _REHEARSAL >= 2 else (["--gpus", str(n)], {})
+
+
 def _multi(store, model, world, exchange, transport, frac=0.95):
     m = hmm.MultiEMList(store, model, world, True, frac, exchange=exchange, transport=transport)
-    if transport == N.HF_TRANSPORT_RCCL:
-        assert int(N.lib().hf_multi_comm_ranks(m._h)) == world          # what ncclCommCount says, not what was asked for
+    assert int(N.lib().hf_multi_comm_ranks(m._h)) == world              # what ncclCommCount says (loopback: the group's size), not what was asked for
     return m
 
 
@@ -381,7 +396,7 @@ def test_rccl_chunk_order_exchange_does_not_depend_on_the_number_of_ranks(model_
         one.launch(model); ref = one.finish().copy(); ref_lab = one.labels()
         one.launch(model, N.HF_MODE_FORWARD_ONLY); ref_fwd = one.finish().copy()
         for world in sorted({2, (n + 1) // 2, n}):
-            m = _multi(store, model, world, N.HF_EXCHANGE_CHUNKS, N.HF_TRANSPORT_RCCL)
+            m = _multi(store, model, world, N.HF_EXCHANGE_CHUNKS, _rccl_transport())
             try:
                 sizes = m.shard_sizes()
                 assert sum(c for c, _ in sizes) == store.n_chunks and sum(w for _, w in sizes) == store.n_windows
@@ -410,14 +425,15 @@ def test_rccl_configs3_rank_order_exchange_at_full_size_prints_the_same_files(tm
     r0 = _cli(args, tmp_path / "one")
     assert r0.returncode == 0 and "Parameters converged after" in r0.stderr, r0.stderr[-2000:]
     names = sorted(x for x in os.listdir(tmp_path / "one") if x.endswith((".tsv", ".bed")))
-    r = _cli(args + ["--gpus", str(n), "--exchange", "ranks"], tmp_path / "rccl")
+    ga, ge = _gpus(n)
+    r = _cli(args + ga + ["--exchange", "ranks"], tmp_path / "rccl", env=ge)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert "GPU %d:" % (n - 1) in r.stderr
+    assert _REHEARSAL or "GPU %d:" % (n - 1) in r.stderr
     for x in names:
         assert (tmp_path / "one" / x).read_text() == (tmp_path / "rccl" / x).read_text(), x
     acc = ["-i", str(binp), "-n", "40", "-t", "1e-3", "-W", "4000", "-A", ALPHA, "--accelerate"]
     ra = _cli(acc, tmp_path / "acc1", env={"HF_STATS": "chunks"})
-    rb = _cli(acc + ["--gpus", str(n)], tmp_path / "accn")
+    rb = _cli(acc + ga, tmp_path / "accn", env=ge)
     assert ra.returncode == 0 and rb.returncode == 0, (ra.stderr[-1000:], rb.stderr[-1000:])
     accnames = sorted(x for x in os.listdir(tmp_path / "acc1") if x.endswith((".tsv", ".bed")))
     assert "final_flagger_prediction.bed" in accnames and "loglikelihood.tsv" in accnames
@@ -446,7 +462,7 @@ def test_rccl_cfg4_at_full_size_sharded_over_all_gpus():
         assert orc.run_iteration() == 0
         o = orc.stats_vector(K)
         assert np.allclose(ref, o, rtol=1e-9, atol=1e-9 * np.abs(o).max()) and np.array_equal(ref_lab, orc.labels())
-        m = _multi(store, model, n, N.HF_EXCHANGE_CHUNKS, N.HF_TRANSPORT_RCCL, 0.8)
+        m = _multi(store, model, n, N.HF_EXCHANGE_CHUNKS, _rccl_transport(), 0.8)
         try:
             got = m.run_sharded(model, N.HF_MODE_FULL)
             assert np.array_equal(got, ref), np.max(np.abs(got - ref))
@@ -456,7 +472,7 @@ def test_rccl_cfg4_at_full_size_sharded_over_all_gpus():
             assert np.array_equal(m.run_sharded(model, N.HF_MODE_FORWARD_ONLY), ref_fwd)
         finally:
             m.close()
-        m = _multi(store, model, n, N.HF_EXCHANGE_RANKS, N.HF_TRANSPORT_RCCL, 0.8)
+        m = _multi(store, model, n, N.HF_EXCHANGE_RANKS, _rccl_transport(), 0.8)
         try:
             got = m.run_sharded(model, N.HF_MODE_FULL)
             scale = np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
@@ -477,7 +493,8 @@ def test_rccl_command_line_gpus_option_cfg4(tmp_path):
     store.write_bin(str(binp))
     args = ["-i", str(binp), "-x", "ont-r10", "-n", "100", "-t", "1e-3", "-A", ALPHA_ONT]
     r0 = _cli(args, tmp_path / "one", env={"HF_STATS": "chunks"})
-    r1 = _cli(args + ["--gpus", str(n)], tmp_path / "rccl")
+    ga, ge = _gpus(n)
+    r1 = _cli(args + ga, tmp_path / "rccl", env=ge)
     assert r0.returncode == 0 and r1.returncode == 0, (r0.stderr[-1000:], r1.stderr[-1000:])
     names = sorted(x for x in os.listdir(tmp_path / "one") if x.endswith((".tsv", ".bed")))
     assert "final_flagger_prediction.bed" in names and "emission_final.tsv" in names
