@@ -884,11 +884,14 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             // quarter-wavefront hit four groups of four banks (a 16-way conflict on a quarter of the LDS: 1 024 conflict cycles per wavefront and
             // launch, 32 % of the LDS cycles: profiles/r05h_pmc_sq_b.json); 20 dwords apart they cover all 64 banks exactly once, on the write and
             // on the read side.  No extra instruction: only the address constants change (round 4 had ROTATED the pieces instead — selects per
-            // register — and lost 0.3 us).  5 120 of the row block's 8 192 bytes.
+            // register — and lost 0.3 us).  5 120 of the row block's 8 192 bytes.  HF_SEG_RECPAD=2: 64 bytes apart, piece j of record r in slot
+            // j ^ ((r >> 2) & 3) — conflict-free on both sides, and 0.8 us slower than the padding (profiles/r06_ab_swizzle.txt): not the default.
 #ifndef HF_SEG_RECPAD
 #define HF_SEG_RECPAD 1
 #endif
-            constexpr int RS = HF_SEG_RECPAD ? 5 : 4;           // double2 per staged record
+            constexpr int RS = HF_SEG_RECPAD == 1 ? 5 : 4;      // double2 per staged record
+            constexpr bool SWZ = HF_SEG_RECPAD == 2;            // (2: 64 bytes apart, piece j of record r at slot j ^ ((r >> 2) & 3))
+            const int wsz = SWZ ? ((lane >> 2) & 3) : 0;
             double2* __restrict__ mine = reinterpret_cast<double2*>(blk) + lane * RS;
             // (rotating the pieces so that these writes are free of bank conflicts — lane by lane at a 64-byte stride they hit four banks of
             // 64 — was measured 0.3 us SLOWER, profiles/r04e_ab_variants.txt: the conflicts are not on the kernel's critical path)
@@ -898,13 +901,13 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
             // the kernel ~1 us, profiles/r05_ab_segfb_regression.txt)
             double f0 = fk[0], f1 = fk[1], f2 = fk[2], f3 = fk[3], sc_ = sck;
             asm("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(sc_));
-            mine[0] = make_double2(f0, f1); mine[1] = make_double2(f2, f3);
-            mine[2] = make_double2(b[0], b[1]); mine[3] = make_double2(b[2], b[3]);
+            mine[0 ^ wsz] = make_double2(f0, f1); mine[1 ^ wsz] = make_double2(f2, f3);
+            mine[2 ^ wsz] = make_double2(b[0], b[1]); mine[3 ^ wsz] = make_double2(b[2], b[3]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // store instruction q writes records 16 q .. 16 q + 15: lane l holds piece l & 3 of record 16 q + (l >> 2)
-            const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + (lane >> 2) * RS + (lane & 3);
+            const double2* __restrict__ img = reinterpret_cast<const double2*>(blk) + (lane >> 2) * RS + ((lane & 3) ^ (SWZ ? ((lane >> 4) & 3) : 0));
             const double2 v0 = img[0], v1 = img[16 * RS], v2 = img[32 * RS], v3 = img[48 * RS];
             double2* __restrict__ R2 = reinterpret_cast<double2*>(recs) + (lane & 3);
             // lanes without a window k write THE SEGMENT'S SPARE RECORD (SegDesc.trash_pos, behind the sub-pass's positions) and a padding slot
