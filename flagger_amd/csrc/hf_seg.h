@@ -71,6 +71,12 @@ __device__ __forceinline__ double seg_xcu_load(const double* p) { return __hip_a
 #ifndef HF_SEG_WIDE
 #define HF_SEG_WIDE 1
 #endif
+#ifndef HF_SEG_STAGGER
+#define HF_SEG_STAGGER 0           // cycles between the starts of the grid's parts (0: all workgroups start together)
+#endif
+#ifndef HF_SEG_STAGGER_PARTS
+#define HF_SEG_STAGGER_PARTS 2
+#endif
 typedef unsigned hf_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void seg_xcu_store_m4(double* p, const double m[16]) {
 #if HF_SEG_WIDE
@@ -607,6 +613,18 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     const int lane = threadIdx.x;
     if (seg_of_block) { g = seg_of_block[g]; if (g < 0) return; }
     const SegDesc d = sd[g];
+#if HF_SEG_STAGGER > 0
+    // EXPERIMENT (round 6): the workgroups of a launch all start together and walk the same phases in step — the row fetches of twelve wavefronts
+    // meet in the CU's one vector-memory path (64 B/clk: a forward step of all twelve takes 96 KB / 64 = 1 536 cycles, what the trace measures),
+    // the scans meet in the VALU.  Later parts of the grid start HF_SEG_STAGGER cycles later each, so that one part's fetches meet another's scans.
+    if (FUSED && BWD) {
+        const unsigned part = (unsigned) (((unsigned long long) blockIdx.x * HF_SEG_STAGGER_PARTS) / gridDim.x);
+        if (part) {
+            const unsigned long long t_end = clock64() + (unsigned long long) part * HF_SEG_STAGGER;
+            while (clock64() < t_end) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+#endif
     const int L = d.L, n = d.n;
     const int a = lane * L;
     const int m = n - a < L ? (n - a > 0 ? n - a : 0) : L;
