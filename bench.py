@@ -571,7 +571,9 @@ def main():
                                                "min": min(dom_samples) if dom_samples else None, "max": max(dom_samples) if dom_samples else None},
                          "kernel_events": (0 if args.no_kernel_events else
                                            f"HIP event pair around {dom} in every {stride}. step of the timed region; kernel_ms_timed = median of n_samples"),
-                         "limiter": "fp64 VALU issue and dependent fp64 chains at three wavefronts per SIMD (see roofline_fp64), not HBM bytes",
+                         "limiter": "no single resource: fp64 VALU issue + dependent chains in the scans (VALU busy 60 % of SIMD time, roofline_fp64) and the CUs' "
+                                    "L1 -> LDS path in the three walks over the rows of A (53 % of its 64 B/clk over the whole kernel, at its rate during the "
+                                    "walks: profiles/r06_pmc_ta_*.json, DESIGN.md section 5), not HBM bytes",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_WINDOW * local_windows,
                          "kernel_ms_all": kavg, "algorithmic_bytes_per_window": ALGO_BYTES_PER_WINDOW,
                          "windows_per_launch": local_windows, "sub_passes": sub_passes, "cached_row_blocks": getattr(em, "seg_cached_steps", None),
