@@ -3,6 +3,16 @@
 // operand order of the reference (programs/submodules/hmm_utils/hmm_utils.c) so that the only
 // differences from the CPU path are the last-ulp behaviour of exp()/log().
 #pragma once
+// -DHF_KSTAMP (profiling builds only): every kernel of the default pass leaves the wall clock (s_memrealtime, 100 MHz) of its block 0 in a ring
+// of 64 passes — start-to-start distances of a pass's launches and of consecutive passes without a profiler in the way; hf_destroy appends the
+// ring to $HF_KSTAMP_FILE (profiles/tools/r06_kstamp.py)
+#ifdef HF_KSTAMP
+__device__ unsigned long long g_kstamp[64 * 4 + 1];
+#define KSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long p_ = g_kstamp[256]; if ((i) == 0) { p_ += 1; g_kstamp[256] = p_; } \
+                                                                 g_kstamp[(p_ & 63) * 4 + (i)] = wall_clock64(); } } while (0)
+#else
+#define KSTAMP(i)
+#endif
 #include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -777,6 +777,14 @@ int hf_warmup(int device) {
 }
 
 void hf_destroy(hf_ctx* ctx) {
+#ifdef HF_KSTAMP
+    if (ctx && std::getenv("HF_KSTAMP_FILE")) {
+        unsigned long long h[64 * 4 + 1];
+        hipSetDevice(ctx->device); hipDeviceSynchronize();
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_kstamp), sizeof(h)) == hipSuccess)
+            if (FILE* fp = std::fopen(std::getenv("HF_KSTAMP_FILE"), "ab")) { std::fwrite(h, 8, 64 * 4 + 1, fp); std::fclose(fp); }
+    }
+#endif
     if (!ctx) return;
     hipSetDevice(ctx->device);
 #ifdef HF_SEG_TRACE

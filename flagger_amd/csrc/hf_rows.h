@@ -45,6 +45,7 @@ __device__ __forceinline__ double quad_perm_f64(double v) {   // quad_perm withi
 __global__ void __launch_bounds__(256) k_pair_sums(int n_groups, const int32_t* __restrict__ grp_ar, const int32_t* __restrict__ grp_n,
                                                    const double* __restrict__ lutA, const double* __restrict__ recs,
                                                    double* __restrict__ grp_sums) {
+    KSTAMP(2);
     const int wave = (int) ((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
     const int g0 = wave * 4;
     if (g0 >= n_groups) return;
@@ -287,6 +288,7 @@ __global__ void __launch_bounds__(64 * HF_RS_WPB) k_row_stats(int n_rowwaves, in
     // pass, in the order rows_total_region / rows_total_ll use (hf_estep.hip host_rows_total: the same bits).  Three dependent global round trips
     // (drained partial -> ticket -> the last block's loads) leave the launch's critical path: k_row_stats 13 -> ~6 us.  The partials also stay in
     // blk_stats / chunk_ll, so that a total on the DEVICE can still be had afterwards (k_rows_total_late: hf_rank_total).
+    KSTAMP(3);
     constexpr int NA = 16 + 9 + 2 + 3 * KT + 1;
     constexpr int NS = 16 + 9 + 2;
     extern __shared__ __attribute__((aligned(16))) double s_rows[];

@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(256) k_tables(const TabWork W, const DevParams
     __shared__ uint8_t s_item[3][HF_TABLE_MAX_ITEMS];
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) *flags = 0u;   // first kernel of every pass
+    KSTAMP(0);
     // the jobs of the block first: their loads are in flight while the parameter block is rebuilt below — two dependent rounds of
     // global latency were the larger part of this launch-bound kernel's critical path
     const int job0 = blockIdx.x * HF_TABLE_JOBS_PER_BLOCK;

@@ -611,6 +611,7 @@ __global__ void __launch_bounds__(64, HF_SEG_OCC) k_seg_fb(const SegDesc* __rest
     // indices congruent mod 8, i.e. (observed, for speed only) on one XCD; < 0: a padding block of the plan.  Null: block b runs segment g0 + b.
     int g = (int) blockIdx.x + g0;
     const int lane = threadIdx.x;
+    if (FUSED && BWD) KSTAMP(1);
     if (seg_of_block) { g = seg_of_block[g]; if (g < 0) return; }
     const SegDesc d = sd[g];
 #if HF_SEG_STAGGER > 0
