@@ -87,9 +87,10 @@ def main():
                                                              "command line) that follows the timed region")
     ap.add_argument("--creates", type=int, default=9, help="fresh contexts of the em_run leg's hf_create timing (median / min / max reported)")
     ap.add_argument("--event-stride", type=int, default=0,
-                    help="the dominant kernel is bracketed by a pair of HIP events in every n-th timed step; default 0 = max(1, min(32, steps // 8)): "
-                         "at least 8 samples however short the timed region is (the driver's --steps 20: every 2nd step, 10 samples; a pair "
-                         "costs a few microseconds of the step it is in); the line reports the MEDIAN of the samples and their number")
+                    help="the dominant kernel is bracketed by a pair of HIP events in every n-th timed step; default 0 = max(1, min(32, steps // 5)): "
+                         "at least 5 samples however short the timed region is (the driver's --steps 20: every 4th step; a pair costs the pass "
+                         "it is in 10 us of turn-around, profiles/r06_kstamp.txt — at every 2nd step that was 5 % of the timed region); the line "
+                         "reports the MEDIAN of the samples and their number")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="no HIP events inside the timed region; the dominant kernel's duration then comes from the untimed "
                          "passes that follow — for comparing launch paths, not the default")
@@ -222,7 +223,7 @@ def main():
         step()
         kt = em.kernel_times()
         dom = max(kt, key=kt.get)
-    stride = args.event_stride if args.event_stride > 0 else max(1, min(32, args.steps // 8))
+    stride = args.event_stride if args.event_stride > 0 else max(1, min(32, args.steps // 5))
     em.set_profiling([] if args.no_kernel_events else [dom])   # timed region: only the dominant kernel is bracketed by HIP events,
     em.set_profiling_stride(stride)                            # and only in every n-th step
     dom_ms, dom_samples = 0.0, []
