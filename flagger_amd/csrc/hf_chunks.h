@@ -4,6 +4,13 @@
 #pragma once
 #include "hf_scan.h"
 
+// Round 6: the per-window arithmetic of k_stats_tile without its IEEE divisions where a prepared reciprocal (divp: within an ulp of the quotient)
+// or no division at all gives the same value to rounding — the kernel is bound by exactly this arithmetic (profiles/r05_chunks_path.txt), and
+// neither statistics path was ever bit-identical to a sequential run.  -DHF_CHUNKS_FASTDIV=0: the divisions of rounds 1-5.
+#ifndef HF_CHUNKS_FASTDIV
+#define HF_CHUNKS_FASTDIV 1
+#endif
+
 // ------------------------------------------------------------------------------------------
 // xi sufficient statistics (A6, A12).  For every pair (i, i+1), i = 1..T-2:
 //   xi = f_i[pre] * T * e * b_{i+1}[s] / terminationProb              (hmm.c:563-650)
@@ -152,8 +159,16 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
                         const int k = HF_PS(p, s);
                         const double alpha = P->alpha[p * 4 + s];
                         // alpha == 0 (wave-uniform): (x - 0*px) / (1 - 0) is x itself
+#if HF_CHUNKS_FASTDIV
+                        // (1 - alpha is wave-uniform and the same for every window: its reciprocal is prepared once — the compiler hoists it out of the
+                        // window loop; count * prob / totProb of a one-component state is the count itself unless the emission value is zero, where
+                        // the reference's 0 * 0 / 0 is a NaN: hmm_utils.c:812-839)
+                        const double x_adj = alpha == 0.0 ? x : divp(x - alpha * px, prediv(1.0 - alpha));
+                        const double w = Ev[k] == 0.0 ? __builtin_nan("") : adj[p];
+#else
                         const double x_adj = alpha == 0.0 ? x : (x - alpha * px) / (1.0 - alpha);
                         const double w = adj[p] * Ev[k] / Ev[k];
+#endif
                         a.g_mnum[s] += w * x_adj;
                         const double z = (x_adj - R->mean[s][0]) * (1.0 - alpha);
                         a.g_vnum[s] += w * z * z;
@@ -166,7 +181,11 @@ __global__ void __launch_bounds__(256, 2) k_stats_tile(int ntiles, const TileDes
 #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const double alpha = P->alpha[p * 4 + 3];
+#if HF_CHUNKS_FASTDIV
+                xa[p] = alpha == 0.0 ? x : divp(x - alpha * px, prediv(1.0 - alpha));
+#else
                 xa[p] = alpha == 0.0 ? x : (x - alpha * px) / (1.0 - alpha);
+#endif
                 om[p] = 1.0 - alpha;
             }
             if (col_fast) {   // w = adj3 * pc / E3 with the four reciprocals of E3 prepared once for all components
